@@ -1,0 +1,75 @@
+"""Oracle: tiny-MLP decoders and the neural-field wiring, torch CPU fp32.
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.
+
+In-tree logic followed:
+  pc_nerf/panoptic_nef.py:108-164        decoder shapes (density ->16, colour (16+PE)->3,
+                                         semantics ->C, instances ->I), density bias[0]=1
+  pc_nerf/panoptic_nef.py:72-77          view embedder (positional, view_multires freqs)
+  pc_nerf/panoptic_delta_nef.py:155-259  rgb_semantics(): interp -> *lod_weights -> density MLP
+                                         -> relu(ch 0) -> colour MLP on cat(density_feats, PE(-d))
+                                         -> sigmoid ; delta grid on detached coords ;
+                                         panoptic feats = feats.detach() + delta ;
+                                         sem / inst MLP -> [sigmoid] -> [normalize] -> [/T] -> [softmax]
+
+Third-party pieces restated from their public semantics (wisp 0.1.1, SURVEY.md
+Appendix A1/A2): BasicDecoder = num_layers x (Linear + activation) then Linear
+"lout"; PositionalEmbedder = cat(x, sin(x*2^k), cos(x*2^k)), frequency-major.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def positional_embed(x, num_freq):
+    """x [N,3] -> [N, 3 + 6*num_freq]  (wisp PositionalEmbedder, max_freq_log2 = num_freq-1)."""
+    bands = 2.0 ** torch.linspace(0.0, num_freq - 1, num_freq)
+    w = (x[:, None, :] * bands[None, :, None]).reshape(x.shape[0], -1)
+    return torch.cat([x, torch.sin(w), torch.cos(w)], dim=-1)
+
+
+def mlp(x, weights, biases, act=torch.relu):
+    """weights[i] is [out,in] (nn.Linear layout); activation after every layer but the last."""
+    h = x
+    for i, (W, b) in enumerate(zip(weights, biases)):
+        h = F.linear(h, W, b)
+        if i + 1 < len(weights):
+            h = act(h)
+    return h
+
+
+def nef_forward(feats, delta_feats, ray_d, params, channels,
+                view_multires=4, lod_weights=None,
+                sem_softmax=True, inst_softmax=True, sem_sigmoid=False, inst_sigmoid=False,
+                sem_normalize=False, inst_normalize=False, inst_soft_temperature=0.0):
+    """Everything of rgb_semantics() after the two grid interpolations.
+
+    feats, delta_feats: [M, L*F] grid features (delta may be None when no panoptic channel).
+    ray_d [M,3] per-sample view direction.  params: dict name -> (weights, biases).
+    Returns dict with density [M,1], rgb [M,3], semantics [M,C], inst_embedding [M,I].
+    """
+    out = {}
+    if lod_weights is not None:
+        feats = feats * lod_weights
+    dfe = mlp(feats, *params["density"])
+    out["density_feats"] = dfe
+    out["density"] = torch.relu(dfe[..., 0:1])
+    if "rgb" in channels:
+        pe = positional_embed(-ray_d, view_multires)
+        out["rgb"] = torch.sigmoid(mlp(torch.cat([dfe, pe], dim=-1), *params["color"]))
+    if "semantics" in channels or "inst_embedding" in channels:
+        d = delta_feats * lod_weights if lod_weights is not None else delta_feats
+        pan = feats.detach() + d
+        if "semantics" in channels:
+            s = mlp(pan, *params["semantics"])
+            s = torch.sigmoid(s) if sem_sigmoid else s
+            s = F.normalize(s, dim=-1) if sem_normalize else s
+            s = F.softmax(s, dim=-1) if sem_softmax else s
+            out["semantics"] = s
+        if "inst_embedding" in channels:
+            e = mlp(pan, *params["inst"])
+            e = torch.sigmoid(e) if inst_sigmoid else e
+            e = F.normalize(e, dim=-1) if inst_normalize else e
+            e = e / inst_soft_temperature if inst_soft_temperature > 0.0 else e
+            e = F.softmax(e, dim=-1) if inst_softmax else e
+            out["inst_embedding"] = e
+    return out

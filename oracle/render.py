@@ -1,0 +1,142 @@
+"""Oracle: packed ray-march and alpha compositing, torch CPU fp32.
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.
+
+In-tree logic followed (tracers/panoptic_packed_rf_tracer.py):
+  :85-86    raymarch -> (ridx, pidx, samples, depths, deltas, boundary)
+  :88-108   voxel-mode max-travel filter (strict <, first sample of each ray as the hit depth)
+  :114      ridx_hit = ridx[mark_pack_boundaries(ridx)]
+  :134-146  tau = density*deltas ; w = T*(1-exp(-tau)) ; alpha = sum w ; hit = alpha > 0
+  :160-170  rgb: white bg (1-alpha) + alpha * sum(w*rgb) ; black bg alpha * sum(w*rgb);
+            rays without samples keep the background
+  :172-176  depth = sum(w*depth)   (no alpha factor)
+  :178-182, :197-205  panoptic channels: alpha * sum(w*feat), weights from detached tau
+  :127-130  ray sparsity loss: mean_ray( sum_samples log(1+2 sigma^2) ) * lambda
+
+Third-party primitives restated from their public semantics (kaolin.render.spc,
+wisp OctreeAS.raymarch 'ray' mode) - PARITY UNPINNED for
+those primitives themselves; the tracer's own host logic is pinned by g4_tracer.npz.
+"""
+import torch
+
+
+def mark_pack_boundaries(pack_ids):
+    b = torch.ones_like(pack_ids, dtype=torch.bool)
+    if pack_ids.numel() > 1:
+        b[1:] = pack_ids[1:] != pack_ids[:-1]
+    return b
+
+
+def _pack_index(boundary):
+    """boundary bool [M] -> pack id per sample (0-based), number of packs."""
+    pid = torch.cumsum(boundary.long(), 0) - 1
+    return pid, int(pid[-1].item()) + 1 if boundary.numel() else 0
+
+
+def sum_reduce(feats, boundary):
+    """feats [M,C] -> [packs,C] per-pack sum in sample order (fp32 sequential order per pack)."""
+    pid, n = _pack_index(boundary)
+    out = torch.zeros(n, feats.shape[1], dtype=feats.dtype)
+    out.index_add_(0, pid, feats)
+    return out
+
+
+def cumsum_packed(feats, boundary, exclusive=False):
+    """Per-pack prefix sum of feats [M,C]."""
+    pid, n = _pack_index(boundary)
+    inc = torch.cumsum(feats, 0)
+    starts = torch.nonzero(boundary).reshape(-1)
+    base = inc[starts] - feats[starts]           # sum of everything before each pack
+    inc = inc - base[pid]
+    return inc - feats if exclusive else inc
+
+
+def exponential_integration_weights(tau, boundary):
+    """w_i = exp(-sum_{j<i in pack} tau_j) * (1 - exp(-tau_i)).  tau [M,1]."""
+    if tau.numel() == 0:
+        return tau.clone()
+    # fp64 prefix so the checker is order-independent; the per-sample weights are then fp32
+    pre = cumsum_packed(tau.double(), boundary, exclusive=True)
+    return (torch.exp(-pre) * (1.0 - torch.exp(-tau.double()))).to(tau.dtype)
+
+
+def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter, occupancy=None, blas_level=7):
+    """'ray' mode sampling: quadratic depth spacing with stratified jitter, then the
+    occupancy query (inside [-1,1]^3 and in an occupied cell of the 2^level grid).
+    jitter f32 [N,S] in [0,1) stands for the torch.rand draw of the upstream code.
+    occupancy: bool [R,R,R] (x,y,z) or None (dense).
+    Returns ridx i64[M], pidx i64[M] (linear cell id), samples [M,1,3], depths [M,1],
+    deltas [M,1], boundary bool[M]."""
+    N = origins.shape[0]
+    S = num_samples
+    depth = torch.linspace(0, 1.0, S)[None] + jitter / S
+    depth = depth ** 2
+    depth = depth * (dist_max - dist_min)
+    depth = depth + dist_min
+    samples = torch.addcmul(origins[:, None], dirs[:, None], depth[..., None])
+    deltas = depth.diff(dim=-1, prepend=torch.zeros(N, 1) + dist_min)
+    R = 2 ** blas_level
+    inside = ((samples >= -1.0) & (samples <= 1.0)).all(-1)
+    cell = torch.floor((samples + 1.0) * (R / 2.0)).long().clamp(0, R - 1)
+    lin = (cell[..., 0] * R + cell[..., 1]) * R + cell[..., 2]
+    mask = inside
+    if occupancy is not None:
+        mask = mask & occupancy.reshape(-1)[lin]
+    ridx = torch.arange(N)[:, None].repeat(1, S)[mask]
+    return (ridx, lin[mask], samples[mask][:, None], depth[mask][:, None],
+            deltas[mask].reshape(-1, 1), mark_pack_boundaries(ridx))
+
+
+def composite(N, ridx, boundary, density, deltas, depths=None, rgb=None, semantics=None,
+              inst=None, bg_color="white", ray_sparcity_reg=0.0):
+    """Compositing half of trace().  Packed inputs ([M,*]); returns dict of [N,*] buffers."""
+    out = {}
+    ridx_hit = ridx[boundary].long()
+    tau = density.reshape(-1, 1) * deltas
+    w = exponential_integration_weights(tau, boundary)
+    alpha = sum_reduce(w, boundary) if w.numel() else torch.zeros(0, 1)
+    out_alpha = torch.zeros(N, 1)
+    out_alpha[ridx_hit] = alpha
+    out["alpha"] = out_alpha
+    hit = torch.zeros(N, dtype=torch.bool)
+    hit[ridx_hit] = alpha[..., 0] > 0.0
+    out["hit"] = hit
+    out["weights"] = w
+    if ray_sparcity_reg > 0.0:
+        per = torch.log(1.0 + 2 * density.reshape(-1) ** 2)
+        out["ray_sparcity_loss"] = torch.zeros(N).scatter_add(0, ridx.long(), per).mean() * ray_sparcity_reg
+    if rgb is not None:
+        rc = sum_reduce(rgb.reshape(-1, 3) * w, boundary) if w.numel() else torch.zeros(0, 3)
+        if bg_color == "white":
+            buf = torch.ones(N, 3)
+            color = (1.0 - alpha) + alpha * rc
+        else:
+            buf = torch.zeros(N, 3)
+            color = alpha * rc
+        buf[ridx_hit] = color
+        out["rgb"] = buf
+    if depths is not None:
+        rd = sum_reduce(depths.reshape(-1, 1) * w, boundary) if w.numel() else torch.zeros(0, 1)
+        d = torch.zeros(N, 1)
+        d[ridx_hit] = rd
+        out["depth"] = d
+    for name, feat in (("semantics", semantics), ("inst_embedding", inst)):
+        if feat is None:
+            continue
+        C = feat.shape[-1]
+        rf = sum_reduce(w * feat.reshape(-1, C), boundary) if w.numel() else torch.zeros(0, C)
+        buf = torch.zeros(N, C)
+        buf[ridx_hit] = alpha * rf
+        out[name] = buf
+    return out
+
+
+def voxel_travel_filter(ridx, depths, ray_max_travel):
+    """tracer :88-108 - keep samples whose depth is < ray_max_travel past the first sample
+    of their ray.  depths [M,k,1] (first column used).  Returns bool mask [M]."""
+    _, counts = ridx.unique(return_counts=True)
+    start = torch.cumsum(counts, 0)
+    start = torch.cat([torch.zeros(1, dtype=start.dtype), start[:-1]])
+    first = torch.take(depths[:, 0, 0], start)
+    travelled = depths[:, 0, 0] - torch.repeat_interleave(first, counts)
+    return travelled < ray_max_travel

@@ -1,0 +1,125 @@
+"""The CPU oracle against the golden vectors captured from the reference's own modules
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import torch
+
+from conftest import golden, table_from_seed
+from oracle import hash_encode as oh
+from oracle import decoders as od
+from oracle import render as orr
+from oracle import lin_assign as ola
+
+
+def test_g2_resolutions_fp32_quirk():
+    g = golden("g2_resolutions.npz")
+    for key in g.files:
+        _, a, b, L = key.split("_")
+        got = oh.level_resolutions(int(a), int(b), int(L))
+        assert np.array_equal(np.array(got, np.float32), g[key]), key
+    assert oh.level_resolutions(16, 2048, 16)[-1] == 2047.0        # Appendix E.7
+
+
+def test_g1_hash_indices_bit_exact_and_feats():
+    g = golden("g1_hash.npz")
+    for tag in ("a", "b"):
+        log2T = int(g[f"{tag}_log2T"])
+        res = g[f"{tag}_res"]
+        L = len(res)
+        tab = torch.from_numpy(table_from_seed(int(g[f"{tag}_seed"]), (L, 2 ** log2T, 2), str(g[f"{tag}_kind"])))
+        x = torch.from_numpy(g[f"{tag}_x"])
+        feats, idx = oh.hash_encode(x, tab, [float(r) for r in res], log2T)
+        assert np.array_equal(idx, g[f"{tag}_idx"]), "hash indices must be bit-exact"
+        assert idx.min() >= 0 and idx.max() < 2 ** log2T
+        assert np.array_equal(feats.numpy(), g[f"{tag}_feats"]), "fp32 features must match the reference bit for bit on CPU"
+
+
+def _g3_params(g):
+    p = {}
+    for short, name in (("density", "decoder_density"), ("color", "decoder_color"),
+                        ("semantics", "decoder_semantics"), ("inst", "decoder_inst")):
+        n = int(g[f"{name}_n"])
+        p[short] = ([torch.from_numpy(g[f"{name}_w{i}"]) for i in range(n)],
+                    [torch.from_numpy(g[f"{name}_b{i}"]) for i in range(n)])
+    return p
+
+
+def test_g3_nef_forward():
+    g = golden("g3_nef.npz")
+    L, log2T = int(g["L"]), int(g["log2T"])
+    res = [float(r) for r in oh.level_resolutions(int(g["res"][0]), int(g["res"][-1]), L)]
+    coords = torch.from_numpy(g["coords"]).reshape(-1, 3)
+    tabs = [torch.from_numpy(table_from_seed(int(g[k]), (L, 2 ** log2T, 2), "normal") * np.float32(0.5))
+            for k in ("seed_main", "seed_delta")]
+    feats, _ = oh.hash_encode(coords, tabs[0], res, log2T)
+    dfeats, _ = oh.hash_encode(coords, tabs[1], res, log2T)
+    assert np.array_equal(feats.numpy(), g["feats"]) and np.array_equal(dfeats.numpy(), g["delta_feats"])
+    params = _g3_params(g)
+    assert params["density"][0][0].shape == (64, 2 * L) and params["density"][0][1].shape == (16, 64)
+    assert params["color"][0][0].shape == (64, 16 + int(g["view_embed_dim"])) and int(g["view_embed_dim"]) == 27
+    assert params["inst"][0][-1].shape == (200, 64) and len(params["inst"][0]) == 3
+    assert float(g["bias0"]) == 1.0
+    out = od.nef_forward(feats, dfeats, torch.from_numpy(g["ray_d"]), params,
+                         {"density", "rgb", "semantics", "inst_embedding"}, lod_weights=torch.ones(2 * L))
+    np.testing.assert_allclose(out["density"].numpy(), g["density"].reshape(-1, 1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["rgb"].numpy(), g["rgb"].reshape(-1, 3), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["semantics"].numpy(), g["semantics"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["inst_embedding"].numpy(), g["inst_embedding"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(g["density_only"], g["density"])
+
+
+def test_g4_tracer_composite_both_backgrounds():
+    g = golden("g4_tracer.npz")
+    N, S = int(g["N"]), int(g["S"])
+    ridx, _, samples, depths, deltas, boundary = orr.raymarch_ray(
+        torch.from_numpy(g["origins"]), torch.from_numpy(g["dirs"]), 0.0, 2.0, S,
+        torch.from_numpy(g["jitter"]), torch.from_numpy(g["occ"]), 3)
+    keep = ridx != int(g["empty_ray"])
+    assert np.array_equal(ridx[keep].numpy(), g["ridx"])
+    np.testing.assert_array_equal(samples[keep].numpy(), g["samples"])
+    t = lambda k: torch.from_numpy(g[k])
+    for bg in ("white", "black"):
+        out = orr.composite(N, t("ridx"), t("boundary"), t("density"), t("deltas"), depths=t("depths"),
+                            rgb=t("rgb"), semantics=t("semantics"), inst=t("inst_embedding"), bg_color=bg,
+                            ray_sparcity_reg=0.01)
+        for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding"):
+            np.testing.assert_allclose(out[ch].numpy(), g[f"{bg}_{ch}"], rtol=1e-5, atol=1e-6, err_msg=f"{bg} {ch}")
+        assert np.array_equal(out["hit"].numpy(), g[f"{bg}_hit"])
+        np.testing.assert_allclose(out["ray_sparcity_loss"].numpy(), g[f"{bg}_ray_sparcity_loss"], rtol=1e-5)
+    e = int(g["empty_ray"])            # Appendix E.10: empty ray keeps the background
+    assert np.all(g["white_rgb"][e] == 1.0) and np.all(g["black_rgb"][e] == 0.0) and not g["white_hit"][e]
+    assert g["white_alpha"][e] == 0 and g["white_depth"][e] == 0 and np.all(g["white_inst_embedding"][e] == 0)
+
+
+def test_g4_voxel_travel_filter():
+    g = golden("g4_tracer.npz")
+    ridx, depths = torch.from_numpy(g["v_ridx"]), torch.from_numpy(g["v_depths"])
+    mask = orr.voxel_travel_filter(ridx, depths, float(g["v_max_travel"]))
+    assert int(mask.sum()) == int(g["v_kept"])
+    k = depths.shape[1]
+    deltas = torch.from_numpy(g["v_deltas"]).reshape(depths.shape)[mask].reshape(-1, 1)
+    boundary = torch.from_numpy(g["v_boundary"]).reshape(depths.shape[:2])[mask].reshape(-1)
+    dens = torch.from_numpy(g["v_density"])[mask]
+    ridx_k = ridx[mask].repeat_interleave(k)
+    out = orr.composite(16, ridx_k, boundary, dens.reshape(-1, 1), deltas, depths=depths[mask].reshape(-1, 1),
+                        rgb=torch.from_numpy(g["v_rgb"])[mask].reshape(-1, 3))
+    np.testing.assert_allclose(out["rgb"].numpy(), g["v_out_rgb"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["alpha"].numpy(), g["v_out_alpha"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["depth"].numpy(), g["v_out_depth"], rtol=1e-5, atol=1e-6)
+
+
+def test_g5_linear_assignment_bit_exact():
+    g = golden("g5_linassign.npz")
+    prob, gt, stuff, pts = g["prob"], g["gt"], g["stuff"], g["points_3d"]
+    for b in range(prob.shape[0]):
+        sm = torch.softmax(torch.from_numpy(g["logits"][b]), -1).numpy()
+        assert np.array_equal(ola.virtual_labels(sm, gt[b]), g["virt_plain"][b])
+        vm = stuff[b] | (gt[b] > 0)
+        assert np.array_equal(ola.virtual_labels_things(prob[b][vm], gt[b][vm]), g[f"virt_things_{b}"])
+        assert np.array_equal(ola.virtual_labels_things(prob[b][vm], gt[b][vm], pts[b][vm], True),
+                              g[f"virt_things_rej_{b}"])
+
+
+def test_g6_sigma_sparsity():
+    g = golden("g6_reg.npz")
+    s = torch.from_numpy(g["sigma"])
+    np.testing.assert_allclose(torch.log(1.0 + 2 * s ** 2).numpy(), g["sparsity"], rtol=1e-6)
