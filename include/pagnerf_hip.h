@@ -1,0 +1,198 @@
+/*
+ * pagnerf_hip.h - C ABI of libpagnerf_hip.so: the MI355X (gfx950) kernels behind the
+ * kaolin-wisp grid / nef / tracer plugin API that PAg-NeRF's trainer drives.
+ *
+ * The reference is 100 % Python and has no FFI of its own; each entry point below replaces
+ * a call the reference makes into a third-party CUDA package (or an in-tree torch op
+ * sequence) at the cited file:line of the upstream repository.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is allocated by the caller (device memory
+ *     unless the name ends in _host); the library owns nothing and keeps no global state
+ *     except the thread-local last-error string.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and is safe to capture into a hipGraph (no allocation, no synchronisation).
+ *   - return value: 0 on success, negative PAG_ERR_* otherwise (pag_last_error_string()).
+ *   - "dtype" arguments take PAG_F32 / PAG_F16 / PAG_BF16.
+ *   - strides are in ELEMENTS; a [M, C] row-major tensor has stride_m = C, stride_c = 1,
+ *     a feature-major one stride_m = 1, stride_c = M.
+ */
+#ifndef PAGNERF_HIP_H
+#define PAGNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAG_ABI_VERSION 1
+
+enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
+enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
+enum { PAG_ACT_NONE = 0, PAG_ACT_SIGMOID = 1, PAG_ACT_SOFTMAX = 2 };
+enum { PAG_MLP_MFMA_BF16 = 0, PAG_MLP_FP32 = 1 };
+enum { PAG_BG_BLACK = 0, PAG_BG_WHITE = 1 };
+#define PAG_MAX_LEVELS 32
+#define PAG_MAX_FEATS 64
+
+int pag_abi_version(void);
+const char *pag_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grid feature interpolation ("encode")
+ * ------------------------------------------------------------------------------------------ */
+
+/* Multiresolution hash grid.  Replaces HashEmbedder.forward (grids/hash_grid_torch.py:95-108:
+ * get_voxel_vertices :26-46, hash :13-24, trilinear_interp :69-93) as reached through
+ * HashGridTorch.interpolate (:130-140); also the tinycudann-backed variant
+ * (grids/hash_grid_tinycudann.py:36-47) with its own resolution list.
+ *   xyz          f32 [M,3]
+ *   tables       [L, 2^log2_T, F] (F = 2 or 4), PAG_F32 or PAG_F16
+ *   resolutions_host  f32 [L]  (grids/hash_grid_torch.py:99)
+ *   feat_scale_host   f32 [L*F] or NULL: per-feature multiplier (nef.lod_weights,
+ *                     pc_nerf/panoptic_delta_nef.py:171)
+ *   out          [M, L*F] via strides, PAG_F32 or PAG_BF16; column = level*F + f
+ * fp32 tables + fp32 out reproduce the reference's fp32 op order (no FMA contraction). */
+int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype,
+                        int n_levels, int n_feat, int log2_T, const float *resolutions_host,
+                        const float *feat_scale_host, void *out, int out_dtype,
+                        int64_t out_stride_m, int64_t out_stride_c, void *stream);
+
+/* d loss / d tables (what autograd through grids/hash_grid_torch.py:95-108 yields).
+ *   grad_out  [M, L*F] via strides (PAG_F32 or PAG_BF16);  grad_tables f32 [L,T,F], ACCUMULATED
+ *   into (caller zeroes). */
+int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
+                        int64_t g_stride_m, int64_t g_stride_c, int n_levels, int n_feat,
+                        int log2_T, const float *resolutions_host, const float *feat_scale_host,
+                        float *grad_tables, void *stream);
+
+/* Permutohedral-lattice hash encoding.  Replaces permutohedral_encoding.PermutoEncoding's
+ * forward as called at grids/permuto_grid.py:57-62,71.
+ *   scale_factor_host f32 [L,3] = 1/(sqrt((i+1)(i+2)) * scale[l]), scale = np.geomspace(...)
+ *                     (grids/permuto_grid.py:53)
+ *   shift_host        f32 [L,3] per-level random shift
+ *   capacity          table rows per level (need not be a power of two) */
+int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype,
+                           int n_levels, int n_feat, uint32_t capacity,
+                           const float *scale_factor_host, const float *shift_host,
+                           const float *feat_scale_host, void *out, int out_dtype,
+                           int64_t out_stride_m, int64_t out_stride_c, void *stream);
+
+int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
+                           int64_t g_stride_m, int64_t g_stride_c, int n_levels, int n_feat,
+                           uint32_t capacity, const float *scale_factor_host,
+                           const float *shift_host, const float *feat_scale_host,
+                           float *grad_tables, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tiny-MLP decoders
+ * ------------------------------------------------------------------------------------------ */
+
+/* One wisp BasicDecoder (n_layers Linear layers, ReLU between, none after the last) fused in
+ * one launch, with an optional output activation.  Replaces decoder_density / decoder_color /
+ * decoder_semantics / decoder_inst (pc_nerf/panoptic_nef.py:114-164) as applied at
+ * pc_nerf/panoptic_delta_nef.py:184,203,240-243,250-255, including the input concat of
+ * :198-199 (x2 rows are gathered per sample through x2_index, so the view embedding is never
+ * repeated in memory).
+ *   x1        [M, k1] row-major (x1_dtype F32 or BF16), k1 % 8 == 0
+ *   x2        f32 [R, k2p] row-major or NULL; k2p % 8 == 0 (caller zero-pads), x2_index i32 [M]
+ *   W[i]      f32 [out_i, in_i] row-major (nn.Linear.weight), b[i] f32 [out_i];
+ *             in_0 = in_dim <= k1 + k2p (columns beyond in_dim are treated as absent)
+ *   n_layers  2 or 3; hidden width = 64; out_dim <= 224
+ *   out       [M, out_dim] row-major (out_dtype F32 or BF16), after out_act
+ *   hidden_save[i]  bf16 (MFMA mode) or f32 (FP32 mode) [M, 64] row-major post-ReLU
+ *             activations of hidden layer i, or NULL when no backward will follow
+ *   mode      PAG_MLP_MFMA_BF16: bf16 operands, fp32 accumulate on the matrix cores;
+ *             PAG_MLP_FP32: fp32 FMA chain in k order (parity path) */
+typedef struct {
+    const void *x1; int x1_dtype; int k1;
+    const float *x2; int k2p; const int32_t *x2_index;
+    int in_dim; int n_layers; int out_dim;
+    const float *W[3]; const float *b[3];
+    int out_act;
+    void *out; int out_dtype;
+    void *hidden_save[2];
+    int mode;
+} pag_mlp_fwd_args;
+int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
+
+/* Data gradients of pag_mlp_fwd.  grad_out is d loss / d (activated output); `out` is the
+ * activated output saved from the forward (needed for sigmoid / softmax).  Writes
+ *   dz[i]   [M, out_i (padded to 64 for hidden layers)] pre-activation gradients of layer i
+ *           (bf16 in MFMA mode, f32 in FP32 mode); dz of the last layer is [M, out_dim]
+ *   dx1     [M, k1] (dx1_dtype) or NULL
+ * Weight gradients are dz[i]^T @ input_i - a plain GEMM left to the caller's BLAS. */
+typedef struct {
+    const float *grad_out; const void *out; int out_dtype; int out_act;
+    int k1; int in_dim; int n_layers; int out_dim;
+    const float *W[3];
+    const void *hidden_save[2];
+    void *dz[3];
+    void *dx1; int dx1_dtype;
+    int mode;
+} pag_mlp_bwd_args;
+int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray march (wisp OctreeAS.raymarch, 'ray' mode) - tracers/panoptic_packed_rf_tracer.py:85-86
+ * ------------------------------------------------------------------------------------------ */
+
+/* Pass 1: per-ray number of surviving samples.
+ *   origins, dirs f32 [N,3]; tvals f32 [S] = linspace(0,1,S); jitter f32 [N,S] in [0,1)
+ *   occupancy_bits u32 [R^3/32] (bit (x*R+y)*R+z), R = 2^blas_level, or NULL for a dense grid
+ *   counts i32 [N] */
+int pag_raymarch_count(const float *origins, const float *dirs, int64_t N, int S,
+                       const float *tvals, const float *jitter, float dist_min, float dist_max,
+                       const uint32_t *occupancy_bits, int blas_level, int32_t *counts,
+                       void *stream);
+/* Pass 2: pack.  offsets i64 [N] = exclusive prefix sum of counts.
+ *   ridx i32 [M], pidx i32 [M] (linear cell id), samples f32 [M,3], depths f32 [M],
+ *   deltas f32 [M], boundary u8 [M] (1 at the first sample of each ray) */
+int pag_raymarch_pack(const float *origins, const float *dirs, int64_t N, int S,
+                      const float *tvals, const float *jitter, float dist_min, float dist_max,
+                      const uint32_t *occupancy_bits, int blas_level, const int64_t *offsets,
+                      int32_t *ridx, int32_t *pidx, float *samples, float *depths, float *deltas,
+                      uint8_t *boundary, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Alpha compositing - kaolin spc_render.exponential_integration / sum_reduce as used at
+ * tracers/panoptic_packed_rf_tracer.py:134-182,197-205
+ * ------------------------------------------------------------------------------------------ */
+
+/* Segmented exclusive scan + per-ray sums for the base channels.
+ *   pack_start i64 [P+1] first packed sample of each non-empty ray (pack), ray_of_pack i32 [P]
+ *   sigma f32 [M] (density, already ReLU'd), deltas f32 [M], depths f32 [M] or NULL,
+ *   rgb f32 [M,3] or NULL
+ *   weights f32 [M] (out): w_i = exp(-sum_{j<i} tau_j) (1 - exp(-tau_i)), tau = sigma*delta
+ *   out_alpha f32 [N], out_rgb f32 [N,3], out_depth f32 [N], out_hit u8 [N]: rows of rays that
+ *   have a pack are overwritten; the caller pre-fills the rest with the background. */
+int pag_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
+                      const float *sigma, const float *deltas, const float *depths,
+                      const float *rgb, int bg_color, float *weights, float *out_alpha,
+                      float *out_rgb, float *out_depth, uint8_t *out_hit, void *stream);
+
+/* Gradients of pag_composite_fwd w.r.t. sigma and rgb.
+ *   g_rgb f32 [N,3] / g_depth f32 [N] / g_alpha f32 [N]: upstream gradients (any may be NULL)
+ *   d_sigma f32 [M], d_rgb f32 [M,3] (NULL allowed when rgb is NULL) */
+int pag_composite_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
+                      const float *sigma, const float *deltas, const float *depths,
+                      const float *rgb, int bg_color, const float *weights,
+                      const float *out_alpha, const float *g_rgb, const float *g_depth,
+                      const float *g_alpha, float *d_sigma, float *d_rgb, void *stream);
+
+/* Per-ray weighted feature sums (tracer :197-205): out[ray, c] = alpha[ray] * sum_i w_i f[i, c].
+ *   feats [M,C] row-major (feat_dtype F32 or BF16); out f32 [N,C] (rows of rays with a pack) */
+int pag_composite_feats_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
+                            const float *weights, const float *alpha, const void *feats,
+                            int feat_dtype, int C, float *out, void *stream);
+/* d feats[i, c] = alpha[ray] * w_i * g_out[ray, c]   (weights and alpha are detached, :148-155) */
+int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
+                            const float *weights, const float *alpha, const float *g_out, int C,
+                            float *d_feats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAGNERF_HIP_H */

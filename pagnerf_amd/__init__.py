@@ -1,0 +1,16 @@
+"""pagnerf_amd - MI355X-native hot path of PAg-NeRF behind the kaolin-wisp grid / nef / tracer API.
+
+    grid  : HashGridHIP, PermutoGridHIP           (grids.py)    <- grids/hash_grid_torch.py, grids/permuto_grid.py
+    nef   : PanopticDeltaNeF                      (nef.py)      <- pc_nerf/panoptic_delta_nef.py
+    tracer: PanopticPackedRFTracer                (tracer.py)   <- tracers/panoptic_packed_rf_tracer.py
+    core  : Rays, RenderBuffer, Pipeline          (core.py)     <- wisp.core / wisp.models.Pipeline
+    shard : ray sharding + RCCL gather/all-reduce (shard.py)
+
+All compute goes through libpagnerf_hip.so (include/pagnerf_hip.h); there is no CPU fallback.
+"""
+from .core import Rays, RenderBuffer, Pipeline                     # noqa: F401
+from .grids import HashGridHIP, PermutoGridHIP                     # noqa: F401
+from .nef import PanopticDeltaNeF, BasicDecoder                    # noqa: F401
+from .tracer import PanopticPackedRFTracer                         # noqa: F401
+
+__version__ = "0.1.0"

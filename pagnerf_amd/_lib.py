@@ -1,0 +1,122 @@
+"""ctypes binding of libpagnerf_hip.so (include/pagnerf_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a GPU tensor is not handed
+in, calls raise.  Import of this module alone never touches the GPU.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_SIGMOID, ACT_SOFTMAX = 0, 1, 2
+MLP_MFMA_BF16, MLP_FP32 = 0, 1
+BG_BLACK, BG_WHITE = 0, 1
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+c_i64, c_i32, c_u32, c_f32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p
+c_fp = ctypes.POINTER(ctypes.c_float)
+
+
+class MlpFwdArgs(ctypes.Structure):
+    _fields_ = [("x1", c_vp), ("x1_dtype", c_i32), ("k1", c_i32),
+                ("x2", c_vp), ("k2p", c_i32), ("x2_index", c_vp),
+                ("in_dim", c_i32), ("n_layers", c_i32), ("out_dim", c_i32),
+                ("W", c_vp * 3), ("b", c_vp * 3),
+                ("out_act", c_i32),
+                ("out", c_vp), ("out_dtype", c_i32),
+                ("hidden_save", c_vp * 2),
+                ("mode", c_i32)]
+
+
+class MlpBwdArgs(ctypes.Structure):
+    _fields_ = [("grad_out", c_vp), ("out", c_vp), ("out_dtype", c_i32), ("out_act", c_i32),
+                ("k1", c_i32), ("in_dim", c_i32), ("n_layers", c_i32), ("out_dim", c_i32),
+                ("W", c_vp * 3),
+                ("hidden_save", c_vp * 2),
+                ("dz", c_vp * 3),
+                ("dx1", c_vp), ("dx1_dtype", c_i32),
+                ("mode", c_i32)]
+
+
+_SIGS = {
+    "pag_abi_version": (c_i32, []),
+    "pag_last_error_string": (ctypes.c_char_p, []),
+    "pag_hash_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_vp]),
+    "pag_hash_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp]),
+    "pag_permuto_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_vp]),
+    "pag_permuto_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp]),
+    "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
+    "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
+    "pag_raymarch_count": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),
+    "pag_raymarch_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_composite_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_composite_feats_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "pag_composite_feats_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen the C-ABI library (building is __graft_entry__.build()'s job); raises if absent."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError("libpagnerf_hip.so not found at %s - run `python -m pagnerf_amd.build` "
+                               "(there is no CPU fallback for the HIP path)" % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.pag_abi_version() != 1:
+            raise RuntimeError("libpagnerf_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        msg = load().pag_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, msg))
+
+
+def dtype_code(t):
+    return _DT[t.dtype]
+
+
+def ptr(t):
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("pagnerf_amd: expected a GPU tensor (the HIP path has no CPU fallback), got %s" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("pagnerf_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def host_floats(values):
+    """python/numpy/torch-CPU float sequence -> ctypes float array (kept alive by the caller)."""
+    if values is None:
+        return None
+    if isinstance(values, torch.Tensor):
+        values = values.detach().cpu().float().reshape(-1).tolist()
+    else:
+        values = [float(v) for v in list(values)]
+    return (ctypes.c_float * len(values))(*values)

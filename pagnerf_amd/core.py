@@ -1,0 +1,109 @@
+"""Minimal stand-ins for the wisp.core data classes the hot path exchanges with its callers
+(wisp itself is a third-party dependency of the reference and is not part of this build).
+
+Uses in the reference that define the contract:
+  Rays          pc_nerf/trainer.py:422,644,958 ; datasets/transforms/ray_sampler.py:19-38 ;
+                pc_nerf/ba_pipeline.py:88-92
+  RenderBuffer  tracers/panoptic_packed_rf_tracer.py:195 ; pc_nerf/trainer.py:648,706,710
+  Pipeline      pc_nerf/ba_pipeline.py:73-76 (forward = tracer(nef, ...) or nef(...))
+"""
+import torch
+import torch.nn as nn
+
+
+class Rays:
+    def __init__(self, origins, dirs, dist_min=0.0, dist_max=6.0):
+        self.origins, self.dirs, self.dist_min, self.dist_max = origins, dirs, dist_min, dist_max
+
+    @property
+    def shape(self):
+        return self.origins.shape[:-1]
+
+    def __len__(self):
+        return self.origins.shape[0]
+
+    def _map(self, fn):
+        return Rays(fn(self.origins), fn(self.dirs), self.dist_min, self.dist_max)
+
+    def reshape(self, *dims):
+        return self._map(lambda t: t.reshape(*dims))
+
+    def to(self, *a, **k):
+        return self._map(lambda t: t.to(*a, **k))
+
+    def __getitem__(self, idx):
+        return self._map(lambda t: t[idx])
+
+    def split(self, n):
+        return [Rays(o, d, self.dist_min, self.dist_max) for o, d in zip(self.origins.split(n), self.dirs.split(n))]
+
+    @classmethod
+    def cat(cls, rays_list, dim=0):
+        return cls(torch.cat([r.origins for r in rays_list], dim), torch.cat([r.dirs for r in rays_list], dim),
+                   rays_list[0].dist_min, rays_list[0].dist_max)
+
+    @classmethod
+    def stack(cls, rays_list, dim=0):
+        return cls(torch.stack([r.origins for r in rays_list], dim), torch.stack([r.dirs for r in rays_list], dim),
+                   rays_list[0].dist_min, rays_list[0].dist_max)
+
+
+class RenderBuffer:
+    """Named per-ray channels; `a += b` concatenates along the ray axis (trainer.py:648)."""
+
+    def __init__(self, **channels):
+        self.__dict__["_ch"] = dict(channels)
+
+    def __getattr__(self, name):
+        ch = self.__dict__["_ch"]
+        if name in ch:
+            return ch[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self.__dict__["_ch"][name] = value
+
+    @property
+    def channels(self):
+        return set(self._ch)
+
+    def _map(self, fn):
+        return RenderBuffer(**{k: (fn(v) if isinstance(v, torch.Tensor) and v.dim() > 0 else v) for k, v in self._ch.items()})
+
+    def __iadd__(self, other):
+        for k, v in other._ch.items():
+            mine = self._ch.get(k)
+            if isinstance(v, torch.Tensor) and v.dim() > 0 and mine is not None:
+                self._ch[k] = torch.cat([mine, v], 0)
+            else:
+                self._ch[k] = v if mine is None else mine
+        return self
+
+    def reshape(self, *dims):
+        return self._map(lambda t: t.reshape(*dims))
+
+    def cpu(self):
+        return self._map(lambda t: t.cpu())
+
+    def detach(self):
+        return self._map(lambda t: t.detach())
+
+    def to(self, *a, **k):
+        return self._map(lambda t: t.to(*a, **k))
+
+    def byte(self):
+        return self._map(lambda t: (t.clamp(0, 1) * 255).byte() if t.is_floating_point() else t)
+
+    def image(self):
+        return self
+
+
+class Pipeline(nn.Module):
+    def __init__(self, nef, tracer=None):
+        super().__init__()
+        self.nef, self.tracer = nef, tracer
+
+    def forward(self, *args, **kwargs):
+        if self.tracer is not None:
+            return self.tracer(self.nef, *args, **kwargs)
+        return self.nef(*args, **kwargs)

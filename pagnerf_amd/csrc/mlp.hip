@@ -1,0 +1,744 @@
+// Fused tiny-MLP decoders for gfx950 (wisp BasicDecoder: Linear+ReLU stacks, width 64).
+//
+// MFMA path (PAG_MLP_MFMA_BF16) - the whole decoder chain of a 32-sample tile stays in one wave's
+// registers:
+//   * everything is computed TRANSPOSED, H^T[neurons x samples] = W[out x in] . X^T[in x samples],
+//     with v_mfma_f32_32x32x16_bf16: A = the nn.Linear weight exactly as torch stores it ([out][in],
+//     read from LDS as one ds_read_b128 per fragment), B = activations with the SAMPLE on the lane
+//     (col = lane & 31) - so a layer's 32x32 fp32 accumulator block, after bias/ReLU and a pairwise
+//     v_cvt_pk_bf16_f32, IS the next layer's B operand: no LDS round trip, no shuffles.
+//   * accumulator register q of lane (r, h = lane >> 5) holds row rho(q,h) = (q&3) + 8(q>>2) + 4h of
+//     its block.  Used as a B fragment, element j of k-step s is therefore input 16s + 8(j>>2) + 4h +
+//     (j&3), not 16s + 8h + j: the weights of every layer fed from registers are staged into LDS
+//     with bits 2 and 3 of the input index swapped, which makes the hardware's k order match.
+//   * biases are the accumulators' initial value; softmax / sigmoid run on the accumulators
+//     (softmax over the registers of a lane + one cross-half shuffle).
+//   * one 256-thread workgroup = 4 waves x 32-sample tiles, grid-strided; weights are converted to
+//     bf16 and staged once per workgroup (<= 51 KiB LDS, rows padded by 16 B against bank conflicts).
+// The backward kernel runs the same structure on the transposed weights and emits the per-layer
+// pre-activation gradients dz (bf16) and dx; weight gradients are dz^T . input, a plain GEMM that is
+// left to the BLAS library.
+//
+// FP32 path (PAG_MLP_FP32): one lane per sample, fp32 FMA chains in k order with the weights
+// broadcast from LDS - the parity path (tolerance 1e-5 against the fp32 oracle).
+#include "common.h"
+
+namespace {
+
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RS = 72;          // LDS row stride (bf16 elements) of a 64-wide weight row: 144 B
+constexpr int HID = 64;
+
+__device__ __forceinline__ int rho(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+__device__ __forceinline__ int swap23(int a) { return (a & ~12) | ((a & 4) << 1) | ((a & 8) >> 1); }
+
+struct FwdParams {
+    const void *x1;
+    const float *x2;
+    const int32_t *x2_index;
+    int k1, k2p, in_dim, in_pad, out_dim, act;
+    const float *W[3];
+    const float *b[3];
+    void *out;
+    void *hsave[2];
+    int64_t M;
+};
+
+struct BwdParams {
+    const float *grad_out;
+    const void *out;
+    int k1, in_dim, in_pad, out_dim, act;
+    const float *W[3];
+    const void *hsave[2];
+    void *dz[3];
+    void *dx1;
+    int64_t M;
+};
+
+// Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
+// optional bit-2/3 swap of the column index (see header).
+__device__ void stage_weight(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in,
+                             bool permute) {
+    for (int e = threadIdx.x; e < rows_pad * cols_pad; e += blockDim.x) {
+        int o = e / cols_pad, a = e - o * cols_pad;
+        float v = (o < n_out && a < n_in) ? W[(int64_t)o * n_in + a] : 0.0f;
+        dst[o * stride + (permute ? swap23(a) : a)] = (bf16_t)v;
+    }
+}
+// Stage W^T: dst[row = input a][col = output o (permuted)]
+__device__ void stage_weight_t(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in) {
+    for (int e = threadIdx.x; e < rows_pad * cols_pad; e += blockDim.x) {
+        int a = e / cols_pad, o = e - a * cols_pad;
+        float v = (o < n_out && a < n_in) ? W[(int64_t)o * n_in + a] : 0.0f;
+        dst[a * stride + swap23(o)] = (bf16_t)v;
+    }
+}
+
+__device__ __forceinline__ bf16x8 load8(const float *p) {
+    f32x4 a = *reinterpret_cast<const f32x4 *>(p);
+    f32x4 b = *reinterpret_cast<const f32x4 *>(p + 4);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (bf16_t)a[j];
+        r[j + 4] = (bf16_t)b[j];
+    }
+    return r;
+}
+__device__ __forceinline__ bf16x8 load8(const bf16_t *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)0.0f;
+    return r;
+}
+
+// accumulator block -> two B fragments (k-steps 2*blk, 2*blk+1)
+__device__ __forceinline__ void pack_block(const f32x16 &acc, bf16x8 &lo, bf16x8 &hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = (bf16_t)acc[j];
+        hi[j] = (bf16_t)acc[8 + j];
+    }
+}
+
+// store one 32-row accumulator block of sample m as 4 groups of 4 consecutive channels
+template <typename T>
+__device__ __forceinline__ void store_block(T *row_ptr, int ch_base, int h, const f32x16 &acc, int n_valid, bool vec_ok) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int c0 = ch_base + 8 * g + 4 * h;
+        if (vec_ok && c0 + 3 < n_valid) {
+            if constexpr (sizeof(T) == 4) {
+                f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(row_ptr + c0) = v;
+            } else {
+                bf16x4 v = {(bf16_t)acc[4 * g], (bf16_t)acc[4 * g + 1], (bf16_t)acc[4 * g + 2], (bf16_t)acc[4 * g + 3]};
+                *reinterpret_cast<bf16x4 *>(row_ptr + c0) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < n_valid) pag_st(row_ptr + c0 + j, acc[4 * g + j]);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void load_block(const T *row_ptr, int ch_base, int h, f32x16 &acc, int n_valid, bool vec_ok) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int c0 = ch_base + 8 * g + 4 * h;
+        if (vec_ok && c0 + 3 < n_valid) {
+            if constexpr (sizeof(T) == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(row_ptr + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * g + j] = v[j];
+            } else {
+                bf16x4 v = *reinterpret_cast<const bf16x4 *>(row_ptr + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * g + j] = (float)v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * g + j] = (c0 + j < n_valid) ? pag_ld(row_ptr + c0 + j) : 0.0f;
+        }
+    }
+}
+
+// hidden layer: acc[2] = bias + W(64 x K) . frags ; K = 16 * nks
+template <int NKS>
+__device__ __forceinline__ void hidden_layer(const bf16_t *Ws, const float *bs, const bf16x8 (&frag)[NKS], int nks, int r, int h,
+                                             f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[mb][q] = bs[32 * mb + rho(q, h)];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            if (s < nks) {
+                bf16x8 a = *reinterpret_cast<const bf16x8 *>(Ws + (32 * mb + r) * RS + 16 * s + 8 * h);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[s], acc[mb], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename X1T, typename OutT, int NL, int OBMAX>
+__global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int OB = (p.out_dim + 31) / 32;
+    bf16_t *W0s = reinterpret_cast<bf16_t *>(smem);                  // [64][RS] natural k
+    bf16_t *W1s = W0s + 64 * RS;                                     // [64][RS] permuted k (NL == 3)
+    bf16_t *WLs = W1s + (NL == 3 ? 64 * RS : 0);                     // [OB*32][RS] permuted k
+    float *b0s = reinterpret_cast<float *>(WLs + OB * 32 * RS);
+    float *b1s = b0s + 64;
+    float *bLs = b1s + 64;
+
+    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false);
+    if (NL == 3) stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
+    stage_weight(WLs, RS, OB * 32, 64, p.W[NL - 1], p.out_dim, HID, true);
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        b0s[e] = p.b[0][e];
+        b1s[e] = NL == 3 ? p.b[1][e] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b[NL - 1][e] : 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nks0 = p.in_pad / 16;
+    const int64_t ntiles = (p.M + 31) / 32;
+    const bool vec_out = (p.out_dim % 4) == 0;
+    const X1T *x1 = reinterpret_cast<const X1T *>(p.x1);
+    OutT *out = reinterpret_cast<OutT *>(p.out);
+
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t m = tile * 32 + r;
+        const bool live = m < p.M;
+        const int64_t mc = live ? m : p.M - 1;
+        // ---- layer-0 B fragments straight from memory: features 16s + 8h .. +7 of sample m
+        bf16x8 xb[4];
+        const int32_t ray = p.x2 ? p.x2_index[mc] : 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int f0 = 16 * s + 8 * h;
+            if (s < nks0 && live && f0 < p.k1)
+                xb[s] = load8(x1 + mc * p.k1 + f0);
+            else if (s < nks0 && live && f0 < p.k1 + p.k2p)
+                xb[s] = load8(p.x2 + (int64_t)ray * p.k2p + (f0 - p.k1));
+            else
+                xb[s] = zero8();
+        }
+        f32x16 acc[2];
+        bf16x8 hb[4];
+        hidden_layer<4>(W0s, b0s, xb, nks0, r, h, acc);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = fmaxf(acc[mb][q], 0.0f);
+            pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
+            if (p.hsave[0] && live) store_block(reinterpret_cast<bf16_t *>(p.hsave[0]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+        }
+        if (NL == 3) {
+            hidden_layer<4>(W1s, b1s, hb, 4, r, h, acc);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mb][q] = fmaxf(acc[mb][q], 0.0f);
+                pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
+                if (p.hsave[1] && live) store_block(reinterpret_cast<bf16_t *>(p.hsave[1]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+            }
+        }
+        // ---- output layer
+        f32x16 o[OBMAX];
+#pragma unroll
+        for (int ob = 0; ob < OBMAX; ++ob) {
+            if (ob < OB) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) o[ob][q] = bLs[32 * ob + rho(q, h)];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
+                    o[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], o[ob], 0, 0, 0);
+                }
+            }
+        }
+        if (p.act == PAG_ACT_SIGMOID) {
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) o[ob][q] = 1.0f / (1.0f + expf(-o[ob][q]));
+        } else if (p.act == PAG_ACT_SOFTMAX) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (32 * ob + rho(q, h) < p.out_dim) mx = fmaxf(mx, o[ob][q]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.0f;
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        float e = (32 * ob + rho(q, h) < p.out_dim) ? expf(o[ob][q] - mx) : 0.0f;
+                        o[ob][q] = e;
+                        sum += e;
+                    }
+            sum += __shfl_xor(sum, 32);
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) o[ob][q] = o[ob][q] / sum;
+        }
+        if (live) {
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB) store_block(out + m * p.out_dim, 32 * ob, h, o[ob], p.out_dim, vec_out);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------- backward
+template <typename OutT, typename DxT, int NL, int OBMAX>
+__global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int OB = (p.out_dim + 31) / 32;
+    const int RSL = OB * 32 + 8;
+    bf16_t *WLt = reinterpret_cast<bf16_t *>(smem);              // [64 in][RSL]  k = output channel (permuted)
+    bf16_t *W1t = WLt + 64 * RSL;                                // [64][RS]      (NL == 3)
+    bf16_t *W0t = W1t + (NL == 3 ? 64 * RS : 0);                 // [64 in-feature rows][RS]
+    stage_weight_t(WLt, RSL, 64, OB * 32, p.W[NL - 1], p.out_dim, HID);
+    if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
+    if (p.dx1) stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (p.M + 31) / 32;
+    const bool vec_out = (p.out_dim % 4) == 0;
+    const OutT *outp = reinterpret_cast<const OutT *>(p.out);
+
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t m = tile * 32 + r;
+        const bool live = m < p.M;
+        const int64_t mc = live ? m : p.M - 1;
+        // ---- dz of the output layer, in accumulator layout
+        f32x16 z[OBMAX];
+#pragma unroll
+        for (int ob = 0; ob < OBMAX; ++ob)
+            if (ob < OB) load_block(p.grad_out + mc * p.out_dim, 32 * ob, h, z[ob], p.out_dim, vec_out);
+        if (p.act != PAG_ACT_NONE) {
+            f32x16 y[OBMAX];
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB) load_block(outp + mc * p.out_dim, 32 * ob, h, y[ob], p.out_dim, vec_out);
+            if (p.act == PAG_ACT_SIGMOID) {
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) z[ob][q] = z[ob][q] * y[ob][q] * (1.0f - y[ob][q]);
+            } else {
+                float dot = 0.0f;
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) dot += z[ob][q] * y[ob][q];
+                dot += __shfl_xor(dot, 32);
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) z[ob][q] = y[ob][q] * (z[ob][q] - dot);
+            }
+        }
+        bf16x8 zb[2 * OBMAX];
+#pragma unroll
+        for (int ob = 0; ob < OBMAX; ++ob) {
+            if (ob < OB) {
+                if (!live) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) z[ob][q] = 0.0f;
+                }
+                pack_block(z[ob], zb[2 * ob], zb[2 * ob + 1]);
+                if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, z[ob], p.out_dim, vec_out);
+            } else {
+                zb[2 * ob] = zero8();
+                zb[2 * ob + 1] = zero8();
+            }
+        }
+        // ---- back through the output layer: dA = W_L^T . dz_L, masked by the saved ReLU output
+        f32x16 acc[2];
+        bf16x8 hb[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2 * OBMAX; ++s) {
+                if (s < 2 * OB) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * s + 8 * h);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[s], acc[mb], 0, 0, 0);
+                }
+            }
+            f32x16 hv;
+            load_block(reinterpret_cast<const bf16_t *>(p.hsave[NL - 2]) + mc * HID, 32 * mb, h, hv, HID, true);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
+            pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
+            if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+        }
+        if (NL == 3) {
+            bf16x8 hb2[4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(W1t + (32 * mb + r) * RS + 16 * s + 8 * h);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
+                }
+                f32x16 hv;
+                load_block(reinterpret_cast<const bf16_t *>(p.hsave[0]) + mc * HID, 32 * mb, h, hv, HID, true);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
+                pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
+                if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[0]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
+        }
+        // ---- dx1 = (W_0^T . dz_0)[0:k1]
+        if (p.dx1) {
+            DxT *dx = reinterpret_cast<DxT *>(p.dx1);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (32 * mb < p.k1) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(W0t + (32 * mb + r) * RS + 16 * s + 8 * h);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
+                    }
+                    if (live) store_block(dx + m * p.k1, 32 * mb, h, acc[mb], p.k1, true);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ FP32 parity path
+// One lane per sample.  Weights transposed in LDS ([k][j]) so the 64 outputs of a layer are 16
+// broadcast ds_read_b128; the per-sample activation column lives in LDS ([k][lane]).
+constexpr int PT = 128;   // threads per block on this path
+
+struct F32Fwd {
+    FwdParams p;
+    float *hsave32[2];
+};
+
+__device__ void stage_f32_t(float *dst, const float *W, int n_out, int n_in, int out_pad) {   // dst[k][out_pad]
+    for (int e = threadIdx.x; e < n_in * out_pad; e += blockDim.x) {
+        int k = e / out_pad, j = e - k * out_pad;
+        dst[e] = j < n_out ? W[(int64_t)j * n_in + k] : 0.0f;
+    }
+}
+
+template <typename X1T, typename OutT>
+__global__ __launch_bounds__(PT) void mlp_fwd_f32(FwdParams p, int n_layers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);          // [64][PT] activation columns
+    float *wt = xs + 64 * PT;                             // current layer's W^T [k][out_pad]
+    const int t = threadIdx.x;
+    const int64_t m = (int64_t)blockIdx.x * PT + t;
+    const bool live = m < p.M;
+    const int64_t mc = live ? m : p.M - 1;
+    const X1T *x1 = reinterpret_cast<const X1T *>(p.x1);
+    OutT *out = reinterpret_cast<OutT *>(p.out);
+    // input column
+    const int32_t ray = p.x2 ? p.x2_index[mc] : 0;
+    for (int k = 0; k < p.in_dim; ++k)
+        xs[k * PT + t] = k < p.k1 ? pag_ld(x1 + mc * p.k1 + k) : p.x2[(int64_t)ray * p.k2p + (k - p.k1)];
+    int n_in = p.in_dim;
+    for (int l = 0; l < n_layers; ++l) {
+        const bool last = l == n_layers - 1;
+        const int n_out = last ? p.out_dim : HID;
+        const int chunks = (n_out + 63) / 64;
+        for (int c = 0; c < chunks; ++c) {
+            __syncthreads();
+            const int rows = min(64, n_out - 64 * c);
+            stage_f32_t(wt, p.W[l] + (int64_t)64 * c * n_in, rows, n_in, 64);
+            __syncthreads();
+            float acc[64];
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc[j] = j < rows ? p.b[l][64 * c + j] : 0.0f;
+            for (int k = 0; k < n_in; ++k) {
+                const float xk = xs[k * PT + t];
+                const f32x4 *wrow = reinterpret_cast<const f32x4 *>(wt + k * 64);
+#pragma unroll
+                for (int j4 = 0; j4 < 16; ++j4) {
+                    f32x4 w = wrow[j4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 * j4 + j] = fmaf(w[j], xk, acc[4 * j4 + j]);
+                }
+            }
+            if (!last) {
+                __syncthreads();   // everyone finished reading xs of the previous layer
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    float v = fmaxf(acc[j], 0.0f);
+                    xs[j * PT + t] = v;
+                    if (p.hsave[l] && live) reinterpret_cast<float *>(p.hsave[l])[m * HID + j] = v;
+                }
+            } else if (live) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j)
+                    if (j < rows) {
+                        float v = acc[j];
+                        if (p.act == PAG_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                        pag_st(out + m * p.out_dim + 64 * c + j, v);
+                    }
+            }
+        }
+        n_in = HID;
+    }
+    if (p.act == PAG_ACT_SOFTMAX && live) {   // second pass over this sample's logits
+        OutT *row = out + m * p.out_dim;
+        float mx = -INFINITY;
+        for (int j = 0; j < p.out_dim; ++j) mx = fmaxf(mx, pag_ld(row + j));
+        float sum = 0.0f;
+        for (int j = 0; j < p.out_dim; ++j) sum += expf(pag_ld(row + j) - mx);
+        for (int j = 0; j < p.out_dim; ++j) pag_st(row + j, expf(pag_ld(row + j) - mx) / sum);
+    }
+}
+
+__device__ void stage_f32_n(float *dst, const float *W, int row0, int rows, int n_in) {   // dst[j][64] = W[row0+j][0:n_in]
+    for (int e = threadIdx.x; e < rows * 64; e += blockDim.x) {
+        int j = e / 64, k = e - j * 64;
+        dst[e] = k < n_in ? W[(int64_t)(row0 + j) * n_in + k] : 0.0f;
+    }
+}
+
+template <typename OutT, typename DxT>
+__global__ __launch_bounds__(PT) void mlp_bwd_f32(BwdParams p, int n_layers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *zs = reinterpret_cast<float *>(smem);          // [224][PT] dz column of the current layer
+    float *wt = zs + 224 * PT;                            // [64 rows j][64 k]
+    const int t = threadIdx.x;
+    const int64_t m = (int64_t)blockIdx.x * PT + t;
+    const bool live = m < p.M;
+    const int64_t mc = live ? m : p.M - 1;
+    const OutT *y = reinterpret_cast<const OutT *>(p.out) + mc * p.out_dim;
+    const float *g = p.grad_out + mc * p.out_dim;
+    float dot = 0.0f;
+    if (p.act == PAG_ACT_SOFTMAX)
+        for (int j = 0; j < p.out_dim; ++j) dot += g[j] * pag_ld(y + j);
+    for (int j = 0; j < p.out_dim; ++j) {
+        float v = g[j];
+        if (p.act == PAG_ACT_SIGMOID) {
+            float yy = pag_ld(y + j);
+            v = v * yy * (1.0f - yy);
+        } else if (p.act == PAG_ACT_SOFTMAX) {
+            v = pag_ld(y + j) * (v - dot);
+        }
+        v = live ? v : 0.0f;
+        zs[j * PT + t] = v;
+        if (live) reinterpret_cast<float *>(p.dz[n_layers - 1])[m * p.out_dim + j] = v;
+    }
+    int n_out = p.out_dim;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const int n_in = l == 0 ? p.in_dim : HID;
+        if (l == 0 && !p.dx1) break;
+        float acc[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc[k] = 0.0f;
+        const int chunks = (n_out + 63) / 64;
+        for (int c = 0; c < chunks; ++c) {
+            __syncthreads();
+            const int rows = min(64, n_out - 64 * c);
+            stage_f32_n(wt, p.W[l], 64 * c, rows, n_in);
+            __syncthreads();
+            for (int j = 0; j < rows; ++j) {
+                const float zj = zs[(64 * c + j) * PT + t];
+                const f32x4 *wrow = reinterpret_cast<const f32x4 *>(wt + j * 64);
+#pragma unroll
+                for (int k4 = 0; k4 < 16; ++k4) {
+                    f32x4 w = wrow[k4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[4 * k4 + k] = fmaf(w[k], zj, acc[4 * k4 + k]);
+                }
+            }
+        }
+        __syncthreads();
+        if (l > 0) {
+            const float *hv = reinterpret_cast<const float *>(p.hsave[l - 1]) + mc * HID;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                float v = (live && hv[k] > 0.0f) ? acc[k] : 0.0f;
+                zs[k * PT + t] = v;
+                if (live) reinterpret_cast<float *>(p.dz[l - 1])[m * HID + k] = v;
+            }
+            n_out = HID;
+        } else if (live) {
+            DxT *dx = reinterpret_cast<DxT *>(p.dx1) + m * p.k1;
+#pragma unroll
+            for (int k = 0; k < 64; ++k)
+                if (k < p.k1) pag_st(dx + k, acc[k]);
+        }
+    }
+}
+
+inline unsigned mlp_grid(int64_t M) {
+    int64_t tiles = (M + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    int64_t cap = 256 * 6;   // a few workgroups per CU; tiles are grid-strided
+    return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
+}
+
+}  // namespace
+
+#define MLP_FWD_LAUNCH(X1T, OutT, NL_, OBM)                                                            \
+    hipLaunchKernelGGL((mlp_fwd_mfma<X1T, OutT, NL_, OBM>), dim3(mlp_grid(M)), dim3(256), lds, st, p)
+#define MLP_FWD_OB(X1T, OutT, NL_)                                   \
+    do {                                                             \
+        if (OB <= 1) MLP_FWD_LAUNCH(X1T, OutT, NL_, 1);              \
+        else if (OB <= 2) MLP_FWD_LAUNCH(X1T, OutT, NL_, 2);         \
+        else if (OB <= 4) MLP_FWD_LAUNCH(X1T, OutT, NL_, 4);         \
+        else MLP_FWD_LAUNCH(X1T, OutT, NL_, 7);                      \
+    } while (0)
+#define MLP_FWD_NL(X1T, OutT)                                        \
+    do {                                                             \
+        if (a->n_layers == 2) MLP_FWD_OB(X1T, OutT, 2);              \
+        else MLP_FWD_OB(X1T, OutT, 3);                               \
+    } while (0)
+
+extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
+    PAG_CHECK_ARG(a, "pag_mlp_fwd: args is NULL");
+    PAG_CHECK_ARG(M >= 0, "pag_mlp_fwd: M < 0");
+    PAG_CHECK_ARG(a->n_layers == 2 || a->n_layers == 3, "pag_mlp_fwd: n_layers %d not in {2,3}", a->n_layers);
+    PAG_CHECK_ARG(a->k1 > 0 && a->k1 % 8 == 0, "pag_mlp_fwd: k1 %d must be a positive multiple of 8", a->k1);
+    PAG_CHECK_ARG(a->x2 == nullptr || (a->k2p > 0 && a->k2p % 8 == 0 && a->x2_index), "pag_mlp_fwd: x2 needs k2p %% 8 == 0 and x2_index");
+    const int k2p = a->x2 ? a->k2p : 0;
+    PAG_CHECK_ARG(a->in_dim > 0 && a->in_dim <= a->k1 + k2p && a->in_dim <= 64 && a->k1 + k2p <= 64,
+                  "pag_mlp_fwd: in_dim %d / k1+k2p %d out of range (<= 64)", a->in_dim, a->k1 + k2p);
+    PAG_CHECK_ARG(a->out_dim >= 1 && a->out_dim <= 224, "pag_mlp_fwd: out_dim %d not in [1,224]", a->out_dim);
+    PAG_CHECK_ARG(a->x1_dtype == PAG_F32 || a->x1_dtype == PAG_BF16, "pag_mlp_fwd: x1 dtype must be F32 or BF16");
+    PAG_CHECK_ARG(a->out_dtype == PAG_F32 || a->out_dtype == PAG_BF16, "pag_mlp_fwd: out dtype must be F32 or BF16");
+    PAG_CHECK_ARG(a->out_act >= PAG_ACT_NONE && a->out_act <= PAG_ACT_SOFTMAX, "pag_mlp_fwd: bad out_act %d", a->out_act);
+    PAG_CHECK_ARG(a->mode == PAG_MLP_MFMA_BF16 || a->mode == PAG_MLP_FP32, "pag_mlp_fwd: bad mode %d", a->mode);
+    if (M == 0) return PAG_OK;
+    for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && a->b[l], "pag_mlp_fwd: NULL weight/bias of layer %d", l);
+    PAG_CHECK_ARG(a->x1 && a->out, "pag_mlp_fwd: NULL x1/out");
+    FwdParams p;
+    p.x1 = a->x1;
+    p.x2 = a->x2;
+    p.x2_index = a->x2_index;
+    p.k1 = a->k1;
+    p.k2p = k2p;
+    p.in_dim = a->in_dim;
+    p.in_pad = ((a->k1 + k2p + 15) / 16) * 16;
+    p.out_dim = a->out_dim;
+    p.act = a->out_act;
+    for (int l = 0; l < 3; ++l) {
+        p.W[l] = l < a->n_layers ? a->W[l] : nullptr;
+        p.b[l] = l < a->n_layers ? a->b[l] : nullptr;
+    }
+    p.out = a->out;
+    p.hsave[0] = a->hidden_save[0];
+    p.hsave[1] = a->n_layers == 3 ? a->hidden_save[1] : nullptr;
+    p.M = M;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->mode == PAG_MLP_MFMA_BF16) {
+        const int OB = (a->out_dim + 31) / 32;
+        const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + OB * 32) * RS * sizeof(bf16_t) + (128 + OB * 32) * sizeof(float);
+        if (a->x1_dtype == PAG_F32 && a->out_dtype == PAG_F32) MLP_FWD_NL(float, float);
+        else if (a->x1_dtype == PAG_F32) MLP_FWD_NL(float, bf16_t);
+        else if (a->out_dtype == PAG_F32) MLP_FWD_NL(bf16_t, float);
+        else MLP_FWD_NL(bf16_t, bf16_t);
+    } else {
+        const size_t lds = (size_t)(64 * PT + 64 * 64) * sizeof(float);
+        dim3 grid((unsigned)((M + PT - 1) / PT)), block(PT);
+        if (a->x1_dtype == PAG_F32 && a->out_dtype == PAG_F32)
+            hipLaunchKernelGGL((mlp_fwd_f32<float, float>), grid, block, lds, st, p, a->n_layers);
+        else if (a->x1_dtype == PAG_F32)
+            hipLaunchKernelGGL((mlp_fwd_f32<float, bf16_t>), grid, block, lds, st, p, a->n_layers);
+        else if (a->out_dtype == PAG_F32)
+            hipLaunchKernelGGL((mlp_fwd_f32<bf16_t, float>), grid, block, lds, st, p, a->n_layers);
+        else
+            hipLaunchKernelGGL((mlp_fwd_f32<bf16_t, bf16_t>), grid, block, lds, st, p, a->n_layers);
+    }
+    PAG_CHECK_LAUNCH("pag_mlp_fwd");
+    return PAG_OK;
+}
+
+#define MLP_BWD_LAUNCH(OutT, DxT, NL_, OBM)                                                            \
+    hipLaunchKernelGGL((mlp_bwd_mfma<OutT, DxT, NL_, OBM>), dim3(mlp_grid(M)), dim3(256), lds, st, p)
+#define MLP_BWD_OB(OutT, DxT, NL_)                                   \
+    do {                                                             \
+        if (OB <= 1) MLP_BWD_LAUNCH(OutT, DxT, NL_, 1);              \
+        else if (OB <= 2) MLP_BWD_LAUNCH(OutT, DxT, NL_, 2);         \
+        else if (OB <= 4) MLP_BWD_LAUNCH(OutT, DxT, NL_, 4);         \
+        else MLP_BWD_LAUNCH(OutT, DxT, NL_, 7);                      \
+    } while (0)
+#define MLP_BWD_NL(OutT, DxT)                                        \
+    do {                                                             \
+        if (a->n_layers == 2) MLP_BWD_OB(OutT, DxT, 2);              \
+        else MLP_BWD_OB(OutT, DxT, 3);                               \
+    } while (0)
+
+extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
+    PAG_CHECK_ARG(a, "pag_mlp_bwd: args is NULL");
+    PAG_CHECK_ARG(M >= 0, "pag_mlp_bwd: M < 0");
+    PAG_CHECK_ARG(a->n_layers == 2 || a->n_layers == 3, "pag_mlp_bwd: n_layers %d not in {2,3}", a->n_layers);
+    PAG_CHECK_ARG(a->k1 > 0 && a->k1 % 8 == 0 && a->k1 <= 64, "pag_mlp_bwd: k1 %d must be a multiple of 8 in (0,64]", a->k1);
+    PAG_CHECK_ARG(a->in_dim > 0 && a->in_dim <= 64, "pag_mlp_bwd: in_dim %d out of range", a->in_dim);
+    PAG_CHECK_ARG(a->out_dim >= 1 && a->out_dim <= 224, "pag_mlp_bwd: out_dim %d not in [1,224]", a->out_dim);
+    PAG_CHECK_ARG(a->out_act >= PAG_ACT_NONE && a->out_act <= PAG_ACT_SOFTMAX, "pag_mlp_bwd: bad out_act %d", a->out_act);
+    PAG_CHECK_ARG(a->out_act == PAG_ACT_NONE || a->out, "pag_mlp_bwd: activated output needed for sigmoid/softmax");
+    PAG_CHECK_ARG(a->out_dtype == PAG_F32 || a->out_dtype == PAG_BF16, "pag_mlp_bwd: out dtype must be F32 or BF16");
+    PAG_CHECK_ARG(a->dx1 == nullptr || a->dx1_dtype == PAG_F32 || a->dx1_dtype == PAG_BF16, "pag_mlp_bwd: dx1 dtype must be F32 or BF16");
+    PAG_CHECK_ARG(a->mode == PAG_MLP_MFMA_BF16 || a->mode == PAG_MLP_FP32, "pag_mlp_bwd: bad mode %d", a->mode);
+    if (M == 0) return PAG_OK;
+    PAG_CHECK_ARG(a->grad_out, "pag_mlp_bwd: NULL grad_out");
+    for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && a->dz[l], "pag_mlp_bwd: NULL weight/dz of layer %d", l);
+    for (int l = 0; l + 1 < a->n_layers; ++l) PAG_CHECK_ARG(a->hidden_save[l], "pag_mlp_bwd: NULL hidden_save[%d]", l);
+    BwdParams p;
+    p.grad_out = a->grad_out;
+    p.out = a->out ? a->out : (const void *)a->grad_out;
+    p.k1 = a->k1;
+    p.in_dim = a->in_dim;
+    p.in_pad = 64;
+    p.out_dim = a->out_dim;
+    p.act = a->out_act;
+    for (int l = 0; l < 3; ++l) {
+        p.W[l] = l < a->n_layers ? a->W[l] : nullptr;
+        p.dz[l] = l < a->n_layers ? a->dz[l] : nullptr;
+    }
+    p.hsave[0] = a->hidden_save[0];
+    p.hsave[1] = a->n_layers == 3 ? a->hidden_save[1] : nullptr;
+    p.dx1 = a->dx1;
+    p.M = M;
+    hipStream_t st = (hipStream_t)stream;
+    const bool out_f32 = a->out_dtype == PAG_F32 || a->out_act == PAG_ACT_NONE;
+    const bool dx_f32 = a->dx1 == nullptr || a->dx1_dtype == PAG_F32;
+    if (a->mode == PAG_MLP_MFMA_BF16) {
+        const int OB = (a->out_dim + 31) / 32;
+        const size_t lds = (size_t)(64 * (OB * 32 + 8) + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t);
+        if (out_f32 && dx_f32) MLP_BWD_NL(float, float);
+        else if (out_f32) MLP_BWD_NL(float, bf16_t);
+        else if (dx_f32) MLP_BWD_NL(bf16_t, float);
+        else MLP_BWD_NL(bf16_t, bf16_t);
+    } else {
+        const size_t lds = (size_t)(224 * PT + 64 * 64) * sizeof(float);
+        dim3 grid((unsigned)((M + PT - 1) / PT)), block(PT);
+        static bool attr_set = false;   // > 64 KiB of dynamic LDS must be opted into once per kernel
+        if (!attr_set) {
+            hipFuncSetAttribute((const void *)mlp_bwd_f32<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void *)mlp_bwd_f32<float, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void *)mlp_bwd_f32<bf16_t, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void *)mlp_bwd_f32<bf16_t, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (out_f32 && dx_f32) hipLaunchKernelGGL((mlp_bwd_f32<float, float>), grid, block, lds, st, p, a->n_layers);
+        else if (out_f32) hipLaunchKernelGGL((mlp_bwd_f32<float, bf16_t>), grid, block, lds, st, p, a->n_layers);
+        else if (dx_f32) hipLaunchKernelGGL((mlp_bwd_f32<bf16_t, float>), grid, block, lds, st, p, a->n_layers);
+        else hipLaunchKernelGGL((mlp_bwd_f32<bf16_t, bf16_t>), grid, block, lds, st, p, a->n_layers);
+    }
+    PAG_CHECK_LAUNCH("pag_mlp_bwd");
+    return PAG_OK;
+}

@@ -1,0 +1,402 @@
+// Packed ray march ('ray' mode) and alpha compositing for gfx950.
+//
+// Compositing = a segmented exclusive scan of the optical thickness along each ray's packed samples
+// plus per-ray sums.  One 64-lane wavefront owns one ray (pack): it walks the ray in 64-sample
+// chunks, does the in-chunk prefix sum with DPP/ds_swizzle-lowered wave shuffles (6 steps) and
+// carries the running total in a scalar, so there are no atomics and the summation order is fixed
+// (bitwise reproducible, unlike the atomicAdd-based sum_reduce this replaces).  Wide per-sample
+// features (semantic / instance probabilities, up to 224 channels) are reduced with the CHANNEL on
+// the lane and the samples walked sequentially: every load is a fully coalesced row read.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------- ray march
+// wisp OctreeAS.raymarch 'ray' mode as restated in oracle/render.py raymarch_ray():
+//   depth = (t_s + jitter/S)^2 * (far - near) + near ;  sample = o + d * depth ;
+//   delta_s = depth_s - depth_{s-1} (delta_0 = depth_0 - near) ;
+//   keep iff inside [-1,1]^3 and the occupancy bit of its 2^level cell is set.
+struct MarchArgs {
+    const float *origins, *dirs, *tvals, *jitter;
+    const uint32_t *occ;
+    int64_t N;
+    int S, level;
+    float dmin, dmax;
+};
+
+__device__ __forceinline__ float march_depth(const MarchArgs &a, int64_t ray, int s) {
+    float d = __fadd_rn(a.tvals[s], __fdiv_rn(a.jitter[ray * a.S + s], (float)a.S));
+    d = __fmul_rn(d, d);
+    d = __fmul_rn(d, __fsub_rn(a.dmax, a.dmin));
+    return __fadd_rn(d, a.dmin);
+}
+
+__device__ __forceinline__ bool march_keep(const MarchArgs &a, const float (&p)[3], int32_t &cell) {
+    const int R = 1 << a.level;
+    const float half = (float)(R / 2) + (R == 1 ? 0.5f : 0.0f);
+    bool inside = true;
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        inside = inside && (p[k] >= -1.0f) && (p[k] <= 1.0f);
+        int v = (int)floorf(__fmul_rn(__fadd_rn(p[k], 1.0f), half));
+        c[k] = min(max(v, 0), R - 1);
+    }
+    cell = (c[0] * R + c[1]) * R + c[2];
+    if (!inside) return false;
+    if (a.occ == nullptr) return true;
+    return (a.occ[cell >> 5] >> (cell & 31)) & 1u;
+}
+
+// one wave per ray; PACK = false: count only
+template <bool PACK>
+__global__ __launch_bounds__(256) void march_kernel(MarchArgs a, int32_t *counts, const int64_t *offsets, int32_t *ridx,
+                                                    int32_t *pidx, float *samples, float *depths, float *deltas,
+                                                    uint8_t *boundary) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= a.N) return;
+    const float o[3] = {a.origins[ray * 3], a.origins[ray * 3 + 1], a.origins[ray * 3 + 2]};
+    const float dr[3] = {a.dirs[ray * 3], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2]};
+    int64_t base = PACK ? offsets[ray] : 0;
+    int total = 0;
+    for (int s0 = 0; s0 < a.S; s0 += 64) {
+        const int s = s0 + lane;
+        bool keep = false;
+        float depth = 0.0f, prev = a.dmin, p[3] = {0.0f, 0.0f, 0.0f};
+        int32_t cell = 0;
+        if (s < a.S) {
+            depth = march_depth(a, ray, s);
+            if (PACK && s > 0) prev = march_depth(a, ray, s - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = __fadd_rn(o[k], __fmul_rn(dr[k], depth));
+            keep = march_keep(a, p, cell);
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (PACK && keep) {
+            const int64_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            ridx[pos] = (int32_t)ray;
+            pidx[pos] = cell;
+            samples[pos * 3 + 0] = p[0];
+            samples[pos * 3 + 1] = p[1];
+            samples[pos * 3 + 2] = p[2];
+            depths[pos] = depth;
+            deltas[pos] = __fsub_rn(depth, prev);
+            boundary[pos] = (total == 0 && (mask & ((1ull << lane) - 1ull)) == 0) ? 1 : 0;
+        }
+        const int n = __popcll(mask);
+        base += n;
+        total += n;
+    }
+    if (!PACK && lane == 0) counts[ray] = total;
+}
+
+// ------------------------------------------------------------------------------------- compositing
+struct CompArgs {
+    const int64_t *pack_start;
+    const int32_t *ray_of_pack;
+    int64_t P;
+    const float *sigma, *deltas, *depths, *rgb;
+    int bg;
+};
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a, float *weights, float *out_alpha, float *out_rgb,
+                                                            float *out_depth, uint8_t *out_hit) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pk >= a.P) return;
+    const int64_t beg = a.pack_start[pk], end = a.pack_start[pk + 1];
+    const int64_t ray = a.ray_of_pack[pk];
+    float carry = 0.0f;                 // sum of tau before this chunk
+    float s_w = 0.0f, s_r = 0.0f, s_g = 0.0f, s_b = 0.0f, s_d = 0.0f;
+    for (int64_t i0 = beg; i0 < end; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const bool live = i < end;
+        const float tau = live ? a.sigma[i] * a.deltas[i] : 0.0f;
+        const float incl = wave_incl_scan(tau, lane);
+        const float excl = carry + (incl - tau);
+        const float w = live ? expf(-excl) * (1.0f - expf(-tau)) : 0.0f;
+        if (live) weights[i] = w;
+        s_w += w;
+        if (a.rgb && live) {
+            s_r += w * a.rgb[i * 3 + 0];
+            s_g += w * a.rgb[i * 3 + 1];
+            s_b += w * a.rgb[i * 3 + 2];
+        }
+        if (a.depths && live) s_d += w * a.depths[i];
+        carry += __shfl(incl, 63);
+    }
+    const float alpha = wave_sum(s_w);
+    s_r = wave_sum(s_r);
+    s_g = wave_sum(s_g);
+    s_b = wave_sum(s_b);
+    s_d = wave_sum(s_d);
+    if (lane == 0) {
+        out_alpha[ray] = alpha;
+        if (out_hit) out_hit[ray] = alpha > 0.0f ? 1 : 0;
+        if (a.rgb) {
+            const float bgv = a.bg == PAG_BG_WHITE ? (1.0f - alpha) : 0.0f;   // tracer :163-168
+            out_rgb[ray * 3 + 0] = bgv + alpha * s_r;
+            out_rgb[ray * 3 + 1] = bgv + alpha * s_g;
+            out_rgb[ray * 3 + 2] = bgv + alpha * s_b;
+        }
+        if (a.depths) out_depth[ray] = s_d;
+    }
+}
+
+// Backward.  Per ray: C = sum w c, D = sum w d, alpha = sum w;
+//   rgb_out = bg(1-alpha) + alpha*C ;  depth_out = D ; alpha_out = alpha
+// upstream -> gC = g_rgb*alpha ; gA = sum_ch g_rgb_ch*(C_ch - bg) + g_alpha ; gD = g_depth
+//   gw_i   = gA + gC.c_i + gD*d_i ;   d c_i = gC * w_i
+//   dtau_i = gw_i * (T_i - w_i) - sum_{k>i} gw_k w_k ,  T_i = exp(-sum_{j<i} tau_j)
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const float *weights, const float *out_alpha,
+                                                            const float *g_rgb, const float *g_depth, const float *g_alpha,
+                                                            float *d_sigma, float *d_rgb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pk >= a.P) return;
+    const int64_t beg = a.pack_start[pk], end = a.pack_start[pk + 1];
+    const int64_t ray = a.ray_of_pack[pk];
+    const float alpha = out_alpha[ray];
+    const bool has_rgb = a.rgb && g_rgb;
+    // pass 1: C (needed for gA)
+    float c_r = 0.0f, c_g = 0.0f, c_b = 0.0f;
+    if (has_rgb) {
+        for (int64_t i = beg + lane; i < end; i += 64) {
+            const float w = weights[i];
+            c_r += w * a.rgb[i * 3 + 0];
+            c_g += w * a.rgb[i * 3 + 1];
+            c_b += w * a.rgb[i * 3 + 2];
+        }
+        c_r = wave_sum(c_r);
+        c_g = wave_sum(c_g);
+        c_b = wave_sum(c_b);
+    }
+    float gC[3] = {0.0f, 0.0f, 0.0f};
+    float gA = g_alpha ? g_alpha[ray] : 0.0f;
+    if (has_rgb) {
+        const float bgv = a.bg == PAG_BG_WHITE ? 1.0f : 0.0f;
+        const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
+        gC[0] = gr * alpha;
+        gC[1] = gg * alpha;
+        gC[2] = gb * alpha;
+        gA += gr * (c_r - bgv) + gg * (c_g - bgv) + gb * (c_b - bgv);
+    }
+    const float gD = (a.depths && g_depth) ? g_depth[ray] : 0.0f;
+    // pass 2: total of gw*w
+    float tot = 0.0f;
+    for (int64_t i = beg + lane; i < end; i += 64) {
+        const float w = weights[i];
+        float gw = gA;
+        if (has_rgb) gw += gC[0] * a.rgb[i * 3 + 0] + gC[1] * a.rgb[i * 3 + 1] + gC[2] * a.rgb[i * 3 + 2];
+        if (gD != 0.0f) gw += gD * a.depths[i];
+        tot += gw * w;
+    }
+    tot = wave_sum(tot);
+    // pass 3: per-sample gradients
+    float carry_tau = 0.0f, carry_gww = 0.0f;
+    for (int64_t i0 = beg; i0 < end; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const bool live = i < end;
+        const float sg = live ? a.sigma[i] : 0.0f;
+        const float dl = live ? a.deltas[i] : 0.0f;
+        const float tau = sg * dl;
+        const float w = live ? weights[i] : 0.0f;
+        float gw = gA;
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        if (has_rgb && live) {
+            c0 = a.rgb[i * 3 + 0];
+            c1 = a.rgb[i * 3 + 1];
+            c2 = a.rgb[i * 3 + 2];
+            gw += gC[0] * c0 + gC[1] * c1 + gC[2] * c2;
+        }
+        if (gD != 0.0f && live) gw += gD * a.depths[i];
+        const float gww = live ? gw * w : 0.0f;
+        const float incl_tau = wave_incl_scan(tau, lane);
+        const float incl_gww = wave_incl_scan(gww, lane);
+        const float T = expf(-(carry_tau + (incl_tau - tau)));
+        const float suffix = tot - (carry_gww + incl_gww);          // sum_{k>i} gw_k w_k
+        if (live) {
+            const float dtau = gw * (T - w) - suffix;
+            d_sigma[i] = dtau * dl;
+            if (d_rgb) {
+                d_rgb[i * 3 + 0] = gC[0] * w;
+                d_rgb[i * 3 + 1] = gC[1] * w;
+                d_rgb[i * 3 + 2] = gC[2] * w;
+            }
+        }
+        carry_tau += __shfl(incl_tau, 63);
+        carry_gww += __shfl(incl_gww, 63);
+    }
+}
+
+// out[ray, c] = alpha[ray] * sum_i w_i f[i, c]; one workgroup (4 waves) per ray, channel on the lane,
+// the ray's samples split in 4 contiguous quarters, partials combined through LDS in wave order.
+template <typename FT>
+__global__ __launch_bounds__(256) void composite_feats_fwd_kernel(const int64_t *pack_start, const int32_t *ray_of_pack,
+                                                                  const float *weights, const float *alpha, const FT *feats, int C,
+                                                                  float *out) {
+    __shared__ float part[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pk = blockIdx.x;
+    const int64_t beg = pack_start[pk], end = pack_start[pk + 1];
+    const int64_t n = end - beg, q = (n + 3) / 4;
+    const int64_t lo = beg + wave * q, hi = min(end, lo + q);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t i = lo; i < hi; ++i) {
+        const float w = weights[i];
+        const FT *row = feats + i * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) acc[k] += w * pag_ld(row + c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[wave][lane + 64 * k] = acc[k];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < C) {
+        const int64_t ray = ray_of_pack[pk];
+        const float s = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        out[ray * C + c] = alpha[ray] * s;
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_feats_bwd_kernel(const int64_t *pack_start, const int32_t *ray_of_pack,
+                                                                  const float *weights, const float *alpha, const float *g_out,
+                                                                  int C, float *d_feats) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pk = blockIdx.x;
+    const int64_t beg = pack_start[pk], end = pack_start[pk + 1];
+    const int64_t ray = ray_of_pack[pk];
+    const float al = alpha[ray];
+    float g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        g[k] = c < C ? al * g_out[ray * C + c] : 0.0f;
+    }
+    for (int64_t i = beg + wave; i < end; i += 4) {
+        const float w = weights[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) d_feats[i * C + c] = w * g[k];
+        }
+    }
+}
+
+}  // namespace
+
+static int march_check(const char *name, const float *origins, const float *dirs, int64_t N, int S, const float *tvals,
+                       const float *jitter, int blas_level) {
+    PAG_CHECK_ARG(N >= 0, "%s: N < 0", name);
+    PAG_CHECK_ARG(S >= 1 && S <= 65536, "%s: S %d out of range", name, S);
+    PAG_CHECK_ARG(blas_level >= 0 && blas_level <= 10, "%s: blas_level %d not in [0,10]", name, blas_level);
+    PAG_CHECK_ARG(N == 0 || (origins && dirs && tvals && jitter), "%s: NULL input", name);
+    return PAG_OK;
+}
+
+extern "C" int pag_raymarch_count(const float *origins, const float *dirs, int64_t N, int S, const float *tvals,
+                                  const float *jitter, float dist_min, float dist_max, const uint32_t *occupancy_bits,
+                                  int blas_level, int32_t *counts, void *stream) {
+    int rc = march_check("pag_raymarch_count", origins, dirs, N, S, tvals, jitter, blas_level);
+    if (rc) return rc;
+    if (N == 0) return PAG_OK;
+    PAG_CHECK_ARG(counts, "pag_raymarch_count: counts is NULL");
+    MarchArgs a{origins, dirs, tvals, jitter, occupancy_bits, N, S, blas_level, dist_min, dist_max};
+    hipLaunchKernelGGL((march_kernel<false>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, counts,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    PAG_CHECK_LAUNCH("pag_raymarch_count");
+    return PAG_OK;
+}
+
+extern "C" int pag_raymarch_pack(const float *origins, const float *dirs, int64_t N, int S, const float *tvals,
+                                 const float *jitter, float dist_min, float dist_max, const uint32_t *occupancy_bits,
+                                 int blas_level, const int64_t *offsets, int32_t *ridx, int32_t *pidx, float *samples,
+                                 float *depths, float *deltas, uint8_t *boundary, void *stream) {
+    int rc = march_check("pag_raymarch_pack", origins, dirs, N, S, tvals, jitter, blas_level);
+    if (rc) return rc;
+    if (N == 0) return PAG_OK;
+    PAG_CHECK_ARG(offsets && ridx && pidx && samples && depths && deltas && boundary, "pag_raymarch_pack: NULL output");
+    MarchArgs a{origins, dirs, tvals, jitter, occupancy_bits, N, S, blas_level, dist_min, dist_max};
+    hipLaunchKernelGGL((march_kernel<true>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, nullptr,
+                       offsets, ridx, pidx, samples, depths, deltas, boundary);
+    PAG_CHECK_LAUNCH("pag_raymarch_pack");
+    return PAG_OK;
+}
+
+extern "C" int pag_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *sigma,
+                                 const float *deltas, const float *depths, const float *rgb, int bg_color, float *weights,
+                                 float *out_alpha, float *out_rgb, float *out_depth, uint8_t *out_hit, void *stream) {
+    PAG_CHECK_ARG(P >= 0, "pag_composite_fwd: P < 0");
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(pack_start && ray_of_pack && sigma && deltas && weights && out_alpha, "pag_composite_fwd: NULL input");
+    PAG_CHECK_ARG(!rgb || out_rgb, "pag_composite_fwd: rgb given but out_rgb is NULL");
+    PAG_CHECK_ARG(!depths || out_depth, "pag_composite_fwd: depths given but out_depth is NULL");
+    PAG_CHECK_ARG(bg_color == PAG_BG_BLACK || bg_color == PAG_BG_WHITE, "pag_composite_fwd: bad bg_color %d", bg_color);
+    CompArgs a{pack_start, ray_of_pack, P, sigma, deltas, depths, rgb, bg_color};
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, weights,
+                       out_alpha, out_rgb, out_depth, out_hit);
+    PAG_CHECK_LAUNCH("pag_composite_fwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_composite_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *sigma,
+                                 const float *deltas, const float *depths, const float *rgb, int bg_color, const float *weights,
+                                 const float *out_alpha, const float *g_rgb, const float *g_depth, const float *g_alpha,
+                                 float *d_sigma, float *d_rgb, void *stream) {
+    PAG_CHECK_ARG(P >= 0, "pag_composite_bwd: P < 0");
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(pack_start && ray_of_pack && sigma && deltas && weights && out_alpha && d_sigma, "pag_composite_bwd: NULL input");
+    PAG_CHECK_ARG(bg_color == PAG_BG_BLACK || bg_color == PAG_BG_WHITE, "pag_composite_bwd: bad bg_color %d", bg_color);
+    CompArgs a{pack_start, ray_of_pack, P, sigma, deltas, depths, rgb, bg_color};
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, weights,
+                       out_alpha, g_rgb, g_depth, g_alpha, d_sigma, d_rgb);
+    PAG_CHECK_LAUNCH("pag_composite_bwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_composite_feats_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *weights,
+                                       const float *alpha, const void *feats, int feat_dtype, int C, float *out, void *stream) {
+    PAG_CHECK_ARG(P >= 0, "pag_composite_feats_fwd: P < 0");
+    PAG_CHECK_ARG(C >= 1 && C <= 256, "pag_composite_feats_fwd: C %d not in [1,256]", C);
+    PAG_CHECK_ARG(feat_dtype == PAG_F32 || feat_dtype == PAG_BF16, "pag_composite_feats_fwd: feats dtype must be F32 or BF16");
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(pack_start && ray_of_pack && weights && alpha && feats && out, "pag_composite_feats_fwd: NULL input");
+    if (feat_dtype == PAG_F32)
+        hipLaunchKernelGGL((composite_feats_fwd_kernel<float>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start,
+                           ray_of_pack, weights, alpha, (const float *)feats, C, out);
+    else
+        hipLaunchKernelGGL((composite_feats_fwd_kernel<bf16_t>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start,
+                           ray_of_pack, weights, alpha, (const bf16_t *)feats, C, out);
+    PAG_CHECK_LAUNCH("pag_composite_feats_fwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *weights,
+                                       const float *alpha, const float *g_out, int C, float *d_feats, void *stream) {
+    PAG_CHECK_ARG(P >= 0, "pag_composite_feats_bwd: P < 0");
+    PAG_CHECK_ARG(C >= 1 && C <= 256, "pag_composite_feats_bwd: C %d not in [1,256]", C);
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(pack_start && ray_of_pack && weights && alpha && g_out && d_feats, "pag_composite_feats_bwd: NULL input");
+    hipLaunchKernelGGL(composite_feats_bwd_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start, ray_of_pack,
+                       weights, alpha, g_out, C, d_feats);
+    PAG_CHECK_LAUNCH("pag_composite_feats_bwd");
+    return PAG_OK;
+}

@@ -1,0 +1,249 @@
+"""PanopticDeltaNeF on the gfx950 kernels - same constructor keywords, channels and output
+shapes as pc_nerf/panoptic_delta_nef.py::PanopticDeltaNeF (+ its base pc_nerf/panoptic_nef.py),
+so it can be registered under pc_nerf/trainer.py in place of the reference class.
+
+Op order of rgb_semantics() follows pc_nerf/panoptic_delta_nef.py:155-259:
+  grid.interpolate -> * lod_weights -> decoder_density -> relu(ch 0) -> decoder_color on
+  cat(density_feats[16], PE(-ray_d)[27]) -> sigmoid ; delta_grid.interpolate(coords.detach())
+  -> * lod_weights ; panoptic feats = feats.detach() + delta ; decoder_semantics / decoder_inst
+  -> [sigmoid] -> [normalize] -> [/T] -> [softmax].
+What is different is only WHERE things run: lod_weights is folded into the encode kernel, each
+decoder (+ its sigmoid / softmax) is one fused launch, and the view embedding is computed once per
+ray and gathered through ridx instead of being repeated per sample.
+"""
+import copy
+import inspect
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .grids import HashGridHIP, PermutoGridHIP
+
+_GRIDS = {"HashGridTorch": HashGridHIP, "HashGridTinyCudaNN": HashGridHIP, "HashGrid": HashGridHIP,
+          "HashGridHIP": HashGridHIP, "PermutoGrid": PermutoGridHIP, "PermutoGridHIP": PermutoGridHIP}
+
+
+class BasicDecoder(nn.Module):
+    """wisp BasicDecoder's parameter layout (layers[i], lout) with a fused forward."""
+
+    def __init__(self, input_dim, output_dim, num_layers=1, hidden_dim=64, bias=True):
+        super().__init__()
+        if hidden_dim != 64 or num_layers not in (1, 2):
+            raise NotImplementedError("fused decoder supports hidden_dim=64 and 1-2 hidden layers (best.yaml); got %d x %d"
+                                      % (num_layers, hidden_dim))
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.layers = nn.ModuleList([nn.Linear(input_dim if i == 0 else hidden_dim, hidden_dim, bias=bias)
+                                     for i in range(num_layers)])
+        self.lout = nn.Linear(hidden_dim, output_dim, bias=bias)
+
+    def weights(self):
+        lins = list(self.layers) + [self.lout]
+        return [l.weight for l in lins], [l.bias for l in lins]
+
+    def forward(self, x1, x2=None, x2_index=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16, out_dtype=torch.float32):
+        W, b = self.weights()
+        return ops.fused_mlp(x1, W, b, x2=x2, x2_index=x2_index, in_dim=self.input_dim, out_act=out_act, mode=mode,
+                             out_dtype=out_dtype)
+
+
+def positional_embed(x, num_freq):
+    """wisp PositionalEmbedder: cat(x, sin(x*2^k), cos(x*2^k)), frequency-major."""
+    bands = 2.0 ** torch.linspace(0.0, num_freq - 1, num_freq, device=x.device)
+    w = (x[:, None, :] * bands[None, :, None]).reshape(x.shape[0], -1)
+    return torch.cat([x, torch.sin(w), torch.cos(w)], dim=-1)
+
+
+class PanopticDeltaNeF(nn.Module):
+    accepts_ray_index = True     # the tracer may pass (ridx, ray_dirs) instead of a per-sample ray_d
+
+    def __init__(self, grid_type="PermutoGrid", interpolation_type="linear", multiscale_type="cat", feature_dim=2,
+                 num_lods=24, base_lod=2, hidden_dim=64, num_layers=1, activation_type="relu", layer_type="none",
+                 embedder_type="positional", view_multires=4, pos_multires=4, position_input=False,
+                 num_classes=-1, num_instances=-1,
+                 sem_activation_type=None, sem_num_layers=None, sem_hidden_dim=None, sem_normalize=False,
+                 sem_softmax=False, sem_sigmoid=False, sem_detach=True,
+                 inst_num_layers=None, inst_hidden_dim=None, inst_normalize=False, inst_softmax=False,
+                 inst_sigmoid=False, inst_detach=True, panoptic_features_type=None,
+                 delta_num_layers=1, delta_hidden_dim=64, inst_soft_temperature=0.0,
+                 raymarch_type="ray", precision="bf16", **kwargs):
+        super().__init__()
+        if activation_type != "relu" or (sem_activation_type or "relu") != "relu":
+            raise NotImplementedError("fused decoders implement ReLU hidden activations (best.yaml)")
+        if position_input:
+            raise NotImplementedError                                   # panoptic_delta_nef.py:177
+        if panoptic_features_type not in (None, "delta", "separate", "appearance"):
+            raise NotImplementedError("panoptic_features_type '%s'" % panoptic_features_type)
+        self.grid_type, self.multiscale_type = grid_type, multiscale_type
+        self.feature_dim, self.num_lods, self.base_lod = feature_dim, num_lods, base_lod
+        self.hidden_dim, self.num_layers = hidden_dim, num_layers
+        self.view_multires, self.embedder_type = view_multires, embedder_type
+        self.num_classes, self.num_instances = num_classes, num_instances
+        self.sem_normalize, self.sem_softmax, self.sem_sigmoid = sem_normalize, sem_softmax, sem_sigmoid
+        self.inst_normalize, self.inst_softmax, self.inst_sigmoid = inst_normalize, inst_softmax, inst_sigmoid
+        self.panoptic_features_type = panoptic_features_type
+        self.inst_soft_temperature = inst_soft_temperature
+        self.raymarch_type = raymarch_type
+        self.kwargs = kwargs
+        self.set_precision(precision)
+        # ---- grids (panoptic_nef.py:184-196, panoptic_delta_nef.py:39-44)
+        gkw = dict(kwargs)
+        gkw.pop("num_lods", None)
+        self.grid = _GRIDS[grid_type](feature_dim, base_lod=base_lod, num_lods=num_lods,
+                                      interpolation_type=interpolation_type, multiscale_type="cat", **gkw)
+        self.lod_weights = torch.ones(num_lods * feature_dim)
+        if panoptic_features_type in ("delta", "separate", None):
+            self.delta_grid = copy.deepcopy(self.grid)
+            if isinstance(self.delta_grid, PermutoGridHIP) and panoptic_features_type in ("delta", "separate") \
+                    and "delta_capacity_log_2" in kwargs:
+                self.delta_grid.set_capacity(kwargs["delta_capacity_log_2"])
+        # ---- embedder (panoptic_nef.py:72-77)
+        self.view_embed_dim = 3 + 6 * view_multires if embedder_type == "positional" else 3
+        # ---- decoders (panoptic_nef.py:108-164)
+        eff = feature_dim * num_lods if multiscale_type == "cat" else feature_dim
+        self.decoder_density = BasicDecoder(eff, 16, num_layers, hidden_dim)
+        with torch.no_grad():
+            self.decoder_density.lout.bias[0] = 1.0                      # panoptic_nef.py:123
+        self.decoder_color = BasicDecoder(16 + self.view_embed_dim, 3, num_layers + 1, hidden_dim)
+        self.decoder_semantics = BasicDecoder(eff, num_classes, sem_num_layers or num_layers, sem_hidden_dim or hidden_dim)
+        assert num_instances > 2
+        self.decoder_inst = BasicDecoder(eff, num_instances, inst_num_layers or num_layers, inst_hidden_dim or hidden_dim)
+        self._fns = [(self.rgb_semantics, {"density", "rgb", "semantics", "inst_embedding"})]
+
+    # -------------------------------------------------------------------------------- configuration
+    def set_precision(self, precision):
+        """'bf16': bf16 MFMA decoders on bf16 features (production); 'fp32': fp32 FMA-chain parity path."""
+        assert precision in ("bf16", "fp32")
+        self.precision = precision
+        self.mlp_mode = L.MLP_MFMA_BF16 if precision == "bf16" else L.MLP_FP32
+        self.feat_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+
+    @property
+    def device(self):
+        return self.decoder_density.lout.weight.device
+
+    def get_nef_type(self):
+        return "delta_panoptic_nef"
+
+    def get_supported_channels(self):
+        s = set()
+        for _, c in self._fns:
+            s |= c
+        return s
+
+    # ----------------------------------------------------------------------------------- dispatcher
+    def forward(self, channels=None, **kwargs):
+        """wisp BaseNeuralField.forward semantics: str -> tensor, list -> list, set -> dict."""
+        kwargs["compute_channels"] = channels                           # panoptic_nef.py:239-242
+        req = {channels} if isinstance(channels, str) else set(channels)
+        unsupported = req - self.get_supported_channels()
+        if unsupported:
+            raise Exception("Channels %s are not supported in %s" % (unsupported, type(self).__name__))
+        out = {}
+        for fn, chans in self._fns:
+            if not (chans & req):
+                continue
+            params = inspect.signature(fn).parameters
+            res = fn(**{k: v for k, v in kwargs.items() if k in params})
+            for c in chans & req:
+                out[c] = res[c]
+        if isinstance(channels, str):
+            return out[channels]
+        if isinstance(channels, list):
+            return [out[c] for c in channels]
+        return out
+
+    # ------------------------------------------------------------------------------------ hot path
+    def _view_embedding(self, ray_d, ridx, ray_dirs):
+        """[R, 32] fp32 view embedding (27 used, zero padded) + int32 row index per sample."""
+        if ray_dirs is not None and ridx is not None:
+            src, index = ray_dirs, ridx
+        else:
+            src, index = ray_d, torch.arange(ray_d.shape[0], device=ray_d.device, dtype=torch.int32)
+        pe = positional_embed(-src.float(), self.view_multires) if self.embedder_type == "positional" else -src.float()
+        return F.pad(pe, (0, (-pe.shape[1]) % 8)).contiguous(), index
+
+    def _interp(self, grid, coords):
+        grid.out_dtype = self.feat_dtype
+        lw = None if bool((self.lod_weights == 1).all()) else self.lod_weights
+        return grid.interpolate_scaled(coords, lw)
+
+    def rgb_semantics(self, coords, ray_d=None, compute_channels=None, pidx=None, lod_idx=None, ridx=None, ray_dirs=None):
+        out = {}
+        if not compute_channels:
+            return out
+        if isinstance(compute_channels, str):
+            compute_channels = {compute_channels}
+        batch, num_samples, _ = coords.shape
+        if self.multiscale_type != "cat":
+            raise NotImplementedError("multiscale_type 'sum' with fused decoders")
+        mode = self.mlp_mode
+        feats = self._interp(self.grid, coords)                                       # :170-171
+        density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype)     # :184
+        density = torch.relu(density_feats[:, 0:1].float()).reshape(batch, num_samples, 1)   # :188
+        if "density" in compute_channels:
+            out["density"] = density
+        if "rgb" in compute_channels:                                                 # :196-204
+            if num_samples != 1 and ridx is None:
+                ray_d = ray_d[:, None].repeat(1, num_samples, 1).reshape(-1, 3)
+            pe, index = self._view_embedding(ray_d, ridx, ray_dirs)
+            rgb = self.decoder_color(density_feats, x2=pe, x2_index=index, out_act=L.ACT_SIGMOID, mode=mode)
+            out["rgb"] = rgb.reshape(batch, num_samples, 3)
+        if "semantics" in compute_channels or "inst_embedding" in compute_channels:    # :210-236
+            t = self.panoptic_features_type
+            if t in ("delta", "separate", None):
+                delta = self._interp(self.delta_grid, coords.detach())
+            if t in ("delta", None):
+                pan = feats.detach() + delta
+            elif t == "separate":
+                pan = delta
+            else:
+                pan = feats.detach()
+            if "semantics" in compute_channels:                                        # :238-244
+                plain = not (self.sem_sigmoid or self.sem_normalize)
+                act = L.ACT_SOFTMAX if (self.sem_softmax and plain) else L.ACT_NONE
+                s = self.decoder_semantics(pan, out_act=act, mode=mode)
+                if not plain:
+                    s = torch.sigmoid(s) if self.sem_sigmoid else s
+                    s = F.normalize(s, dim=-1) if self.sem_normalize else s
+                    s = F.softmax(s, dim=-1) if self.sem_softmax else s
+                out["semantics"] = s
+            if "inst_embedding" in compute_channels:                                   # :246-257
+                plain = not (self.inst_sigmoid or self.inst_normalize or self.inst_soft_temperature > 0.0)
+                act = L.ACT_SOFTMAX if (self.inst_softmax and plain) else L.ACT_NONE
+                e = self.decoder_inst(pan, out_act=act, mode=mode)
+                if not plain:
+                    e = torch.sigmoid(e) if self.inst_sigmoid else e
+                    e = F.normalize(e, dim=-1) if self.inst_normalize else e
+                    e = e / self.inst_soft_temperature if self.inst_soft_temperature > 0.0 else e
+                    e = F.softmax(e, dim=-1) if self.inst_softmax else e
+                out["inst_embedding"] = e
+        return out
+
+    # ---------------------------------------------------------------------------------------- prune
+    @torch.no_grad()
+    def prune(self, jitter=None):
+        """Occupancy update (panoptic_delta_nef.py:63-104): EMA-max of the density at one jittered
+        sample per dense cell, threshold (0.01*512)/sqrt(3), both grids get the new mask."""
+        if self.grid is None:
+            return
+        density_decay = 0.6
+        min_density = (0.01 * 512) / np.sqrt(3)
+        dev = self.device
+        g = self.grid
+        g.occupancy = g.occupancy.to(dev) * density_decay
+        points = g.dense_points.to(dev)
+        res = 2.0 ** g.blas_level
+        if jitter is None:
+            jitter = torch.rand(points.shape[0], 3, device=dev)
+        samples = (points.float() + jitter) / res * 2.0 - 1.0
+        views = torch.zeros(points.shape[0], 3, device=dev)
+        views[:, 2] = 1.0
+        density = self.forward(coords=samples[:, None], ray_d=views, channels="density")
+        g.occupancy = torch.stack([density[:, 0, 0], g.occupancy], -1).max(dim=-1)[0]
+        mask = g.occupancy > min_density
+        for grid in [self.grid] + ([self.delta_grid] if hasattr(self, "delta_grid") else []):
+            grid.blas_init(mask)

@@ -1,0 +1,356 @@
+"""torch.autograd wrappers around the C-ABI kernels (include/pagnerf_hip.h).
+
+Everything here runs on GPU tensors only; there is no CPU fallback (the oracle under oracle/
+is test infrastructure and is never imported from this package).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _check_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pagnerf_amd ops need GPU tensors (no CPU fallback); got a tensor on %s" % t.device)
+
+
+# ------------------------------------------------------------------------------------------- encode
+class _EncodeSpec:
+    """Static description of a grid encoder (host-side per-level parameters)."""
+
+    def __init__(self, kind, n_levels, n_feat, **kw):
+        self.kind = kind
+        self.L = int(n_levels)
+        self.F = int(n_feat)
+        self.kw = kw
+        if kind == "hash":
+            self.log2_T = int(kw["log2_T"])
+            self.res = L.host_floats(kw["resolutions"])
+        elif kind == "permuto":
+            self.capacity = int(kw["capacity"])
+            self.sf = L.host_floats(kw["scale_factor"])
+            self.shift = L.host_floats(kw["shift"])
+        else:
+            raise ValueError(kind)
+
+    def rows(self):
+        return (1 << self.log2_T) if self.kind == "hash" else self.capacity
+
+
+def hash_spec(resolutions, log2_T, n_feat):
+    return _EncodeSpec("hash", len(resolutions), n_feat, log2_T=log2_T, resolutions=resolutions)
+
+
+def permuto_spec(scale_factor, shift, capacity, n_feat):
+    """scale_factor, shift: [L,3] (torch CPU / numpy)."""
+    return _EncodeSpec("permuto", len(scale_factor), n_feat, capacity=capacity, scale_factor=scale_factor, shift=shift)
+
+
+def _encode_fwd(spec, xyz, tables, feat_scale, out):
+    lib = L.load()
+    M = xyz.shape[0]
+    fs = L.host_floats(feat_scale)
+    sm, sc = out.stride(0), out.stride(1)
+    if spec.kind == "hash":
+        rc = lib.pag_hash_encode_fwd(L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
+                                     spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
+        L.check(rc, "pag_hash_encode_fwd")
+    else:
+        rc = lib.pag_permuto_encode_fwd(L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity,
+                                        spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
+        L.check(rc, "pag_permuto_encode_fwd")
+
+
+def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
+    lib = L.load()
+    M = xyz.shape[0]
+    fs = L.host_floats(feat_scale)
+    sm, sc = grad_out.stride(0), grad_out.stride(1)
+    if spec.kind == "hash":
+        rc = lib.pag_hash_encode_bwd(L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
+                                     spec.log2_T, spec.res, fs, L.ptr(grad_tables), L.stream())
+        L.check(rc, "pag_hash_encode_bwd")
+    else:
+        rc = lib.pag_permuto_encode_bwd(L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
+                                        spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), L.stream())
+        L.check(rc, "pag_permuto_encode_bwd")
+
+
+class _Encode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, tables, spec, feat_scale, out_dtype, feature_major):
+        _check_gpu(xyz, tables)
+        xyz = xyz.detach().contiguous().float()
+        M, C = xyz.shape[0], spec.L * spec.F
+        if tables.shape != (spec.L, spec.rows(), spec.F):
+            raise RuntimeError("tables shape %s does not match the encoder spec %s" % (tuple(tables.shape), (spec.L, spec.rows(), spec.F)))
+        if feature_major:
+            out = torch.empty(C, M, device=xyz.device, dtype=out_dtype).t()
+        else:
+            out = torch.empty(M, C, device=xyz.device, dtype=out_dtype)
+        if M:
+            _encode_fwd(spec, xyz, tables.detach().contiguous(), feat_scale, out)
+        ctx.spec, ctx.feat_scale = spec, feat_scale
+        ctx.save_for_backward(xyz)
+        ctx.tshape, ctx.tdtype = tables.shape, tables.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (xyz,) = ctx.saved_tensors
+        gt = torch.zeros(ctx.tshape, device=xyz.device, dtype=torch.float32)
+        if xyz.shape[0]:
+            if g.dtype not in (torch.float32, torch.bfloat16):
+                g = g.float()
+            _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt)
+        return None, gt.to(ctx.tdtype), None, None, None, None
+
+
+def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False):
+    """Grid features [M, L*F] (column = level*F + f).  d/d tables is supported, d/d xyz is not."""
+    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, feature_major)
+
+
+# ---------------------------------------------------------------------------------------------- MLP
+def _mm_f32(a, b):
+    """a^T-free helper: a [K,M] @ b [M,N] with fp32 result (bf16 inputs accumulate in fp32)."""
+    if a.dtype == torch.float32:
+        return a @ b
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return (a @ b).float()
+
+
+class _FusedMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, save_dtype_unused, *wb):
+        _check_gpu(x1, x2, x2_index, *wb)
+        lib = L.load()
+        n_layers = len(wb) // 2
+        Ws, bs = wb[:n_layers], wb[n_layers:]
+        M, k1 = x1.shape
+        x1 = x1.detach()
+        if not x1.is_contiguous():
+            x1 = x1.contiguous()
+        if x1.dtype not in (torch.float32, torch.bfloat16):
+            x1 = x1.float()
+        out_dim = Ws[-1].shape[0]
+        out = torch.empty(M, out_dim, device=x1.device, dtype=out_dtype)
+        need_grad = any(t.requires_grad for t in wb) or ctx.needs_input_grad[0]
+        hdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
+        hidden = [torch.empty(M, 64, device=x1.device, dtype=hdt) for _ in range(n_layers - 1)] if need_grad else []
+        a = L.MlpFwdArgs()
+        a.x1, a.x1_dtype, a.k1 = L.ptr(x1), L.dtype_code(x1), k1
+        if x2 is not None:
+            x2 = x2.detach().contiguous().float()
+            x2_index = x2_index.detach().contiguous()
+            if x2_index.dtype != torch.int32:
+                x2_index = x2_index.int()
+            a.x2, a.k2p, a.x2_index = L.ptr(x2), x2.shape[1], L.ptr(x2_index)
+        a.in_dim, a.n_layers, a.out_dim = in_dim, n_layers, out_dim
+        Wc = [w.detach().contiguous().float() for w in Ws]
+        bc = [b.detach().contiguous().float() for b in bs]
+        for i in range(n_layers):
+            a.W[i], a.b[i] = L.ptr(Wc[i]), L.ptr(bc[i])
+        a.out_act, a.out, a.out_dtype, a.mode = out_act, L.ptr(out), L.dtype_code(out), mode
+        for i, h in enumerate(hidden):
+            a.hidden_save[i] = L.ptr(h)
+        if M:
+            L.check(lib.pag_mlp_fwd(ctypes.byref(a), M, L.stream()), "pag_mlp_fwd")
+        ctx.cfg = (in_dim, out_act, mode, n_layers, k1)
+        ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc)
+        ctx.n_hidden = len(hidden)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        in_dim, out_act, mode, n_layers, k1 = ctx.cfg
+        saved = ctx.saved_tensors
+        x1, x2, x2_index, out = saved[:4]
+        hidden = list(saved[4:4 + ctx.n_hidden])
+        Wc = list(saved[4 + ctx.n_hidden:])
+        M = x1.shape[0]
+        out_dim = Wc[-1].shape[0]
+        dev = x1.device
+        zdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
+        dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
+        need_dx = ctx.needs_input_grad[0]
+        dx1 = torch.empty(M, k1, device=dev, dtype=x1.dtype) if need_dx else None
+        g = g.contiguous().float()
+        a = L.MlpBwdArgs()
+        a.grad_out, a.out, a.out_dtype, a.out_act = L.ptr(g), L.ptr(out), L.dtype_code(out), out_act
+        a.k1, a.in_dim, a.n_layers, a.out_dim = k1, in_dim, n_layers, out_dim
+        for i in range(n_layers):
+            a.W[i], a.dz[i] = L.ptr(Wc[i]), L.ptr(dz[i])
+        for i, h in enumerate(hidden):
+            a.hidden_save[i] = L.ptr(h)
+        a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
+        if M:
+            L.check(lib.pag_mlp_bwd(ctypes.byref(a), M, L.stream()), "pag_mlp_bwd")
+        # weight gradients: dz_l^T @ input_l - plain GEMMs, left to the BLAS library
+        gW, gb = [], []
+        for l in range(n_layers):
+            z = dz[l]
+            if l == 0:
+                n1 = min(k1, in_dim)
+                xa = x1[:, :n1]
+                if xa.dtype != z.dtype:
+                    xa = xa.to(z.dtype)
+                w = _mm_f32(z.t(), xa)
+                if in_dim > k1:
+                    seg = torch.zeros(x2.shape[0], 64, device=dev, dtype=torch.float32)
+                    seg.index_add_(0, x2_index.long(), z.float())
+                    w = torch.cat([w, seg.t() @ x2[:, :in_dim - k1]], dim=1)
+            else:
+                w = _mm_f32(z.t(), hidden[l - 1])
+            gW.append(w)
+            gb.append(z.sum(0, dtype=torch.float32))
+        return (dx1, None, None, None, None, None, None, None, *gW, *gb)
+
+
+def fused_mlp(x1, weights, biases, x2=None, x2_index=None, in_dim=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16,
+              out_dtype=torch.float32):
+    """wisp BasicDecoder (Linear+ReLU ... Linear) [+ sigmoid/softmax] in one launch.
+    x1 [M,k1] (+ optional per-ray x2 [R,k2p] gathered by x2_index [M]); weights[i] is [out,in]."""
+    if in_dim is None:
+        in_dim = weights[0].shape[1]
+    return _FusedMLP.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
+
+
+# ------------------------------------------------------------------------------------------ ray march
+def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, occupancy_bits=None, blas_level=7):
+    """'ray'-mode march + occupancy filter + pack.  Returns
+    (ridx i32[M], pidx i32[M], samples f32[M,3], depths f32[M], deltas f32[M], boundary bool[M],
+     pack_start i64[P+1], ray_of_pack i32[P])."""
+    _check_gpu(origins, dirs)
+    lib = L.load()
+    dev = origins.device
+    N, S = origins.shape[0], int(num_samples)
+    origins = origins.detach().contiguous().float()
+    dirs = dirs.detach().contiguous().float()
+    if jitter is None:
+        jitter = torch.rand(N, S, device=dev)
+    jitter = jitter.contiguous().float()
+    tvals = torch.linspace(0, 1.0, S).to(dev)          # CPU linspace: bit-identical to the oracle's
+    counts = torch.empty(N, device=dev, dtype=torch.int32)
+    occ = L.ptr(occupancy_bits) if occupancy_bits is not None else None
+    st = L.stream()
+    if N:
+        L.check(lib.pag_raymarch_count(L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
+                                       float(dist_max), occ, blas_level, L.ptr(counts), st), "pag_raymarch_count")
+    csum = torch.cumsum(counts.long(), 0)
+    offsets = csum - counts
+    M = int(csum[-1].item()) if N else 0
+    ridx = torch.empty(M, device=dev, dtype=torch.int32)
+    pidx = torch.empty(M, device=dev, dtype=torch.int32)
+    samples = torch.empty(M, 3, device=dev)
+    depths = torch.empty(M, device=dev)
+    deltas = torch.empty(M, device=dev)
+    boundary = torch.empty(M, device=dev, dtype=torch.uint8)
+    if M:
+        L.check(lib.pag_raymarch_pack(L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
+                                      float(dist_max), occ, blas_level, L.ptr(offsets), L.ptr(ridx), L.ptr(pidx),
+                                      L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), st), "pag_raymarch_pack")
+    nonempty = counts > 0
+    ray_of_pack = torch.nonzero(nonempty).reshape(-1).int()
+    pack_start = torch.cat([offsets[nonempty], csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)
+    return ridx, pidx, samples, depths, deltas, boundary.bool(), pack_start.contiguous(), ray_of_pack
+
+
+def packs_from_boundary(ridx, boundary):
+    """(pack_start i64[P+1], ray_of_pack i32[P]) from kaolin-style (ridx, boundary) arrays."""
+    starts = torch.nonzero(boundary).reshape(-1)
+    end = torch.tensor([boundary.shape[0]], device=boundary.device, dtype=torch.int64)
+    return torch.cat([starts, end]).contiguous(), ridx[starts].int().contiguous()
+
+
+# ----------------------------------------------------------------------------------------- composite
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigma, rgb, deltas, depths, pack_start, ray_of_pack, N, bg_white):
+        _check_gpu(sigma, deltas)
+        lib = L.load()
+        dev = sigma.device
+        M = sigma.shape[0]
+        P = ray_of_pack.shape[0]
+        sigma = sigma.detach().contiguous().float()
+        deltas = deltas.detach().contiguous().float()
+        rgbc = rgb.detach().contiguous().float() if rgb is not None else None
+        depc = depths.detach().contiguous().float() if depths is not None else None
+        w = torch.empty(M, device=dev)
+        alpha = torch.zeros(N, device=dev)
+        hit = torch.zeros(N, device=dev, dtype=torch.uint8)
+        out_rgb = (torch.ones if bg_white else torch.zeros)(N, 3, device=dev) if rgb is not None else None
+        out_depth = torch.zeros(N, device=dev) if depths is not None else None
+        if P:
+            L.check(lib.pag_composite_fwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
+                                          L.ptr(rgbc), L.BG_WHITE if bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
+                                          L.ptr(out_rgb), L.ptr(out_depth), L.ptr(hit), L.stream()), "pag_composite_fwd")
+        ctx.save_for_backward(sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha)
+        ctx.bg_white = bg_white
+        ctx.mark_non_differentiable(hit, w)
+        return alpha, hit, out_rgb, out_depth, w
+
+    @staticmethod
+    def backward(ctx, g_alpha, _g_hit, g_rgb, g_depth, _g_w):
+        lib = L.load()
+        sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha = ctx.saved_tensors
+        M, P = sigma.shape[0], ray_of_pack.shape[0]
+        d_sigma = torch.zeros(M, device=sigma.device)
+        d_rgb = torch.zeros(M, 3, device=sigma.device) if rgbc is not None else None
+        gc = lambda t: t.contiguous().float() if t is not None else None
+        g_alpha, g_rgb, g_depth = gc(g_alpha), gc(g_rgb), gc(g_depth)
+        if P:
+            L.check(lib.pag_composite_bwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
+                                          L.ptr(rgbc), L.BG_WHITE if ctx.bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
+                                          L.ptr(g_rgb), L.ptr(g_depth), L.ptr(g_alpha), L.ptr(d_sigma), L.ptr(d_rgb),
+                                          L.stream()), "pag_composite_bwd")
+        return d_sigma, d_rgb, None, None, None, None, None, None
+
+
+def composite(sigma, rgb, deltas, depths, pack_start, ray_of_pack, N, bg_white=True):
+    """-> (alpha [N], hit u8 [N], rgb [N,3] | None, depth [N] | None, weights [M]); tracer :134-176."""
+    return _Composite.apply(sigma, rgb, deltas, depths, pack_start, ray_of_pack, N, bg_white)
+
+
+class _CompositeFeats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, weights, alpha, pack_start, ray_of_pack, N):
+        _check_gpu(feats, weights, alpha)
+        lib = L.load()
+        feats = feats.detach().contiguous()
+        if feats.dtype not in (torch.float32, torch.bfloat16):
+            feats = feats.float()
+        C = feats.shape[1]
+        P = ray_of_pack.shape[0]
+        out = torch.zeros(N, C, device=feats.device)
+        weights = weights.detach().contiguous()
+        alpha = alpha.detach().contiguous()
+        if P:
+            L.check(lib.pag_composite_feats_fwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
+                                                L.ptr(feats), L.dtype_code(feats), C, L.ptr(out), L.stream()),
+                    "pag_composite_feats_fwd")
+        ctx.save_for_backward(weights, alpha, pack_start, ray_of_pack)
+        ctx.shape, ctx.fdtype = feats.shape, feats.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        weights, alpha, pack_start, ray_of_pack = ctx.saved_tensors
+        M, C = ctx.shape
+        P = ray_of_pack.shape[0]
+        d = torch.zeros(M, C, device=weights.device)
+        if P:
+            L.check(lib.pag_composite_feats_bwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
+                                                L.ptr(g.contiguous().float()), C, L.ptr(d), L.stream()), "pag_composite_feats_bwd")
+        return d.to(ctx.fdtype), None, None, None, None, None
+
+
+def composite_feats(feats, weights, alpha, pack_start, ray_of_pack, N):
+    """out[ray] = alpha[ray] * sum_i w_i feats[i]  (weights/alpha detached; tracer :148-155,:197-205)."""
+    return _CompositeFeats.apply(feats, weights, alpha, pack_start, ray_of_pack, N)

@@ -1,0 +1,115 @@
+"""PanopticPackedRFTracer on the gfx950 kernels - same channels, arguments and output buffers as
+tracers/panoptic_packed_rf_tracer.py::PanopticPackedRFTracer.
+
+trace() follows the reference step by step (file:line of the reference in comments); the kaolin
+calls it makes (mark_pack_boundaries / exponential_integration / sum_reduce, :114,:135,:138,...)
+are replaced by two fused launches: ops.composite (segmented scan + alpha/rgb/depth sums) and
+ops.composite_feats (wide per-ray feature sums).  Quirks kept on purpose:
+colour and panoptic features are multiplied by alpha a second time, depth is not; panoptic
+channels use weights that carry no gradient; rays without samples keep the background.
+"""
+import inspect
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .core import RenderBuffer
+
+
+class PanopticPackedRFTracer(nn.Module):
+    def __init__(self, ray_sparcity_reg=0.0, ray_max_travel=6.0, raymarch_type="voxel", num_steps=64, step_size=1.0,
+                 bg_color="white", **kwargs):
+        super().__init__()
+        self.raymarch_type, self.num_steps, self.step_size, self.bg_color = raymarch_type, num_steps, step_size, bg_color
+        self.render_channels = {"depth", "alpha", "hit"}
+        self.base_channels = {"rgb", "density"}
+        self.panoptic_channels = {"semantics", "inst_embedding"}
+        self.ray_sparcity_reg = ray_sparcity_reg
+        self.ray_max_travel = ray_max_travel
+
+    def get_supported_channels(self):
+        return {"depth", "hit", "rgb", "alpha", "semantics", "inst_embedding"}
+
+    def get_required_nef_channels(self):
+        return {"rgb", "density"}
+
+    def forward(self, nef, channels=None, extra_channels=None, **kwargs):
+        """wisp BaseTracer.forward: trace() arguments come from kwargs, else
+        from a same-named attribute of the tracer, else from the Python default."""
+        missing = self.get_required_nef_channels() - nef.get_supported_channels()
+        if missing:
+            raise Exception("nef does not supply the channels this tracer needs: %s" % missing)
+        if channels is None:
+            requested = self.get_supported_channels()
+        elif isinstance(channels, str):
+            requested = {channels}
+        else:
+            requested = set(channels)
+        extra = requested - self.get_supported_channels()
+        if extra_channels is not None:
+            extra |= {extra_channels} if isinstance(extra_channels, str) else set(extra_channels)
+        unsupported = extra - nef.get_supported_channels()
+        if unsupported:
+            raise Exception("channels %s are supported by neither the tracer nor the nef" % unsupported)
+        args = {}
+        for name, prm in inspect.signature(self.trace).parameters.items():
+            if name in ("nef", "channels", "extra_channels"):
+                continue
+            if name in kwargs:
+                args[name] = kwargs[name]
+            elif hasattr(self, name):
+                args[name] = getattr(self, name)
+            elif prm.default is not inspect.Parameter.empty:
+                args[name] = prm.default
+        return self.trace(nef, requested - extra, extra, **args)
+
+    def trace(self, nef, channels, extra_channels, rays, lod_idx=None, raymarch_type="voxel", num_steps=64, step_size=1.0,
+              bg_color="white", stage="val", jitter=None):
+        assert nef.grid is not None, "this tracer requires a grid"                      # :76
+        N = rays.origins.shape[0]
+        dev = rays.origins.device
+        if lod_idx is None:
+            lod_idx = nef.grid.num_lods - 1
+        kw = {"jitter": jitter} if jitter is not None else {}
+        ridx, pidx, samples, depths, deltas, boundary = nef.grid.raymarch(                 # :85-86
+            rays, level=nef.grid.active_lods[lod_idx], num_samples=num_steps, raymarch_type=raymarch_type, **kw)
+        if raymarch_type == "voxel" and depths.numel() != 0:
+            raise NotImplementedError("voxel-mode travel filter (:88-108) is a next-row item (SURVEY 8f f3)")
+        cache = getattr(nef.grid, "_pack_cache", None)
+        if cache is not None and cache[0] is ridx:
+            _, ridx32, pack_start, ray_of_pack = cache
+        else:                                                                              # :114
+            ridx32 = ridx.int()
+            pack_start, ray_of_pack = ops.packs_from_boundary(ridx32, boundary)
+        outputs = {}
+        sample_channels = set(channels - self.render_channels)                             # :121-124
+        sample_channels.update(["density"])
+        if getattr(nef, "accepts_ray_index", False):      # per-ray view embedding gathered through ridx (no [M,3] dirs)
+            feats = nef(coords=samples, ridx=ridx32, ray_dirs=rays.dirs, pidx=pidx, lod_idx=lod_idx, channels=sample_channels)
+        else:                                              # :117,:124
+            feats = nef(coords=samples, ray_d=rays.dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx,
+                        channels=sample_channels)
+        sigma = feats["density"].reshape(-1)
+        if self.ray_sparcity_reg > 0.0 and stage == "train":                               # :127-130
+            per = torch.log(1.0 + 2 * sigma ** 2)
+            ray_wise = torch.zeros(N, device=dev).scatter_add(0, ridx, per)
+            outputs["ray_sparcity_loss"] = ray_wise.mean() * self.ray_sparcity_reg
+        rgb = feats["rgb"].reshape(-1, 3) if "rgb" in channels else None
+        dep = depths.reshape(-1) if "depth" in channels else None
+        alpha, hit, out_rgb, out_depth, w = ops.composite(sigma, rgb, deltas.reshape(-1), dep, pack_start, ray_of_pack, N,
+                                                          bg_white=(bg_color == "white"))  # :134-176
+        outputs["alpha"] = alpha[:, None]
+        outputs["hit"] = hit.bool()
+        if rgb is not None:
+            outputs["rgb"] = out_rgb
+        if dep is not None:
+            outputs["depth"] = out_depth[:, None]
+        alpha_d = alpha.detach()
+        for ch in [c for c in channels if c in self.panoptic_channels]:                     # :148-155,:178-182
+            outputs[ch] = ops.composite_feats(feats[ch].reshape(-1, feats[ch].shape[-1]), w, alpha_d, pack_start, ray_of_pack, N)
+        extra_outputs = {}
+        for ch in extra_channels:                                                          # :184-192
+            f = nef(coords=samples, ray_d=rays.dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx, channels=ch)
+            extra_outputs[ch] = ops.composite_feats(f.reshape(-1, f.shape[-1]), w, alpha_d, pack_start, ray_of_pack, N)
+        return RenderBuffer(**outputs, **extra_outputs)

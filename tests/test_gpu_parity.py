@@ -1,0 +1,445 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors captured from the reference.  Need a real MI355X:  pytest -m gpu
+
+Tolerances:
+  integer / index work                      bit-exact
+  fp32 encode (hash, permuto)               bit-exact against the oracle (same op order, no FMA)
+  fp32 decoders / compositing               rtol 1e-5 (+ tiny atol) - summation order differs
+  bf16 MFMA decoders                        2e-2 absolute on post-activation values
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, table_from_seed
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from pagnerf_amd import ops, _lib
+    return ops, _lib
+
+
+# ---------------------------------------------------------------------------------------------- encode
+def test_hash_encode_matches_reference_golden_bit_exact(gpu_device):
+    ops, L = _ops()
+    g = golden("g1_hash.npz")
+    for tag in ("a", "b"):
+        log2T, res = int(g[f"{tag}_log2T"]), [float(r) for r in g[f"{tag}_res"]]
+        tab = torch.from_numpy(table_from_seed(int(g[f"{tag}_seed"]), (len(res), 2 ** log2T, 2), str(g[f"{tag}_kind"])))
+        x = torch.from_numpy(g[f"{tag}_x"])
+        spec = ops.hash_spec(res, log2T, 2)
+        out = ops.encode(x.to(gpu_device), tab.to(gpu_device), spec).cpu().numpy()
+        ref = g[f"{tag}_feats"]
+        assert out.shape == ref.shape
+        assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+        fm = ops.encode(x.to(gpu_device), tab.to(gpu_device), spec, feature_major=True)
+        assert fm.stride() == (1, x.shape[0]) and np.array_equal(fm.cpu().numpy(), ref)
+
+
+def test_hash_encode_variants_and_backward(gpu_device):
+    ops, L = _ops()
+    from oracle import hash_encode as oh
+    rs = np.random.RandomState(0)
+    for (Lv, F, log2T) in ((16, 2, 14), (5, 4, 10), (9, 1, 8), (32, 2, 6)):
+        res = oh.level_resolutions(16, 512, Lv)
+        x = torch.from_numpy(rs.uniform(-1.1, 1.1, size=(777, 3)).astype(np.float32))
+        tab = torch.from_numpy(rs.standard_normal(size=(Lv, 2 ** log2T, F)).astype(np.float32))
+        if F == 2:
+            ref, _ = oh.hash_encode(x, tab, res, log2T)
+        else:   # oracle is written for any F
+            ref, _ = oh.hash_encode(x, tab, res, log2T)
+        spec = ops.hash_spec(res, log2T, F)
+        tg = tab.to(gpu_device).requires_grad_(True)
+        scale = torch.from_numpy(rs.uniform(0.5, 1.5, size=(Lv * F,)).astype(np.float32))
+        out = ops.encode(x.to(gpu_device), tg, spec)
+        assert np.array_equal(out.detach().cpu().numpy(), ref.numpy())
+        outs = ops.encode(x.to(gpu_device), tg, spec, feat_scale=scale)
+        assert np.array_equal(outs.detach().cpu().numpy(), (ref * scale).numpy())
+        go = torch.from_numpy(rs.standard_normal(size=ref.shape).astype(np.float32))
+        outs.backward(go.to(gpu_device))
+        gref = oh.hash_encode_bwd(x, go * scale, 2 ** log2T, res, log2T)
+        np.testing.assert_allclose(tg.grad.cpu().numpy(), gref.numpy(), rtol=2e-4, atol=2e-5)
+        # bf16 output / fp16 tables stay within their rounding
+        ob = ops.encode(x.to(gpu_device), tg.detach(), spec, out_dtype=torch.bfloat16).float().cpu()
+        np.testing.assert_allclose(ob.numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+        oh16 = ops.encode(x.to(gpu_device), tg.detach().half(), spec).cpu()
+        ref16, _ = oh.hash_encode(x, tab.half().float(), res, log2T)
+        assert np.array_equal(oh16.numpy(), ref16.numpy())
+    empty = ops.encode(torch.zeros(0, 3, device=gpu_device), tg.detach(), spec)
+    assert empty.shape == (0, Lv * F)
+
+
+def test_permuto_encode_bit_exact_vs_oracle_and_backward(gpu_device):
+    ops, L = _ops()
+    from oracle import permuto_encode as op
+    rs = np.random.RandomState(1)
+    for (Lv, F, cap, fine) in ((24, 2, 2 ** 12, 1e-4), (8, 2, 1000, 1e-2), (3, 4, 2 ** 8, 0.1), (17, 1, 2 ** 10, 1e-3)):
+        scales = np.geomspace(1.0, fine, Lv)
+        sf = op.scale_factors(scales)
+        shifts = (rs.standard_normal(size=(Lv, 3)) * 10).astype(np.float32)
+        x = rs.uniform(-1, 1, size=(1501, 3)).astype(np.float32)
+        x[:8] = [[0, 0, 0], [1, 1, 1], [-1, -1, -1], [0.5, -0.25, 0.125], [1, -1, 0], [1e-6, 0, 0], [0, 1e-6, 0], [-1e-6, 0, 1]]
+        tab = rs.standard_normal(size=(Lv, cap, F)).astype(np.float32)
+        ref, idx, bary = op.permuto_encode(x, tab, shifts, sf)
+        assert idx.min() >= 0 and idx.max() < cap
+        np.testing.assert_allclose(bary.sum(-1), 1.0, atol=2e-5)
+        spec = ops.permuto_spec(sf, shifts, cap, F)
+        tg = torch.from_numpy(tab).to(gpu_device).requires_grad_(True)
+        xg = torch.from_numpy(x).to(gpu_device)
+        out = ops.encode(xg, tg, spec)
+        got = out.detach().cpu().numpy()
+        assert np.array_equal(got, ref), "max abs diff %g at L=%d" % (np.abs(got - ref).max(), Lv)
+        go = rs.standard_normal(size=ref.shape).astype(np.float32)
+        out.backward(torch.from_numpy(go).to(gpu_device))
+        gref = op.permuto_encode_bwd(x, go, cap, shifts, sf)
+        np.testing.assert_allclose(tg.grad.cpu().numpy(), gref, rtol=2e-4, atol=2e-5)
+        fm = ops.encode(xg, tg.detach(), spec, out_dtype=torch.bfloat16, feature_major=True)
+        np.testing.assert_allclose(fm.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------- MLP
+def _rand_mlp(rs, dims):
+    W = [torch.from_numpy((rs.standard_normal(size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(len(dims) - 1)]
+    b = [torch.from_numpy((rs.standard_normal(size=(dims[i + 1],)) * 0.1).astype(np.float32)) for i in range(len(dims) - 1)]
+    return W, b
+
+
+def _torch_mlp(x, W, b, act):
+    from oracle import decoders as od
+    y = od.mlp(x, W, b)
+    if act == 1:
+        y = torch.sigmoid(y)
+    elif act == 2:
+        y = torch.softmax(y, -1)
+    return y
+
+
+@pytest.mark.parametrize("mode_name", ["fp32", "bf16"])
+def test_fused_mlp_forward_backward(gpu_device, mode_name):
+    ops, L = _ops()
+    mode = L.MLP_FP32 if mode_name == "fp32" else L.MLP_MFMA_BF16
+    rs = np.random.RandomState(2)
+    cases = [((48, 64, 16), 0, None), ((43, 64, 64, 3), 1, 16), ((48, 64, 6), 2, None), ((48, 64, 64, 200), 2, None),
+             ((32, 64, 64, 40), 0, None), ((16, 64, 100), 1, None)]
+    for dims, act, k1 in cases:
+        M, R = 1000 + 37, 50
+        W, b = _rand_mlp(rs, dims)
+        in_dim = dims[0]
+        if k1 is None:
+            x1 = torch.from_numpy(rs.standard_normal(size=(M, in_dim)).astype(np.float32))
+            x2 = idx = None
+            xfull = x1
+        else:
+            x1 = torch.from_numpy(rs.standard_normal(size=(M, k1)).astype(np.float32))
+            x2 = torch.zeros(R, 32)
+            x2[:, :in_dim - k1] = torch.from_numpy(rs.standard_normal(size=(R, in_dim - k1)).astype(np.float32))
+            idx = torch.from_numpy(np.sort(rs.randint(0, R, size=M)).astype(np.int32))
+            xfull = torch.cat([x1, x2[idx.long(), :in_dim - k1]], -1)
+        if mode_name == "bf16":   # the kernel rounds inputs and weights to bf16: compare like with like for the tight check
+            Wr = [w.bfloat16().float() for w in W]
+            xr = xfull.bfloat16().float()
+        else:
+            Wr, xr = W, xfull
+        Wt = [w.clone().requires_grad_(True) for w in Wr]
+        bt = [v.clone().requires_grad_(True) for v in b]
+        xt = xr.clone().requires_grad_(True)
+        ref = _torch_mlp(xt, Wt, bt, act)
+        go = torch.from_numpy(rs.standard_normal(size=ref.shape).astype(np.float32))
+        ref.backward(go)
+        Wg = [w.to(gpu_device).requires_grad_(True) for w in W]
+        bg = [v.to(gpu_device).requires_grad_(True) for v in b]
+        x1g = x1.to(gpu_device).requires_grad_(True)
+        out = ops.fused_mlp(x1g, Wg, bg, x2=None if x2 is None else x2.to(gpu_device),
+                            x2_index=None if idx is None else idx.to(gpu_device), in_dim=in_dim, out_act=act, mode=mode)
+        out.backward(go.to(gpu_device))
+        o = out.detach().cpu()
+        if mode_name == "fp32":
+            np.testing.assert_allclose(o.numpy(), ref.detach().numpy(), rtol=1e-5, atol=2e-6, err_msg=str(dims))
+            tol = dict(rtol=2e-4, atol=2e-4)
+        else:
+            assert (o - ref.detach()).abs().max() < 2e-2, (dims, float((o - ref.detach()).abs().max()))
+            tol = dict(rtol=5e-2, atol=None)
+        n1 = x1.shape[1]
+        gx_ref = xt.grad[:, :n1]
+        for name, got, want in [("dx", x1g.grad.cpu(), gx_ref)] + \
+                [("dW%d" % i, Wg[i].grad.cpu(), Wt[i].grad) for i in range(len(W))] + \
+                [("db%d" % i, bg[i].grad.cpu(), bt[i].grad) for i in range(len(W))]:
+            scale = float(want.abs().max()) + 1e-12
+            err = float((got - want).abs().max()) / scale
+            lim = 2e-4 if mode_name == "fp32" else 3e-2
+            assert err < lim, "%s %s %s: rel-to-max err %g" % (mode_name, dims, name, err)
+
+
+def test_g3_nef_forward_against_reference_golden(gpu_device):
+    """PanopticDeltaNeF (HIP) vs the reference's rgb_semantics() outputs (g3_nef.npz)."""
+    import pagnerf_amd
+    from oracle import hash_encode as oh
+    g = golden("g3_nef.npz")
+    Lv, log2T = int(g["L"]), int(g["log2T"])
+    for precision in ("fp32", "bf16"):
+        nef = pagnerf_amd.PanopticDeltaNeF(grid_type="HashGridTorch", feature_dim=2, num_lods=Lv, num_classes=6, num_instances=200,
+                                           sem_num_layers=1, sem_softmax=True, inst_num_layers=2, inst_softmax=True,
+                                           panoptic_features_type="delta", codebook_bitwidth=log2T, precision=precision)
+        res = [int(g["res"][0])] * (Lv - 1) + [int(g["res"][-1])]
+        for gi, grid in enumerate((nef.grid, nef.delta_grid)):
+            grid.init_from_resolutions(res)
+            tab = table_from_seed(int(g["seed_main"]) + gi, (Lv, 2 ** log2T, 2), "normal") * np.float32(0.5)
+            grid.tables.data.copy_(torch.from_numpy(tab))
+        for short in ("density", "color", "semantics", "inst"):
+            dec = getattr(nef, "decoder_" + short)
+            lins = list(dec.layers) + [dec.lout]
+            for i, lin in enumerate(lins):
+                lin.weight.data.copy_(torch.from_numpy(g[f"decoder_{short}_w{i}"]))
+                lin.bias.data.copy_(torch.from_numpy(g[f"decoder_{short}_b{i}"]))
+        nef = nef.to(gpu_device)
+        coords = torch.from_numpy(g["coords"]).to(gpu_device)
+        ray_d = torch.from_numpy(g["ray_d"]).to(gpu_device)
+        with torch.no_grad():
+            out = nef(coords=coords, ray_d=ray_d, pidx=None, lod_idx=None, channels={"density", "rgb", "semantics", "inst_embedding"})
+            dens = nef(coords=coords, ray_d=ray_d, channels="density")
+        assert out["density"].shape == (256, 1, 1) and out["rgb"].shape == (256, 1, 3)
+        assert out["semantics"].shape == (256, 6) and out["inst_embedding"].shape == (256, 200)     # Appendix E.11
+        assert torch.equal(dens, out["density"])
+        tol = dict(rtol=1e-5, atol=2e-6) if precision == "fp32" else dict(rtol=0, atol=2e-2)
+        for ch in ("rgb", "semantics", "inst_embedding"):
+            np.testing.assert_allclose(out[ch].float().cpu().numpy(), g[ch], err_msg=f"{precision} {ch}", **tol)
+        dref = g["density"]
+        dtol = dict(rtol=1e-5, atol=2e-6) if precision == "fp32" else dict(rtol=3e-2, atol=3e-2)
+        np.testing.assert_allclose(out["density"].float().cpu().numpy(), dref, err_msg=f"{precision} density", **dtol)
+
+
+# ------------------------------------------------------------------------------------ march + composite
+def test_raymarch_matches_oracle_bit_exact(gpu_device):
+    ops, L = _ops()
+    from oracle import render as orr
+    rs = np.random.RandomState(3)
+    for (N, S, level, dense) in ((37, 24, 3, False), (130, 100, 5, False), (64, 512, 7, True), (5, 1, 2, False)):
+        o = torch.from_numpy(rs.uniform(-0.6, 0.6, size=(N, 3)).astype(np.float32))
+        d = rs.standard_normal(size=(N, 3)).astype(np.float32)
+        d = torch.from_numpy(d / np.linalg.norm(d, axis=1, keepdims=True))
+        jit = torch.from_numpy(rs.uniform(0, 1, size=(N, S)).astype(np.float32))
+        R = 2 ** level
+        occ = None if dense else torch.from_numpy(rs.uniform(size=(R, R, R)) > 0.4)
+        ref = orr.raymarch_ray(o, d, 0.0, 2.0, S, jit, occ, level)
+        bits = None
+        if occ is not None:
+            from pagnerf_amd.grids import OccupancyBLAS
+            blas = OccupancyBLAS(level)
+            blas.blas_init(occ.reshape(-1))
+            assert torch.equal(blas.occupancy_mask(), occ.reshape(-1))
+            bits = blas.blas_bits.to(gpu_device)
+        got = ops.raymarch_ray(o.to(gpu_device), d.to(gpu_device), 0.0, 2.0, S, jit.to(gpu_device), bits, level)
+        ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack = [t.cpu() for t in got]
+        assert torch.equal(ridx.long(), ref[0]) and torch.equal(pidx.long(), ref[1])
+        assert torch.equal(samples, ref[2][:, 0]) and torch.equal(depths, ref[3][:, 0]) and torch.equal(deltas, ref[4][:, 0])
+        assert torch.equal(boundary, ref[5])
+        ps, rp = ops.packs_from_boundary(got[0], got[5])
+        assert torch.equal(ps.cpu(), pack_start) and torch.equal(rp.cpu(), ray_of_pack)
+
+
+def _composite_gpu(ops, dev, g, prefix, bg, N, with_panoptic=True):
+    t = lambda k: torch.from_numpy(g[k])
+    ridx, boundary = t(prefix + "ridx").to(dev), t(prefix + "boundary").to(dev)
+    ps, rp = ops.packs_from_boundary(ridx.int(), boundary)
+    return ps, rp
+
+
+def test_g4_tracer_composite_against_reference_golden(gpu_device):
+    ops, L = _ops()
+    g = golden("g4_tracer.npz")
+    N = int(g["N"])
+    t = lambda k: torch.from_numpy(g[k]).to(gpu_device)
+    ps, rp = ops.packs_from_boundary(t("ridx").int(), t("boundary"))
+    for bg in ("white", "black"):
+        alpha, hit, rgb, depth, w = ops.composite(t("density").reshape(-1), t("rgb").reshape(-1, 3), t("deltas").reshape(-1),
+                                                  t("depths").reshape(-1), ps, rp, N, bg_white=(bg == "white"))
+        sem = ops.composite_feats(t("semantics"), w, alpha, ps, rp, N)
+        inst = ops.composite_feats(t("inst_embedding").bfloat16(), w, alpha, ps, rp, N)
+        inst32 = ops.composite_feats(t("inst_embedding"), w, alpha, ps, rp, N)
+        tol = dict(rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(alpha.cpu().numpy()[:, None], g[f"{bg}_alpha"], **tol)
+        np.testing.assert_allclose(rgb.cpu().numpy(), g[f"{bg}_rgb"], **tol)
+        np.testing.assert_allclose(depth.cpu().numpy()[:, None], g[f"{bg}_depth"], **tol)
+        np.testing.assert_allclose(sem.cpu().numpy(), g[f"{bg}_semantics"], **tol)
+        np.testing.assert_allclose(inst32.cpu().numpy(), g[f"{bg}_inst_embedding"], **tol)
+        np.testing.assert_allclose(inst.cpu().numpy(), g[f"{bg}_inst_embedding"], rtol=2e-2, atol=1e-3)
+        assert np.array_equal(hit.bool().cpu().numpy(), g[f"{bg}_hit"])
+        assert float(w.min()) >= 0 and float(alpha.max()) <= 1 + 1e-6
+
+
+def test_composite_backward_vs_oracle_autograd(gpu_device):
+    ops, L = _ops()
+    from oracle import render as orr
+    rs = np.random.RandomState(4)
+    N, S = 70, 90
+    counts = rs.randint(0, S, size=N)
+    counts[3] = 0
+    counts[10] = 200      # longer than 3 wave chunks
+    ridx = torch.from_numpy(np.repeat(np.arange(N), counts)).long()
+    M = ridx.shape[0]
+    boundary = orr.mark_pack_boundaries(ridx)
+    mk = lambda *s: torch.from_numpy(rs.uniform(0, 1, size=s).astype(np.float32))
+    sigma = (mk(M) * 20 * (mk(M) > 0.3)).requires_grad_(True)
+    rgb = mk(M, 3).requires_grad_(True)
+    deltas = mk(M) * 0.02
+    depths = torch.from_numpy(np.concatenate([np.sort(rs.uniform(0, 2, size=c)) for c in counts]).astype(np.float32))
+    sem = torch.softmax(torch.from_numpy(rs.standard_normal(size=(M, 7)).astype(np.float32)), -1).requires_grad_(True)
+    for bg in ("white", "black"):
+        ref = orr.composite(N, ridx, boundary, sigma, deltas[:, None], depths=depths, rgb=rgb, semantics=sem, bg_color=bg)
+        g_rgb, g_depth, g_alpha, g_sem = mk(N, 3), mk(N, 1), mk(N, 1), mk(N, 7)
+        loss = (ref["rgb"] * g_rgb).sum() + (ref["depth"] * g_depth).sum() + (ref["alpha"] * g_alpha).sum()
+        grads = torch.autograd.grad(loss, [sigma, rgb], retain_graph=True)
+        # panoptic: weights and alpha detached (tracer :148-155)
+        w_d = ref["weights"].detach()
+        a_d = ref["alpha"].detach()
+        sem_ref = torch.zeros(N, 7)
+        sem_ref[ridx[boundary]] = (a_d[ridx[boundary]] * orr.sum_reduce(w_d * sem, boundary))
+        (g_sem_ref,) = torch.autograd.grad((sem_ref * g_sem).sum(), [sem])
+        dev = gpu_device
+        sg = sigma.detach().to(dev).requires_grad_(True)
+        rg = rgb.detach().to(dev).requires_grad_(True)
+        ps, rp = ops.packs_from_boundary(ridx.int().to(dev), boundary.to(dev))
+        alpha, hit, orgb, odepth, w = ops.composite(sg, rg, deltas.to(dev), depths.to(dev), ps, rp, N, bg_white=(bg == "white"))
+        np.testing.assert_allclose(orgb.detach().cpu().numpy(), ref["rgb"].detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(w.cpu().numpy(), ref["weights"].detach().numpy()[:, 0], rtol=2e-5, atol=1e-7)
+        l2 = (orgb * g_rgb.to(dev)).sum() + (odepth[:, None] * g_depth.to(dev)).sum() + (alpha[:, None] * g_alpha.to(dev)).sum()
+        l2.backward()
+        np.testing.assert_allclose(sg.grad.cpu().numpy(), grads[0].numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(rg.grad.cpu().numpy(), grads[1].numpy(), rtol=2e-5, atol=1e-6)
+        semg = sem.detach().to(dev).requires_grad_(True)
+        so = ops.composite_feats(semg, w, alpha.detach(), ps, rp, N)
+        np.testing.assert_allclose(so.detach().cpu().numpy(), sem_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+        (so * g_sem.to(dev)).sum().backward()
+        np.testing.assert_allclose(semg.grad.cpu().numpy(), g_sem_ref.numpy(), rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------- end to end + properties
+def _make_scene(dev, precision, seed=0, L_perm=24, cap_log2=14, N=256, S=64, level=5):
+    import pagnerf_amd
+    torch.manual_seed(seed)
+    nef = pagnerf_amd.PanopticDeltaNeF(grid_type="PermutoGrid", feature_dim=2, num_lods=L_perm, num_classes=6, num_instances=200,
+                                       sem_num_layers=1, sem_softmax=True, inst_num_layers=2, inst_softmax=True,
+                                       panoptic_features_type="delta", capacity_log_2=cap_log2, delta_capacity_log_2=cap_log2,
+                                       coarsest_scale=1.0, finest_scale=1e-4, blas_level=level, precision=precision)
+    gen = torch.Generator().manual_seed(seed)
+    for grid in (nef.grid, nef.delta_grid):
+        grid.init_from_scales(random_shift=torch.randn(L_perm, 3, generator=gen) * 10,
+                              tables=torch.randn(L_perm, 2 ** cap_log2, 2, generator=gen) * 0.3)
+    nef = nef.to(dev)
+    tracer = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=S, bg_color="white")
+    o = (torch.rand(N, 3, generator=gen) - 0.5) * 0.6
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1)
+    rays = pagnerf_amd.Rays(o.to(dev), d.to(dev), dist_min=0.0, dist_max=2.0)
+    occ = torch.rand(2 ** level, 2 ** level, 2 ** level, generator=gen) > 0.35
+    for grid in (nef.grid, nef.delta_grid):
+        grid.blas_init(occ.reshape(-1))
+    jitter = torch.rand(N, S, generator=gen)
+    return nef, tracer, rays, occ, jitter
+
+
+def _oracle_render(nef, rays, occ, jitter, S, channels):
+    """The same scene through the CPU oracle, fp32."""
+    from oracle import permuto_encode as op, decoders as od, render as orr
+    o, d = rays.origins.cpu(), rays.dirs.cpu()
+    ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_ray(o, d, rays.dist_min, rays.dist_max, S, jitter, occ, nef.grid.blas_level)
+    xyz = samples[:, 0].numpy()
+
+    def enc(grid):
+        sf = grid.scale_factors(grid.resolutions).numpy()
+        f, _, _ = op.permuto_encode(xyz, grid.tables.detach().cpu().numpy(), grid.random_shift_per_level.cpu().numpy(), sf)
+        return torch.from_numpy(f)
+    params = {}
+    for short in ("density", "color", "semantics", "inst"):
+        W, b = getattr(nef, "decoder_" + short).weights()
+        params[short] = ([w.detach().cpu() for w in W], [v.detach().cpu() for v in b])
+    out = od.nef_forward(enc(nef.grid), enc(nef.delta_grid), d[ridx], params, channels, lod_weights=nef.lod_weights)
+    comp = orr.composite(o.shape[0], ridx, boundary, out["density"], deltas, depths=depths, rgb=out.get("rgb"),
+                         semantics=out.get("semantics"), inst=out.get("inst_embedding"), bg_color="white")
+    return comp, out, ridx
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_end_to_end_render_vs_oracle(gpu_device, precision):
+    nef, tracer, rays, occ, jitter = _make_scene(gpu_device, precision)
+    chans = {"rgb", "depth", "semantics", "inst_embedding"}
+    with torch.no_grad():
+        rb = tracer(nef, channels=chans, rays=rays, jitter=jitter.to(gpu_device), stage="val")
+    comp, _, _ = _oracle_render(nef, rays, occ, jitter, 64, chans)
+    tol = dict(rtol=2e-4, atol=2e-5) if precision == "fp32" else dict(rtol=0, atol=2e-2)
+    for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding"):
+        np.testing.assert_allclose(getattr(rb, ch).float().cpu().numpy(), comp[ch].numpy(), err_msg=f"{precision} {ch}", **tol)
+    if precision == "fp32":
+        assert torch.equal(rb.hit.cpu(), comp["hit"])
+    psnr = -10 * np.log10(np.mean((rb.rgb.cpu().numpy() - comp["rgb"].numpy()) ** 2) + 1e-20)
+    assert psnr > (60 if precision == "fp32" else 35), psnr
+
+
+def test_end_to_end_train_step_gradients_fp32(gpu_device):
+    """d loss / d {tables, decoder weights} of rgb L1 (trainer.py:443-446) vs autograd through the oracle."""
+    from oracle import permuto_encode as op, decoders as od, render as orr
+    nef, tracer, rays, occ, jitter = _make_scene(gpu_device, "fp32", N=96, S=32, cap_log2=10)
+    gt = torch.rand(96, 3, generator=torch.Generator().manual_seed(5))
+    rb = tracer(nef, channels={"rgb"}, rays=rays, jitter=jitter.to(gpu_device), stage="train")
+    loss = 10.0 * torch.abs(rb.rgb - gt.to(gpu_device)).mean()
+    loss.backward()
+    # oracle: differentiable wrt tables through bary weights (indices fixed), decoders through torch
+    o, d = rays.origins.cpu(), rays.dirs.cpu()
+    ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_ray(o, d, 0.0, 2.0, 32, jitter, occ, nef.grid.blas_level)
+    g = nef.grid
+    sf = g.scale_factors(g.resolutions).numpy()
+    tab = g.tables.detach().cpu().clone().requires_grad_(True)
+    _, idx, bary = op.permuto_encode(samples[:, 0].numpy(), tab.detach().numpy(), g.random_shift_per_level.cpu().numpy(), sf)
+    idx_t, bary_t = torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(bary)
+    feats = torch.cat([(tab[l][idx_t[l]] * bary_t[l][..., None]).sum(1) for l in range(tab.shape[0])], -1)
+    params = {}
+    leaves = []
+    for short in ("density", "color"):
+        W, b = getattr(nef, "decoder_" + short).weights()
+        Wc = [w.detach().cpu().clone().requires_grad_(True) for w in W]
+        bc = [v.detach().cpu().clone().requires_grad_(True) for v in b]
+        params[short] = (Wc, bc)
+        leaves += [(f"decoder_{short} W{i}", W[i], Wc[i]) for i in range(len(W))] + [(f"decoder_{short} b{i}", b[i], bc[i]) for i in range(len(b))]
+    out = od.nef_forward(feats, None, d[ridx], params, {"rgb"}, lod_weights=nef.lod_weights)
+    comp = orr.composite(96, ridx, boundary, out["density"], deltas, rgb=out["rgb"], bg_color="white")
+    ref_loss = 10.0 * torch.abs(comp["rgb"] - gt).mean()
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * max(1.0, abs(float(ref_loss)))
+    for name, p_gpu, p_ref in leaves + [("grid.tables", nef.grid.tables, tab)]:
+        got, want = p_gpu.grad.cpu(), p_ref.grad
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) / scale < 2e-3, name
+    assert nef.delta_grid.tables.grad is None      # Appendix E.3: rgb loss never reaches the delta grid
+
+
+def test_properties_at_full_size(gpu_device):
+    """Size-independent properties at BASELINE config-2 size (4096 rays x 512 samples)."""
+    import pagnerf_amd
+    from pagnerf_amd import ops
+    nef, tracer, rays, occ, jitter = _make_scene(gpu_device, "bf16", N=4096, S=512, cap_log2=18, level=7)
+    for grid in (nef.grid, nef.delta_grid):
+        grid.blas_init(torch.ones(128 ** 3, dtype=torch.bool))
+    jit = torch.rand(4096, 512, device=gpu_device)
+    with torch.no_grad():
+        rb = tracer(nef, channels={"rgb", "depth", "semantics", "inst_embedding"}, rays=rays, jitter=jit)
+        assert rb.rgb.shape == (4096, 3) and rb.inst_embedding.shape == (4096, 200)
+        a = rb.alpha[:, 0]
+        assert float(a.min()) >= 0 and float(a.max()) <= 1 + 1e-5
+        # composited probabilities are alpha^2-weighted mixtures: rows sum to alpha^2 (Appendix E.12)
+        np.testing.assert_allclose(rb.semantics.sum(-1).cpu().numpy(), (a * a).cpu().numpy(), rtol=2e-2, atol=2e-3)
+        np.testing.assert_allclose(rb.inst_embedding.sum(-1).cpu().numpy(), (a * a).cpu().numpy(), rtol=2e-2, atol=2e-3)
+        # ray-permutation equivariance (bitwise: no atomics, fixed summation order)
+        perm = torch.randperm(4096, device=gpu_device)
+        rays_p = pagnerf_amd.Rays(rays.origins[perm], rays.dirs[perm], rays.dist_min, rays.dist_max)
+        rb_p = tracer(nef, channels={"rgb", "depth"}, rays=rays_p, jitter=jit[perm])
+        assert torch.equal(rb_p.rgb, rb.rgb[perm]) and torch.equal(rb_p.depth, rb.depth[perm])
+        # determinism
+        rb2 = tracer(nef, channels={"rgb", "depth", "semantics", "inst_embedding"}, rays=rays, jitter=jit)
+        assert torch.equal(rb2.inst_embedding, rb.inst_embedding) and torch.equal(rb2.rgb, rb.rgb)
+        # encode linearity in the table: enc(a*T1 + T2) == a*enc(T1) + enc(T2) up to fp32 rounding
+        x = torch.rand(1 << 20, 3, device=gpu_device) * 2 - 1
+        g = nef.grid
+        t1, t2 = g.tables.detach(), torch.randn_like(g.tables)
+        e = lambda t: ops.encode(x, t, g._spec)
+        np.testing.assert_allclose(e(2 * t1 + t2).cpu().numpy(), (2 * e(t1) + e(t2)).cpu().numpy(), rtol=1e-4, atol=1e-5)
