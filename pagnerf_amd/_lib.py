@@ -118,5 +118,6 @@ def host_floats(values):
     if isinstance(values, torch.Tensor):
         values = values.detach().cpu().float().reshape(-1).tolist()
     else:
-        values = [float(v) for v in list(values)]
+        import numpy as np
+        values = np.asarray(values, dtype=np.float32).reshape(-1).tolist()
     return (ctypes.c_float * len(values))(*values)

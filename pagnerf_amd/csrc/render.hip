@@ -27,7 +27,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------------------------------- ray march
 // wisp OctreeAS.raymarch 'ray' mode as restated in oracle/render.py raymarch_ray():
-//   depth = (t_s + jitter/S)^2 * (far - near) + near ;  sample = o + d * depth ;
+//   depth = (t_s + jitter/S)^2 * (far - near) + near ;  sample = fma(d, depth, o) (torch.addcmul) ;
 //   delta_s = depth_s - depth_{s-1} (delta_0 = depth_0 - near) ;
 //   keep iff inside [-1,1]^3 and the occupancy bit of its 2^level cell is set.
 struct MarchArgs {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a, int32_t *counts
             depth = march_depth(a, ray, s);
             if (PACK && s > 0) prev = march_depth(a, ray, s - 1);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) p[k] = __fadd_rn(o[k], __fmul_rn(dr[k], depth));
+            for (int k = 0; k < 3; ++k) p[k] = __fmaf_rn(dr[k], depth, o[k]);   // torch.addcmul is a fused multiply-add
             keep = march_keep(a, p, cell);
         }
         const unsigned long long mask = __ballot(keep);

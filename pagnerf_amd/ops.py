@@ -10,6 +10,36 @@ import torch
 from . import _lib as L
 
 
+# Optional per-entry-point device timing (bench.py): HIP events recorded on the launch stream
+# (torch's current stream, which is the stream every kernel is launched on) around each C-ABI call.
+_PROFILE = None
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_stop():
+    """-> {entry point: [milliseconds per call]} (synchronises)."""
+    global _PROFILE
+    prof, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (prof or {}).items()}
+
+
+def _call(name, *args):
+    fn = getattr(L.load(), name)
+    if _PROFILE is None:
+        L.check(fn(*args), name)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    L.check(fn(*args), name)
+    b.record()
+    _PROFILE.setdefault(name, []).append((a, b))
+
+
 def _check_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -54,13 +84,11 @@ def _encode_fwd(spec, xyz, tables, feat_scale, out):
     fs = L.host_floats(feat_scale)
     sm, sc = out.stride(0), out.stride(1)
     if spec.kind == "hash":
-        rc = lib.pag_hash_encode_fwd(L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
-                                     spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
-        L.check(rc, "pag_hash_encode_fwd")
+        _call("pag_hash_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
+              spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
     else:
-        rc = lib.pag_permuto_encode_fwd(L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity,
-                                        spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
-        L.check(rc, "pag_permuto_encode_fwd")
+        _call("pag_permuto_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity,
+              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
 
 
 def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
@@ -69,13 +97,11 @@ def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
     fs = L.host_floats(feat_scale)
     sm, sc = grad_out.stride(0), grad_out.stride(1)
     if spec.kind == "hash":
-        rc = lib.pag_hash_encode_bwd(L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
-                                     spec.log2_T, spec.res, fs, L.ptr(grad_tables), L.stream())
-        L.check(rc, "pag_hash_encode_bwd")
+        _call("pag_hash_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
+              spec.log2_T, spec.res, fs, L.ptr(grad_tables), L.stream())
     else:
-        rc = lib.pag_permuto_encode_bwd(L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
-                                        spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), L.stream())
-        L.check(rc, "pag_permuto_encode_bwd")
+        _call("pag_permuto_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
+              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), L.stream())
 
 
 class _Encode(torch.autograd.Function):
@@ -159,7 +185,7 @@ class _FusedMLP(torch.autograd.Function):
         for i, h in enumerate(hidden):
             a.hidden_save[i] = L.ptr(h)
         if M:
-            L.check(lib.pag_mlp_fwd(ctypes.byref(a), M, L.stream()), "pag_mlp_fwd")
+            _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
         ctx.cfg = (in_dim, out_act, mode, n_layers, k1)
         ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc)
         ctx.n_hidden = len(hidden)
@@ -190,7 +216,7 @@ class _FusedMLP(torch.autograd.Function):
             a.hidden_save[i] = L.ptr(h)
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
         if M:
-            L.check(lib.pag_mlp_bwd(ctypes.byref(a), M, L.stream()), "pag_mlp_bwd")
+            _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
         # weight gradients: dz_l^T @ input_l - plain GEMMs, left to the BLAS library
         gW, gb = [], []
         for l in range(n_layers):
@@ -240,8 +266,8 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     occ = L.ptr(occupancy_bits) if occupancy_bits is not None else None
     st = L.stream()
     if N:
-        L.check(lib.pag_raymarch_count(L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
-                                       float(dist_max), occ, blas_level, L.ptr(counts), st), "pag_raymarch_count")
+        _call("pag_raymarch_count", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
+                                       float(dist_max), occ, blas_level, L.ptr(counts), st)
     csum = torch.cumsum(counts.long(), 0)
     offsets = csum - counts
     M = int(csum[-1].item()) if N else 0
@@ -252,9 +278,9 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     deltas = torch.empty(M, device=dev)
     boundary = torch.empty(M, device=dev, dtype=torch.uint8)
     if M:
-        L.check(lib.pag_raymarch_pack(L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
+        _call("pag_raymarch_pack", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
                                       float(dist_max), occ, blas_level, L.ptr(offsets), L.ptr(ridx), L.ptr(pidx),
-                                      L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), st), "pag_raymarch_pack")
+                                      L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), st)
     nonempty = counts > 0
     ray_of_pack = torch.nonzero(nonempty).reshape(-1).int()
     pack_start = torch.cat([offsets[nonempty], csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)
@@ -287,9 +313,9 @@ class _Composite(torch.autograd.Function):
         out_rgb = (torch.ones if bg_white else torch.zeros)(N, 3, device=dev) if rgb is not None else None
         out_depth = torch.zeros(N, device=dev) if depths is not None else None
         if P:
-            L.check(lib.pag_composite_fwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
+            _call("pag_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
                                           L.ptr(rgbc), L.BG_WHITE if bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
-                                          L.ptr(out_rgb), L.ptr(out_depth), L.ptr(hit), L.stream()), "pag_composite_fwd")
+                                          L.ptr(out_rgb), L.ptr(out_depth), L.ptr(hit), L.stream())
         ctx.save_for_backward(sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha)
         ctx.bg_white = bg_white
         ctx.mark_non_differentiable(hit, w)
@@ -305,10 +331,10 @@ class _Composite(torch.autograd.Function):
         gc = lambda t: t.contiguous().float() if t is not None else None
         g_alpha, g_rgb, g_depth = gc(g_alpha), gc(g_rgb), gc(g_depth)
         if P:
-            L.check(lib.pag_composite_bwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
+            _call("pag_composite_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
                                           L.ptr(rgbc), L.BG_WHITE if ctx.bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
                                           L.ptr(g_rgb), L.ptr(g_depth), L.ptr(g_alpha), L.ptr(d_sigma), L.ptr(d_rgb),
-                                          L.stream()), "pag_composite_bwd")
+                                          L.stream())
         return d_sigma, d_rgb, None, None, None, None, None, None
 
 
@@ -331,9 +357,8 @@ class _CompositeFeats(torch.autograd.Function):
         weights = weights.detach().contiguous()
         alpha = alpha.detach().contiguous()
         if P:
-            L.check(lib.pag_composite_feats_fwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
-                                                L.ptr(feats), L.dtype_code(feats), C, L.ptr(out), L.stream()),
-                    "pag_composite_feats_fwd")
+            _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
+                                                L.ptr(feats), L.dtype_code(feats), C, L.ptr(out), L.stream())
         ctx.save_for_backward(weights, alpha, pack_start, ray_of_pack)
         ctx.shape, ctx.fdtype = feats.shape, feats.dtype
         return out
@@ -346,8 +371,8 @@ class _CompositeFeats(torch.autograd.Function):
         P = ray_of_pack.shape[0]
         d = torch.zeros(M, C, device=weights.device)
         if P:
-            L.check(lib.pag_composite_feats_bwd(L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
-                                                L.ptr(g.contiguous().float()), C, L.ptr(d), L.stream()), "pag_composite_feats_bwd")
+            _call("pag_composite_feats_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
+                                                L.ptr(g.contiguous().float()), C, L.ptr(d), L.stream())
         return d.to(ctx.fdtype), None, None, None, None, None
 
 

@@ -106,14 +106,24 @@ def _rand_mlp(rs, dims):
     return W, b
 
 
-def _torch_mlp(x, W, b, act):
-    from oracle import decoders as od
-    y = od.mlp(x, W, b)
+def _torch_mlp(x, W, b, act, round_hidden=False):
+    """fp32 reference; round_hidden emulates the MFMA path's bf16 hidden activations (straight-through)."""
+    h = x
+    for i in range(len(W)):
+        h = torch.nn.functional.linear(h, W[i], b[i])
+        if i + 1 < len(W):
+            h = torch.relu(h)
+            if round_hidden:
+                h = h + (h.bfloat16().float() - h).detach()
     if act == 1:
-        y = torch.sigmoid(y)
+        h = torch.sigmoid(h)
     elif act == 2:
-        y = torch.softmax(y, -1)
-    return y
+        h = torch.softmax(h, -1)
+    return h
+
+
+def _rel_l2(got, want):
+    return float((got - want).norm() / (want.norm() + 1e-20))
 
 
 @pytest.mark.parametrize("mode_name", ["fp32", "bf16"])
@@ -145,7 +155,7 @@ def test_fused_mlp_forward_backward(gpu_device, mode_name):
         Wt = [w.clone().requires_grad_(True) for w in Wr]
         bt = [v.clone().requires_grad_(True) for v in b]
         xt = xr.clone().requires_grad_(True)
-        ref = _torch_mlp(xt, Wt, bt, act)
+        ref = _torch_mlp(xt, Wt, bt, act, round_hidden=(mode_name == "bf16"))
         go = torch.from_numpy(rs.standard_normal(size=ref.shape).astype(np.float32))
         ref.backward(go)
         Wg = [w.to(gpu_device).requires_grad_(True) for w in W]
@@ -166,10 +176,10 @@ def test_fused_mlp_forward_backward(gpu_device, mode_name):
         for name, got, want in [("dx", x1g.grad.cpu(), gx_ref)] + \
                 [("dW%d" % i, Wg[i].grad.cpu(), Wt[i].grad) for i in range(len(W))] + \
                 [("db%d" % i, bg[i].grad.cpu(), bt[i].grad) for i in range(len(W))]:
-            scale = float(want.abs().max()) + 1e-12
-            err = float((got - want).abs().max()) / scale
-            lim = 2e-4 if mode_name == "fp32" else 3e-2
-            assert err < lim, "%s %s %s: rel-to-max err %g" % (mode_name, dims, name, err)
+            # relative L2: a ReLU decision that flips on a last-bit difference moves single entries, not the norm
+            err = _rel_l2(got, want)
+            lim = 1e-4 if mode_name == "fp32" else 2e-2
+            assert err < lim, "%s %s %s: rel L2 err %g" % (mode_name, dims, name, err)
 
 
 def test_g3_nef_forward_against_reference_golden(gpu_device):
