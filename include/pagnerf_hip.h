@@ -62,11 +62,11 @@ int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int tab
 
 /* d loss / d tables (what autograd through grids/hash_grid_torch.py:95-108 yields).
  *   grad_out  [M, L*F] via strides (PAG_F32 or PAG_BF16);  grad_tables f32 [L,T,F], ACCUMULATED
- *   into (caller zeroes). */
+ *   into (caller zeroes).  workspace: see pag_encode_bwd_workspace_bytes(). */
 int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
                         int64_t g_stride_m, int64_t g_stride_c, int n_levels, int n_feat,
                         int log2_T, const float *resolutions_host, const float *feat_scale_host,
-                        float *grad_tables, void *stream);
+                        float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Permutohedral-lattice hash encoding.  Replaces permutohedral_encoding.PermutoEncoding's
  * forward as called at grids/permuto_grid.py:57-62,71.
@@ -84,7 +84,14 @@ int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, in
                            int64_t g_stride_m, int64_t g_stride_c, int n_levels, int n_feat,
                            uint32_t capacity, const float *scale_factor_host,
                            const float *shift_host, const float *feat_scale_host,
-                           float *grad_tables, void *stream);
+                           float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Scratch size for the atomic-free ("binned") backward of either encoder: n_vertices = 8 (hash) or
+ * 4 (permuto), rows_per_level = 2^log2_T or capacity.  The caller allocates it (device memory) and
+ * passes it as `workspace`; with workspace == NULL the backward falls back to per-vertex fp32
+ * global atomics (slow on MI355X, kept as the reference path for tests). */
+int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int n_vertices,
+                                       int64_t rows_per_level);
 
 /* ------------------------------------------------------------------------------------------
  * Tiny-MLP decoders

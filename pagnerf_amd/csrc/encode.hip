@@ -13,71 +13,11 @@
 // Numerics: all fp32 arithmetic is written with explicit round-to-nearest intrinsics in the op
 // order of the oracle (oracle/hash_encode.py, oracle/permuto_encode.py); the file is compiled with
 // -ffp-contract=off.  With fp32 tables and fp32 output the result is bit-identical to the oracle.
-#include "common.h"
+#include "encode_common.h"
+
+using namespace pag_enc;
 
 namespace {
-
-struct HashParams {
-    float res[PAG_MAX_LEVELS];
-    float scale[PAG_MAX_FEATS];
-    int L, log2T, has_scale;
-};
-
-struct PermutoParams {
-    float sf[PAG_MAX_LEVELS][3];
-    float shift[PAG_MAX_LEVELS][3];
-    float scale[PAG_MAX_FEATS];
-    int L, has_scale;
-    uint32_t capacity, pow2mask;   // pow2mask = capacity-1 when capacity is a power of two, else 0
-};
-
-template <typename T, int F> struct Vec;
-template <> struct Vec<float, 1> { typedef float type; };
-template <> struct Vec<float, 2> { typedef float2 type; };
-template <> struct Vec<float, 4> { typedef float4 type; };
-template <> struct Vec<__half, 1> { typedef __half type; };
-template <> struct Vec<__half, 2> { typedef __half2 type; };
-template <> struct Vec<__half, 4> { typedef uint2 type; };
-
-template <int F> __device__ __forceinline__ void gather(const float *row, float (&v)[F]) {
-    typename Vec<float, F>::type t = *reinterpret_cast<const typename Vec<float, F>::type *>(row);
-    const float *p = reinterpret_cast<const float *>(&t);
-#pragma unroll
-    for (int f = 0; f < F; ++f) v[f] = p[f];
-}
-template <int F> __device__ __forceinline__ void gather(const __half *row, float (&v)[F]) {
-    typename Vec<__half, F>::type t = *reinterpret_cast<const typename Vec<__half, F>::type *>(row);
-    const __half *p = reinterpret_cast<const __half *>(&t);
-#pragma unroll
-    for (int f = 0; f < F; ++f) v[f] = __half2float(p[f]);
-}
-
-// ------------------------------------------------------------------------------------ hash grid
-// grids/hash_grid_torch.py:26-46 (cell lookup) and :69-77 (weights), one level.
-__device__ __forceinline__ void hash_cell(const float (&x)[3], float res, int log2T, uint32_t (&idx)[8], float (&w)[3]) {
-    const float cell = __fdiv_rn(2.0f, res);
-    uint32_t c[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float xc = fminf(fmaxf(x[a], -1.0f), 1.0f);
-        float t = __fdiv_rn(__fadd_rn(xc, 1.0f), cell);
-        int bl = (int)floorf(t);
-        float vmin = __fadd_rn(__fmul_rn((float)bl, cell), -1.0f);
-        float vmax = __fadd_rn(vmin, cell);
-        w[a] = __fdiv_rn(__fsub_rn(x[a], vmin), __fsub_rn(vmax, vmin));
-        c[a] = (uint32_t)bl;
-    }
-    const uint32_t mask = (1u << log2T) - 1u;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {   // corner k = 4i + 2j + kk (hash_grid_torch.py:10)
-        uint32_t cx = c[0] + ((k >> 2) & 1), cy = c[1] + ((k >> 1) & 1), cz = c[2] + (k & 1);
-        idx[k] = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & mask;
-    }
-}
-
-__device__ __forceinline__ float lerp_ref(float a, float b, float w, float omw) {
-    return __fadd_rn(__fmul_rn(a, omw), __fmul_rn(b, w));
-}
 
 template <typename TableT, typename OutT, int F, int LPX>
 __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__ xyz, int64_t M,
@@ -153,80 +93,6 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(const float *__restrict__
     }
 }
 
-// --------------------------------------------------------------------------- permutohedral lattice
-// oracle/permuto_encode.py lattice_simplex() + vertex_indices(), one level, d = 3.
-__device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float (&sh)[3], const float (&sf)[3],
-                                                uint32_t capacity, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4]) {
-    float cf[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) cf[a] = __fmul_rn(__fadd_rn(x[a], sh[a]), sf[a]);
-    float E[4];
-    float s = 0.0f;
-    E[3] = __fsub_rn(s, __fmul_rn(3.0f, cf[2]));
-    s = __fadd_rn(s, cf[2]);
-    E[2] = __fsub_rn(s, __fmul_rn(2.0f, cf[1]));
-    s = __fadd_rn(s, cf[1]);
-    E[1] = __fsub_rn(s, cf[0]);
-    s = __fadd_rn(s, cf[0]);
-    E[0] = s;
-
-    int rem0[4], rank[4] = {0, 0, 0, 0};
-    float resid[4];
-    int sum = 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        float v = E[a] * 0.25f;
-        float up = ceilf(v) * 4.0f, dn = floorf(v) * 4.0f;
-        float r = (__fsub_rn(up, E[a]) < __fsub_rn(E[a], dn)) ? up : dn;
-        rem0[a] = (int)r;
-        sum += rem0[a];
-        resid[a] = __fsub_rn(E[a], r);
-    }
-    sum >>= 2;   // exact: every rem0 is a multiple of 4
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = a + 1; b < 4; ++b) {
-            int lt = resid[a] < resid[b];
-            rank[a] += lt;
-            rank[b] += 1 - lt;
-        }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        rank[a] += sum;
-        if (rank[a] < 0) {
-            rank[a] += 4;
-            rem0[a] += 4;
-        } else if (rank[a] > 3) {
-            rank[a] -= 4;
-            rem0[a] -= 4;
-        }
-    }
-    float b5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        float delta = __fsub_rn(E[a], (float)rem0[a]) * 0.25f;
-        int slot = 3 - rank[a];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {   // predicated: no runtime-indexed private array
-            b5[k] = (k == slot) ? __fadd_rn(b5[k], delta) : b5[k];
-            b5[k] = (k == slot + 1) ? __fsub_rn(b5[k], delta) : b5[k];
-        }
-    }
-    b5[0] = __fadd_rn(b5[0], __fadd_rn(1.0f, b5[4]));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bary[r] = b5[r];
-        uint32_t k = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            int key = rem0[a] + r - ((rank[a] > 3 - r) ? 4 : 0);
-            k = (k + (uint32_t)key) * 2531011u;
-        }
-        idx[r] = pow2mask ? (k & pow2mask) : (k % capacity);
-    }
-}
-
 template <typename TableT, typename OutT, int F, int LPX>
 __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                           const TableT *__restrict__ tables, PermutoParams p,
@@ -289,6 +155,233 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(const float *__restric
 #pragma unroll
             for (int f = 0; f < F; ++f) atomicAdd(tab + (int64_t)idx[r] * F + f, gv[f] * bary[r]);
     }
+}
+
+
+// ------------------------------------------------------------------- binned (atomic-free) backward
+// d loss / d tables without global atomics.  Scattered fp32 global atomics run at ~6 G adds/s on
+// MI355X (they execute at the memory side, one 64-B request per lane), which made the scatter 77 % of
+// a train step.  Instead:
+//   pass 1 (bin_kernel)   one workgroup = (tile of TS consecutive samples, level).  Every lane
+//       recomputes its sample's vertices, the wave merges runs of equal vertex ids in adjacent lanes
+//       (consecutive samples of a ray share their simplex on the coarse levels), and the surviving
+//       (row, weighted gradient) entries are counting-sorted by table SLICE (slice = row >> shift,
+//       2^shift rows = 64 KiB of fp32 accumulators) into the tile's fixed-size region of the workspace;
+//       the per-slice offsets go to a header.  No global atomics, no counting pre-pass.
+//   pass 2 (reduce_kernel) one workgroup = (level, slice): it owns that slice of the gradient
+//       table in LDS, walks every tile's segment for its slice (coalesced reads, each entry read
+//       exactly once), accumulates with ds_add_f32 and finally adds the slice to the table with plain
+//       coalesced stores.
+constexpr int TS = 1024;          // samples per pass-1 tile (= threads per workgroup)
+constexpr int SLICE_SHIFT = 13;   // 8192 rows per slice: 64 KiB of fp32 accumulators at F = 2
+constexpr int NS_MAX = 256;       // slices per level supported (T <= 2^21)
+
+struct BinLayout {
+    uint32_t *keys;      // [L][ntiles][TS*NV]      row index inside its slice
+    float *vals;         // [L][ntiles][TS*NV][F]
+    uint32_t *header;    // [L][NS+1][ntiles]       exclusive offsets of each slice inside the tile region
+    int64_t ntiles;
+    int NS, shift;
+};
+
+// merge runs of equal keys in adjacent lanes: on return `emit` is set on the last lane of every run
+// and that lane's v[] holds the run's sum.  Skipped (wave-uniformly) when the wave has few repeats.
+template <int F>
+__device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[F], bool &emit, int lane) {
+    const uint32_t prev = __shfl_up(key, 1);
+    const bool same = live && lane > 0 && prev == key;
+    const unsigned long long m = __ballot(same);
+    emit = live;
+    if (__popcll(m) < 8) return;
+    bool f = !same;                      // head flag
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float up[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) up[k] = __shfl_up(v[k], d);
+        const bool fu = __shfl_up((int)f, d) != 0;
+        if (lane >= d && !f) {
+#pragma unroll
+            for (int k = 0; k < F; ++k) v[k] += up[k];
+            f = fu;
+        }
+    }
+    const bool next_same = (m >> ((lane + 1) & 63)) & 1ull;
+    emit = live && (lane == 63 || !next_same);
+}
+
+template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F>
+__global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
+                                                 int64_t sm, int64_t sc, HashParams hp, PermutoParams pp, BinLayout lay) {
+    constexpr int NV = KIND == 0 ? 8 : 4;
+    __shared__ uint32_t cnt[NS_MAX + 1];
+    __shared__ uint32_t offs[NS_MAX + 1];
+    const int level = blockIdx.y;
+    const int64_t tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t i = tile * TS + tid;
+    const bool live = i < M;
+    for (int s = tid; s <= lay.NS; s += TS) cnt[s] = 0;
+    uint32_t idx[NV];
+    float w[NV];
+    float gv[F];
+    {
+        const int64_t ic = live ? i : M - 1;
+        float x[3] = {xyz[ic * 3 + 0], xyz[ic * 3 + 1], xyz[ic * 3 + 2]};
+        if (KIND == 0) {
+            float w3[3];
+            uint32_t id8[8];
+            hash_cell(x, hp.res[level], hp.log2T, id8, w3);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                idx[k] = id8[k & 7];
+                w[k] = ((k & 4) ? w3[0] : 1.0f - w3[0]) * ((k & 2) ? w3[1] : 1.0f - w3[1]) * ((k & 1) ? w3[2] : 1.0f - w3[2]);
+            }
+        } else {
+            uint32_t id4[4];
+            float b4[4];
+            permuto_simplex(x, pp.shift[level], pp.sf[level], pp.capacity, pp.pow2mask, id4, b4);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                idx[k] = id4[k & 3];
+                w[k] = b4[k & 3];
+            }
+        }
+        const float *scale = KIND == 0 ? hp.scale : pp.scale;
+        const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            gv[f] = pag_ld(go + ic * sm + (int64_t)(level * F + f) * sc);
+            if (has_scale) gv[f] *= scale[level * F + f];
+        }
+    }
+    __syncthreads();
+    float ev[NV][F];
+    bool emit[NV];
+    uint32_t rank[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) ev[k][f] = gv[f] * w[k];
+        run_combine<F>(live ? idx[k] : 0xFFFFFFFFu, live, ev[k], emit[k], lane);
+        rank[k] = emit[k] ? atomicAdd(&cnt[idx[k] >> lay.shift], 1u) : 0u;
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive prefix over the NS slice counters by one wave
+        uint32_t carry = 0;
+        for (int s0 = 0; s0 < lay.NS; s0 += 64) {
+            const int s = s0 + lane;
+            uint32_t c = s < lay.NS ? cnt[s] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            if (s < lay.NS) offs[s] = carry + incl - c;
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0) offs[lay.NS] = carry;
+    }
+    __syncthreads();
+    const int64_t region = ((int64_t)level * lay.ntiles + tile) * (TS * NV);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (emit[k]) {
+            const uint32_t s = idx[k] >> lay.shift;
+            const int64_t pos = region + offs[s] + rank[k];
+            lay.keys[pos] = idx[k] & ((1u << lay.shift) - 1u);
+#pragma unroll
+            for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[k][f];
+        }
+    }
+    for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[s];
+}
+
+template <int F, int NV>
+__global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [2^shift][F]
+    const int level = blockIdx.x / lay.NS, slice = blockIdx.x % lay.NS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int slice_rows = 1 << lay.shift;
+    for (int j = tid; j < slice_rows * F; j += blockDim.x) acc[j] = 0.0f;
+    __syncthreads();
+    const uint32_t *hb = lay.header + ((int64_t)level * (lay.NS + 1) + slice) * lay.ntiles;
+    const uint32_t *he = hb + lay.ntiles;
+    for (int64_t t0 = (int64_t)wave * 64; t0 < lay.ntiles; t0 += (int64_t)nwaves * 64) {
+        const int64_t tl = t0 + lane;
+        const uint32_t mb = tl < lay.ntiles ? hb[tl] : 0u, me = tl < lay.ntiles ? he[tl] : 0u;
+        const int nt = (int)min((int64_t)64, lay.ntiles - t0);
+        for (int j = 0; j < nt; ++j) {
+            const uint32_t b = __shfl(mb, j), e = __shfl(me, j);
+            const int64_t region = ((int64_t)level * lay.ntiles + (t0 + j)) * (TS * NV);
+            for (uint32_t q = b + lane; q < e; q += 64) {
+                const uint32_t key = lay.keys[region + q];
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[key * F + f], lay.vals[(region + q) * F + f]);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)slice * slice_rows;
+    float *dst = gtab + ((int64_t)level * rows_per_level + row0) * F;
+    const int64_t valid = min((int64_t)slice_rows, rows_per_level - row0) * F;
+    for (int64_t j = tid; j < valid; j += blockDim.x) dst[j] += acc[j];
+}
+
+struct BinPlan {
+    int64_t ntiles, keys_bytes, vals_bytes, header_bytes, total;
+    int NS, shift;
+};
+inline BinPlan bin_plan(int64_t M, int L, int F, int NV, int64_t rows) {
+    BinPlan b;
+    b.shift = SLICE_SHIFT;
+    while (b.shift > 0 && ((int64_t)1 << b.shift) * F * 4 > 65536) --b.shift;
+    b.NS = (int)((rows + ((int64_t)1 << b.shift) - 1) >> b.shift);
+    b.ntiles = (M + TS - 1) / TS;
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    b.keys_bytes = up((int64_t)L * b.ntiles * TS * NV * 4);
+    b.vals_bytes = up((int64_t)L * b.ntiles * TS * NV * F * 4);
+    b.header_bytes = up((int64_t)L * (b.NS + 1) * b.ntiles * 4);
+    b.total = b.keys_bytes + b.vals_bytes + b.header_bytes;
+    return b;
+}
+
+template <int KIND>
+int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t sm, int64_t sc, int L, int F,
+                  int64_t rows, const HashParams &hp, const PermutoParams &pp, float *gtab, void *workspace,
+                  int64_t workspace_bytes, hipStream_t st, const char *name) {
+    constexpr int NV = KIND == 0 ? 8 : 4;
+    const BinPlan b = bin_plan(M, L, F, NV, rows);
+    PAG_CHECK_ARG(workspace_bytes >= b.total, "%s: workspace %lld B < required %lld B", name, (long long)workspace_bytes, (long long)b.total);
+    PAG_CHECK_ARG(b.NS <= NS_MAX, "%s: table too large for the binned backward (%d slices > %d)", name, b.NS, NS_MAX);
+    PAG_CHECK_ARG(F == 2 || F == 4 || F == 1, "%s: n_feat", name);
+    BinLayout lay;
+    char *wsp = (char *)workspace;
+    lay.keys = (uint32_t *)wsp;
+    lay.vals = (float *)(wsp + b.keys_bytes);
+    lay.header = (uint32_t *)(wsp + b.keys_bytes + b.vals_bytes);
+    lay.ntiles = b.ntiles;
+    lay.NS = b.NS;
+    lay.shift = b.shift;
+    dim3 g1((unsigned)b.ntiles, (unsigned)L), g2((unsigned)(L * b.NS));
+    const size_t lds = ((size_t)1 << b.shift) * F * sizeof(float);
+#define BIN_LAUNCH(GT, F_)                                                                                              \
+    do {                                                                                                                \
+        hipLaunchKernelGGL((bin_kernel<KIND, GT, F_>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, hp, pp, lay); \
+        hipLaunchKernelGGL((reduce_kernel<F_, NV>), g2, dim3(1024), lds, st, lay, rows, gtab);                         \
+    } while (0)
+    if (grad_dtype == PAG_F32) {
+        if (F == 2) BIN_LAUNCH(float, 2);
+        else if (F == 4) BIN_LAUNCH(float, 4);
+        else BIN_LAUNCH(float, 1);
+    } else {
+        if (F == 2) BIN_LAUNCH(bf16_t, 2);
+        else if (F == 4) BIN_LAUNCH(bf16_t, 4);
+        else BIN_LAUNCH(bf16_t, 1);
+    }
+#undef BIN_LAUNCH
+    return PAG_OK;
 }
 
 inline unsigned encode_grid(int64_t M) { return (unsigned)(((M + 255) / 256) * 8); }
@@ -363,7 +456,8 @@ extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tabl
 
 extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                    int64_t g_stride_c, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
-                                   const float *feat_scale_host, float *grad_tables, void *stream) {
+                                   const float *feat_scale_host, float *grad_tables, void *workspace,
+                                   int64_t workspace_bytes, void *stream) {
     int rc = check_common("pag_hash_encode_bwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_bwd: log2_T %d not in [1,30]", log2_T);
@@ -379,6 +473,14 @@ extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad
     for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
     const int lpx = (n_levels + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
+    if (workspace) {
+        PermutoParams unused{};
+        int r2 = launch_binned<0>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, n_levels, n_feat, (int64_t)1 << log2_T, p,
+                                  unused, grad_tables, workspace, workspace_bytes, st, "pag_hash_encode_bwd");
+        if (r2) return r2;
+        PAG_CHECK_LAUNCH("pag_hash_encode_bwd");
+        return PAG_OK;
+    }
     dim3 grid(encode_grid(M)), block(256);
     bool launched = false;
     if (grad_dtype == PAG_F32) {
@@ -442,7 +544,7 @@ extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *t
 extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                       int64_t g_stride_c, int n_levels, int n_feat, uint32_t capacity,
                                       const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                      float *grad_tables, void *stream) {
+                                      float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
     int rc = check_common("pag_permuto_encode_bwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_bwd: capacity is 0");
@@ -454,6 +556,14 @@ extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *g
     fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host);
     const int lpx = (n_levels + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
+    if (workspace) {
+        HashParams unused{};
+        int r2 = launch_binned<1>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, n_levels, n_feat, (int64_t)capacity, unused,
+                                  p, grad_tables, workspace, workspace_bytes, st, "pag_permuto_encode_bwd");
+        if (r2) return r2;
+        PAG_CHECK_LAUNCH("pag_permuto_encode_bwd");
+        return PAG_OK;
+    }
     dim3 grid(encode_grid(M)), block(256);
     bool launched = false;
     if (grad_dtype == PAG_F32) {
@@ -464,4 +574,9 @@ extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *g
     PAG_CHECK_ARG(launched, "pag_permuto_encode_bwd: unsupported (n_feat=%d, n_levels=%d)", n_feat, n_levels);
     PAG_CHECK_LAUNCH("pag_permuto_encode_bwd");
     return PAG_OK;
+}
+
+extern "C" int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int n_vertices, int64_t rows_per_level) {
+    if (M <= 0 || n_levels <= 0 || (n_vertices != 4 && n_vertices != 8) || rows_per_level <= 0) return 0;
+    return bin_plan(M, n_levels, n_feat, n_vertices, rows_per_level).total;
 }

@@ -1,0 +1,147 @@
+// Per-level vertex lookup shared by the encode forward / backward kernels (gfx950).
+// Numerics: explicit round-to-nearest intrinsics in the op order of the oracle
+// (oracle/hash_encode.py, oracle/permuto_encode.py); translation units that include this are
+// compiled with -ffp-contract=off.
+#pragma once
+#include "common.h"
+
+namespace pag_enc {
+
+struct HashParams {
+    float res[PAG_MAX_LEVELS];
+    float scale[PAG_MAX_FEATS];
+    int L, log2T, has_scale;
+};
+
+struct PermutoParams {
+    float sf[PAG_MAX_LEVELS][3];
+    float shift[PAG_MAX_LEVELS][3];
+    float scale[PAG_MAX_FEATS];
+    int L, has_scale;
+    uint32_t capacity, pow2mask;   // pow2mask = capacity-1 when capacity is a power of two, else 0
+};
+
+template <typename T, int F> struct Vec;
+template <> struct Vec<float, 1> { typedef float type; };
+template <> struct Vec<float, 2> { typedef float2 type; };
+template <> struct Vec<float, 4> { typedef float4 type; };
+template <> struct Vec<__half, 1> { typedef __half type; };
+template <> struct Vec<__half, 2> { typedef __half2 type; };
+template <> struct Vec<__half, 4> { typedef uint2 type; };
+
+template <int F> __device__ __forceinline__ void gather(const float *row, float (&v)[F]) {
+    typename Vec<float, F>::type t = *reinterpret_cast<const typename Vec<float, F>::type *>(row);
+    const float *p = reinterpret_cast<const float *>(&t);
+#pragma unroll
+    for (int f = 0; f < F; ++f) v[f] = p[f];
+}
+template <int F> __device__ __forceinline__ void gather(const __half *row, float (&v)[F]) {
+    typename Vec<__half, F>::type t = *reinterpret_cast<const typename Vec<__half, F>::type *>(row);
+    const __half *p = reinterpret_cast<const __half *>(&t);
+#pragma unroll
+    for (int f = 0; f < F; ++f) v[f] = __half2float(p[f]);
+}
+
+// ------------------------------------------------------------------------------------ hash grid
+// grids/hash_grid_torch.py:26-46 (cell lookup) and :69-77 (weights), one level.
+__device__ __forceinline__ void hash_cell(const float (&x)[3], float res, int log2T, uint32_t (&idx)[8], float (&w)[3]) {
+    const float cell = __fdiv_rn(2.0f, res);
+    uint32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float xc = fminf(fmaxf(x[a], -1.0f), 1.0f);
+        float t = __fdiv_rn(__fadd_rn(xc, 1.0f), cell);
+        int bl = (int)floorf(t);
+        float vmin = __fadd_rn(__fmul_rn((float)bl, cell), -1.0f);
+        float vmax = __fadd_rn(vmin, cell);
+        w[a] = __fdiv_rn(__fsub_rn(x[a], vmin), __fsub_rn(vmax, vmin));
+        c[a] = (uint32_t)bl;
+    }
+    const uint32_t mask = (1u << log2T) - 1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // corner k = 4i + 2j + kk (hash_grid_torch.py:10)
+        uint32_t cx = c[0] + ((k >> 2) & 1), cy = c[1] + ((k >> 1) & 1), cz = c[2] + (k & 1);
+        idx[k] = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & mask;
+    }
+}
+
+__device__ __forceinline__ float lerp_ref(float a, float b, float w, float omw) {
+    return __fadd_rn(__fmul_rn(a, omw), __fmul_rn(b, w));
+}
+
+// --------------------------------------------------------------------------- permutohedral lattice
+// oracle/permuto_encode.py lattice_simplex() + vertex_indices(), one level, d = 3.
+__device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float (&sh)[3], const float (&sf)[3],
+                                                uint32_t capacity, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4]) {
+    float cf[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) cf[a] = __fmul_rn(__fadd_rn(x[a], sh[a]), sf[a]);
+    float E[4];
+    float s = 0.0f;
+    E[3] = __fsub_rn(s, __fmul_rn(3.0f, cf[2]));
+    s = __fadd_rn(s, cf[2]);
+    E[2] = __fsub_rn(s, __fmul_rn(2.0f, cf[1]));
+    s = __fadd_rn(s, cf[1]);
+    E[1] = __fsub_rn(s, cf[0]);
+    s = __fadd_rn(s, cf[0]);
+    E[0] = s;
+
+    int rem0[4], rank[4] = {0, 0, 0, 0};
+    float resid[4];
+    int sum = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float v = E[a] * 0.25f;
+        float up = ceilf(v) * 4.0f, dn = floorf(v) * 4.0f;
+        float r = (__fsub_rn(up, E[a]) < __fsub_rn(E[a], dn)) ? up : dn;
+        rem0[a] = (int)r;
+        sum += rem0[a];
+        resid[a] = __fsub_rn(E[a], r);
+    }
+    sum >>= 2;   // exact: every rem0 is a multiple of 4
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            int lt = resid[a] < resid[b];
+            rank[a] += lt;
+            rank[b] += 1 - lt;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        rank[a] += sum;
+        if (rank[a] < 0) {
+            rank[a] += 4;
+            rem0[a] += 4;
+        } else if (rank[a] > 3) {
+            rank[a] -= 4;
+            rem0[a] -= 4;
+        }
+    }
+    float b5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float delta = __fsub_rn(E[a], (float)rem0[a]) * 0.25f;
+        int slot = 3 - rank[a];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {   // predicated: no runtime-indexed private array
+            b5[k] = (k == slot) ? __fadd_rn(b5[k], delta) : b5[k];
+            b5[k] = (k == slot + 1) ? __fsub_rn(b5[k], delta) : b5[k];
+        }
+    }
+    b5[0] = __fadd_rn(b5[0], __fadd_rn(1.0f, b5[4]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bary[r] = b5[r];
+        uint32_t k = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int key = rem0[a] + r - ((rank[a] > 3 - r) ? 4 : 0);
+            k = (k + (uint32_t)key) * 2531011u;
+        }
+        idx[r] = pow2mask ? (k & pow2mask) : (k % capacity);
+    }
+}
+
+
+}  // namespace pag_enc

@@ -91,17 +91,25 @@ def _encode_fwd(spec, xyz, tables, feat_scale, out):
               spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
 
 
+BWD_ALGO = "binned"     # "binned": atomic-free two-pass scatter (default); "atomic": per-vertex fp32 global atomics
+
+
 def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
     lib = L.load()
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
     sm, sc = grad_out.stride(0), grad_out.stride(1)
+    ws, ws_ptr, ws_bytes = None, None, 0
+    if BWD_ALGO == "binned":
+        ws_bytes = lib.pag_encode_bwd_workspace_bytes(M, spec.L, spec.F, 8 if spec.kind == "hash" else 4, spec.rows())
+        ws = torch.empty(ws_bytes, device=xyz.device, dtype=torch.uint8)
+        ws_ptr = ws.data_ptr()
     if spec.kind == "hash":
         _call("pag_hash_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
-              spec.log2_T, spec.res, fs, L.ptr(grad_tables), L.stream())
+              spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
     else:
         _call("pag_permuto_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
-              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), L.stream())
+              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
 
 
 class _Encode(torch.autograd.Function):

@@ -58,9 +58,12 @@ def test_hash_encode_variants_and_backward(gpu_device):
         outs = ops.encode(x.to(gpu_device), tg, spec, feat_scale=scale)
         assert np.array_equal(outs.detach().cpu().numpy(), (ref * scale).numpy())
         go = torch.from_numpy(rs.standard_normal(size=ref.shape).astype(np.float32))
-        outs.backward(go.to(gpu_device))
         gref = oh.hash_encode_bwd(x, go * scale, 2 ** log2T, res, log2T)
-        np.testing.assert_allclose(tg.grad.cpu().numpy(), gref.numpy(), rtol=2e-4, atol=2e-5)
+        for algo in ("binned", "atomic"):
+            ops.BWD_ALGO, tg.grad = algo, None
+            ops.encode(x.to(gpu_device), tg, spec, feat_scale=scale).backward(go.to(gpu_device))
+            np.testing.assert_allclose(tg.grad.cpu().numpy(), gref.numpy(), rtol=2e-4, atol=2e-5, err_msg=algo)
+        ops.BWD_ALGO = "binned"
         # bf16 output / fp16 tables stay within their rounding
         ob = ops.encode(x.to(gpu_device), tg.detach(), spec, out_dtype=torch.bfloat16).float().cpu()
         np.testing.assert_allclose(ob.numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
@@ -92,9 +95,17 @@ def test_permuto_encode_bit_exact_vs_oracle_and_backward(gpu_device):
         got = out.detach().cpu().numpy()
         assert np.array_equal(got, ref), "max abs diff %g at L=%d" % (np.abs(got - ref).max(), Lv)
         go = rs.standard_normal(size=ref.shape).astype(np.float32)
-        out.backward(torch.from_numpy(go).to(gpu_device))
         gref = op.permuto_encode_bwd(x, go, cap, shifts, sf)
-        np.testing.assert_allclose(tg.grad.cpu().numpy(), gref, rtol=2e-4, atol=2e-5)
+        for algo in ("binned", "atomic"):
+            ops.BWD_ALGO, tg.grad = algo, None
+            ops.encode(xg, tg, spec).backward(torch.from_numpy(go).to(gpu_device))
+            np.testing.assert_allclose(tg.grad.cpu().numpy(), gref, rtol=2e-4, atol=2e-5, err_msg=algo)
+            # bf16 upstream gradient, feature-major (the production layout)
+            tg.grad = None
+            ops.encode(xg, tg, spec, out_dtype=torch.bfloat16, feature_major=True).backward(torch.from_numpy(go).to(gpu_device).bfloat16())
+            gref16 = op.permuto_encode_bwd(x, torch.from_numpy(go).bfloat16().float().numpy(), cap, shifts, sf)
+            np.testing.assert_allclose(tg.grad.cpu().numpy(), gref16, rtol=2e-4, atol=2e-5, err_msg=algo + " bf16")
+        ops.BWD_ALGO = "binned"
         fm = ops.encode(xg, tg.detach(), spec, out_dtype=torch.bfloat16, feature_major=True)
         np.testing.assert_allclose(fm.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
 
