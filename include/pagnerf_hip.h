@@ -142,6 +142,19 @@ typedef struct {
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 
+/* Weight and bias gradients of one Linear layer of pag_mlp_fwd (MFMA mode):
+ *   dW[o][i] = sum_m dz[m][o] * a[m][i],  db[o] = sum_m dz[m][o]
+ * with a = the layer's input: [M,k1] (F32 or BF16) optionally followed by gathered per-ray columns
+ * a2[a2_index[m]] (layer 0 of the colour decoder), n_in <= 64 columns used.
+ *   dz      bf16 [M, dz_cols] (dz_cols >= n_out; the hidden layers' dz are [M,64])
+ *   slabs   f32 [n_blocks][ceil(n_out/32)*32][96] per-workgroup partial sums written (not
+ *           accumulated) by the kernel: columns 0..n_in-1 = dW rows, column 64 = db.  The caller sums
+ *           over n_blocks (n_blocks = pag_mlp_wgrad_blocks(M)) - deterministic, no atomics. */
+int pag_mlp_wgrad_blocks(int64_t M);
+int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1_dtype, int k1,
+                  const float *a2, int k2p, const int32_t *a2_index, int n_in, float *slabs,
+                  int n_blocks, int64_t M, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray march (wisp OctreeAS.raymarch, 'ray' mode) - tracers/panoptic_packed_rf_tracer.py:85-86
  * ------------------------------------------------------------------------------------------ */

@@ -583,6 +583,112 @@ __global__ __launch_bounds__(PT) void mlp_bwd_f32(BwdParams p, int n_layers) {
     }
 }
 
+
+// ------------------------------------------------------------------------------- weight gradients
+// dW[out][in] = sum_m dz[m][out] * a[m][in]  and  db[out] = sum_m dz[m][out]: a GEMM whose reduction
+// runs over the M ~ 2e6 samples with both operands K-major in memory, which BLAS libraries handle
+// badly (2.5 ms per layer measured).  Here each workgroup walks 64-sample chunks: the [64 x n_out] dz
+// tile and the [64 x n_in] input tile are transposed into LDS (lane = sample, so the ds_write_b16
+// stores are conflict-free), every wave owns up to 6 of the 32x32 (out-block, in-block) pairs and
+// feeds them with ds_read_b128 fragments; an extra in-block whose B fragment is the constant
+// "1 in column 0" yields db for free.  Partial sums are written as per-workgroup fp32 slabs
+// [blocks][OB*32][96] (cols 0..63 = dW, col 64 = db) and summed by the caller - deterministic, no atomics.
+struct WgradParams {
+    const bf16_t *dz;
+    int dz_cols, n_out;
+    const void *a1;
+    int k1;
+    const float *a2;
+    int k2p;
+    const int32_t *a2_index;
+    int n_in;
+    float *slabs;
+    int64_t M;
+};
+constexpr int WG_RS = 72;       // LDS row stride (bf16) of the transposed tiles: 64 samples + 8 pad
+constexpr int WG_SLAB_COLS = 96;
+
+template <typename A1T>
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int OB = (p.n_out + 31) / 32;
+    const int IB = (p.n_in + 31) / 32;                 // 1 or 2
+    bf16_t *Zt = reinterpret_cast<bf16_t *>(smem);      // [OB*32][WG_RS]
+    bf16_t *At = Zt + OB * 32 * WG_RS;                  // [IB*32][WG_RS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int npairs = OB * (IB + 1);
+    f32x16 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(r == 0 ? 1.0f : 0.0f);
+    const A1T *a1 = reinterpret_cast<const A1T *>(p.a1);
+    const bool dz_vec = (p.dz_cols % 8) == 0;
+    const int64_t nchunks = (p.M + 63) / 64;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t m = chunk * 64 + lane;
+        const bool live = m < p.M;
+        const int64_t mc = live ? m : p.M - 1;
+        // ---- dz tile, transposed: Zt[col][sample]
+        for (int cg = wave; cg < OB * 4; cg += 4) {
+            const int c0 = 8 * cg;
+            bf16x8 v = zero8();
+            if (live && c0 < p.dz_cols) {
+                if (dz_vec) {
+                    v = load8(p.dz + mc * p.dz_cols + c0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (c0 + j < p.dz_cols) v[j] = p.dz[mc * p.dz_cols + c0 + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Zt[(c0 + j) * WG_RS + lane] = v[j];
+        }
+        // ---- input tile, transposed: At[col][sample]
+        for (int cg = wave; cg < IB * 4; cg += 4) {
+            const int c0 = 8 * cg;
+            bf16x8 v = zero8();
+            if (live && c0 < p.k1)
+                v = load8(a1 + mc * p.k1 + c0);
+            else if (live && p.a2 && c0 < p.k1 + p.k2p)
+                v = load8(p.a2 + (int64_t)p.a2_index[mc] * p.k2p + (c0 - p.k1));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) At[(c0 + j) * WG_RS + lane] = (c0 + j < p.n_in) ? v[j] : (bf16_t)0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pr = wave + 4 * i;
+            if (pr < npairs) {
+                const int ob = pr / (IB + 1), ib = pr - ob * (IB + 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(Zt + (32 * ob + r) * WG_RS + 16 * ks + 8 * h);
+                    bf16x8 b = ones;
+                    if (ib < IB) b = *reinterpret_cast<const bf16x8 *>(At + (32 * ib + r) * WG_RS + 16 * ks + 8 * h);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *slab = p.slabs + (int64_t)blockIdx.x * OB * 32 * WG_SLAB_COLS;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pr = wave + 4 * i;
+        if (pr < npairs) {
+            const int ob = pr / (IB + 1), ib = pr - ob * (IB + 1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) slab[(32 * ob + rho(q, h)) * WG_SLAB_COLS + (ib < IB ? 32 * ib : 64) + r] = acc[i][q];
+        }
+    }
+}
+
 inline unsigned mlp_grid(int64_t M) {
     int64_t tiles = (M + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
@@ -740,5 +846,32 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         else hipLaunchKernelGGL((mlp_bwd_f32<bf16_t, bf16_t>), grid, block, lds, st, p, a->n_layers);
     }
     PAG_CHECK_LAUNCH("pag_mlp_bwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_mlp_wgrad_blocks(int64_t M) {
+    int64_t chunks = (M + 63) / 64;
+    return (int)(chunks < 512 ? (chunks > 0 ? chunks : 1) : 512);
+}
+
+extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1_dtype, int k1, const float *a2,
+                             int k2p, const int32_t *a2_index, int n_in, float *slabs, int n_blocks, int64_t M, void *stream) {
+    PAG_CHECK_ARG(M >= 0, "pag_mlp_wgrad: M < 0");
+    PAG_CHECK_ARG(n_out >= 1 && n_out <= 224 && dz_cols >= n_out, "pag_mlp_wgrad: n_out %d / dz_cols %d out of range", n_out, dz_cols);
+    PAG_CHECK_ARG(k1 > 0 && k1 % 8 == 0, "pag_mlp_wgrad: k1 %d must be a positive multiple of 8", k1);
+    PAG_CHECK_ARG(a2 == nullptr || (k2p > 0 && k2p % 8 == 0 && a2_index), "pag_mlp_wgrad: a2 needs k2p %% 8 == 0 and a2_index");
+    PAG_CHECK_ARG(n_in >= 1 && n_in <= 64 && n_in <= k1 + (a2 ? k2p : 0), "pag_mlp_wgrad: n_in %d out of range", n_in);
+    PAG_CHECK_ARG(a1_dtype == PAG_F32 || a1_dtype == PAG_BF16, "pag_mlp_wgrad: a1 dtype must be F32 or BF16");
+    PAG_CHECK_ARG(n_blocks >= 1, "pag_mlp_wgrad: n_blocks < 1");
+    if (M == 0) return PAG_OK;
+    PAG_CHECK_ARG(dz && a1 && slabs, "pag_mlp_wgrad: NULL dz/a1/slabs");
+    WgradParams p{(const bf16_t *)dz, dz_cols, n_out, a1, k1, a2, a2 ? k2p : 0, a2_index, n_in, slabs, M};
+    const int OB = (n_out + 31) / 32, IB = (n_in + 31) / 32;
+    const size_t lds = (size_t)(OB + IB) * 32 * WG_RS * sizeof(bf16_t);
+    if (a1_dtype == PAG_F32)
+        hipLaunchKernelGGL((mlp_wgrad_kernel<float>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+    PAG_CHECK_LAUNCH("pag_mlp_wgrad");
     return PAG_OK;
 }

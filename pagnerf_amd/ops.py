@@ -225,24 +225,39 @@ class _FusedMLP(torch.autograd.Function):
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
         if M:
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
-        # weight gradients: dz_l^T @ input_l - plain GEMMs, left to the BLAS library
         gW, gb = [], []
-        for l in range(n_layers):
-            z = dz[l]
-            if l == 0:
-                n1 = min(k1, in_dim)
-                xa = x1[:, :n1]
-                if xa.dtype != z.dtype:
-                    xa = xa.to(z.dtype)
-                w = _mm_f32(z.t(), xa)
-                if in_dim > k1:
-                    seg = torch.zeros(x2.shape[0], 64, device=dev, dtype=torch.float32)
-                    seg.index_add_(0, x2_index.long(), z.float())
-                    w = torch.cat([w, seg.t() @ x2[:, :in_dim - k1]], dim=1)
-            else:
-                w = _mm_f32(z.t(), hidden[l - 1])
-            gW.append(w)
-            gb.append(z.sum(0, dtype=torch.float32))
+        if mode == L.MLP_MFMA_BF16 and M:
+            # weight gradients on the matrix cores: per-workgroup fp32 slabs, summed here (deterministic)
+            nblk = lib.pag_mlp_wgrad_blocks(M)
+            for l in range(n_layers):
+                n_out = Wc[l].shape[0]
+                slabs = torch.empty(nblk, (n_out + 31) // 32 * 32, 96, device=dev)
+                if l == 0:
+                    _call("pag_mlp_wgrad", L.ptr(dz[0]), dz[0].shape[1], n_out, L.ptr(x1), L.dtype_code(x1), k1, L.ptr(x2),
+                          x2.shape[1] if x2 is not None else 0, L.ptr(x2_index), in_dim, L.ptr(slabs), nblk, M, L.stream())
+                    n_in = in_dim
+                else:
+                    _call("pag_mlp_wgrad", L.ptr(dz[l]), dz[l].shape[1], n_out, L.ptr(hidden[l - 1]), L.BF16, 64, None, 0, None, 64,
+                          L.ptr(slabs), nblk, M, L.stream())
+                    n_in = 64
+                red = slabs.sum(0)
+                gW.append(red[:n_out, :n_in].contiguous())
+                gb.append(red[:n_out, 64].contiguous())
+        else:
+            # fp32 parity path: dz_l^T @ input_l as plain fp32 GEMMs (BLAS)
+            for l in range(n_layers):
+                z = dz[l]
+                if l == 0:
+                    n1 = min(k1, in_dim)
+                    w = _mm_f32(z.t(), x1[:, :n1].to(z.dtype))
+                    if in_dim > k1:
+                        seg = torch.zeros(x2.shape[0], 64, device=dev, dtype=torch.float32)
+                        seg.index_add_(0, x2_index.long(), z.float())
+                        w = torch.cat([w, seg.t() @ x2[:, :in_dim - k1]], dim=1)
+                else:
+                    w = _mm_f32(z.t(), hidden[l - 1])
+                gW.append(w)
+                gb.append(z.sum(0, dtype=torch.float32))
         return (dx1, None, None, None, None, None, None, None, *gW, *gb)
 
 
