@@ -34,6 +34,11 @@ enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = 
 enum { PAG_ACT_NONE = 0, PAG_ACT_SIGMOID = 1, PAG_ACT_SOFTMAX = 2 };
 enum { PAG_MLP_MFMA_BF16 = 0, PAG_MLP_FP32 = 1 };
 enum { PAG_BG_BLACK = 0, PAG_BG_WHITE = 1 };
+/* feature-tensor layouts of the encoders / decoder inputs:
+ *   PAG_LAYOUT_STRIDED  [M, L*F] addressed through (stride_m, stride_c); column = level*F + f
+ *   PAG_LAYOUT_XCD8     bf16 [8][M][8]: group g = level % 8, element e = (level / 8)*F + f, zero padded
+ *                       (requires ceil(L/8)*F <= 8).  Strides are ignored. */
+enum { PAG_LAYOUT_STRIDED = 0, PAG_LAYOUT_XCD8 = 1 };
 #define PAG_MAX_LEVELS 32
 #define PAG_MAX_FEATS 64
 
@@ -58,13 +63,13 @@ const char *pag_last_error_string(void);
 int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype,
                         int n_levels, int n_feat, int log2_T, const float *resolutions_host,
                         const float *feat_scale_host, void *out, int out_dtype,
-                        int64_t out_stride_m, int64_t out_stride_c, void *stream);
+                        int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream);
 
 /* d loss / d tables (what autograd through grids/hash_grid_torch.py:95-108 yields).
  *   grad_out  [M, L*F] via strides (PAG_F32 or PAG_BF16);  grad_tables f32 [L,T,F], ACCUMULATED
  *   into (caller zeroes).  workspace: see pag_encode_bwd_workspace_bytes(). */
 int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
-                        int64_t g_stride_m, int64_t g_stride_c, int n_levels, int n_feat,
+                        int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                         int log2_T, const float *resolutions_host, const float *feat_scale_host,
                         float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
 
@@ -78,10 +83,10 @@ int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int 
                            int n_levels, int n_feat, uint32_t capacity,
                            const float *scale_factor_host, const float *shift_host,
                            const float *feat_scale_host, void *out, int out_dtype,
-                           int64_t out_stride_m, int64_t out_stride_c, void *stream);
+                           int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream);
 
 int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
-                           int64_t g_stride_m, int64_t g_stride_c, int n_levels, int n_feat,
+                           int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                            uint32_t capacity, const float *scale_factor_host,
                            const float *shift_host, const float *feat_scale_host,
                            float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
@@ -115,6 +120,8 @@ int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int 
  *             PAG_MLP_FP32: fp32 FMA chain in k order (parity path) */
 typedef struct {
     const void *x1; int x1_dtype; int k1;
+    int x1_layout; int x1_levels; int x1_feats;   /* PAG_LAYOUT_XCD8: x1 is the encoders' bf16 [8][M][8]
+                                                     output for (levels, feats); k1 = 64, in_dim = levels*feats */
     const float *x2; int k2p; const int32_t *x2_index;
     int in_dim; int n_layers; int out_dim;
     const float *W[3]; const float *b[3];
@@ -134,6 +141,7 @@ int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
 typedef struct {
     const float *grad_out; const void *out; int out_dtype; int out_act;
     int k1; int in_dim; int n_layers; int out_dim;
+    int x1_layout; int x1_levels; int x1_feats;   /* as in pag_mlp_fwd_args: dx1 is then written as bf16 [8][M][8] */
     const float *W[3];
     const void *hidden_save[2];
     void *dz[3];
@@ -147,13 +155,15 @@ int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
  * with a = the layer's input: [M,k1] (F32 or BF16) optionally followed by gathered per-ray columns
  * a2[a2_index[m]] (layer 0 of the colour decoder), n_in <= 64 columns used.
  *   dz      bf16 [M, dz_cols] (dz_cols >= n_out; the hidden layers' dz are [M,64])
+ *   a1_layout PAG_LAYOUT_XCD8: a1 is the encoders' bf16 [8][M][8] tensor (k1 = n_in = 64); slab column p
+ *           then holds the gradient of feature column level*F+f with p = 8*(level%8) + (level/8)*F + f.
  *   slabs   f32 [n_blocks][ceil(n_out/32)*32][96] per-workgroup partial sums written (not
  *           accumulated) by the kernel: columns 0..n_in-1 = dW rows, column 64 = db.  The caller sums
  *           over n_blocks (n_blocks = pag_mlp_wgrad_blocks(M)) - deterministic, no atomics. */
 int pag_mlp_wgrad_blocks(int64_t M);
-int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1_dtype, int k1,
-                  const float *a2, int k2p, const int32_t *a2_index, int n_in, float *slabs,
-                  int n_blocks, int64_t M, void *stream);
+int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1_dtype,
+                  int a1_layout, int k1, const float *a2, int k2p, const int32_t *a2_index, int n_in,
+                  float *slabs, int n_blocks, int64_t M, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray march (wisp OctreeAS.raymarch, 'ray' mode) - tracers/panoptic_packed_rf_tracer.py:85-86

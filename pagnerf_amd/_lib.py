@@ -14,6 +14,7 @@ F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_SIGMOID, ACT_SOFTMAX = 0, 1, 2
 MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
+LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -23,6 +24,7 @@ c_fp = ctypes.POINTER(ctypes.c_float)
 
 class MlpFwdArgs(ctypes.Structure):
     _fields_ = [("x1", c_vp), ("x1_dtype", c_i32), ("k1", c_i32),
+                ("x1_layout", c_i32), ("x1_levels", c_i32), ("x1_feats", c_i32),
                 ("x2", c_vp), ("k2p", c_i32), ("x2_index", c_vp),
                 ("in_dim", c_i32), ("n_layers", c_i32), ("out_dim", c_i32),
                 ("W", c_vp * 3), ("b", c_vp * 3),
@@ -35,6 +37,7 @@ class MlpFwdArgs(ctypes.Structure):
 class MlpBwdArgs(ctypes.Structure):
     _fields_ = [("grad_out", c_vp), ("out", c_vp), ("out_dtype", c_i32), ("out_act", c_i32),
                 ("k1", c_i32), ("in_dim", c_i32), ("n_layers", c_i32), ("out_dim", c_i32),
+                ("x1_layout", c_i32), ("x1_levels", c_i32), ("x1_feats", c_i32),
                 ("W", c_vp * 3),
                 ("hidden_save", c_vp * 2),
                 ("dz", c_vp * 3),
@@ -45,15 +48,15 @@ class MlpBwdArgs(ctypes.Structure):
 _SIGS = {
     "pag_abi_version": (c_i32, []),
     "pag_last_error_string": (ctypes.c_char_p, []),
-    "pag_hash_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_vp]),
-    "pag_hash_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
-    "pag_permuto_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_vp]),
-    "pag_permuto_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
+    "pag_hash_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
+    "pag_hash_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
+    "pag_permuto_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
+    "pag_permuto_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
     "pag_encode_bwd_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32, c_i64]),
     "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
     "pag_mlp_wgrad_blocks": (c_i32, [c_i64]),
-    "pag_mlp_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
+    "pag_mlp_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
     "pag_raymarch_count": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),
     "pag_raymarch_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -19,10 +19,24 @@ using namespace pag_enc;
 
 namespace {
 
+// XCD-grouped feature layout (PAG_LAYOUT_XCD8): out[g][m][8] bf16, g = level % 8, element e = (level / 8) * F + f
+// (zero padded): each lane stores ONE aligned 16-byte piece holding all the levels it computed, a wave
+// stores 1 KiB contiguously - instead of LPX*F scattered 2-byte pieces per sample in a [M, L*F] row
+// (measured 8x write amplification).  The decoders read the same pieces as MFMA B fragments.
+template <int N>
+__device__ __forceinline__ void store_grouped(bf16_t *out, int64_t M, int g, int64_t i, const float (&v)[N]) {
+    typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(e < N ? v[e < N ? e : 0] : 0.0f);
+    *reinterpret_cast<bf16x8_t *>(out + ((int64_t)g * M + i) * 8) = o;
+}
+__device__ __forceinline__ void store_grouped(float *, int64_t, int, int64_t, ...) {}
+
 template <typename TableT, typename OutT, int F, int LPX>
 __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                        const TableT *__restrict__ tables, HashParams p,
-                                                       OutT *__restrict__ out, int64_t sm, int64_t sc) {
+                                                       OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped) {
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
@@ -30,6 +44,9 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
     const int64_t T = (int64_t)1 << p.log2T;
     float e[LPX][8][F];
     float w[LPX][3];
+    float gvals[LPX * F <= 8 ? LPX * F : 1];
+#pragma unroll
+    for (int q = 0; q < (LPX * F <= 8 ? LPX * F : 1); ++q) gvals[q] = 0.0f;
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
         int l = g + 8 * j;
@@ -56,9 +73,12 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
             float c1 = lerp_ref(c01, c11, wy, oy);
             float v = lerp_ref(c0, c1, wz, oz);
             if (p.has_scale) v = __fmul_rn(v, p.scale[l * F + f]);
-            pag_st(out + i * sm + (int64_t)(l * F + f) * sc, v);
+            if (!grouped) pag_st(out + i * sm + (int64_t)(l * F + f) * sc, v);
+            if constexpr (LPX * F <= 8) gvals[j * F + f] = v;
         }
     }
+    if constexpr (LPX * F <= 8 && sizeof(OutT) == 2)
+        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals);
 }
 
 template <typename GradT, int F, int LPX>
@@ -96,13 +116,16 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(const float *__restrict__
 template <typename TableT, typename OutT, int F, int LPX>
 __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                           const TableT *__restrict__ tables, PermutoParams p,
-                                                          OutT *__restrict__ out, int64_t sm, int64_t sc) {
+                                                          OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped) {
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
     float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
     float e[LPX][4][F];
     float bary[LPX][4];
+    float gvals[LPX * F <= 8 ? LPX * F : 1];
+#pragma unroll
+    for (int q = 0; q < (LPX * F <= 8 ? LPX * F : 1); ++q) gvals[q] = 0.0f;
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
         int l = g + 8 * j;
@@ -123,9 +146,12 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __fadd_rn(acc, __fmul_rn(e[j][r][f], bary[j][r]));
             if (p.has_scale) acc = __fmul_rn(acc, p.scale[l * F + f]);
-            pag_st(out + i * sm + (int64_t)(l * F + f) * sc, acc);
+            if (!grouped) pag_st(out + i * sm + (int64_t)(l * F + f) * sc, acc);
+            if constexpr (LPX * F <= 8) gvals[j * F + f] = acc;
         }
     }
+    if constexpr (LPX * F <= 8 && sizeof(OutT) == 2)
+        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals);
 }
 
 template <typename GradT, int F, int LPX>
@@ -212,22 +238,35 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[
 
 template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F>
 __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
-                                                 int64_t sm, int64_t sc, HashParams hp, PermutoParams pp, BinLayout lay) {
+                                                 int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
     __shared__ uint32_t cnt[NS_MAX + 1];
     __shared__ uint32_t offs[NS_MAX + 1];
-    const int level = blockIdx.y;
+    const int L = KIND == 0 ? hp.L : pp.L;
     const int64_t tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t i = tile * TS + tid;
     const bool live = i < M;
-    for (int s = tid; s <= lay.NS; s += TS) cnt[s] = 0;
-    uint32_t idx[NV];
-    float w[NV];
-    float gv[F];
-    {
-        const int64_t ic = live ? i : M - 1;
-        float x[3] = {xyz[ic * 3 + 0], xyz[ic * 3 + 1], xyz[ic * 3 + 2]};
+    const int64_t ic = live ? i : M - 1;
+    float x[3] = {xyz[ic * 3 + 0], xyz[ic * 3 + 1], xyz[ic * 3 + 2]};
+    // grouped: blockIdx.y = XCD group g, levels g, g+8, ...; the 16-byte gradient piece is read once.
+    // strided: blockIdx.y = level.
+    float gpiece[8];
+    if (grouped) {
+        typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t t = *reinterpret_cast<const bf16x8_t *>(reinterpret_cast<const bf16_t *>(go) + ((int64_t)blockIdx.y * M + ic) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gpiece[e] = (float)t[e];
+    }
+    const float *scale = KIND == 0 ? hp.scale : pp.scale;
+    const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
+    for (int j = 0; j < (grouped ? 4 : 1); ++j) {
+        const int level = grouped ? (int)blockIdx.y + 8 * j : (int)blockIdx.y;
+        if (level >= L) break;
+        for (int s = tid; s <= lay.NS; s += TS) cnt[s] = 0;
+        uint32_t idx[NV];
+        float w[NV];
+        float gv[F];
         if (KIND == 0) {
             float w3[3];
             uint32_t id8[8];
@@ -247,55 +286,90 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
                 w[k] = b4[k & 3];
             }
         }
-        const float *scale = KIND == 0 ? hp.scale : pp.scale;
-        const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            gv[f] = pag_ld(go + ic * sm + (int64_t)(level * F + f) * sc);
+            if (grouped) {
+                float t = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t = (e == j * F + f) ? gpiece[e] : t;
+                gv[f] = t;
+            } else {
+                gv[f] = pag_ld(go + ic * sm + (int64_t)(level * F + f) * sc);
+            }
             if (has_scale) gv[f] *= scale[level * F + f];
         }
-    }
-    __syncthreads();
-    float ev[NV][F];
-    bool emit[NV];
-    uint32_t rank[NV];
+        __syncthreads();
+        float ev[NV][F];
+        bool emit[NV];
+        uint32_t rank[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
+        for (int k = 0; k < NV; ++k) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) ev[k][f] = gv[f] * w[k];
-        run_combine<F>(live ? idx[k] : 0xFFFFFFFFu, live, ev[k], emit[k], lane);
-        rank[k] = emit[k] ? atomicAdd(&cnt[idx[k] >> lay.shift], 1u) : 0u;
-    }
-    __syncthreads();
-    if (tid < 64) {   // exclusive prefix over the NS slice counters by one wave
-        uint32_t carry = 0;
-        for (int s0 = 0; s0 < lay.NS; s0 += 64) {
-            const int s = s0 + lane;
-            uint32_t c = s < lay.NS ? cnt[s] : 0u;
-            uint32_t incl = c;
+            for (int f = 0; f < F; ++f) ev[k][f] = gv[f] * w[k];
+            run_combine<F>(live ? idx[k] : 0xFFFFFFFFu, live, ev[k], emit[k], lane);
+            rank[k] = emit[k] ? atomicAdd(&cnt[idx[k] >> lay.shift], 1u) : 0u;
+        }
+        __syncthreads();
+        if (tid < 64) {   // exclusive prefix over the NS slice counters by one wave
+            uint32_t carry = 0;
+            for (int s0 = 0; s0 < lay.NS; s0 += 64) {
+                const int s = s0 + lane;
+                uint32_t c = s < lay.NS ? cnt[s] : 0u;
+                uint32_t incl = c;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
+                for (int d = 1; d < 64; d <<= 1) {
+                    uint32_t t = __shfl_up(incl, d);
+                    if (lane >= d) incl += t;
+                }
+                if (s < lay.NS) offs[s] = carry + incl - c;
+                carry += __shfl(incl, 63);
             }
-            if (s < lay.NS) offs[s] = carry + incl - c;
-            carry += __shfl(incl, 63);
+            if (lane == 0) offs[lay.NS] = carry;
         }
-        if (lane == 0) offs[lay.NS] = carry;
-    }
-    __syncthreads();
-    const int64_t region = ((int64_t)level * lay.ntiles + tile) * (TS * NV);
+        __syncthreads();
+        const int64_t region = ((int64_t)level * lay.ntiles + tile) * (TS * NV);
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (emit[k]) {
-            const uint32_t s = idx[k] >> lay.shift;
-            const int64_t pos = region + offs[s] + rank[k];
-            lay.keys[pos] = idx[k] & ((1u << lay.shift) - 1u);
+        for (int k = 0; k < NV; ++k) {
+            if (emit[k]) {
+                const uint32_t s = idx[k] >> lay.shift;
+                const int64_t pos = region + offs[s] + rank[k];
+                lay.keys[pos] = idx[k] & ((1u << lay.shift) - 1u);
 #pragma unroll
-            for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[k][f];
+                for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[k][f];
+            }
         }
+        for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[s];
+        __syncthreads();
     }
-    for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[s];
+}
+
+// Add one wave's 64 (key, value) entries into the LDS slice.  On the coarse levels a few rows receive
+// almost every entry; 64 lanes hitting one LDS address serialise, so rows that several lanes share are
+// first summed across the wave (ballot-match on the leading lane's key, masked butterfly sum) and added
+// once; what is left goes in directly.
+template <int F>
+__device__ __forceinline__ void lds_accumulate(float *acc, uint32_t key, const float (&val)[F], bool valid, int lane) {
+    unsigned long long active = __ballot(valid);
+#pragma unroll 1
+    for (int it = 0; it < 8 && active; ++it) {
+        const int leader = __ffsll((long long)active) - 1;
+        const uint32_t lk = __shfl(key, leader);
+        const unsigned long long m = __ballot(valid && key == lk) & active;
+        if (__popcll(m) < 4) break;
+        const bool mine = (m >> lane) & 1ull;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            float v = mine ? val[f] : 0.0f;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+            if (lane == leader) atomicAdd(&acc[lk * F + f], v);
+        }
+        active &= ~m;
+    }
+    if ((active >> lane) & 1ull) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(&acc[key * F + f], val[f]);
+    }
 }
 
 template <int F, int NV>
@@ -312,13 +386,52 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         const int64_t tl = t0 + lane;
         const uint32_t mb = tl < lay.ntiles ? hb[tl] : 0u, me = tl < lay.ntiles ? he[tl] : 0u;
         const int nt = (int)min((int64_t)64, lay.ntiles - t0);
+        // software pipeline: the first 64 entries of tile j+1 are in flight while tile j is accumulated
+        uint32_t key_n = 0;
+        float val_n[F];
+        bool ok_n = false;
+        {
+            const uint32_t b = __shfl(mb, 0), e = __shfl(me, 0);
+            const int64_t region = ((int64_t)level * lay.ntiles + t0) * (TS * NV);
+            ok_n = b + lane < e;
+            if (ok_n) {
+                key_n = lay.keys[region + b + lane];
+#pragma unroll
+                for (int f = 0; f < F; ++f) val_n[f] = lay.vals[(region + b + lane) * F + f];
+            }
+        }
         for (int j = 0; j < nt; ++j) {
+            const uint32_t key = key_n;
+            float val[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) val[f] = val_n[f];
+            const bool ok = ok_n;
             const uint32_t b = __shfl(mb, j), e = __shfl(me, j);
             const int64_t region = ((int64_t)level * lay.ntiles + (t0 + j)) * (TS * NV);
-            for (uint32_t q = b + lane; q < e; q += 64) {
-                const uint32_t key = lay.keys[region + q];
+            if (j + 1 < nt) {
+                const uint32_t b2 = __shfl(mb, j + 1), e2 = __shfl(me, j + 1);
+                const int64_t region2 = region + TS * NV;
+                ok_n = b2 + lane < e2;
+                if (ok_n) {
+                    key_n = lay.keys[region2 + b2 + lane];
 #pragma unroll
-                for (int f = 0; f < F; ++f) atomicAdd(&acc[key * F + f], lay.vals[(region + q) * F + f]);
+                    for (int f = 0; f < F; ++f) val_n[f] = lay.vals[(region2 + b2 + lane) * F + f];
+                }
+            }
+            lds_accumulate<F>(acc, key, val, ok, lane);
+            for (uint32_t q0 = b + 64; q0 < e; q0 += 64) {       // long segments (hot slices)
+                const uint32_t q = q0 + lane;
+                const bool okq = q < e;
+                uint32_t kq = 0;
+                float vq[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) vq[f] = 0.0f;
+                if (okq) {
+                    kq = lay.keys[region + q];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) vq[f] = lay.vals[(region + q) * F + f];
+                }
+                lds_accumulate<F>(acc, kq, vq, okq, lane);
             }
         }
     }
@@ -348,7 +461,7 @@ inline BinPlan bin_plan(int64_t M, int L, int F, int NV, int64_t rows) {
 }
 
 template <int KIND>
-int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t sm, int64_t sc, int L, int F,
+int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t sm, int64_t sc, int grouped, int L, int F,
                   int64_t rows, const HashParams &hp, const PermutoParams &pp, float *gtab, void *workspace,
                   int64_t workspace_bytes, hipStream_t st, const char *name) {
     constexpr int NV = KIND == 0 ? 8 : 4;
@@ -364,11 +477,11 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
     lay.ntiles = b.ntiles;
     lay.NS = b.NS;
     lay.shift = b.shift;
-    dim3 g1((unsigned)b.ntiles, (unsigned)L), g2((unsigned)(L * b.NS));
+    dim3 g1((unsigned)b.ntiles, (unsigned)(grouped ? (L < 8 ? L : 8) : L)), g2((unsigned)(L * b.NS));
     const size_t lds = ((size_t)1 << b.shift) * F * sizeof(float);
 #define BIN_LAUNCH(GT, F_)                                                                                              \
     do {                                                                                                                \
-        hipLaunchKernelGGL((bin_kernel<KIND, GT, F_>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, hp, pp, lay); \
+        hipLaunchKernelGGL((bin_kernel<KIND, GT, F_>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay); \
         hipLaunchKernelGGL((reduce_kernel<F_, NV>), g2, dim3(1024), lds, st, lay, rows, gtab);                         \
     } while (0)
     if (grad_dtype == PAG_F32) {
@@ -421,13 +534,16 @@ int check_common(const char *name, const void *xyz, int64_t M, int n_levels, int
 
 extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                    int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
-                                   void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, void *stream) {
+                                   void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream) {
     int rc = check_common("pag_hash_encode_fwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_fwd: log2_T %d not in [1,30]", log2_T);
     PAG_CHECK_ARG(resolutions_host, "pag_hash_encode_fwd: resolutions_host is NULL");
     PAG_CHECK_ARG(table_dtype == PAG_F32 || table_dtype == PAG_F16, "pag_hash_encode_fwd: table dtype must be F32 or F16");
     PAG_CHECK_ARG(out_dtype == PAG_F32 || out_dtype == PAG_BF16, "pag_hash_encode_fwd: out dtype must be F32 or BF16");
+    PAG_CHECK_ARG(layout == PAG_LAYOUT_STRIDED || (layout == PAG_LAYOUT_XCD8 && out_dtype == PAG_BF16 && ((n_levels + 7) / 8) * n_feat <= 8),
+                  "pag_hash_encode_fwd: XCD8 layout needs bf16 output and ceil(L/8)*F <= 8");
+    const int grouped = layout == PAG_LAYOUT_XCD8;
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(tables && out, "pag_hash_encode_fwd: NULL tables/out");
     HashParams p;
@@ -441,13 +557,13 @@ extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tabl
     dim3 grid(encode_grid(M)), block(256);
     bool launched = false;
     if (table_dtype == PAG_F32 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
     } else if (table_dtype == PAG_F32 && out_dtype == PAG_BF16) {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
     } else if (table_dtype == PAG_F16 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
     } else {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
     }
     PAG_CHECK_ARG(launched, "pag_hash_encode_fwd: unsupported (n_feat=%d, n_levels=%d)", n_feat, n_levels);
     PAG_CHECK_LAUNCH("pag_hash_encode_fwd");
@@ -455,7 +571,7 @@ extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tabl
 }
 
 extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
-                                   int64_t g_stride_c, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
+                                   int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
                                    const float *feat_scale_host, float *grad_tables, void *workspace,
                                    int64_t workspace_bytes, void *stream) {
     int rc = check_common("pag_hash_encode_bwd", xyz, M, n_levels, n_feat);
@@ -463,6 +579,9 @@ extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad
     PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_bwd: log2_T %d not in [1,30]", log2_T);
     PAG_CHECK_ARG(resolutions_host, "pag_hash_encode_bwd: resolutions_host is NULL");
     PAG_CHECK_ARG(grad_dtype == PAG_F32 || grad_dtype == PAG_BF16, "pag_hash_encode_bwd: grad dtype must be F32 or BF16");
+    const int grouped = layout == PAG_LAYOUT_XCD8;
+    PAG_CHECK_ARG(!grouped || (workspace && grad_dtype == PAG_BF16 && ((n_levels + 7) / 8) * n_feat <= 8),
+                  "pag_hash_encode_bwd: XCD8 layout needs bf16 gradients, a workspace and ceil(L/8)*F <= 8");
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(grad_out && grad_tables, "pag_hash_encode_bwd: NULL grad_out/grad_tables");
     HashParams p;
@@ -475,7 +594,7 @@ extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad
     hipStream_t st = (hipStream_t)stream;
     if (workspace) {
         PermutoParams unused{};
-        int r2 = launch_binned<0>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, n_levels, n_feat, (int64_t)1 << log2_T, p,
+        int r2 = launch_binned<0>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, grouped, n_levels, n_feat, (int64_t)1 << log2_T, p,
                                   unused, grad_tables, workspace, workspace_bytes, st, "pag_hash_encode_bwd");
         if (r2) return r2;
         PAG_CHECK_LAUNCH("pag_hash_encode_bwd");
@@ -512,13 +631,16 @@ static int fill_permuto(PermutoParams &p, int n_levels, int n_feat, uint32_t cap
 extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                       int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                       const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
-                                      int64_t out_stride_c, void *stream) {
+                                      int64_t out_stride_c, int layout, void *stream) {
     int rc = check_common("pag_permuto_encode_fwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_fwd: capacity is 0");
     PAG_CHECK_ARG(scale_factor_host && shift_host, "pag_permuto_encode_fwd: NULL scale_factor/shift");
     PAG_CHECK_ARG(table_dtype == PAG_F32 || table_dtype == PAG_F16, "pag_permuto_encode_fwd: table dtype must be F32 or F16");
     PAG_CHECK_ARG(out_dtype == PAG_F32 || out_dtype == PAG_BF16, "pag_permuto_encode_fwd: out dtype must be F32 or BF16");
+    PAG_CHECK_ARG(layout == PAG_LAYOUT_STRIDED || (layout == PAG_LAYOUT_XCD8 && out_dtype == PAG_BF16 && ((n_levels + 7) / 8) * n_feat <= 8),
+                  "pag_permuto_encode_fwd: XCD8 layout needs bf16 output and ceil(L/8)*F <= 8");
+    const int grouped = layout == PAG_LAYOUT_XCD8;
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(tables && out, "pag_permuto_encode_fwd: NULL tables/out");
     PermutoParams p;
@@ -528,13 +650,13 @@ extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *t
     dim3 grid(encode_grid(M)), block(256);
     bool launched = false;
     if (table_dtype == PAG_F32 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
     } else if (table_dtype == PAG_F32 && out_dtype == PAG_BF16) {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
     } else if (table_dtype == PAG_F16 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
     } else {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
     }
     PAG_CHECK_ARG(launched, "pag_permuto_encode_fwd: unsupported (n_feat=%d, n_levels=%d)", n_feat, n_levels);
     PAG_CHECK_LAUNCH("pag_permuto_encode_fwd");
@@ -542,7 +664,7 @@ extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *t
 }
 
 extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
-                                      int64_t g_stride_c, int n_levels, int n_feat, uint32_t capacity,
+                                      int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
                                       const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
                                       float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
     int rc = check_common("pag_permuto_encode_bwd", xyz, M, n_levels, n_feat);
@@ -550,6 +672,9 @@ extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *g
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_bwd: capacity is 0");
     PAG_CHECK_ARG(scale_factor_host && shift_host, "pag_permuto_encode_bwd: NULL scale_factor/shift");
     PAG_CHECK_ARG(grad_dtype == PAG_F32 || grad_dtype == PAG_BF16, "pag_permuto_encode_bwd: grad dtype must be F32 or BF16");
+    const int grouped = layout == PAG_LAYOUT_XCD8;
+    PAG_CHECK_ARG(!grouped || (workspace && grad_dtype == PAG_BF16 && ((n_levels + 7) / 8) * n_feat <= 8),
+                  "pag_permuto_encode_bwd: XCD8 layout needs bf16 gradients, a workspace and ceil(L/8)*F <= 8");
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(grad_out && grad_tables, "pag_permuto_encode_bwd: NULL grad_out/grad_tables");
     PermutoParams p;
@@ -558,7 +683,7 @@ extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *g
     hipStream_t st = (hipStream_t)stream;
     if (workspace) {
         HashParams unused{};
-        int r2 = launch_binned<1>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, n_levels, n_feat, (int64_t)capacity, unused,
+        int r2 = launch_binned<1>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, grouped, n_levels, n_feat, (int64_t)capacity, unused,
                                   p, grad_tables, workspace, workspace_bytes, st, "pag_permuto_encode_bwd");
         if (r2) return r2;
         PAG_CHECK_LAUNCH("pag_permuto_encode_bwd");

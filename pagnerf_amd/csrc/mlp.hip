@@ -36,6 +36,14 @@ constexpr int HID = 64;
 __device__ __forceinline__ int rho(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 __device__ __forceinline__ int swap23(int a) { return (a & ~12) | ((a & 4) << 1) | ((a & 8) >> 1); }
 
+// staged position (8*g + e) of the XCD8 layout -> column level*F + f of the [M, L*F] feature row, or -1 (padding)
+__device__ __forceinline__ int grp_col(int pos, int L, int F) {
+    const int g = pos >> 3, e = pos & 7;
+    const int j = e / F, f = e - j * F;
+    const int level = g + 8 * j;
+    return (j < (L + 7) / 8 && level < L) ? level * F + f : -1;
+}
+
 struct FwdParams {
     const void *x1;
     const float *x2;
@@ -46,6 +54,7 @@ struct FwdParams {
     void *out;
     void *hsave[2];
     int64_t M;
+    int grp_L, grp_F;      // x1 in PAG_LAYOUT_XCD8 (bf16 [8][M][8]) when grp_L > 0
 };
 
 struct BwdParams {
@@ -57,23 +66,27 @@ struct BwdParams {
     void *dz[3];
     void *dx1;
     int64_t M;
+    int grp_L, grp_F;      // dx1 (and layer-0 weight columns) in PAG_LAYOUT_XCD8 order when grp_L > 0
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
 // optional bit-2/3 swap of the column index (see header).
 __device__ void stage_weight(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in,
-                             bool permute) {
+                             bool permute, int grp_L = 0, int grp_F = 0) {
     for (int e = threadIdx.x; e < rows_pad * cols_pad; e += blockDim.x) {
         int o = e / cols_pad, a = e - o * cols_pad;
-        float v = (o < n_out && a < n_in) ? W[(int64_t)o * n_in + a] : 0.0f;
+        int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
+        float v = (o < n_out && col >= 0 && col < n_in) ? W[(int64_t)o * n_in + col] : 0.0f;
         dst[o * stride + (permute ? swap23(a) : a)] = (bf16_t)v;
     }
 }
 // Stage W^T: dst[row = input a][col = output o (permuted)]
-__device__ void stage_weight_t(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in) {
+__device__ void stage_weight_t(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in,
+                               int grp_L = 0, int grp_F = 0) {
     for (int e = threadIdx.x; e < rows_pad * cols_pad; e += blockDim.x) {
         int a = e / cols_pad, o = e - a * cols_pad;
-        float v = (o < n_out && a < n_in) ? W[(int64_t)o * n_in + a] : 0.0f;
+        int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
+        float v = (o < n_out && col >= 0 && col < n_in) ? W[(int64_t)o * n_in + col] : 0.0f;
         dst[a * stride + swap23(o)] = (bf16_t)v;
     }
 }
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
     float *b1s = b0s + 64;
     float *bLs = b1s + 64;
 
-    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false);
+    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
     if (NL == 3) stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
     stage_weight(WLs, RS, OB * 32, 64, p.W[NL - 1], p.out_dim, HID, true);
     for (int e = threadIdx.x; e < 64; e += blockDim.x) {
@@ -209,7 +222,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int f0 = 16 * s + 8 * h;
-            if (s < nks0 && live && f0 < p.k1)
+            if (p.grp_L && live)
+                xb[s] = load8(reinterpret_cast<const bf16_t *>(p.x1) + ((int64_t)(2 * s + h) * p.M + mc) * 8);
+            else if (s < nks0 && live && f0 < p.k1)
                 xb[s] = load8(x1 + mc * p.k1 + f0);
             else if (s < nks0 && live && f0 < p.k1 + p.k2p)
                 xb[s] = load8(p.x2 + (int64_t)ray * p.k2p + (f0 - p.k1));
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
     bf16_t *W0t = W1t + (NL == 3 ? 64 * RS : 0);                 // [64 in-feature rows][RS]
     stage_weight_t(WLt, RSL, 64, OB * 32, p.W[NL - 1], p.out_dim, HID);
     if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
-    if (p.dx1) stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim);
+    if (p.dx1) stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -415,7 +430,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
                         bf16x8 a = *reinterpret_cast<const bf16x8 *>(W0t + (32 * mb + r) * RS + 16 * s + 8 * h);
                         acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
                     }
-                    if (live) store_block(dx + m * p.k1, 32 * mb, h, acc[mb], p.k1, true);
+                    if (live && !p.grp_L) store_block(dx + m * p.k1, 32 * mb, h, acc[mb], p.k1, true);
+                    if (live && p.grp_L) {      // XCD8: row 32mb + 8g + 4h + j of dx^T -> piece [4mb + g][m][4h + j]
+                        bf16_t *dg = reinterpret_cast<bf16_t *>(p.dx1);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            bf16x4 v = {(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
+                            *reinterpret_cast<bf16x4 *>(dg + ((int64_t)(4 * mb + g) * p.M + m) * 8 + 4 * h) = v;
+                        }
+                    }
                 }
             }
         }
@@ -604,6 +627,7 @@ struct WgradParams {
     int n_in;
     float *slabs;
     int64_t M;
+    int a1_grouped;        // a1 is bf16 [8][M][8] (PAG_LAYOUT_XCD8); slab columns are then staged positions
 };
 constexpr int WG_RS = 72;       // LDS row stride (bf16) of the transposed tiles: 64 samples + 8 pad
 constexpr int WG_SLAB_COLS = 96;
@@ -653,7 +677,9 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
         for (int cg = wave; cg < IB * 4; cg += 4) {
             const int c0 = 8 * cg;
             bf16x8 v = zero8();
-            if (live && c0 < p.k1)
+            if (live && p.a1_grouped)
+                v = load8(reinterpret_cast<const bf16_t *>(p.a1) + ((int64_t)cg * p.M + mc) * 8);
+            else if (live && c0 < p.k1)
                 v = load8(a1 + mc * p.k1 + c0);
             else if (live && p.a2 && c0 < p.k1 + p.k2p)
                 v = load8(p.a2 + (int64_t)p.a2_index[mc] * p.k2p + (c0 - p.k1));
@@ -748,6 +774,14 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     p.hsave[0] = a->hidden_save[0];
     p.hsave[1] = a->n_layers == 3 ? a->hidden_save[1] : nullptr;
     p.M = M;
+    p.grp_L = a->x1_layout == PAG_LAYOUT_XCD8 ? a->x1_levels : 0;
+    p.grp_F = a->x1_feats;
+    if (p.grp_L) {
+        PAG_CHECK_ARG(a->mode == PAG_MLP_MFMA_BF16 && a->x1_dtype == PAG_BF16 && a->k1 == 64 && a->x2 == nullptr && p.grp_F >= 1 &&
+                          ((p.grp_L + 7) / 8) * p.grp_F <= 8 && a->in_dim == p.grp_L * p.grp_F,
+                      "pag_mlp_fwd: XCD8 input needs MFMA mode, bf16, k1 = 64, no x2 and in_dim = levels*feats");
+        p.in_pad = 64;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;
@@ -819,6 +853,12 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     p.hsave[1] = a->n_layers == 3 ? a->hidden_save[1] : nullptr;
     p.dx1 = a->dx1;
     p.M = M;
+    p.grp_L = a->x1_layout == PAG_LAYOUT_XCD8 ? a->x1_levels : 0;
+    p.grp_F = a->x1_feats;
+    if (p.grp_L)
+        PAG_CHECK_ARG(a->mode == PAG_MLP_MFMA_BF16 && (a->dx1 == nullptr || a->dx1_dtype == PAG_BF16) && a->k1 == 64 &&
+                          ((p.grp_L + 7) / 8) * p.grp_F <= 8 && a->in_dim == p.grp_L * p.grp_F,
+                      "pag_mlp_bwd: XCD8 dx1 needs MFMA mode, bf16, k1 = 64 and in_dim = levels*feats");
     hipStream_t st = (hipStream_t)stream;
     const bool out_f32 = a->out_dtype == PAG_F32 || a->out_act == PAG_ACT_NONE;
     const bool dx_f32 = a->dx1 == nullptr || a->dx1_dtype == PAG_F32;
@@ -854,8 +894,9 @@ extern "C" int pag_mlp_wgrad_blocks(int64_t M) {
     return (int)(chunks < 512 ? (chunks > 0 ? chunks : 1) : 512);
 }
 
-extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1_dtype, int k1, const float *a2,
-                             int k2p, const int32_t *a2_index, int n_in, float *slabs, int n_blocks, int64_t M, void *stream) {
+extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1_dtype, int a1_layout, int k1,
+                             const float *a2, int k2p, const int32_t *a2_index, int n_in, float *slabs, int n_blocks, int64_t M,
+                             void *stream) {
     PAG_CHECK_ARG(M >= 0, "pag_mlp_wgrad: M < 0");
     PAG_CHECK_ARG(n_out >= 1 && n_out <= 224 && dz_cols >= n_out, "pag_mlp_wgrad: n_out %d / dz_cols %d out of range", n_out, dz_cols);
     PAG_CHECK_ARG(k1 > 0 && k1 % 8 == 0, "pag_mlp_wgrad: k1 %d must be a positive multiple of 8", k1);
@@ -865,7 +906,9 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
     PAG_CHECK_ARG(n_blocks >= 1, "pag_mlp_wgrad: n_blocks < 1");
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(dz && a1 && slabs, "pag_mlp_wgrad: NULL dz/a1/slabs");
-    WgradParams p{(const bf16_t *)dz, dz_cols, n_out, a1, k1, a2, a2 ? k2p : 0, a2_index, n_in, slabs, M};
+    PAG_CHECK_ARG(a1_layout == PAG_LAYOUT_STRIDED || (a1_dtype == PAG_BF16 && k1 == 64 && n_in == 64 && a2 == nullptr),
+                  "pag_mlp_wgrad: XCD8 a1 needs bf16, k1 = n_in = 64 and no a2");
+    WgradParams p{(const bf16_t *)dz, dz_cols, n_out, a1, k1, a2, a2 ? k2p : 0, a2_index, n_in, slabs, M, a1_layout == PAG_LAYOUT_XCD8};
     const int OB = (n_out + 31) / 32, IB = (n_in + 31) / 32;
     const size_t lds = (size_t)(OB + IB) * 32 * WG_RS * sizeof(bf16_t);
     if (a1_dtype == PAG_F32)

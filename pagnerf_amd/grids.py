@@ -90,8 +90,6 @@ class _GridBase(OccupancyBLAS):
         self.max_lod = self.num_lods - 1
         self.tables = None
         self._spec = None
-        self.out_dtype = torch.float32     # torch.bfloat16 selects the fused-pipeline layout
-        self.feature_major = False
 
     def _finish(self, feats, batch, num_samples):
         if self.multiscale_type == "cat":
@@ -100,9 +98,13 @@ class _GridBase(OccupancyBLAS):
             return feats.reshape(batch, num_samples, self.num_lods, self.feature_dim).sum(-2)
         raise NotImplementedError(self.multiscale_type)
 
-    def interpolate_scaled(self, coords, feat_scale=None):
-        """interpolate() with the nef's lod_weights folded into the kernel."""
-        return ops.encode(coords.reshape(-1, 3), self.tables, self._spec, feat_scale, self.out_dtype, self.feature_major)
+    def _coords(self, coords):
+        return coords.reshape(-1, 3)
+
+    def interpolate_scaled(self, coords, feat_scale=None, out_dtype=torch.float32, layout=None):
+        """interpolate() with the nef's lod_weights folded into the kernel; layout="xcd8" returns the bf16
+        [8, M, 8] XCD-grouped features the fused decoders consume (ops.encode)."""
+        return ops.encode(self._coords(coords), self.tables, self._spec, feat_scale, out_dtype, False, layout=layout)
 
 
 class HashGridHIP(_GridBase):
@@ -188,8 +190,6 @@ class PermutoGridHIP(_GridBase):
             return torch.empty([0, 1, self.num_lods * self.feature_dim], device=coords.device)   # permuto_grid.py:68-69
         return self.interpolate_scaled(coords)
 
-    def interpolate_scaled(self, coords, feat_scale=None):
+    def _coords(self, coords):
         c = coords.reshape(-1, 3)
-        if self.half_coords:
-            c = c.half().float()
-        return ops.encode(c, self.tables, self._spec, feat_scale, self.out_dtype, self.feature_major)
+        return c.half().float() if self.half_coords else c

@@ -44,10 +44,11 @@ class BasicDecoder(nn.Module):
         lins = list(self.layers) + [self.lout]
         return [l.weight for l in lins], [l.bias for l in lins]
 
-    def forward(self, x1, x2=None, x2_index=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16, out_dtype=torch.float32):
+    def forward(self, x1, x2=None, x2_index=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16, out_dtype=torch.float32,
+                x1_grouped=None):
         W, b = self.weights()
         return ops.fused_mlp(x1, W, b, x2=x2, x2_index=x2_index, in_dim=self.input_dim, out_act=out_act, mode=mode,
-                             out_dtype=out_dtype)
+                             out_dtype=out_dtype, x1_grouped=x1_grouped)
 
 
 def positional_embed(x, num_freq):
@@ -166,10 +167,15 @@ class PanopticDeltaNeF(nn.Module):
         pe = positional_embed(-src.float(), self.view_multires) if self.embedder_type == "positional" else -src.float()
         return F.pad(pe, (0, (-pe.shape[1]) % 8)).contiguous(), index
 
+    def _grouped(self):
+        """(levels, feats) when the bf16 path can use the XCD-grouped feature layout, else None."""
+        if self.precision == "bf16" and ops.xcd8_supported(self.num_lods, self.feature_dim):
+            return (self.num_lods, self.feature_dim)
+        return None
+
     def _interp(self, grid, coords):
-        grid.out_dtype = self.feat_dtype
         lw = None if bool((self.lod_weights == 1).all()) else self.lod_weights
-        return grid.interpolate_scaled(coords, lw)
+        return grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None)
 
     def rgb_semantics(self, coords, ray_d=None, compute_channels=None, pidx=None, lod_idx=None, ridx=None, ray_dirs=None):
         out = {}
@@ -182,7 +188,8 @@ class PanopticDeltaNeF(nn.Module):
             raise NotImplementedError("multiscale_type 'sum' with fused decoders")
         mode = self.mlp_mode
         feats = self._interp(self.grid, coords)                                       # :170-171
-        density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype)     # :184
+        grp = self._grouped()
+        density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
         density = torch.relu(density_feats[:, 0:1].float()).reshape(batch, num_samples, 1)   # :188
         if "density" in compute_channels:
             out["density"] = density
@@ -205,7 +212,7 @@ class PanopticDeltaNeF(nn.Module):
             if "semantics" in compute_channels:                                        # :238-244
                 plain = not (self.sem_sigmoid or self.sem_normalize)
                 act = L.ACT_SOFTMAX if (self.sem_softmax and plain) else L.ACT_NONE
-                s = self.decoder_semantics(pan, out_act=act, mode=mode)
+                s = self.decoder_semantics(pan, out_act=act, mode=mode, x1_grouped=grp)
                 if not plain:
                     s = torch.sigmoid(s) if self.sem_sigmoid else s
                     s = F.normalize(s, dim=-1) if self.sem_normalize else s
@@ -214,7 +221,7 @@ class PanopticDeltaNeF(nn.Module):
             if "inst_embedding" in compute_channels:                                   # :246-257
                 plain = not (self.inst_sigmoid or self.inst_normalize or self.inst_soft_temperature > 0.0)
                 act = L.ACT_SOFTMAX if (self.inst_softmax and plain) else L.ACT_NONE
-                e = self.decoder_inst(pan, out_act=act, mode=mode)
+                e = self.decoder_inst(pan, out_act=act, mode=mode, x1_grouped=grp)
                 if not plain:
                     e = torch.sigmoid(e) if self.inst_sigmoid else e
                     e = F.normalize(e, dim=-1) if self.inst_normalize else e

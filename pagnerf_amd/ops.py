@@ -78,17 +78,25 @@ def permuto_spec(scale_factor, shift, capacity, n_feat):
     return _EncodeSpec("permuto", len(scale_factor), n_feat, capacity=capacity, scale_factor=scale_factor, shift=shift)
 
 
+def _layout_args(t):
+    """(stride_m, stride_c, layout) of a feature tensor: [M, C] strided or bf16 [8, M, 8] XCD-grouped."""
+    if t.dim() == 3:
+        assert t.shape[0] == 8 and t.shape[2] == 8 and t.dtype == torch.bfloat16 and t.is_contiguous()
+        return 0, 0, L.LAYOUT_XCD8
+    return t.stride(0), t.stride(1), L.LAYOUT_STRIDED
+
+
 def _encode_fwd(spec, xyz, tables, feat_scale, out):
     lib = L.load()
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
-    sm, sc = out.stride(0), out.stride(1)
+    sm, sc, lay = _layout_args(out)
     if spec.kind == "hash":
         _call("pag_hash_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
-              spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
+              spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, L.stream())
     else:
         _call("pag_permuto_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity,
-              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, L.stream())
+              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, L.stream())
 
 
 BWD_ALGO = "binned"     # "binned": atomic-free two-pass scatter (default); "atomic": per-vertex fp32 global atomics
@@ -98,17 +106,17 @@ def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
     lib = L.load()
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
-    sm, sc = grad_out.stride(0), grad_out.stride(1)
+    sm, sc, lay = _layout_args(grad_out)
     ws, ws_ptr, ws_bytes = None, None, 0
-    if BWD_ALGO == "binned":
+    if BWD_ALGO == "binned" or lay == L.LAYOUT_XCD8:
         ws_bytes = lib.pag_encode_bwd_workspace_bytes(M, spec.L, spec.F, 8 if spec.kind == "hash" else 4, spec.rows())
         ws = torch.empty(ws_bytes, device=xyz.device, dtype=torch.uint8)
         ws_ptr = ws.data_ptr()
     if spec.kind == "hash":
-        _call("pag_hash_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
+        _call("pag_hash_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
               spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
     else:
-        _call("pag_permuto_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, spec.L, spec.F,
+        _call("pag_permuto_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
               spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
 
 
@@ -120,7 +128,9 @@ class _Encode(torch.autograd.Function):
         M, C = xyz.shape[0], spec.L * spec.F
         if tables.shape != (spec.L, spec.rows(), spec.F):
             raise RuntimeError("tables shape %s does not match the encoder spec %s" % (tuple(tables.shape), (spec.L, spec.rows(), spec.F)))
-        if feature_major:
+        if feature_major == "xcd8":
+            out = torch.empty(8, M, 8, device=xyz.device, dtype=torch.bfloat16)
+        elif feature_major:
             out = torch.empty(C, M, device=xyz.device, dtype=out_dtype).t()
         else:
             out = torch.empty(M, C, device=xyz.device, dtype=out_dtype)
@@ -138,13 +148,31 @@ class _Encode(torch.autograd.Function):
         if xyz.shape[0]:
             if g.dtype not in (torch.float32, torch.bfloat16):
                 g = g.float()
+            if g.dim() == 3:
+                g = g.contiguous()
             _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt)
         return None, gt.to(ctx.tdtype), None, None, None, None
 
 
-def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False):
-    """Grid features [M, L*F] (column = level*F + f).  d/d tables is supported, d/d xyz is not."""
-    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, feature_major)
+def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None):
+    """Grid features [M, L*F] (column = level*F + f); layout="xcd8" returns the bf16 [8, M, 8] XCD-grouped tensor the
+    fused decoders consume directly.  d/d tables is supported, d/d xyz is not."""
+    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major)
+
+
+def xcd8_supported(n_levels, n_feat):
+    return ((n_levels + 7) // 8) * n_feat <= 8
+
+
+def xcd8_columns(n_levels, n_feat):
+    """staged position p = 8*g + e  ->  feature column level*F + f (or -1 for padding), as a list of 64."""
+    cols = []
+    for p in range(64):
+        g, e = p >> 3, p & 7
+        j, f = divmod(e, n_feat)
+        level = g + 8 * j
+        cols.append(level * n_feat + f if (j < (n_levels + 7) // 8 and level < n_levels) else -1)
+    return cols
 
 
 # ---------------------------------------------------------------------------------------------- MLP
@@ -160,12 +188,15 @@ def _mm_f32(a, b):
 
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, save_dtype_unused, *wb):
+    def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb):
         _check_gpu(x1, x2, x2_index, *wb)
         lib = L.load()
         n_layers = len(wb) // 2
         Ws, bs = wb[:n_layers], wb[n_layers:]
-        M, k1 = x1.shape
+        if grouped is not None:
+            M, k1 = x1.shape[1], 64
+        else:
+            M, k1 = x1.shape
         x1 = x1.detach()
         if not x1.is_contiguous():
             x1 = x1.contiguous()
@@ -178,6 +209,8 @@ class _FusedMLP(torch.autograd.Function):
         hidden = [torch.empty(M, 64, device=x1.device, dtype=hdt) for _ in range(n_layers - 1)] if need_grad else []
         a = L.MlpFwdArgs()
         a.x1, a.x1_dtype, a.k1 = L.ptr(x1), L.dtype_code(x1), k1
+        if grouped is not None:
+            a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
         if x2 is not None:
             x2 = x2.detach().contiguous().float()
             x2_index = x2_index.detach().contiguous()
@@ -194,7 +227,7 @@ class _FusedMLP(torch.autograd.Function):
             a.hidden_save[i] = L.ptr(h)
         if M:
             _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
-        ctx.cfg = (in_dim, out_act, mode, n_layers, k1)
+        ctx.cfg = (in_dim, out_act, mode, n_layers, k1, grouped)
         ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc)
         ctx.n_hidden = len(hidden)
         return out
@@ -202,22 +235,24 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         lib = L.load()
-        in_dim, out_act, mode, n_layers, k1 = ctx.cfg
+        in_dim, out_act, mode, n_layers, k1, grouped = ctx.cfg
         saved = ctx.saved_tensors
         x1, x2, x2_index, out = saved[:4]
         hidden = list(saved[4:4 + ctx.n_hidden])
         Wc = list(saved[4 + ctx.n_hidden:])
-        M = x1.shape[0]
+        M = x1.shape[1] if grouped is not None else x1.shape[0]
         out_dim = Wc[-1].shape[0]
         dev = x1.device
         zdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
         dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
         need_dx = ctx.needs_input_grad[0]
-        dx1 = torch.empty(M, k1, device=dev, dtype=x1.dtype) if need_dx else None
+        dx1 = torch.empty(x1.shape, device=dev, dtype=x1.dtype) if need_dx else None
         g = g.contiguous().float()
         a = L.MlpBwdArgs()
         a.grad_out, a.out, a.out_dtype, a.out_act = L.ptr(g), L.ptr(out), L.dtype_code(out), out_act
         a.k1, a.in_dim, a.n_layers, a.out_dim = k1, in_dim, n_layers, out_dim
+        if grouped is not None:
+            a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
         for i in range(n_layers):
             a.W[i], a.dz[i] = L.ptr(Wc[i]), L.ptr(dz[i])
         for i, h in enumerate(hidden):
@@ -232,16 +267,27 @@ class _FusedMLP(torch.autograd.Function):
             for l in range(n_layers):
                 n_out = Wc[l].shape[0]
                 slabs = torch.empty(nblk, (n_out + 31) // 32 * 32, 96, device=dev)
-                if l == 0:
-                    _call("pag_mlp_wgrad", L.ptr(dz[0]), dz[0].shape[1], n_out, L.ptr(x1), L.dtype_code(x1), k1, L.ptr(x2),
-                          x2.shape[1] if x2 is not None else 0, L.ptr(x2_index), in_dim, L.ptr(slabs), nblk, M, L.stream())
+                if l == 0 and grouped is not None:
+                    _call("pag_mlp_wgrad", L.ptr(dz[0]), dz[0].shape[1], n_out, L.ptr(x1), L.BF16, L.LAYOUT_XCD8, 64, None, 0, None,
+                          64, L.ptr(slabs), nblk, M, L.stream())
+                    n_in = 64
+                elif l == 0:
+                    _call("pag_mlp_wgrad", L.ptr(dz[0]), dz[0].shape[1], n_out, L.ptr(x1), L.dtype_code(x1), L.LAYOUT_STRIDED, k1,
+                          L.ptr(x2), x2.shape[1] if x2 is not None else 0, L.ptr(x2_index), in_dim, L.ptr(slabs), nblk, M, L.stream())
                     n_in = in_dim
                 else:
-                    _call("pag_mlp_wgrad", L.ptr(dz[l]), dz[l].shape[1], n_out, L.ptr(hidden[l - 1]), L.BF16, 64, None, 0, None, 64,
-                          L.ptr(slabs), nblk, M, L.stream())
+                    _call("pag_mlp_wgrad", L.ptr(dz[l]), dz[l].shape[1], n_out, L.ptr(hidden[l - 1]), L.BF16, L.LAYOUT_STRIDED, 64,
+                          None, 0, None, 64, L.ptr(slabs), nblk, M, L.stream())
                     n_in = 64
                 red = slabs.sum(0)
-                gW.append(red[:n_out, :n_in].contiguous())
+                w = red[:n_out, :n_in]
+                if l == 0 and grouped is not None:      # staged XCD8 positions -> feature columns
+                    cols = xcd8_columns(*grouped)
+                    pos = [p for p, c in enumerate(cols) if c >= 0]
+                    full = torch.zeros(n_out, in_dim, device=dev)
+                    full[:, torch.tensor([cols[p] for p in pos], device=dev)] = w[:, torch.tensor(pos, device=dev)]
+                    w = full
+                gW.append(w.contiguous())
                 gb.append(red[:n_out, 64].contiguous())
         else:
             # fp32 parity path: dz_l^T @ input_l as plain fp32 GEMMs (BLAS)
@@ -262,12 +308,13 @@ class _FusedMLP(torch.autograd.Function):
 
 
 def fused_mlp(x1, weights, biases, x2=None, x2_index=None, in_dim=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16,
-              out_dtype=torch.float32):
+              out_dtype=torch.float32, x1_grouped=None):
     """wisp BasicDecoder (Linear+ReLU ... Linear) [+ sigmoid/softmax] in one launch.
-    x1 [M,k1] (+ optional per-ray x2 [R,k2p] gathered by x2_index [M]); weights[i] is [out,in]."""
+    x1 [M,k1] (+ optional per-ray x2 [R,k2p] gathered by x2_index [M]); weights[i] is [out,in].
+    x1_grouped=(levels, feats): x1 is the encoders' bf16 [8, M, 8] XCD-grouped tensor."""
     if in_dim is None:
         in_dim = weights[0].shape[1]
-    return _FusedMLP.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
+    return _FusedMLP.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, x1_grouped, *weights, *biases)
 
 
 # ------------------------------------------------------------------------------------------ ray march

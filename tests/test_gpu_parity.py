@@ -110,6 +110,47 @@ def test_permuto_encode_bit_exact_vs_oracle_and_backward(gpu_device):
         np.testing.assert_allclose(fm.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
 
 
+def test_xcd8_layout_encode_and_decoder_match_strided(gpu_device):
+    """The XCD-grouped bf16 [8,M,8] feature layout is a pure re-arrangement: same values, same decoder outputs / gradients."""
+    ops, L = _ops()
+    from oracle import permuto_encode as op
+    rs = np.random.RandomState(7)
+    for (Lv, F) in ((24, 2), (16, 2), (13, 1), (8, 4)):
+        cap, M = 2 ** 10, 3000
+        sf = op.scale_factors(np.geomspace(1.0, 1e-3, Lv))
+        shifts = (rs.standard_normal(size=(Lv, 3)) * 10).astype(np.float32)
+        spec = ops.permuto_spec(sf, shifts, cap, F)
+        x = torch.from_numpy(rs.uniform(-1, 1, size=(M, 3)).astype(np.float32)).to(gpu_device)
+        tab = torch.from_numpy(rs.standard_normal(size=(Lv, cap, F)).astype(np.float32)).to(gpu_device)
+        cols = ops.xcd8_columns(Lv, F)
+        t1 = tab.clone().requires_grad_(True)
+        t2 = tab.clone().requires_grad_(True)
+        strided = ops.encode(x, t1, spec, out_dtype=torch.bfloat16)
+        grouped = ops.encode(x, t2, spec, layout="xcd8")
+        assert grouped.shape == (8, M, 8)
+        flat = grouped.permute(1, 0, 2).reshape(M, 64)
+        for p, c in enumerate(cols):
+            if c >= 0:
+                assert torch.equal(flat[:, p], strided[:, c]), (Lv, F, p, c)
+            else:
+                assert float(flat[:, p].abs().max()) == 0.0
+        dims = (Lv * F, 64, 64, 10)
+        W, b = _rand_mlp(rs, dims)
+        outs = []
+        for feats, t, grp in ((strided, t1, None), (grouped, t2, (Lv, F))):
+            Wg = [w.to(gpu_device).requires_grad_(True) for w in W]
+            bg = [v.to(gpu_device).requires_grad_(True) for v in b]
+            if grp is None and (Lv * F) % 8:
+                feats = torch.nn.functional.pad(feats, (0, (-Lv * F) % 8))
+            y = ops.fused_mlp(feats, Wg, bg, in_dim=Lv * F, out_act=L.ACT_SOFTMAX, x1_grouped=grp)
+            (y[:, 0].sum() + (y[:, 3] ** 2).sum()).backward()
+            outs.append((y.detach(), [w.grad for w in Wg], [v.grad for v in bg], t.grad))
+        (y1, w1, b1, g1), (y2, w2, b2, g2) = outs
+        np.testing.assert_allclose(y2.cpu().numpy(), y1.cpu().numpy(), rtol=0, atol=5e-4)   # summation order over k differs
+        for a_, b_ in list(zip(w1, w2)) + list(zip(b1, b2)) + [(g1, g2)]:
+            assert _rel_l2(b_.cpu(), a_.cpu()) < 2e-3, (Lv, F, _rel_l2(b_.cpu(), a_.cpu()))
+
+
 # ------------------------------------------------------------------------------------------------- MLP
 def _rand_mlp(rs, dims):
     W = [torch.from_numpy((rs.standard_normal(size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(len(dims) - 1)]
