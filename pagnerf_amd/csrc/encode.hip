@@ -196,16 +196,17 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(const float *__restric
 //       the per-slice offsets go to a header.  No global atomics, no counting pre-pass.
 //   pass 2 (reduce_kernel) one workgroup = (level, slice): it owns that slice of the gradient
 //       table in LDS, walks every tile's segment for its slice (coalesced reads, each entry read
-//       exactly once), accumulates with ds_add_f32 and finally adds the slice to the table with plain
-//       coalesced stores.
+//       exactly once), accumulates in 64-bit fixed point with ds_add_u64 (order-independent, hence
+//       bitwise reproducible) and finally adds the slice to the table with plain coalesced stores.
 constexpr int TS = 1024;          // samples per pass-1 tile (= threads per workgroup)
-constexpr int SLICE_SHIFT = 13;   // 8192 rows per slice: 64 KiB of fp32 accumulators at F = 2
+constexpr int SLICE_SHIFT = 13;   // upper bound; bin_plan() shrinks it so a slice's int64 accumulators fit 64 KiB
 constexpr int NS_MAX = 256;       // slices per level supported (T <= 2^21)
 
 struct BinLayout {
     uint32_t *keys;      // [L][ntiles][TS*NV]      row index inside its slice
     float *vals;         // [L][ntiles][TS*NV][F]
     uint32_t *header;    // [L][NS+1][ntiles]       exclusive offsets of each slice inside the tile region
+    uint32_t *tile_max;  // [L][ntiles] bit pattern of max |gradient| of each (level, tile): no atomics, pass 2 reduces it
     int64_t ntiles;
     int NS, shift;
 };
@@ -240,7 +241,7 @@ template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F>
 __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
                                                  int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
-    __shared__ uint32_t cnt[NS_MAX + 1];
+    __shared__ uint32_t cnt[NS_MAX + 2];     // [NS_MAX + 1] = max |g| of this (tile, level)
     __shared__ uint32_t offs[NS_MAX + 1];
     const int L = KIND == 0 ? hp.L : pp.L;
     const int64_t tile = blockIdx.x;
@@ -264,6 +265,8 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
         const int level = grouped ? (int)blockIdx.y + 8 * j : (int)blockIdx.y;
         if (level >= L) break;
         for (int s = tid; s <= lay.NS; s += TS) cnt[s] = 0;
+        if (tid == 0) cnt[NS_MAX + 1] = 0;
+        __syncthreads();
         uint32_t idx[NV];
         float w[NV];
         float gv[F];
@@ -297,6 +300,16 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
                 gv[f] = pag_ld(go + ic * sm + (int64_t)(level * F + f) * sc);
             }
             if (has_scale) gv[f] *= scale[level * F + f];
+        }
+        {   // per-level max |g| (positive floats order like their bit patterns): feeds the fixed-point scale of pass 2
+            float mx = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) mx = fmaxf(mx, live ? fabsf(gv[f]) : 0.0f);
+            uint32_t mb = __float_as_uint(mx);
+            if (mx != mx) mb = 0x7FC00000u;   // NaN poisons the level
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, d));
+            if (lane == 0 && mb) atomicMax(&cnt[NS_MAX + 1], mb);     // LDS, one per wave
         }
         __syncthreads();
         float ev[NV][F];
@@ -339,46 +352,66 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
             }
         }
         for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[s];
+        if (tid == 0) lay.tile_max[(int64_t)level * lay.ntiles + tile] = cnt[NS_MAX + 1];
         __syncthreads();
     }
 }
 
-// Add one wave's 64 (key, value) entries into the LDS slice.  On the coarse levels a few rows receive
-// almost every entry; 64 lanes hitting one LDS address serialise, so rows that several lanes share are
-// first summed across the wave (ballot-match on the leading lane's key, masked butterfly sum) and added
-// once; what is left goes in directly.
+// Add one wave's 64 (key, value) entries into the LDS slice.  LDS float atomics (ds_add_f32) serialise
+// at ~3 cycles per active lane on gfx950 (194 cycles per wave-instruction measured) while 64-bit integer
+// adds run at ~12 cycles per wave-instruction, so the slice is accumulated in 2^-S fixed point with
+// ds_add_u64: S is chosen per level from the largest |gradient| so that 2^23 worst-case addends cannot
+// overflow.  Integer addition is associative: the result does not depend on arrival order (bitwise
+// reproducible).  Rows that several lanes share (coarse levels) are first summed across the wave.
 template <int F>
-__device__ __forceinline__ void lds_accumulate(float *acc, uint32_t key, const float (&val)[F], bool valid, int lane) {
+__device__ __forceinline__ void lds_accumulate(unsigned long long *acc, uint32_t key, const long long (&val)[F], bool valid, int lane) {
     unsigned long long active = __ballot(valid);
 #pragma unroll 1
     for (int it = 0; it < 8 && active; ++it) {
         const int leader = __ffsll((long long)active) - 1;
         const uint32_t lk = __shfl(key, leader);
         const unsigned long long m = __ballot(valid && key == lk) & active;
-        if (__popcll(m) < 4) break;
+        if (__popcll(m) < 8) break;
         const bool mine = (m >> lane) & 1ull;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            float v = mine ? val[f] : 0.0f;
+            long long v = mine ? val[f] : 0ll;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-            if (lane == leader) atomicAdd(&acc[lk * F + f], v);
+            if (lane == leader) atomicAdd(&acc[lk * F + f], (unsigned long long)v);
         }
         active &= ~m;
     }
     if ((active >> lane) & 1ull) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) atomicAdd(&acc[key * F + f], val[f]);
+        for (int f = 0; f < F; ++f) atomicAdd(&acc[key * F + f], (unsigned long long)val[f]);
     }
 }
 
 template <int F, int NV>
 __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];      // [2^shift][F]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [2^shift][F] fixed point
     const int level = blockIdx.x / lay.NS, slice = blockIdx.x % lay.NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int slice_rows = 1 << lay.shift;
-    for (int j = tid; j < slice_rows * F; j += blockDim.x) acc[j] = 0.0f;
+    __shared__ uint32_t lvl_max;
+    if (tid == 0) lvl_max = 0;
+    __syncthreads();
+    {
+        uint32_t mb = 0;
+        for (int64_t t = tid; t < lay.ntiles; t += blockDim.x) mb = max(mb, lay.tile_max[(int64_t)level * lay.ntiles + t]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, d));
+        if (lane == 0 && mb) atomicMax(&lvl_max, mb);
+    }
+    __syncthreads();
+    const float maxabs = __uint_as_float(lvl_max);
+    if (maxabs == 0.0f) return;                       // no gradient reached this level
+    const bool poisoned = !(maxabs <= 3.4e38f);       // inf / NaN upstream: propagate NaN
+    int ex;
+    frexpf(poisoned ? 1.0f : maxabs, &ex);            // maxabs < 2^ex
+    const int S = 38 - ex;                            // |val| * 2^S < 2^38 ; 2^23 addends stay below 2^61
+    for (int j = tid; j < slice_rows * F; j += blockDim.x) acc[j] = 0ull;
     __syncthreads();
     const uint32_t *hb = lay.header + ((int64_t)level * (lay.NS + 1) + slice) * lay.ntiles;
     const uint32_t *he = hb + lay.ntiles;
@@ -402,9 +435,9 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         }
         for (int j = 0; j < nt; ++j) {
             const uint32_t key = key_n;
-            float val[F];
+            long long val[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) val[f] = val_n[f];
+            for (int f = 0; f < F; ++f) val[f] = ok_n ? __float2ll_rn(ldexpf(val_n[f], S)) : 0ll;
             const bool ok = ok_n;
             const uint32_t b = __shfl(mb, j), e = __shfl(me, j);
             const int64_t region = ((int64_t)level * lay.ntiles + (t0 + j)) * (TS * NV);
@@ -419,17 +452,17 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
                 }
             }
             lds_accumulate<F>(acc, key, val, ok, lane);
-            for (uint32_t q0 = b + 64; q0 < e; q0 += 64) {       // long segments (hot slices)
+            for (uint32_t q0 = b + 64; q0 < e; q0 += 64) {       // long segments
                 const uint32_t q = q0 + lane;
                 const bool okq = q < e;
                 uint32_t kq = 0;
-                float vq[F];
+                long long vq[F];
 #pragma unroll
-                for (int f = 0; f < F; ++f) vq[f] = 0.0f;
+                for (int f = 0; f < F; ++f) vq[f] = 0ll;
                 if (okq) {
                     kq = lay.keys[region + q];
 #pragma unroll
-                    for (int f = 0; f < F; ++f) vq[f] = lay.vals[(region + q) * F + f];
+                    for (int f = 0; f < F; ++f) vq[f] = __float2ll_rn(ldexpf(lay.vals[(region + q) * F + f], S));
                 }
                 lds_accumulate<F>(acc, kq, vq, okq, lane);
             }
@@ -439,7 +472,10 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
     const int64_t row0 = (int64_t)slice * slice_rows;
     float *dst = gtab + ((int64_t)level * rows_per_level + row0) * F;
     const int64_t valid = min((int64_t)slice_rows, rows_per_level - row0) * F;
-    for (int64_t j = tid; j < valid; j += blockDim.x) dst[j] += acc[j];
+    for (int64_t j = tid; j < valid; j += blockDim.x) {
+        const float v = poisoned ? __uint_as_float(0x7FC00000u) : (float)ldexp((double)(long long)acc[j], -S);
+        dst[j] += v;
+    }
 }
 
 struct BinPlan {
@@ -449,14 +485,14 @@ struct BinPlan {
 inline BinPlan bin_plan(int64_t M, int L, int F, int NV, int64_t rows) {
     BinPlan b;
     b.shift = SLICE_SHIFT;
-    while (b.shift > 0 && ((int64_t)1 << b.shift) * F * 4 > 65536) --b.shift;
+    while (b.shift > 0 && ((int64_t)1 << b.shift) * F * 8 > 65536) --b.shift;      // int64 accumulators, 64 KiB of LDS
     b.NS = (int)((rows + ((int64_t)1 << b.shift) - 1) >> b.shift);
     b.ntiles = (M + TS - 1) / TS;
     auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
     b.keys_bytes = up((int64_t)L * b.ntiles * TS * NV * 4);
     b.vals_bytes = up((int64_t)L * b.ntiles * TS * NV * F * 4);
     b.header_bytes = up((int64_t)L * (b.NS + 1) * b.ntiles * 4);
-    b.total = b.keys_bytes + b.vals_bytes + b.header_bytes;
+    b.total = b.keys_bytes + b.vals_bytes + b.header_bytes + up((int64_t)L * b.ntiles * 4);   // + tile_max[L][ntiles]
     return b;
 }
 
@@ -474,11 +510,12 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
     lay.keys = (uint32_t *)wsp;
     lay.vals = (float *)(wsp + b.keys_bytes);
     lay.header = (uint32_t *)(wsp + b.keys_bytes + b.vals_bytes);
+    lay.tile_max = (uint32_t *)(wsp + b.keys_bytes + b.vals_bytes + b.header_bytes);
     lay.ntiles = b.ntiles;
     lay.NS = b.NS;
     lay.shift = b.shift;
     dim3 g1((unsigned)b.ntiles, (unsigned)(grouped ? (L < 8 ? L : 8) : L)), g2((unsigned)(L * b.NS));
-    const size_t lds = ((size_t)1 << b.shift) * F * sizeof(float);
+    const size_t lds = ((size_t)1 << b.shift) * F * sizeof(unsigned long long);
 #define BIN_LAUNCH(GT, F_)                                                                                              \
     do {                                                                                                                \
         hipLaunchKernelGGL((bin_kernel<KIND, GT, F_>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay); \
