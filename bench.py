@@ -106,14 +106,8 @@ def train_step(nef, tracer, opt, rays, gt, channels, world):
         loss = loss + 1000.0 * (-torch.log(rb.inst_embedding[idx, gt["inst"]] + 1e-27)).mean()
     loss.backward()
     if world > 1:
-        grads = [p.grad for p in nef.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        flat /= world
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        from pagnerf_amd import shard
+        shard.allreduce_grads(nef.parameters())     # one flat RCCL all-reduce (pagnerf_amd/shard.py)
     opt.step()
     return loss
 
@@ -121,7 +115,9 @@ def train_step(nef, tracer, opt, rays, gt, channels, world):
 def cpu_baseline(n_rays, n_samples, budget_s=25.0):
     """The oracle's torch-CPU restatement of the reference's hash_grid_torch path, forward + backward."""
     from oracle import hash_encode as oh, decoders as od, render as orr
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch-CPU ops on these small tensors scale badly past a few dozen threads (256 threads on the GPU
+    # box's host ran 400x slower than 8): use at most 32 and report the count actually used.
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     rs = np.random.RandomState(0)
     L_, log2T = 16, 19
     res = oh.level_resolutions(16, 2048, L_)
@@ -143,7 +139,12 @@ def cpu_baseline(n_rays, n_samples, budget_s=25.0):
         comp = orr.composite(n_rays, ridx, boundary, out["density"], deltas, rgb=out["rgb"])
         loss = 10.0 * torch.abs(comp["rgb"] - gt).mean()
         loss.backward()
-    step()                                   # warm-up
+    t_w = time.perf_counter()
+    step()                                   # warm-up (also sizes the budget)
+    t_w = time.perf_counter() - t_w
+    if t_w > budget_s:                       # pathological host: report the single step rather than overrun
+        return dict(value=n_rays / t_w, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                    sample="%d rays x %d samples, 1 step of %.1f s (warm-up only; host too slow for more)" % (n_rays, n_samples, t_w))
     t0, n = time.perf_counter(), 0
     while True:
         step()

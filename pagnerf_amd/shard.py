@@ -1,0 +1,90 @@
+"""Ray sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference is single-GPU; this is the build's own addition.  Rays are
+independent, so the hot path shards with no data-path exchange: every rank marches a contiguous block
+of rays against replicated tables / decoders / occupancy.  Two collectives exist around it:
+  * rendering: ONE all_gather of the per-rank [n_local, C] buffer (all channels packed side by side);
+  * training:  ONE flat all_reduce of the gradients per step (2 x 50.3 MB tables + 0.14 MB decoders).
+Both are single large messages - on MI355X's point-to-point xGMI mesh a ring is bound by one link, so
+fewer, larger collectives let RCCL spread traffic over all 7 links.
+"""
+import torch
+import torch.distributed as dist
+
+from .core import Rays, RenderBuffer
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous block partition of n rays: the first n % world ranks get one extra ray."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_rays(rays, rank=None, world=None):
+    r, w = world_info()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    lo, hi = shard_bounds(rays.origins.shape[0], rank, world)
+    return rays[lo:hi]
+
+
+def all_gather_render(rb, n_total, channels=None):
+    """Gather per-rank RenderBuffers (rows = this rank's ray block) into the full [n_total, .] buffers
+    on every rank with one all_gather.  Bool channels travel as floats."""
+    rank, world = world_info()
+    if world == 1:
+        return rb
+    names = sorted(channels or [c for c in rb.channels if isinstance(getattr(rb, c), torch.Tensor) and getattr(rb, c).dim() > 0])
+    cols = [getattr(rb, c).reshape(getattr(rb, c).shape[0], -1).float() for c in names]
+    widths = [c.shape[1] for c in cols]
+    n_max = (n_total + world - 1) // world
+    lo, hi = shard_bounds(n_total, rank, world)
+    packed = torch.zeros(n_max, sum(widths), device=cols[0].device)
+    packed[:hi - lo] = torch.cat(cols, 1)
+    out = torch.empty(world * n_max, sum(widths), device=packed.device)
+    dist.all_gather_into_tensor(out, packed)
+    rows = torch.cat([out[r * n_max:r * n_max + (shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0])]
+                      for r in range(world)], 0)
+    res, off = {}, 0
+    for name, w in zip(names, widths):
+        t = rows[:, off:off + w]
+        src = getattr(rb, name)
+        if src.dtype == torch.bool:
+            t = t > 0.5
+        res[name] = t.reshape(n_total, *src.shape[1:])
+        off += w
+    return RenderBuffer(**res)
+
+
+def allreduce_grads(params, average=True):
+    """One flat all_reduce over every gradient (bucket = everything: ~100 MB fp32)."""
+    rank, world = world_info()
+    if world == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    dist.all_reduce(flat)
+    if average:
+        flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def render_sharded(pipeline, rays, channels, **kwargs):
+    """Every rank renders its block of `rays` and receives the full image buffers."""
+    n = rays.origins.shape[0]
+    local = shard_rays(rays)
+    rb = pipeline(rays=local, channels=channels, **kwargs)
+    return all_gather_render(rb, n, channels=None)
