@@ -139,7 +139,7 @@ int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
  *   dx1     [M, k1] (dx1_dtype) or NULL
  * Weight gradients are dz[i]^T @ input_i - a plain GEMM left to the caller's BLAS. */
 typedef struct {
-    const float *grad_out; const void *out; int out_dtype; int out_act;
+    const void *grad_out; const void *out; int out_dtype; int out_act;   /* grad_out has out's dtype */
     int k1; int in_dim; int n_layers; int out_dim;
     int x1_layout; int x1_levels; int x1_feats;   /* as in pag_mlp_fwd_args: dx1 is then written as bf16 [8][M][8] */
     const float *W[3];
@@ -217,10 +217,11 @@ int pag_composite_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int
 int pag_composite_feats_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
                             const float *weights, const float *alpha, const void *feats,
                             int feat_dtype, int C, float *out, void *stream);
-/* d feats[i, c] = alpha[ray] * w_i * g_out[ray, c]   (weights and alpha are detached, :148-155) */
+/* d feats[i, c] = alpha[ray] * w_i * g_out[ray, c]   (weights and alpha are detached, :148-155);
+ * d_feats [M,C] in feat_dtype (F32 or BF16). */
 int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
                             const float *weights, const float *alpha, const float *g_out, int C,
-                            float *d_feats, void *stream);
+                            void *d_feats, int feat_dtype, void *stream);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,8 @@ def _digest():
     h.update(repr((COMMON, sorted(SOURCES.items()))).encode())
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for f in sorted(os.listdir(root)):
+            if not os.path.isfile(os.path.join(root, f)):
+                continue
             with open(os.path.join(root, f), "rb") as fh:
                 h.update(f.encode())
                 h.update(fh.read())

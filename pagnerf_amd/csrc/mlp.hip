@@ -58,7 +58,7 @@ struct FwdParams {
 };
 
 struct BwdParams {
-    const float *grad_out;
+    const void *grad_out;      // same dtype as `out` (autograd hands back the output's dtype)
     const void *out;
     int k1, in_dim, in_pad, out_dim, act;
     const float *W[3];
@@ -123,18 +123,24 @@ __device__ __forceinline__ void pack_block(const f32x16 &acc, bf16x8 &lo, bf16x8
 // store one 32-row accumulator block of sample m as 4 groups of 4 consecutive channels
 template <typename T>
 __device__ __forceinline__ void store_block(T *row_ptr, int ch_base, int h, const f32x16 &acc, int n_valid, bool vec_ok) {
+    if (vec_ok) {      // n_valid % 4 == 0: whole groups only
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        int c0 = ch_base + 8 * g + 4 * h;
-        if (vec_ok && c0 + 3 < n_valid) {
-            if constexpr (sizeof(T) == 4) {
-                f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(row_ptr + c0) = v;
-            } else {
-                bf16x4 v = {(bf16_t)acc[4 * g], (bf16_t)acc[4 * g + 1], (bf16_t)acc[4 * g + 2], (bf16_t)acc[4 * g + 3]};
-                *reinterpret_cast<bf16x4 *>(row_ptr + c0) = v;
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = ch_base + 8 * g + 4 * h;
+            if (c0 < n_valid) {
+                if constexpr (sizeof(T) == 4) {
+                    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(row_ptr + c0) = v;
+                } else {
+                    bf16x4 v = {(bf16_t)acc[4 * g], (bf16_t)acc[4 * g + 1], (bf16_t)acc[4 * g + 2], (bf16_t)acc[4 * g + 3]};
+                    *reinterpret_cast<bf16x4 *>(row_ptr + c0) = v;
+                }
             }
-        } else {
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = ch_base + 8 * g + 4 * h;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (c0 + j < n_valid) pag_st(row_ptr + c0 + j, acc[4 * g + j]);
@@ -162,6 +168,66 @@ __device__ __forceinline__ void load_block(const T *row_ptr, int ch_base, int h,
             for (int j = 0; j < 4; ++j) acc[4 * g + j] = (c0 + j < n_valid) ? pag_ld(row_ptr + c0 + j) : 0.0f;
         }
     }
+}
+
+// two-phase variant of load_block: issue every load of a block first (raw registers), convert later, so that
+// the compiler can keep all of a tile's loads in flight instead of waiting on each one before its conversion
+template <typename T> struct RawVec { typedef f32x4 type; };
+template <> struct RawVec<bf16_t> { typedef bf16x4 type; };
+
+template <typename T>
+__device__ __forceinline__ void load_block_raw(const T *row_ptr, int ch_base, int h, typename RawVec<T>::type (&raw)[4], int n_valid,
+                                               bool vec_ok) {
+    typedef typename RawVec<T>::type V;
+    if (vec_ok) {      // n_valid % 4 == 0: a group is wholly in range or wholly out; branch-free (clamped address + select)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = ch_base + 8 * g + 4 * h;
+            const bool ok = c0 < n_valid;
+            V v = *reinterpret_cast<const V *>(row_ptr + (ok ? c0 : 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : (T)0.0f;
+            raw[g] = v;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = ch_base + 8 * g + 4 * h;
+            V v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (c0 + j < n_valid) ? row_ptr[c0 + j] : (T)0.0f;
+            raw[g] = v;
+        }
+    }
+}
+// whole 64-wide rows (hidden activations): no range checks at all
+template <typename T>
+__device__ __forceinline__ void load_block_full(const T *row_ptr, int ch_base, int h, f32x16 &acc) {
+    typename RawVec<T>::type raw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) raw[g] = *reinterpret_cast<const typename RawVec<T>::type *>(row_ptr + ch_base + 8 * g + 4 * h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * g + j] = (float)raw[g][j];
+}
+template <typename T>
+__device__ __forceinline__ void store_block_full(T *row_ptr, int ch_base, int h, const f32x16 &acc) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        typename RawVec<T>::type v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (T)acc[4 * g + j];
+        *reinterpret_cast<typename RawVec<T>::type *>(row_ptr + ch_base + 8 * g + 4 * h) = v;
+    }
+}
+
+template <typename V>
+__device__ __forceinline__ void raw_to_block(const V (&raw)[4], f32x16 &acc) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * g + j] = (float)raw[g][j];
 }
 
 // hidden layer: acc[2] = bias + W(64 x K) . frags ; K = 16 * nks
@@ -239,7 +305,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = fmaxf(acc[mb][q], 0.0f);
             pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
-            if (p.hsave[0] && live) store_block(reinterpret_cast<bf16_t *>(p.hsave[0]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+            if (p.hsave[0] && live) store_block_full(reinterpret_cast<bf16_t *>(p.hsave[0]) + m * HID, 32 * mb, h, acc[mb]);
         }
         if (NL == 3) {
             hidden_layer<4>(W1s, b1s, hb, 4, r, h, acc);
@@ -248,7 +314,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mb][q] = fmaxf(acc[mb][q], 0.0f);
                 pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
-                if (p.hsave[1] && live) store_block(reinterpret_cast<bf16_t *>(p.hsave[1]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+                if (p.hsave[1] && live) store_block_full(reinterpret_cast<bf16_t *>(p.hsave[1]) + m * HID, 32 * mb, h, acc[mb]);
             }
         }
         // ---- output layer
@@ -329,35 +395,44 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
         const int64_t m = tile * 32 + r;
         const bool live = m < p.M;
         const int64_t mc = live ? m : p.M - 1;
-        // ---- dz of the output layer, in accumulator layout
+        // ---- dz of the output layer, in accumulator layout (all loads issued before any use)
         f32x16 z[OBMAX];
-#pragma unroll
-        for (int ob = 0; ob < OBMAX; ++ob)
-            if (ob < OB) load_block(p.grad_out + mc * p.out_dim, 32 * ob, h, z[ob], p.out_dim, vec_out);
-        if (p.act != PAG_ACT_NONE) {
-            f32x16 y[OBMAX];
+        {
+            typename RawVec<OutT>::type rz[OBMAX][4], ry[OBMAX][4];
+            const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
-                if (ob < OB) load_block(outp + mc * p.out_dim, 32 * ob, h, y[ob], p.out_dim, vec_out);
+                if (ob < OB) load_block_raw(gop, 32 * ob, h, rz[ob], p.out_dim, vec_out);
+            if (p.act != PAG_ACT_NONE) {
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB) load_block_raw(outp + mc * p.out_dim, 32 * ob, h, ry[ob], p.out_dim, vec_out);
+            }
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB) raw_to_block(rz[ob], z[ob]);
             if (p.act == PAG_ACT_SIGMOID) {
 #pragma unroll
                 for (int ob = 0; ob < OBMAX; ++ob)
                     if (ob < OB)
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) z[ob][q] = z[ob][q] * y[ob][q] * (1.0f - y[ob][q]);
-            } else {
+                        for (int q = 0; q < 16; ++q) {
+                            const float y = (float)ry[ob][q >> 2][q & 3];
+                            z[ob][q] = z[ob][q] * y * (1.0f - y);
+                        }
+            } else if (p.act == PAG_ACT_SOFTMAX) {
                 float dot = 0.0f;
 #pragma unroll
                 for (int ob = 0; ob < OBMAX; ++ob)
                     if (ob < OB)
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) dot += z[ob][q] * y[ob][q];
+                        for (int q = 0; q < 16; ++q) dot += z[ob][q] * (float)ry[ob][q >> 2][q & 3];
                 dot += __shfl_xor(dot, 32);
 #pragma unroll
                 for (int ob = 0; ob < OBMAX; ++ob)
                     if (ob < OB)
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) z[ob][q] = y[ob][q] * (z[ob][q] - dot);
+                        for (int q = 0; q < 16; ++q) z[ob][q] = (float)ry[ob][q >> 2][q & 3] * (z[ob][q] - dot);
             }
         }
         bf16x8 zb[2 * OBMAX];
@@ -390,11 +465,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
                 }
             }
             f32x16 hv;
-            load_block(reinterpret_cast<const bf16_t *>(p.hsave[NL - 2]) + mc * HID, 32 * mb, h, hv, HID, true);
+            load_block_full(reinterpret_cast<const bf16_t *>(p.hsave[NL - 2]) + mc * HID, 32 * mb, h, hv);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
             pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
-            if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+            if (live) store_block_full(reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + m * HID, 32 * mb, h, acc[mb]);
         }
         if (NL == 3) {
             bf16x8 hb2[4];
@@ -408,11 +483,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
                     acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
                 }
                 f32x16 hv;
-                load_block(reinterpret_cast<const bf16_t *>(p.hsave[0]) + mc * HID, 32 * mb, h, hv, HID, true);
+                load_block_full(reinterpret_cast<const bf16_t *>(p.hsave[0]) + mc * HID, 32 * mb, h, hv);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
                 pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
-                if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[0]) + m * HID, 32 * mb, h, acc[mb], HID, true);
+                if (live) store_block_full(reinterpret_cast<bf16_t *>(p.dz[0]) + m * HID, 32 * mb, h, acc[mb]);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
@@ -547,12 +622,12 @@ __global__ __launch_bounds__(PT) void mlp_bwd_f32(BwdParams p, int n_layers) {
     const bool live = m < p.M;
     const int64_t mc = live ? m : p.M - 1;
     const OutT *y = reinterpret_cast<const OutT *>(p.out) + mc * p.out_dim;
-    const float *g = p.grad_out + mc * p.out_dim;
+    const OutT *g = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
     float dot = 0.0f;
     if (p.act == PAG_ACT_SOFTMAX)
-        for (int j = 0; j < p.out_dim; ++j) dot += g[j] * pag_ld(y + j);
+        for (int j = 0; j < p.out_dim; ++j) dot += pag_ld(g + j) * pag_ld(y + j);
     for (int j = 0; j < p.out_dim; ++j) {
-        float v = g[j];
+        float v = pag_ld(g + j);
         if (p.act == PAG_ACT_SIGMOID) {
             float yy = pag_ld(y + j);
             v = v * yy * (1.0f - yy);
@@ -860,7 +935,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
                           ((p.grp_L + 7) / 8) * p.grp_F <= 8 && a->in_dim == p.grp_L * p.grp_F,
                       "pag_mlp_bwd: XCD8 dx1 needs MFMA mode, bf16, k1 = 64 and in_dim = levels*feats");
     hipStream_t st = (hipStream_t)stream;
-    const bool out_f32 = a->out_dtype == PAG_F32 || a->out_act == PAG_ACT_NONE;
+    const bool out_f32 = a->out_dtype == PAG_F32;      // dtype of grad_out and of the saved activated output
     const bool dx_f32 = a->dx1 == nullptr || a->dx1_dtype == PAG_F32;
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;

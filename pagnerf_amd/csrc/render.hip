@@ -277,9 +277,10 @@ __global__ __launch_bounds__(256) void composite_feats_fwd_kernel(const int64_t 
     }
 }
 
+template <typename FT>
 __global__ __launch_bounds__(256) void composite_feats_bwd_kernel(const int64_t *pack_start, const int32_t *ray_of_pack,
                                                                   const float *weights, const float *alpha, const float *g_out,
-                                                                  int C, float *d_feats) {
+                                                                  int C, FT *d_feats) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pk = blockIdx.x;
     const int64_t beg = pack_start[pk], end = pack_start[pk + 1];
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void composite_feats_bwd_kernel(const int64_t 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = lane + 64 * k;
-            if (c < C) d_feats[i * C + c] = w * g[k];
+            if (c < C) pag_st(d_feats + i * C + c, w * g[k]);
         }
     }
 }
@@ -390,13 +391,19 @@ extern "C" int pag_composite_feats_fwd(const int64_t *pack_start, const int32_t 
 }
 
 extern "C" int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *weights,
-                                       const float *alpha, const float *g_out, int C, float *d_feats, void *stream) {
+                                       const float *alpha, const float *g_out, int C, void *d_feats, int feat_dtype,
+                                       void *stream) {
     PAG_CHECK_ARG(P >= 0, "pag_composite_feats_bwd: P < 0");
     PAG_CHECK_ARG(C >= 1 && C <= 256, "pag_composite_feats_bwd: C %d not in [1,256]", C);
+    PAG_CHECK_ARG(feat_dtype == PAG_F32 || feat_dtype == PAG_BF16, "pag_composite_feats_bwd: feats dtype must be F32 or BF16");
     if (P == 0) return PAG_OK;
     PAG_CHECK_ARG(pack_start && ray_of_pack && weights && alpha && g_out && d_feats, "pag_composite_feats_bwd: NULL input");
-    hipLaunchKernelGGL(composite_feats_bwd_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start, ray_of_pack,
-                       weights, alpha, g_out, C, d_feats);
+    if (feat_dtype == PAG_F32)
+        hipLaunchKernelGGL((composite_feats_bwd_kernel<float>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start,
+                           ray_of_pack, weights, alpha, g_out, C, (float *)d_feats);
+    else
+        hipLaunchKernelGGL((composite_feats_bwd_kernel<bf16_t>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start,
+                           ray_of_pack, weights, alpha, g_out, C, (bf16_t *)d_feats);
     PAG_CHECK_LAUNCH("pag_composite_feats_bwd");
     return PAG_OK;
 }

@@ -212,7 +212,7 @@ class PanopticDeltaNeF(nn.Module):
             if "semantics" in compute_channels:                                        # :238-244
                 plain = not (self.sem_sigmoid or self.sem_normalize)
                 act = L.ACT_SOFTMAX if (self.sem_softmax and plain) else L.ACT_NONE
-                s = self.decoder_semantics(pan, out_act=act, mode=mode, x1_grouped=grp)
+                s = self.decoder_semantics(pan, out_act=act, mode=mode, x1_grouped=grp, out_dtype=self.feat_dtype)
                 if not plain:
                     s = torch.sigmoid(s) if self.sem_sigmoid else s
                     s = F.normalize(s, dim=-1) if self.sem_normalize else s
@@ -221,7 +221,7 @@ class PanopticDeltaNeF(nn.Module):
             if "inst_embedding" in compute_channels:                                   # :246-257
                 plain = not (self.inst_sigmoid or self.inst_normalize or self.inst_soft_temperature > 0.0)
                 act = L.ACT_SOFTMAX if (self.inst_softmax and plain) else L.ACT_NONE
-                e = self.decoder_inst(pan, out_act=act, mode=mode, x1_grouped=grp)
+                e = self.decoder_inst(pan, out_act=act, mode=mode, x1_grouped=grp, out_dtype=self.feat_dtype)
                 if not plain:
                     e = torch.sigmoid(e) if self.inst_sigmoid else e
                     e = F.normalize(e, dim=-1) if self.inst_normalize else e

@@ -247,7 +247,7 @@ class _FusedMLP(torch.autograd.Function):
         dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
         need_dx = ctx.needs_input_grad[0]
         dx1 = torch.empty(x1.shape, device=dev, dtype=x1.dtype) if need_dx else None
-        g = g.contiguous().float()
+        g = g.contiguous().to(out.dtype)       # grad_out travels in the output's dtype
         a = L.MlpBwdArgs()
         a.grad_out, a.out, a.out_dtype, a.out_act = L.ptr(g), L.ptr(out), L.dtype_code(out), out_act
         a.k1, a.in_dim, a.n_layers, a.out_dim = k1, in_dim, n_layers, out_dim
@@ -439,11 +439,11 @@ class _CompositeFeats(torch.autograd.Function):
         weights, alpha, pack_start, ray_of_pack = ctx.saved_tensors
         M, C = ctx.shape
         P = ray_of_pack.shape[0]
-        d = torch.zeros(M, C, device=weights.device)
+        d = torch.zeros(M, C, device=weights.device, dtype=ctx.fdtype)
         if P:
             _call("pag_composite_feats_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
-                                                L.ptr(g.contiguous().float()), C, L.ptr(d), L.stream())
-        return d.to(ctx.fdtype), None, None, None, None, None
+                  L.ptr(g.contiguous().float()), C, L.ptr(d), L.dtype_code(d), L.stream())
+        return d, None, None, None, None, None
 
 
 def composite_feats(feats, weights, alpha, pack_start, ray_of_pack, N):
