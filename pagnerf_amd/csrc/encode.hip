@@ -220,6 +220,13 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[
     const unsigned long long m = __ballot(same);
     emit = live;
     if (__popcll(m) < 8) return;
+#ifdef PAG_BIN_FAKE_COMBINE
+    {
+        const bool ns = (m >> ((lane + 1) & 63)) & 1ull;
+        emit = live && (lane == 63 || !ns);
+        return;
+    }
+#endif
     bool f = !same;                      // head flag
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -319,8 +326,16 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
             for (int f = 0; f < F; ++f) ev[k][f] = gv[f] * w[k];
+#ifdef PAG_BIN_NO_COMBINE
+            emit[k] = live;
+#else
             run_combine<F>(live ? idx[k] : 0xFFFFFFFFu, live, ev[k], emit[k], lane);
+#endif
+#ifdef PAG_BIN_NO_SORT
+            rank[k] = 0u;
+#else
             rank[k] = emit[k] ? atomicAdd(&cnt[idx[k] >> lay.shift], 1u) : 0u;
+#endif
         }
         __syncthreads();
         if (tid < 64) {   // exclusive prefix over the NS slice counters by one wave
@@ -343,9 +358,17 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
         const int64_t region = ((int64_t)level * lay.ntiles + tile) * (TS * NV);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
+#ifdef PAG_BIN_NO_WRITE
+            if (emit[k] && idx[k] == 0xFFFFFFF0u) {
+#else
             if (emit[k]) {
+#endif
                 const uint32_t s = idx[k] >> lay.shift;
+#ifdef PAG_BIN_NO_SORT
+                const int64_t pos = region + (int64_t)tid * NV + k;
+#else
                 const int64_t pos = region + offs[s] + rank[k];
+#endif
                 lay.keys[pos] = idx[k] & ((1u << lay.shift) - 1u);
 #pragma unroll
                 for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[k][f];

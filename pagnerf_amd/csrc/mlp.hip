@@ -120,10 +120,15 @@ __device__ __forceinline__ void pack_block(const f32x16 &acc, bf16x8 &lo, bf16x8
     }
 }
 
+template <typename T>
+__device__ __forceinline__ void store_block_full(T *row_ptr, int ch_base, int h, const f32x16 &acc);
+
 // store one 32-row accumulator block of sample m as 4 groups of 4 consecutive channels
 template <typename T>
 __device__ __forceinline__ void store_block(T *row_ptr, int ch_base, int h, const f32x16 &acc, int n_valid, bool vec_ok) {
-    if (vec_ok) {      // n_valid % 4 == 0: whole groups only
+    if (vec_ok && ch_base + 32 <= n_valid) {
+        store_block_full(row_ptr, ch_base, h, acc);
+    } else if (vec_ok) {      // n_valid % 4 == 0: whole groups only
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = ch_base + 8 * g + 4 * h;
@@ -179,7 +184,10 @@ template <typename T>
 __device__ __forceinline__ void load_block_raw(const T *row_ptr, int ch_base, int h, typename RawVec<T>::type (&raw)[4], int n_valid,
                                                bool vec_ok) {
     typedef typename RawVec<T>::type V;
-    if (vec_ok) {      // n_valid % 4 == 0: a group is wholly in range or wholly out; branch-free (clamped address + select)
+    if (vec_ok && ch_base + 32 <= n_valid) {      // block wholly in range (all but the last block): plain vector loads
+#pragma unroll
+        for (int g = 0; g < 4; ++g) raw[g] = *reinterpret_cast<const V *>(row_ptr + ch_base + 8 * g + 4 * h);
+    } else if (vec_ok) {      // n_valid % 4 == 0: a group is wholly in range or wholly out; branch-free (clamped address + select)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = ch_base + 8 * g + 4 * h;
@@ -278,25 +286,36 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
     const X1T *x1 = reinterpret_cast<const X1T *>(p.x1);
     OutT *out = reinterpret_cast<OutT *>(p.out);
 
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    // layer-0 B fragments straight from memory (features 16s + 8h .. +7 of sample m); the NEXT tile's fragments are
+    // requested before the current tile is computed so that their HBM latency hides under the MFMA / epilogue work
+    auto load_x = [&](int64_t tile, bf16x8 (&xf)[4]) {
         const int64_t m = tile * 32 + r;
-        const bool live = m < p.M;
-        const int64_t mc = live ? m : p.M - 1;
-        // ---- layer-0 B fragments straight from memory: features 16s + 8h .. +7 of sample m
-        bf16x8 xb[4];
-        const int32_t ray = p.x2 ? p.x2_index[mc] : 0;
+        const bool live = tile < ntiles && m < p.M;
+        const int64_t mc = live ? m : 0;
+        const int32_t ray = (p.x2 && live) ? p.x2_index[mc] : 0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int f0 = 16 * s + 8 * h;
             if (p.grp_L && live)
-                xb[s] = load8(reinterpret_cast<const bf16_t *>(p.x1) + ((int64_t)(2 * s + h) * p.M + mc) * 8);
+                xf[s] = load8(reinterpret_cast<const bf16_t *>(p.x1) + ((int64_t)(2 * s + h) * p.M + mc) * 8);
             else if (s < nks0 && live && f0 < p.k1)
-                xb[s] = load8(x1 + mc * p.k1 + f0);
+                xf[s] = load8(x1 + mc * p.k1 + f0);
             else if (s < nks0 && live && f0 < p.k1 + p.k2p)
-                xb[s] = load8(p.x2 + (int64_t)ray * p.k2p + (f0 - p.k1));
+                xf[s] = load8(p.x2 + (int64_t)ray * p.k2p + (f0 - p.k1));
             else
-                xb[s] = zero8();
+                xf[s] = zero8();
         }
+    };
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    bf16x8 xnext[4];
+    load_x((int64_t)blockIdx.x * 4 + wave, xnext);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
+        const int64_t m = tile * 32 + r;
+        const bool live = m < p.M;
+        bf16x8 xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = xnext[s];
+        load_x(tile + tile_step, xnext);
         f32x16 acc[2];
         bf16x8 hb[4];
         hidden_layer<4>(W0s, b0s, xb, nks0, r, h, acc);
@@ -331,37 +350,58 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
                 }
             }
         }
+        // Output activations on the accumulators.  The bf16 path uses the hardware exp2 / rcp (v_exp_f32, v_rcp_f32:
+        // ~1 ulp) - an accurate expf() and a true division per element made this epilogue 5400 VALU instructions per
+        // 32-sample tile and the kernel VALU-bound (rocprofv3 SQ_INSTS_VALU); only the last block can hold padding rows.
+        constexpr float LOG2E = 1.4426950408889634f;
         if (p.act == PAG_ACT_SIGMOID) {
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
                 if (ob < OB)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) o[ob][q] = 1.0f / (1.0f + expf(-o[ob][q]));
+                    for (int q = 0; q < 16; ++q)
+                        o[ob][q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * o[ob][q]));
         } else if (p.act == PAG_ACT_SOFTMAX) {
             float mx = -INFINITY;
 #pragma unroll
-            for (int ob = 0; ob < OBMAX; ++ob)
-                if (ob < OB)
+            for (int ob = 0; ob < OBMAX; ++ob) {
+                if (ob < OB - 1) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) mx = fmaxf(mx, o[ob][q]);
+                } else if (ob == OB - 1) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         if (32 * ob + rho(q, h) < p.out_dim) mx = fmaxf(mx, o[ob][q]);
+                }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mxs = mx * LOG2E;
             float sum = 0.0f;
 #pragma unroll
-            for (int ob = 0; ob < OBMAX; ++ob)
-                if (ob < OB)
+            for (int ob = 0; ob < OBMAX; ++ob) {
+                if (ob < OB - 1) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        float e = (32 * ob + rho(q, h) < p.out_dim) ? expf(o[ob][q] - mx) : 0.0f;
+                        const float e = __builtin_amdgcn_exp2f(fmaf(o[ob][q], LOG2E, -mxs));
                         o[ob][q] = e;
                         sum += e;
                     }
+                } else if (ob == OB - 1) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float e = (32 * ob + rho(q, h) < p.out_dim) ? __builtin_amdgcn_exp2f(fmaf(o[ob][q], LOG2E, -mxs)) : 0.0f;
+                        o[ob][q] = e;
+                        sum += e;
+                    }
+                }
+            }
             sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
                 if (ob < OB)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) o[ob][q] = o[ob][q] / sum;
+                    for (int q = 0; q < 16; ++q) o[ob][q] *= inv;
         }
         if (live) {
 #pragma unroll
@@ -391,23 +431,59 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
     const bool vec_out = (p.out_dim % 4) == 0;
     const OutT *outp = reinterpret_cast<const OutT *>(p.out);
 
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    typedef typename RawVec<OutT>::type RawO;
+    constexpr bool PREFETCH = OBMAX <= 2;          // registers allow keeping the next tile's gradients in flight
+    auto load_g = [&](int64_t tile, RawO (&rz)[OBMAX][4], RawO (&ry)[OBMAX][4]) {
+        const int64_t m = tile * 32 + r;
+        const int64_t mc = (tile < ntiles && m < p.M) ? m : p.M - 1;
+        const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
+#pragma unroll
+        for (int ob = 0; ob < OBMAX; ++ob)
+            if (ob < OB) load_block_raw(gop, 32 * ob, h, rz[ob], p.out_dim, vec_out);
+        if (p.act != PAG_ACT_NONE) {
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB) load_block_raw(outp + mc * p.out_dim, 32 * ob, h, ry[ob], p.out_dim, vec_out);
+        }
+    };
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    RawO nz[PREFETCH ? OBMAX : 1][4], ny[PREFETCH ? OBMAX : 1][4];
+    if constexpr (PREFETCH) load_g((int64_t)blockIdx.x * 4 + wave, nz, ny);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
         const int64_t m = tile * 32 + r;
         const bool live = m < p.M;
         const int64_t mc = live ? m : p.M - 1;
-        // ---- dz of the output layer, in accumulator layout (all loads issued before any use)
-        f32x16 z[OBMAX];
-        {
-            typename RawVec<OutT>::type rz[OBMAX][4], ry[OBMAX][4];
-            const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
+        // ReLU masks of the hidden layers: requested first, consumed after the first MFMA chain
+        bf16x4 hraw[NL - 1][2][4];
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hraw[l][mb][g] = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.hsave[l]) + mc * HID + 32 * mb + 8 * g + 4 * h);
+        // ---- dz of the output layer -> bf16 B fragments zb[] (k-steps of the first backward MFMA chain)
+        bf16x8 zb[2 * OBMAX];
+        const bool tile_full = (tile + 1) * 32 <= p.M;      // wave-uniform: only the last tile has dead lanes
+        auto finish_block = [&](int ob, f32x16 &zz) {      // zero dead lanes, store dz, pack
+            if (!tile_full) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) zz[q] = live ? zz[q] : 0.0f;
+            }
+            pack_block(zz, zb[2 * ob], zb[2 * ob + 1]);
+            if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, zz, p.out_dim, vec_out);
+        };
+        if constexpr (PREFETCH) {
+            f32x16 z[OBMAX];
+            RawO rz[OBMAX][4], ry[OBMAX][4];
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
-                if (ob < OB) load_block_raw(gop, 32 * ob, h, rz[ob], p.out_dim, vec_out);
-            if (p.act != PAG_ACT_NONE) {
 #pragma unroll
-                for (int ob = 0; ob < OBMAX; ++ob)
-                    if (ob < OB) load_block_raw(outp + mc * p.out_dim, 32 * ob, h, ry[ob], p.out_dim, vec_out);
-            }
+                for (int g = 0; g < 4; ++g) {
+                    rz[ob][g] = nz[ob][g];
+                    ry[ob][g] = ny[ob][g];
+                }
+            load_g(tile + tile_step, nz, ny);
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
                 if (ob < OB) raw_to_block(rz[ob], z[ob]);
@@ -434,20 +510,56 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
 #pragma unroll
                         for (int q = 0; q < 16; ++q) z[ob][q] = (float)ry[ob][q >> 2][q & 3] * (z[ob][q] - dot);
             }
-        }
-        bf16x8 zb[2 * OBMAX];
 #pragma unroll
-        for (int ob = 0; ob < OBMAX; ++ob) {
-            if (ob < OB) {
-                if (!live) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) z[ob][q] = 0.0f;
+            for (int ob = 0; ob < OBMAX; ++ob) {
+                if (ob < OB) {
+                    finish_block(ob, z[ob]);
+                } else {
+                    zb[2 * ob] = zero8();
+                    zb[2 * ob + 1] = zero8();
                 }
-                pack_block(z[ob], zb[2 * ob], zb[2 * ob + 1]);
-                if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, z[ob], p.out_dim, vec_out);
-            } else {
-                zb[2 * ob] = zero8();
-                zb[2 * ob + 1] = zero8();
+            }
+        } else {
+            // wide heads: two passes over the (L2-resident) gradient / probability rows keep only ONE 32-channel
+            // block live at a time instead of all of them (256 VGPRs -> 1 wave per SIMD before)
+            const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
+            const OutT *yop = outp + mc * p.out_dim;
+            float dot = 0.0f;
+            if (p.act == PAG_ACT_SOFTMAX) {
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB) {
+                        RawO rz1[4], ry1[4];
+                        load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
+                        load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) dot += (float)rz1[q >> 2][q & 3] * (float)ry1[q >> 2][q & 3];
+                    }
+                dot += __shfl_xor(dot, 32);
+            }
+#pragma unroll
+            for (int ob = 0; ob < OBMAX; ++ob) {
+                if (ob < OB) {
+                    RawO rz1[4], ry1[4];
+                    f32x16 zz;
+                    load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
+                    if (p.act != PAG_ACT_NONE) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+                    raw_to_block(rz1, zz);
+                    if (p.act == PAG_ACT_SIGMOID) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float y = (float)ry1[q >> 2][q & 3];
+                            zz[q] = zz[q] * y * (1.0f - y);
+                        }
+                    } else if (p.act == PAG_ACT_SOFTMAX) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) zz[q] = (float)ry1[q >> 2][q & 3] * (zz[q] - dot);
+                    }
+                    finish_block(ob, zz);
+                } else {
+                    zb[2 * ob] = zero8();
+                    zb[2 * ob + 1] = zero8();
+                }
             }
         }
         // ---- back through the output layer: dA = W_L^T . dz_L, masked by the saved ReLU output
@@ -465,7 +577,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
                 }
             }
             f32x16 hv;
-            load_block_full(reinterpret_cast<const bf16_t *>(p.hsave[NL - 2]) + mc * HID, 32 * mb, h, hv);
+            raw_to_block(hraw[NL - 2][mb], hv);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
             pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
@@ -483,7 +595,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
                     acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
                 }
                 f32x16 hv;
-                load_block_full(reinterpret_cast<const bf16_t *>(p.hsave[0]) + mc * HID, 32 * mb, h, hv);
+                raw_to_block(hraw[0][mb], hv);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
                 pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
