@@ -819,7 +819,7 @@ struct WgradParams {
 constexpr int WG_RS = 72;       // LDS row stride (bf16) of the transposed tiles: 64 samples + 8 pad
 constexpr int WG_SLAB_COLS = 96;
 
-template <typename A1T>
+template <typename A1T, int APW /* accumulator blocks per wave: 2 (<= 8 block pairs) or 6 */>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.n_out + 31) / 32;
@@ -829,9 +829,9 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int npairs = OB * (IB + 1);
-    f32x16 acc[6];
+    f32x16 acc[APW];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < APW; ++i)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
     bf16x8 ones;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < APW; ++i) {
             const int pr = wave + 4 * i;
             if (pr < npairs) {
                 const int ob = pr / (IB + 1), ib = pr - ob * (IB + 1);
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
     }
     float *slab = p.slabs + (int64_t)blockIdx.x * OB * 32 * WG_SLAB_COLS;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < APW; ++i) {
         const int pr = wave + 4 * i;
         if (pr < npairs) {
             const int ob = pr / (IB + 1), ib = pr - ob * (IB + 1);
@@ -1078,7 +1078,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
 
 extern "C" int pag_mlp_wgrad_blocks(int64_t M) {
     int64_t chunks = (M + 63) / 64;
-    return (int)(chunks < 512 ? (chunks > 0 ? chunks : 1) : 512);
+    return (int)(chunks < 1024 ? (chunks > 0 ? chunks : 1) : 1024);
 }
 
 extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1_dtype, int a1_layout, int k1,
@@ -1098,10 +1098,14 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
     WgradParams p{(const bf16_t *)dz, dz_cols, n_out, a1, k1, a2, a2 ? k2p : 0, a2_index, n_in, slabs, M, a1_layout == PAG_LAYOUT_XCD8};
     const int OB = (n_out + 31) / 32, IB = (n_in + 31) / 32;
     const size_t lds = (size_t)(OB + IB) * 32 * WG_RS * sizeof(bf16_t);
-    if (a1_dtype == PAG_F32)
-        hipLaunchKernelGGL((mlp_wgrad_kernel<float>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+    const bool small = OB * (IB + 1) <= 8;      // fewer accumulators -> fewer VGPRs -> more resident workgroups
+    if (a1_dtype == PAG_F32) {
+        if (small) hipLaunchKernelGGL((mlp_wgrad_kernel<float, 2>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((mlp_wgrad_kernel<float, 6>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+    } else {
+        if (small) hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 2>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 6>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+    }
     PAG_CHECK_LAUNCH("pag_mlp_wgrad");
     return PAG_OK;
 }
