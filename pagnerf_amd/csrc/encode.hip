@@ -213,9 +213,26 @@ struct BinLayout {
 
 // merge runs of equal keys in adjacent lanes: on return `emit` is set on the last lane of every run
 // and that lane's v[] holds the run's sum.  Skipped (wave-uniformly) when the wave has few repeats.
+// The segmented inclusive scan runs on DPP moves (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 and
+// row_bcast:31 to carry the row totals across) - VALU-rate lane crossings instead of ds_bpermute through the LDS.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int src) {
+    return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, 0xF, true);   // masked / out-of-row sources read as 0 = the scan identity
+}
+template <int F, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(float (&v)[F], int &f) {
+    // element = (f: a run head lies between the source lane (exclusive) and this lane (inclusive), v: sum since that head)
+    const int fp = dpp_i<CTRL, ROW_MASK>(f);
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        const float vp = __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v[k])));
+        v[k] = f ? v[k] : v[k] + vp;
+    }
+    f |= fp;
+}
 template <int F>
 __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[F], bool &emit, int lane) {
-    const uint32_t prev = __shfl_up(key, 1);
+    const uint32_t prev = (uint32_t)dpp_i<0x138, 0xF>((int)key);             // wave_shr:1
     const bool same = live && lane > 0 && prev == key;
     const unsigned long long m = __ballot(same);
     emit = live;
@@ -227,38 +244,32 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[
         return;
     }
 #endif
-    bool f = !same;                      // head flag
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float up[F];
-#pragma unroll
-        for (int k = 0; k < F; ++k) up[k] = __shfl_up(v[k], d);
-        const bool fu = __shfl_up((int)f, d) != 0;
-        if (lane >= d && !f) {
-#pragma unroll
-            for (int k = 0; k < F; ++k) v[k] += up[k];
-            f = fu;
-        }
-    }
+    int f = same ? 0 : 1;                 // run head
+    seg_step<F, 0x111, 0xF>(v, f);        // row_shr:1
+    seg_step<F, 0x112, 0xF>(v, f);        // row_shr:2
+    seg_step<F, 0x114, 0xF>(v, f);        // row_shr:4
+    seg_step<F, 0x118, 0xF>(v, f);        // row_shr:8
+    seg_step<F, 0x142, 0xA>(v, f);        // row_bcast:15 -> rows 1, 3
+    seg_step<F, 0x143, 0xC>(v, f);        // row_bcast:31 -> rows 2, 3
     const bool next_same = (m >> ((lane + 1) & 63)) & 1ull;
     emit = live && (lane == 63 || !next_same);
 }
 
-template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F>
+template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX>
 __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
                                                  int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
-    __shared__ uint32_t cnt[NS_MAX + 2];     // [NS_MAX + 1] = max |g| of this (tile, level)
-    __shared__ uint32_t offs[NS_MAX + 1];
+    __shared__ uint32_t cnt[LPX][NS_MAX + 2];     // [.][NS_MAX + 1] = max |g| of this (tile, level)
+    __shared__ uint32_t offs[LPX][NS_MAX + 1];
     const int L = KIND == 0 ? hp.L : pp.L;
     const int64_t tile = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i = tile * TS + tid;
     const bool live = i < M;
     const int64_t ic = live ? i : M - 1;
     float x[3] = {xyz[ic * 3 + 0], xyz[ic * 3 + 1], xyz[ic * 3 + 2]};
-    // grouped: blockIdx.y = XCD group g, levels g, g+8, ...; the 16-byte gradient piece is read once.
-    // strided: blockIdx.y = level.
+    // grouped (LPX = ceil(L/8)): blockIdx.y = XCD group g, levels g, g+8, ... share ONE counting sort and the 16-byte
+    // gradient piece is read once.  strided (LPX = 1): blockIdx.y = level.
     float gpiece[8];
     if (grouped) {
         typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
@@ -268,115 +279,105 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
     }
     const float *scale = KIND == 0 ? hp.scale : pp.scale;
     const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
-    for (int j = 0; j < (grouped ? 4 : 1); ++j) {
+    for (int s = tid; s < LPX * (NS_MAX + 2); s += TS) (&cnt[0][0])[s] = 0;
+    __syncthreads();
+    uint32_t idx[LPX][NV];
+    float ev[LPX][NV][F];
+    bool emit[LPX][NV];
+    uint32_t rank[LPX][NV];
+#pragma unroll
+    for (int j = 0; j < LPX; ++j) {
         const int level = grouped ? (int)blockIdx.y + 8 * j : (int)blockIdx.y;
-        if (level >= L) break;
-        for (int s = tid; s <= lay.NS; s += TS) cnt[s] = 0;
-        if (tid == 0) cnt[NS_MAX + 1] = 0;
-        __syncthreads();
-        uint32_t idx[NV];
+        const bool lv = level < L;
+        const int lc = lv ? level : L - 1;
         float w[NV];
         float gv[F];
         if (KIND == 0) {
             float w3[3];
             uint32_t id8[8];
-            hash_cell(x, hp.res[level], hp.log2T, id8, w3);
+            hash_cell(x, hp.res[lc], hp.log2T, id8, w3);
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                idx[k] = id8[k & 7];
+                idx[j][k] = id8[k & 7];
                 w[k] = ((k & 4) ? w3[0] : 1.0f - w3[0]) * ((k & 2) ? w3[1] : 1.0f - w3[1]) * ((k & 1) ? w3[2] : 1.0f - w3[2]);
             }
         } else {
             uint32_t id4[4];
             float b4[4];
-            permuto_simplex(x, pp.shift[level], pp.sf[level], pp.capacity, pp.pow2mask, id4, b4);
+            permuto_simplex(x, pp.shift[lc], pp.sf[lc], pp.capacity, pp.pow2mask, id4, b4);
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                idx[k] = id4[k & 3];
+                idx[j][k] = id4[k & 3];
                 w[k] = b4[k & 3];
             }
         }
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             if (grouped) {
-                float t = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t = (e == j * F + f) ? gpiece[e] : t;
-                gv[f] = t;
+                gv[f] = gpiece[(j * F + f) & 7];
             } else {
-                gv[f] = pag_ld(go + ic * sm + (int64_t)(level * F + f) * sc);
+                gv[f] = pag_ld(go + ic * sm + (int64_t)(lc * F + f) * sc);
             }
-            if (has_scale) gv[f] *= scale[level * F + f];
+            if (has_scale) gv[f] *= scale[lc * F + f];
         }
-        {   // per-level max |g| (positive floats order like their bit patterns): feeds the fixed-point scale of pass 2
+        {   // per-(tile, level) max |g| (positive floats order like their bit patterns): feeds the fixed-point scale of pass 2
             float mx = 0.0f;
 #pragma unroll
-            for (int f = 0; f < F; ++f) mx = fmaxf(mx, live ? fabsf(gv[f]) : 0.0f);
+            for (int f = 0; f < F; ++f) mx = fmaxf(mx, (live && lv) ? fabsf(gv[f]) : 0.0f);
             uint32_t mb = __float_as_uint(mx);
             if (mx != mx) mb = 0x7FC00000u;   // NaN poisons the level
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, d));
-            if (lane == 0 && mb) atomicMax(&cnt[NS_MAX + 1], mb);     // LDS, one per wave
+            if (lane == 0 && mb) atomicMax(&cnt[j][NS_MAX + 1], mb);     // LDS, one per wave
         }
-        __syncthreads();
-        float ev[NV][F];
-        bool emit[NV];
-        uint32_t rank[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
-            for (int f = 0; f < F; ++f) ev[k][f] = gv[f] * w[k];
+            for (int f = 0; f < F; ++f) ev[j][k][f] = gv[f] * w[k];
+            const bool lk = live && lv;
 #ifdef PAG_BIN_NO_COMBINE
-            emit[k] = live;
+            emit[j][k] = lk;
 #else
-            run_combine<F>(live ? idx[k] : 0xFFFFFFFFu, live, ev[k], emit[k], lane);
+            run_combine<F>(lk ? idx[j][k] : 0xFFFFFFFFu, lk, ev[j][k], emit[j][k], lane);
 #endif
-#ifdef PAG_BIN_NO_SORT
-            rank[k] = 0u;
-#else
-            rank[k] = emit[k] ? atomicAdd(&cnt[idx[k] >> lay.shift], 1u) : 0u;
-#endif
+            rank[j][k] = emit[j][k] ? atomicAdd(&cnt[j][idx[j][k] >> lay.shift], 1u) : 0u;
         }
-        __syncthreads();
-        if (tid < 64) {   // exclusive prefix over the NS slice counters by one wave
-            uint32_t carry = 0;
-            for (int s0 = 0; s0 < lay.NS; s0 += 64) {
-                const int s = s0 + lane;
-                uint32_t c = s < lay.NS ? cnt[s] : 0u;
-                uint32_t incl = c;
+    }
+    __syncthreads();
+    if (wave < LPX) {   // wave j: exclusive prefix over level j's NS slice counters
+        uint32_t carry = 0;
+        for (int s0 = 0; s0 < lay.NS; s0 += 64) {
+            const int s = s0 + lane;
+            uint32_t c = s < lay.NS ? cnt[wave][s] : 0u;
+            uint32_t incl = c;
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    uint32_t t = __shfl_up(incl, d);
-                    if (lane >= d) incl += t;
-                }
-                if (s < lay.NS) offs[s] = carry + incl - c;
-                carry += __shfl(incl, 63);
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
             }
-            if (lane == 0) offs[lay.NS] = carry;
+            if (s < lay.NS) offs[wave][s] = carry + incl - c;
+            carry += __shfl(incl, 63);
         }
-        __syncthreads();
+        if (lane == 0) offs[wave][lay.NS] = carry;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LPX; ++j) {
+        const int level = grouped ? (int)blockIdx.y + 8 * j : (int)blockIdx.y;
+        if (level >= L) break;
         const int64_t region = ((int64_t)level * lay.ntiles + tile) * (TS * NV);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-#ifdef PAG_BIN_NO_WRITE
-            if (emit[k] && idx[k] == 0xFFFFFFF0u) {
-#else
-            if (emit[k]) {
-#endif
-                const uint32_t s = idx[k] >> lay.shift;
-#ifdef PAG_BIN_NO_SORT
-                const int64_t pos = region + (int64_t)tid * NV + k;
-#else
-                const int64_t pos = region + offs[s] + rank[k];
-#endif
-                lay.keys[pos] = idx[k] & ((1u << lay.shift) - 1u);
+            if (emit[j][k]) {
+                const uint32_t s = idx[j][k] >> lay.shift;
+                const int64_t pos = region + offs[j][s] + rank[j][k];
+                lay.keys[pos] = idx[j][k] & ((1u << lay.shift) - 1u);
 #pragma unroll
-                for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[k][f];
+                for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[j][k][f];
             }
         }
-        for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[s];
-        if (tid == 0) lay.tile_max[(int64_t)level * lay.ntiles + tile] = cnt[NS_MAX + 1];
-        __syncthreads();
+        for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[j][s];
+        if (tid == 0) lay.tile_max[(int64_t)level * lay.ntiles + tile] = cnt[j][NS_MAX + 1];
     }
 }
 
@@ -539,9 +540,15 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
     lay.shift = b.shift;
     dim3 g1((unsigned)b.ntiles, (unsigned)(grouped ? (L < 8 ? L : 8) : L)), g2((unsigned)(L * b.NS));
     const size_t lds = ((size_t)1 << b.shift) * F * sizeof(unsigned long long);
+    const int lpx = grouped ? (L + 7) / 8 : 1;
+#define BIN_LAUNCH1(GT, F_, LPX_)                                                                                       \
+    hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay)
 #define BIN_LAUNCH(GT, F_)                                                                                              \
     do {                                                                                                                \
-        hipLaunchKernelGGL((bin_kernel<KIND, GT, F_>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay); \
+        if (lpx == 1) BIN_LAUNCH1(GT, F_, 1);                                                                           \
+        else if (lpx == 2) BIN_LAUNCH1(GT, F_, 2);                                                                      \
+        else if (lpx == 3) BIN_LAUNCH1(GT, F_, 3);                                                                      \
+        else BIN_LAUNCH1(GT, F_, 4);                                                                                    \
         hipLaunchKernelGGL((reduce_kernel<F_, NV>), g2, dim3(1024), lds, st, lay, rows, gtab);                         \
     } while (0)
     if (grad_dtype == PAG_F32) {
@@ -554,6 +561,7 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
         else BIN_LAUNCH(bf16_t, 1);
     }
 #undef BIN_LAUNCH
+#undef BIN_LAUNCH1
     return PAG_OK;
 }
 
