@@ -186,6 +186,21 @@ int pag_raymarch_pack(const float *origins, const float *dirs, int64_t N, int S,
                       int32_t *ridx, int32_t *pidx, float *samples, float *depths, float *deltas,
                       uint8_t *boundary, void *stream);
 
+/* 'voxel' mode (wisp OctreeAS.raymarch after pc_nerf/trainer.py:362-366 switches the tracer): every ray is walked
+ * through the 2^blas_level occupancy grid (3-D DDA); each occupied cell it crosses (a "nugget") receives
+ * samples_per_voxel samples.  Pass 1 counts nuggets per ray; pass 2 (offsets = exclusive prefix sum) writes
+ *   ridx i32 [M'], pidx i32 [M'] per nugget; samples f32 [M',k,3], depths f32 [M',k], deltas f32 [M'*k],
+ *   boundary u8 [M'*k] (1 at the first sample of a ray's first nugget) - the shapes
+ *   tracers/panoptic_packed_rf_tracer.py:88-108 indexes. */
+int pag_raymarch_voxel_count(const float *origins, const float *dirs, int64_t N, float dist_min,
+                             float dist_max, const uint32_t *occupancy_bits, int blas_level,
+                             int32_t *counts, void *stream);
+int pag_raymarch_voxel_pack(const float *origins, const float *dirs, int64_t N, int samples_per_voxel,
+                            float dist_min, float dist_max, const uint32_t *occupancy_bits,
+                            int blas_level, const int64_t *offsets, int32_t *ridx, int32_t *pidx,
+                            float *samples, float *depths, float *deltas, uint8_t *boundary,
+                            void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Alpha compositing - kaolin spc_render.exponential_integration / sum_reduce as used at
  * tracers/panoptic_packed_rf_tracer.py:134-182,197-205

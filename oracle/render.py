@@ -140,3 +140,84 @@ def voxel_travel_filter(ridx, depths, ray_max_travel):
     first = torch.take(depths[:, 0, 0], start)
     travelled = depths[:, 0, 0] - torch.repeat_interleave(first, counts)
     return travelled < ray_max_travel
+
+
+def raymarch_voxel(origins, dirs, dist_min, dist_max, num_samples, occupancy=None, blas_level=7):
+    """'voxel' mode: every ray is walked cell by cell (3-D DDA) through the 2^level occupancy grid over [-1,1]^3;
+    each occupied cell it crosses (a "nugget" [t_in, t_out], clipped to [dist_min, dist_max]) gets k = num_samples
+    samples at t_in + (t_out - t_in) * (i + 0.5) / k with delta (t_out - t_in) / k.
+
+    PARITY UNPINNED: upstream this is kaolin unbatched_raytrace + wisp OctreeAS.raymarch (third party, not in the
+    reference tree); the reference only fixes the output contract (tracers/panoptic_packed_rf_tracer.py:88-108 and
+    SURVEY Appendix A5): ridx per nugget [M'], samples [M',k,3], depths [M',k,1], deltas [M'*k,1], boundary [M'*k].
+    Scalar fp32 arithmetic in the exact order of the HIP kernel (pagnerf_amd/csrc/render.hip voxel_march_kernel)."""
+    import numpy as np
+    f = np.float32
+    R = 2 ** blas_level
+    cs = f(2.0) / f(R)
+    k = num_samples
+    o_all, d_all = origins.numpy().astype(np.float32), dirs.numpy().astype(np.float32)
+    occ = None if occupancy is None else occupancy.reshape(-1).numpy()
+    ridx, pidx, tin_l, tout_l = [], [], [], []
+    INF = f(np.inf)
+    for r in range(o_all.shape[0]):
+        o, d = o_all[r], d_all[r]
+        t0, t1 = f(dist_min), f(dist_max)
+        for a in range(3):                       # slab test against the cube
+            if d[a] != 0:
+                ta = (f(-1.0) - o[a]) / d[a]
+                tb = (f(1.0) - o[a]) / d[a]
+                lo, hi = (ta, tb) if ta < tb else (tb, ta)
+                t0, t1 = max(t0, lo), min(t1, hi)
+            elif o[a] < -1.0 or o[a] > 1.0:
+                t1 = f(-1.0)
+        if not (t0 < t1):
+            continue
+        tm = t0 + (t1 - t0) * f(1e-6)            # a point just inside, to pick the first cell
+        c = [0, 0, 0]
+        step, tnext, tdelta = [0, 0, 0], [INF] * 3, [INF] * 3
+        for a in range(3):
+            pa = f(np.float32(d[a] * tm) + o[a])
+            ci = int(np.floor((pa + f(1.0)) / cs))
+            c[a] = min(max(ci, 0), R - 1)
+            if d[a] > 0:
+                step[a] = 1
+                tnext[a] = (f(f(-1.0) + f(c[a] + 1) * cs) - o[a]) / d[a]
+                tdelta[a] = cs / d[a]
+            elif d[a] < 0:
+                step[a] = -1
+                tnext[a] = (f(f(-1.0) + f(c[a]) * cs) - o[a]) / d[a]
+                tdelta[a] = cs / (-d[a])
+        t = t0
+        for _ in range(3 * R + 3):
+            ax = 0 if (tnext[0] <= tnext[1] and tnext[0] <= tnext[2]) else (1 if tnext[1] <= tnext[2] else 2)
+            tout = min(tnext[ax], t1)
+            lin = (c[0] * R + c[1]) * R + c[2]
+            if tout > t and (occ is None or occ[lin]):
+                ridx.append(r); pidx.append(lin); tin_l.append(t); tout_l.append(tout)
+            if tout >= t1:
+                break
+            t = tout
+            c[ax] += step[ax]
+            tnext[ax] = f(tnext[ax] + tdelta[ax])
+            if c[ax] < 0 or c[ax] >= R:
+                break
+    n = len(ridx)
+    ridx_t = torch.tensor(ridx, dtype=torch.int64)
+    pidx_t = torch.tensor(pidx, dtype=torch.int64)
+    tin = np.array(tin_l, dtype=np.float32).reshape(n)
+    tout = np.array(tout_l, dtype=np.float32).reshape(n)
+    frac = ((np.arange(k, dtype=np.float32) + f(0.5)) / f(k)).astype(np.float32)
+    span = (tout - tin).astype(np.float32)
+    depth = (tin[:, None] + (span[:, None] * frac[None]).astype(np.float32)).astype(np.float32)          # [n,k]
+    o_n, d_n = o_all[ridx] if n else np.zeros((0, 3), np.float32), d_all[ridx] if n else np.zeros((0, 3), np.float32)
+    samples = np.empty((n, k, 3), dtype=np.float32)
+    for a in range(3):      # fma(d, t, o), as torch.addcmul / the kernel do
+        samples[:, :, a] = (d_n[:, None, a].astype(np.float64) * depth.astype(np.float64) + o_n[:, None, a].astype(np.float64)).astype(np.float32)
+    deltas = np.repeat((span / f(k)).astype(np.float32), k).reshape(-1, 1)
+    b = mark_pack_boundaries(ridx_t) if n else torch.zeros(0, dtype=torch.bool)
+    boundary = torch.zeros(n, k, dtype=torch.bool)
+    if n:
+        boundary[:, 0] = b
+    return (ridx_t, pidx_t, torch.from_numpy(samples), torch.from_numpy(depth[..., None].copy()), torch.from_numpy(deltas),
+            boundary.reshape(-1))

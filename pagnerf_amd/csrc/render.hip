@@ -105,6 +105,92 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a, int32_t *counts
     if (!PACK && lane == 0) counts[ray] = total;
 }
 
+// ------------------------------------------------------------------------------ voxel-mode ray march
+// 3-D DDA through the 2^level occupancy grid (oracle/render.py raymarch_voxel(), same fp32 op order): every occupied
+// cell a ray crosses is a nugget [t_in, t_out] that receives k samples at t_in + (t_out - t_in) (i + 0.5) / k.
+// One lane per ray (rays are few - 4k..25k - and each walks <= 3R cells); PACK = false counts nuggets only.
+template <bool PACK>
+__global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, int32_t *counts, const int64_t *offsets,
+                                                          int32_t *ridx, int32_t *pidx, float *samples, float *depths,
+                                                          float *deltas, uint8_t *boundary) {
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= a.N) return;
+    const int R = 1 << a.level;
+    const float cs = __fdiv_rn(2.0f, (float)R);
+    const float o[3] = {a.origins[ray * 3], a.origins[ray * 3 + 1], a.origins[ray * 3 + 2]};
+    const float d[3] = {a.dirs[ray * 3], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2]};
+    float t0 = a.dmin, t1 = a.dmax;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (d[ax] != 0.0f) {
+            const float ta = __fdiv_rn(__fsub_rn(-1.0f, o[ax]), d[ax]), tb = __fdiv_rn(__fsub_rn(1.0f, o[ax]), d[ax]);
+            const float lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+            t0 = t0 >= lo ? t0 : lo;
+            t1 = t1 <= hi ? t1 : hi;
+        } else if (o[ax] < -1.0f || o[ax] > 1.0f) {
+            t1 = -1.0f;
+        }
+    }
+    int n = 0;
+    int64_t base = PACK ? offsets[ray] : 0;
+    if (t0 < t1) {
+        const float tm = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), 1e-6f));
+        int c0, c1, c2, s0 = 0, s1 = 0, s2 = 0;
+        float n0 = INFINITY, n1 = INFINITY, n2 = INFINITY, e0 = INFINITY, e1 = INFINITY, e2 = INFINITY;
+        auto setup = [&](int ax, int &c, int &st, float &tn, float &td) {
+            const float pa = __fadd_rn(__fmul_rn(d[ax], tm), o[ax]);
+            int ci = (int)floorf(__fdiv_rn(__fadd_rn(pa, 1.0f), cs));
+            c = min(max(ci, 0), R - 1);
+            if (d[ax] > 0.0f) {
+                st = 1;
+                tn = __fdiv_rn(__fsub_rn(__fadd_rn(-1.0f, __fmul_rn((float)(c + 1), cs)), o[ax]), d[ax]);
+                td = __fdiv_rn(cs, d[ax]);
+            } else if (d[ax] < 0.0f) {
+                st = -1;
+                tn = __fdiv_rn(__fsub_rn(__fadd_rn(-1.0f, __fmul_rn((float)c, cs)), o[ax]), d[ax]);
+                td = __fdiv_rn(cs, -d[ax]);
+            }
+        };
+        setup(0, c0, s0, n0, e0);
+        setup(1, c1, s1, n1, e1);
+        setup(2, c2, s2, n2, e2);
+        float t = t0;
+        for (int it = 0; it < 3 * R + 3; ++it) {
+            const int ax = (n0 <= n1 && n0 <= n2) ? 0 : (n1 <= n2 ? 1 : 2);
+            const float tn = ax == 0 ? n0 : (ax == 1 ? n1 : n2);
+            const float tout = tn <= t1 ? tn : t1;
+            const int lin = (c0 * R + c1) * R + c2;
+            const bool occ = a.occ == nullptr || ((a.occ[lin >> 5] >> (lin & 31)) & 1u);
+            if (tout > t && occ) {
+                if (PACK) {
+                    const int64_t g = base + n;
+                    ridx[g] = (int32_t)ray;
+                    pidx[g] = lin;
+                    const float span = __fsub_rn(tout, t);
+                    const float dl = __fdiv_rn(span, (float)k);
+                    for (int i = 0; i < k; ++i) {
+                        const float fr = __fdiv_rn((float)i + 0.5f, (float)k);
+                        const float dep = __fadd_rn(t, __fmul_rn(span, fr));
+                        const int64_t q = g * k + i;
+                        depths[q] = dep;
+                        deltas[q] = dl;
+                        boundary[q] = (n == 0 && i == 0) ? 1 : 0;
+#pragma unroll
+                        for (int x = 0; x < 3; ++x) samples[q * 3 + x] = __fmaf_rn(d[x], dep, o[x]);
+                    }
+                }
+                ++n;
+            }
+            if (tout >= t1) break;
+            t = tout;
+            if (ax == 0) { c0 += s0; n0 = __fadd_rn(n0, e0); if (c0 < 0 || c0 >= R) break; }
+            else if (ax == 1) { c1 += s1; n1 = __fadd_rn(n1, e1); if (c1 < 0 || c1 >= R) break; }
+            else { c2 += s2; n2 = __fadd_rn(n2, e2); if (c2 < 0 || c2 >= R) break; }
+        }
+    }
+    if (!PACK) counts[ray] = n;
+}
+
 // ------------------------------------------------------------------------------------- compositing
 struct CompArgs {
     const int64_t *pack_start;
@@ -405,5 +491,34 @@ extern "C" int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t 
         hipLaunchKernelGGL((composite_feats_bwd_kernel<bf16_t>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start,
                            ray_of_pack, weights, alpha, g_out, C, (bf16_t *)d_feats);
     PAG_CHECK_LAUNCH("pag_composite_feats_bwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_raymarch_voxel_count(const float *origins, const float *dirs, int64_t N, float dist_min, float dist_max,
+                                        const uint32_t *occupancy_bits, int blas_level, int32_t *counts, void *stream) {
+    PAG_CHECK_ARG(N >= 0, "pag_raymarch_voxel_count: N < 0");
+    PAG_CHECK_ARG(blas_level >= 0 && blas_level <= 10, "pag_raymarch_voxel_count: blas_level %d not in [0,10]", blas_level);
+    if (N == 0) return PAG_OK;
+    PAG_CHECK_ARG(origins && dirs && counts, "pag_raymarch_voxel_count: NULL input");
+    MarchArgs a{origins, dirs, nullptr, nullptr, occupancy_bits, N, 0, blas_level, dist_min, dist_max};
+    hipLaunchKernelGGL((voxel_march_kernel<false>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, 1, counts,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    PAG_CHECK_LAUNCH("pag_raymarch_voxel_count");
+    return PAG_OK;
+}
+
+extern "C" int pag_raymarch_voxel_pack(const float *origins, const float *dirs, int64_t N, int samples_per_voxel, float dist_min,
+                                       float dist_max, const uint32_t *occupancy_bits, int blas_level, const int64_t *offsets,
+                                       int32_t *ridx, int32_t *pidx, float *samples, float *depths, float *deltas,
+                                       uint8_t *boundary, void *stream) {
+    PAG_CHECK_ARG(N >= 0, "pag_raymarch_voxel_pack: N < 0");
+    PAG_CHECK_ARG(samples_per_voxel >= 1 && samples_per_voxel <= 64, "pag_raymarch_voxel_pack: samples_per_voxel %d not in [1,64]", samples_per_voxel);
+    PAG_CHECK_ARG(blas_level >= 0 && blas_level <= 10, "pag_raymarch_voxel_pack: blas_level %d not in [0,10]", blas_level);
+    if (N == 0) return PAG_OK;
+    PAG_CHECK_ARG(origins && dirs && offsets && ridx && pidx && samples && depths && deltas && boundary, "pag_raymarch_voxel_pack: NULL input/output");
+    MarchArgs a{origins, dirs, nullptr, nullptr, occupancy_bits, N, 0, blas_level, dist_min, dist_max};
+    hipLaunchKernelGGL((voxel_march_kernel<true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       samples_per_voxel, nullptr, offsets, ridx, pidx, samples, depths, deltas, boundary);
+    PAG_CHECK_LAUNCH("pag_raymarch_voxel_pack");
     return PAG_OK;
 }

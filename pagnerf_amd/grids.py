@@ -62,12 +62,19 @@ class OccupancyBLAS(nn.Module):
         return m[:self.num_cells]
 
     def raymarch(self, rays, level=None, num_samples=64, raymarch_type="ray", jitter=None):
-        """-> (ridx i64[M], pidx i32[M], samples [M,1,3], depths [M,1], deltas [M,1], boundary bool[M])"""
-        if raymarch_type != "ray":
-            raise NotImplementedError("raymarch_type '%s': only 'ray' mode is built (voxel mode is a next-row item)" % raymarch_type)
+        """'ray'  : (ridx i64[M], pidx i32[M], samples [M,1,3], depths [M,1], deltas [M,1], boundary bool[M])
+        'voxel': per nugget ridx i64[M'], pidx i32[M']; samples [M',k,3], depths [M',k,1], deltas [M'*k,1], boundary bool[M'*k]
+        (the shapes tracers/panoptic_packed_rf_tracer.py:88-108 indexes; k = num_samples)."""
         bits = None if self._all_occupied else self.blas_bits
         if bits is not None and bits.device != rays.origins.device:
             self.blas_bits = bits = bits.to(rays.origins.device)
+        if raymarch_type == "voxel":
+            ridx, pidx, samples, depths, deltas, boundary = ops.raymarch_voxel(
+                rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, bits, self.blas_level)
+            self._pack_cache = None
+            return ridx.long(), pidx, samples, depths[..., None], deltas[:, None], boundary
+        if raymarch_type != "ray":
+            raise NotImplementedError("raymarch_type '%s'" % raymarch_type)
         ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack = ops.raymarch_ray(
             rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, jitter, bits, self.blas_level)
         ridx64 = ridx.long()

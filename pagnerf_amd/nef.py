@@ -194,7 +194,7 @@ class PanopticDeltaNeF(nn.Module):
         if "density" in compute_channels:
             out["density"] = density
         if "rgb" in compute_channels:                                                 # :196-204
-            if num_samples != 1 and ridx is None:
+            if num_samples != 1 and ridx is None:                                  # one direction per pack entry -> per sample
                 ray_d = ray_d[:, None].repeat(1, num_samples, 1).reshape(-1, 3)
             pe, index = self._view_embedding(ray_d, ridx, ray_dirs)
             rgb = self.decoder_color(density_feats, x2=pe, x2_index=index, out_act=L.ACT_SIGMOID, mode=mode)

@@ -357,6 +357,34 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     return ridx, pidx, samples, depths, deltas, boundary.bool(), pack_start.contiguous(), ray_of_pack
 
 
+def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupancy_bits=None, blas_level=7):
+    """'voxel'-mode march (3-D DDA over the occupancy grid).  Returns per NUGGET ridx i32[M'], pidx i32[M'] and per sample
+    samples f32[M',k,3], depths f32[M',k], deltas f32[M'*k], boundary bool[M'*k]."""
+    _check_gpu(origins, dirs)
+    dev = origins.device
+    N, k = origins.shape[0], int(samples_per_voxel)
+    origins = origins.detach().contiguous().float()
+    dirs = dirs.detach().contiguous().float()
+    counts = torch.empty(N, device=dev, dtype=torch.int32)
+    occ = L.ptr(occupancy_bits) if occupancy_bits is not None else None
+    if N:
+        _call("pag_raymarch_voxel_count", L.ptr(origins), L.ptr(dirs), N, float(dist_min), float(dist_max), occ, blas_level,
+              L.ptr(counts), L.stream())
+    csum = torch.cumsum(counts.long(), 0)
+    offsets = csum - counts
+    Mn = int(csum[-1].item()) if N else 0
+    ridx = torch.empty(Mn, device=dev, dtype=torch.int32)
+    pidx = torch.empty(Mn, device=dev, dtype=torch.int32)
+    samples = torch.empty(Mn, k, 3, device=dev)
+    depths = torch.empty(Mn, k, device=dev)
+    deltas = torch.empty(Mn * k, device=dev)
+    boundary = torch.empty(Mn * k, device=dev, dtype=torch.uint8)
+    if Mn:
+        _call("pag_raymarch_voxel_pack", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, blas_level,
+              L.ptr(offsets), L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), L.stream())
+    return ridx, pidx, samples, depths, deltas, boundary.bool()
+
+
 def packs_from_boundary(ridx, boundary):
     """(pack_start i64[P+1], ray_of_pack i32[P]) from kaolin-style (ridx, boundary) arrays."""
     starts = torch.nonzero(boundary).reshape(-1)
@@ -396,8 +424,9 @@ class _Composite(torch.autograd.Function):
         lib = L.load()
         sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha = ctx.saved_tensors
         M, P = sigma.shape[0], ray_of_pack.shape[0]
-        d_sigma = torch.zeros(M, device=sigma.device)
-        d_rgb = torch.zeros(M, 3, device=sigma.device) if rgbc is not None else None
+        mk = torch.empty if P else torch.zeros          # all samples are covered by packs: kernels write every element
+        d_sigma = mk(M, device=sigma.device)
+        d_rgb = mk(M, 3, device=sigma.device) if rgbc is not None else None
         gc = lambda t: t.contiguous().float() if t is not None else None
         g_alpha, g_rgb, g_depth = gc(g_alpha), gc(g_rgb), gc(g_depth)
         if P:
@@ -439,7 +468,8 @@ class _CompositeFeats(torch.autograd.Function):
         weights, alpha, pack_start, ray_of_pack = ctx.saved_tensors
         M, C = ctx.shape
         P = ray_of_pack.shape[0]
-        d = torch.zeros(M, C, device=weights.device, dtype=ctx.fdtype)
+        # every packed sample belongs to a pack, so the kernel writes every row: no zero fill of the [M,C] buffer
+        d = torch.empty(M, C, device=weights.device, dtype=ctx.fdtype) if P else torch.zeros(M, C, device=weights.device, dtype=ctx.fdtype)
         if P:
             _call("pag_composite_feats_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
                   L.ptr(g.contiguous().float()), C, L.ptr(d), L.dtype_code(d), L.stream())

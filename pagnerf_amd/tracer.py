@@ -74,13 +74,23 @@ class PanopticPackedRFTracer(nn.Module):
         kw = {"jitter": jitter} if jitter is not None else {}
         ridx, pidx, samples, depths, deltas, boundary = nef.grid.raymarch(                 # :85-86
             rays, level=nef.grid.active_lods[lod_idx], num_samples=num_steps, raymarch_type=raymarch_type, **kw)
-        if raymarch_type == "voxel" and depths.numel() != 0:
-            raise NotImplementedError("voxel-mode travel filter (:88-108) is a next-row item (SURVEY 8f f3)")
+        if raymarch_type == "voxel" and depths.numel() != 0:                              # :88-108
+            # drop nuggets further than ray_max_travel past the first hit of their ray (strict <)
+            _, counts_per_ray = ridx.unique(return_counts=True)
+            ray_start_idx = torch.cumsum(counts_per_ray, dim=0)
+            ray_start_idx = torch.cat([torch.zeros(1, dtype=ray_start_idx.dtype, device=dev), ray_start_idx[:-1]])
+            hit_depth = torch.take(depths[:, 0, 0], ray_start_idx)
+            traveled_depth = depths[:, 0, 0] - torch.repeat_interleave(hit_depth, counts_per_ray)
+            valid_mask = traveled_depth < self.ray_max_travel
+            deltas = deltas.reshape(depths.shape)[valid_mask].reshape(-1, 1)
+            boundary = boundary.reshape(depths.shape)[valid_mask].reshape(-1)
+            ridx, pidx, samples, depths = ridx[valid_mask], pidx[valid_mask], samples[valid_mask], depths[valid_mask]
+        k = samples.shape[1] if samples.dim() == 3 else 1                                   # samples per pack entry
         cache = getattr(nef.grid, "_pack_cache", None)
         if cache is not None and cache[0] is ridx:
             _, ridx32, pack_start, ray_of_pack = cache
         else:                                                                              # :114
-            ridx32 = ridx.int()
+            ridx32 = ridx.int() if k == 1 else ridx.int().repeat_interleave(k)            # one entry per SAMPLE
             pack_start, ray_of_pack = ops.packs_from_boundary(ridx32, boundary)
         outputs = {}
         sample_channels = set(channels - self.render_channels)                             # :121-124
@@ -93,7 +103,7 @@ class PanopticPackedRFTracer(nn.Module):
         sigma = feats["density"].reshape(-1)
         if self.ray_sparcity_reg > 0.0 and stage == "train":                               # :127-130
             per = torch.log(1.0 + 2 * sigma ** 2)
-            ray_wise = torch.zeros(N, device=dev).scatter_add(0, ridx, per)
+            ray_wise = torch.zeros(N, device=dev).scatter_add(0, ridx32.long(), per)
             outputs["ray_sparcity_loss"] = ray_wise.mean() * self.ray_sparcity_reg
         rgb = feats["rgb"].reshape(-1, 3) if "rgb" in channels else None
         dep = depths.reshape(-1) if "depth" in channels else None

@@ -301,6 +301,112 @@ def test_raymarch_matches_oracle_bit_exact(gpu_device):
         assert torch.equal(ps.cpu(), pack_start) and torch.equal(rp.cpu(), ray_of_pack)
 
 
+def test_voxel_raymarch_matches_oracle(gpu_device):
+    ops, L = _ops()
+    from oracle import render as orr
+    from pagnerf_amd.grids import OccupancyBLAS
+    rs = np.random.RandomState(11)
+    for (N, k, level, dense, far) in ((61, 2, 3, False, 3.0), (200, 2, 5, False, 2.0), (33, 4, 4, True, 6.0), (17, 1, 2, False, 0.7)):
+        o = torch.from_numpy(rs.uniform(-1.3, 1.3, size=(N, 3)).astype(np.float32))
+        d = rs.standard_normal(size=(N, 3)).astype(np.float32)
+        d = torch.from_numpy(d / np.linalg.norm(d, axis=1, keepdims=True))
+        d[0] = torch.tensor([0.0, 0.0, 1.0])            # axis-aligned rays (zero direction components)
+        d[1] = torch.tensor([1.0, 0.0, 0.0])
+        R = 2 ** level
+        occ = None if dense else torch.from_numpy(rs.uniform(size=(R, R, R)) > 0.5)
+        ref = orr.raymarch_voxel(o, d, 0.0, far, k, occ, level)
+        bits = None
+        if occ is not None:
+            blas = OccupancyBLAS(level)
+            blas.blas_init(occ.reshape(-1))
+            bits = blas.blas_bits.to(gpu_device)
+        got = [t.cpu() for t in ops.raymarch_voxel(o.to(gpu_device), d.to(gpu_device), 0.0, far, k, bits, level)]
+        assert torch.equal(got[0].long(), ref[0]) and torch.equal(got[1].long(), ref[1]), (N, k, level)
+        assert torch.equal(got[3], ref[3][..., 0]) and torch.equal(got[4], ref[4][:, 0]) and torch.equal(got[5], ref[5])
+        np.testing.assert_allclose(got[2].numpy(), ref[2].numpy(), rtol=0, atol=2e-7)     # fma emulated in fp64 by the oracle
+        assert got[2].shape == (ref[0].shape[0], k, 3)
+
+
+def test_g4_voxel_mode_trace_against_reference_golden(gpu_device):
+    """The reference tracer's voxel-mode path (travel filter :88-108 + compositing) on its own golden inputs,
+    through this build's tracer and HIP compositing."""
+    import pagnerf_amd
+    g = golden("g4_tracer.npz")
+    dev = gpu_device
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    v_ridx, v_depths = t("v_ridx").long(), t("v_depths")
+    Mv = v_ridx.shape[0]
+    v_samples = torch.zeros(Mv, 2, 3, device=dev)
+    captured = {}
+
+    class Grid:
+        num_lods, active_lods = 4, [0, 1, 2, 3]
+
+        def raymarch(self, rays, level, num_samples, raymarch_type):
+            return v_ridx, v_ridx.int(), v_samples, v_depths, t("v_deltas"), t("v_boundary")
+
+    class Nef:
+        grid = Grid()
+
+        def get_supported_channels(self):
+            return {"rgb", "density"}
+
+        def __call__(self, coords, ray_d, pidx, lod_idx, channels):
+            # the reference filters before querying the nef: recover which nuggets survived from pidx
+            keep = captured.setdefault("keep", None)
+            m = torch.from_numpy(np.asarray(captured["mask"])).to(dev)
+            full = {"density": t("v_density")[m], "rgb": t("v_rgb")[m]}
+            captured["n"] = coords.shape[0]
+            return {c: full[c] for c in channels}
+
+    from oracle import render as orr
+    captured["mask"] = orr.voxel_travel_filter(v_ridx.cpu(), v_depths.cpu(), float(g["v_max_travel"])).numpy()
+    tr = pagnerf_amd.PanopticPackedRFTracer(ray_max_travel=float(g["v_max_travel"]), raymarch_type="voxel", num_steps=2, bg_color="white")
+    rays = pagnerf_amd.Rays(torch.zeros(16, 3, device=dev), torch.ones(16, 3, device=dev), 0.0, 2.0)
+    rb = tr(Nef(), channels={"rgb", "depth"}, rays=rays)
+    assert captured["n"] == int(g["v_kept"])
+    np.testing.assert_allclose(rb.rgb.cpu().numpy(), g["v_out_rgb"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rb.alpha.cpu().numpy(), g["v_out_alpha"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rb.depth.cpu().numpy(), g["v_out_depth"], rtol=1e-5, atol=1e-6)
+
+
+def test_voxel_mode_end_to_end_after_prune(gpu_device):
+    """prune() -> occupancy bitfield -> voxel-mode trace (trainer.py:338-366 sequence) vs the oracle pipeline."""
+    from oracle import permuto_encode as op, decoders as od, render as orr
+    nef, tracer, rays, occ, jitter = _make_scene(gpu_device, "fp32", N=128, S=2, cap_log2=12, level=4)
+    with torch.no_grad():
+        nef.decoder_density.lout.bias[0] = 2.9                      # densities straddle the 2.956 prune threshold
+        nef.prune(jitter=torch.rand(16 ** 3, 3, generator=torch.Generator().manual_seed(3)).to(gpu_device))
+    mask = nef.grid.occupancy_mask().cpu()
+    assert 0 < int(mask.sum()) < mask.numel() and torch.equal(mask, nef.delta_grid.occupancy_mask().cpu())
+    tracer.raymarch_type, tracer.num_steps, tracer.ray_max_travel = "voxel", 2, 0.6          # trainer.py:362-366
+    rays.dist_max = 3.0
+    with torch.no_grad():
+        rb = tracer(nef, channels={"rgb", "depth", "semantics"}, rays=rays)
+    o, d = rays.origins.cpu(), rays.dirs.cpu()
+    ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_voxel(o, d, 0.0, 3.0, 2, mask.reshape(16, 16, 16), 4)
+    keep = orr.voxel_travel_filter(ridx, depths, 0.6)
+    ridx, samples, depths = ridx[keep], samples[keep], depths[keep]
+    deltas = deltas.reshape(-1, 2)[keep].reshape(-1, 1)
+    boundary = boundary.reshape(-1, 2)[keep].reshape(-1)
+    xyz = samples.reshape(-1, 3).numpy()
+
+    def enc(grid):
+        f, _, _ = op.permuto_encode(xyz, grid.tables.detach().cpu().numpy(), grid.random_shift_per_level.cpu().numpy(),
+                                    grid.scale_factors(grid.resolutions).numpy())
+        return torch.from_numpy(f)
+    params = {}
+    for short in ("density", "color", "semantics", "inst"):
+        W, b = getattr(nef, "decoder_" + short).weights()
+        params[short] = ([w.detach().cpu() for w in W], [v.detach().cpu() for v in b])
+    rk = ridx.repeat_interleave(2)
+    out = od.nef_forward(enc(nef.grid), enc(nef.delta_grid), d[rk], params, {"rgb", "semantics"}, lod_weights=nef.lod_weights)
+    comp = orr.composite(128, rk, boundary, out["density"], deltas, depths=depths.reshape(-1, 1), rgb=out["rgb"],
+                         semantics=out["semantics"], bg_color="white")
+    for ch in ("rgb", "alpha", "depth", "semantics"):
+        np.testing.assert_allclose(getattr(rb, ch).cpu().numpy(), comp[ch].numpy(), rtol=2e-4, atol=2e-5, err_msg=ch)
+
+
 def _composite_gpu(ops, dev, g, prefix, bg, N, with_panoptic=True):
     t = lambda k: torch.from_numpy(g[k])
     ridx, boundary = t(prefix + "ridx").to(dev), t(prefix + "boundary").to(dev)
