@@ -331,7 +331,7 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     if jitter is None:
         jitter = torch.rand(N, S, device=dev)
     jitter = jitter.contiguous().float()
-    tvals = torch.linspace(0, 1.0, S).to(dev)          # CPU linspace: bit-identical to the oracle's
+    tvals = _tvals(S, dev)
     counts = torch.empty(N, device=dev, dtype=torch.int32)
     occ = L.ptr(occupancy_bits) if occupancy_bits is not None else None
     st = L.stream()
@@ -351,10 +351,22 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
         _call("pag_raymarch_pack", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
                                       float(dist_max), occ, blas_level, L.ptr(offsets), L.ptr(ridx), L.ptr(pidx),
                                       L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), st)
-    nonempty = counts > 0
-    ray_of_pack = torch.nonzero(nonempty).reshape(-1).int()
-    pack_start = torch.cat([offsets[nonempty], csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)
+    # one pack per RAY (empty packs allowed): no nonzero() / second host sync.  A ray without samples composites to the
+    # background with alpha = depth = 0 and hit = False, exactly what the pre-filled buffers hold (Appendix E.10).
+    ray_of_pack = torch.arange(N, device=dev, dtype=torch.int32)
+    pack_start = torch.cat([offsets, csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)
     return ridx, pidx, samples, depths, deltas, boundary.bool(), pack_start.contiguous(), ray_of_pack
+
+
+_TVALS = {}
+
+
+def _tvals(S, dev):
+    """linspace(0,1,S) computed on the CPU (bit-identical to the oracle's) and cached per (S, device)."""
+    key = (S, str(dev))
+    if key not in _TVALS:
+        _TVALS[key] = torch.linspace(0, 1.0, S).to(dev)
+    return _TVALS[key]
 
 
 def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupancy_bits=None, blas_level=7):

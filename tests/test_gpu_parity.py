@@ -297,8 +297,11 @@ def test_raymarch_matches_oracle_bit_exact(gpu_device):
         assert torch.equal(ridx.long(), ref[0]) and torch.equal(pidx.long(), ref[1])
         assert torch.equal(samples, ref[2][:, 0]) and torch.equal(depths, ref[3][:, 0]) and torch.equal(deltas, ref[4][:, 0])
         assert torch.equal(boundary, ref[5])
+        # raymarch_ray returns one (possibly empty) pack per ray; the non-empty ones are the kaolin-style packs
         ps, rp = ops.packs_from_boundary(got[0], got[5])
-        assert torch.equal(ps.cpu(), pack_start) and torch.equal(rp.cpu(), ray_of_pack)
+        assert ray_of_pack.tolist() == list(range(N)) and int(pack_start[-1]) == ridx.shape[0]
+        nonempty = (pack_start[1:] - pack_start[:-1]) > 0
+        assert torch.equal(rp.cpu(), ray_of_pack[nonempty]) and torch.equal(ps.cpu()[:-1], pack_start[:-1][nonempty])
 
 
 def test_voxel_raymarch_matches_oracle(gpu_device):
