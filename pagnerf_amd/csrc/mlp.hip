@@ -258,7 +258,7 @@ __device__ __forceinline__ void hidden_layer(const bf16_t *Ws, const float *bs, 
 
 // ------------------------------------------------------------------------------------------ forward
 template <typename X1T, typename OutT, int NL, int OBMAX>
-__global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
+__global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.out_dim + 31) / 32;
     bf16_t *W0s = reinterpret_cast<bf16_t *>(smem);                  // [64][RS] natural k
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    int r = lane & 31, h = lane >> 5;
     const int nks0 = p.in_pad / 16;
     const int64_t ntiles = (p.M + 31) / 32;
     const bool vec_out = (p.out_dim % 4) == 0;
@@ -316,6 +316,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) xb[s] = xnext[s];
         load_x(tile + tile_step, xnext);
+        if constexpr (OBMAX > 2) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
+            asm volatile("" : "+v"(r), "+v"(h));
+        }
         f32x16 acc[2];
         bf16x8 hb[4];
         hidden_layer<4>(W0s, b0s, xb, nks0, r, h, acc);
@@ -337,83 +340,113 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma(FwdParams p) {
             }
         }
         // ---- output layer
-        f32x16 o[OBMAX];
+        auto out_block = [&](int ob, f32x16 &o) __attribute__((always_inline)) {      // bias + W_L[32ob .. 32ob+31, :] . h : 4 MFMAs
 #pragma unroll
-        for (int ob = 0; ob < OBMAX; ++ob) {
-            if (ob < OB) {
+            for (int q = 0; q < 16; ++q) o[q] = bLs[32 * ob + rho(q, h)];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) o[ob][q] = bLs[32 * ob + rho(q, h)];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
-                    o[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], o[ob], 0, 0, 0);
-                }
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], o, 0, 0, 0);
             }
-        }
-        // Output activations on the accumulators.  The bf16 path uses the hardware exp2 / rcp (v_exp_f32, v_rcp_f32:
-        // ~1 ulp) - an accurate expf() and a true division per element made this epilogue 5400 VALU instructions per
-        // 32-sample tile and the kernel VALU-bound (rocprofv3 SQ_INSTS_VALU); only the last block can hold padding rows.
+        };
         constexpr float LOG2E = 1.4426950408889634f;
-        if (p.act == PAG_ACT_SIGMOID) {
-#pragma unroll
-            for (int ob = 0; ob < OBMAX; ++ob)
-                if (ob < OB)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        o[ob][q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * o[ob][q]));
-        } else if (p.act == PAG_ACT_SOFTMAX) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int ob = 0; ob < OBMAX; ++ob) {
-                if (ob < OB - 1) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) mx = fmaxf(mx, o[ob][q]);
-                } else if (ob == OB - 1) {
+        if constexpr (OBMAX > 2) {
+            // Wide heads (e.g. 200 instance logits): ONE 32-channel block is live at a time.  Softmax is computed online
+            // (running max / sum over the blocks), then the blocks are recomputed (4 MFMAs each - the matrix cores are
+            // idle anyway) to be normalised and stored.  Holding all 7 blocks took 256 VGPRs = 1 wave per SIMD with every
+            // latency exposed; this form fits 128 VGPRs = 4 waves per SIMD.
+            float M_ = 0.0f, inv = 1.0f;
+            if (p.act == PAG_ACT_SOFTMAX) {
+                float mrun = -INFINITY, srun = 0.0f;
+                for (int ob = 0; ob < OB; ++ob) {
+                    f32x16 o;
+                    out_block(ob, o);
+                    const bool lastb = ob == OB - 1;
+                    float bm = -INFINITY;
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        if (32 * ob + rho(q, h) < p.out_dim) mx = fmaxf(mx, o[ob][q]);
+                        if (!lastb || 32 * ob + rho(q, h) < p.out_dim) bm = fmaxf(bm, o[q]);
+                    const float mn = fmaxf(mrun, bm);
+                    float bs = 0.0f;
+                    const float mns = mn * LOG2E;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (!lastb || 32 * ob + rho(q, h) < p.out_dim) bs += __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -mns));
+                    srun = srun * __builtin_amdgcn_exp2f((mrun - mn) * LOG2E) + bs;
+                    mrun = mn;
                 }
+                const float mo = __shfl_xor(mrun, 32), so = __shfl_xor(srun, 32);
+                M_ = fmaxf(mrun, mo);
+                const float S_ = srun * __builtin_amdgcn_exp2f((mrun - M_) * LOG2E) + so * __builtin_amdgcn_exp2f((mo - M_) * LOG2E);
+                inv = 1.0f / S_;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mxs = mx * LOG2E;
-            float sum = 0.0f;
+            const float Ms = M_ * LOG2E;
+            for (int ob = 0; ob < OB; ++ob) {
+                f32x16 o;
+                out_block(ob, o);
+                if (p.act == PAG_ACT_SOFTMAX) {
 #pragma unroll
-            for (int ob = 0; ob < OBMAX; ++ob) {
-                if (ob < OB - 1) {
+                    for (int q = 0; q < 16; ++q) o[q] = __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -Ms)) * inv;
+                } else if (p.act == PAG_ACT_SIGMOID) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(o[ob][q], LOG2E, -mxs));
-                        o[ob][q] = e;
-                        sum += e;
-                    }
-                } else if (ob == OB - 1) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float e = (32 * ob + rho(q, h) < p.out_dim) ? __builtin_amdgcn_exp2f(fmaf(o[ob][q], LOG2E, -mxs)) : 0.0f;
-                        o[ob][q] = e;
-                        sum += e;
-                    }
+                    for (int q = 0; q < 16; ++q) o[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * o[q]));
                 }
+                if (live) store_block(out + m * p.out_dim, 32 * ob, h, o, p.out_dim, vec_out);
             }
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
+        } else {
+            f32x16 o[OBMAX];
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
-                if (ob < OB)
+                if (ob < OB) out_block(ob, o[ob]);
+            // Output activations on the accumulators.  The bf16 path uses the hardware exp2 / rcp (v_exp_f32, v_rcp_f32:
+            // ~1 ulp) - an accurate expf() and a true division per element made this epilogue 5400 VALU instructions per
+            // 32-sample tile and the kernel VALU-bound (rocprofv3 SQ_INSTS_VALU); only the last block can hold padding rows.
+            if (p.act == PAG_ACT_SIGMOID) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) o[ob][q] *= inv;
-        }
-        if (live) {
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB)
 #pragma unroll
-            for (int ob = 0; ob < OBMAX; ++ob)
-                if (ob < OB) store_block(out + m * p.out_dim, 32 * ob, h, o[ob], p.out_dim, vec_out);
+                        for (int q = 0; q < 16; ++q) o[ob][q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * o[ob][q]));
+            } else if (p.act == PAG_ACT_SOFTMAX) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            if (ob < OB - 1 || 32 * ob + rho(q, h) < p.out_dim) mx = fmaxf(mx, o[ob][q]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mxs = mx * LOG2E;
+                float sum = 0.0f;
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float e = (ob < OB - 1 || 32 * ob + rho(q, h) < p.out_dim) ? __builtin_amdgcn_exp2f(fmaf(o[ob][q], LOG2E, -mxs)) : 0.0f;
+                            o[ob][q] = e;
+                            sum += e;
+                        }
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) o[ob][q] *= inv;
+            }
+            if (live) {
+#pragma unroll
+                for (int ob = 0; ob < OBMAX; ++ob)
+                    if (ob < OB) store_block(out + m * p.out_dim, 32 * ob, h, o[ob], p.out_dim, vec_out);
+            }
         }
     }
 }
 
 // ----------------------------------------------------------------------------------------- backward
 template <typename OutT, typename DxT, int NL, int OBMAX>
-__global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
+__global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.out_dim + 31) / 32;
     const int RSL = OB * 32 + 8;
@@ -426,7 +459,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    int r = lane & 31, h = lane >> 5;
     const int64_t ntiles = (p.M + 31) / 32;
     const bool vec_out = (p.out_dim % 4) == 0;
     const OutT *outp = reinterpret_cast<const OutT *>(p.out);
@@ -450,6 +483,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
     RawO nz[PREFETCH ? OBMAX : 1][4], ny[PREFETCH ? OBMAX : 1][4];
     if constexpr (PREFETCH) load_g((int64_t)blockIdx.x * 4 + wave, nz, ny);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
+        if constexpr (OBMAX > 2) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
+            asm volatile("" : "+v"(r), "+v"(h));
+        }
         const int64_t m = tile * 32 + r;
         const bool live = m < p.M;
         const int64_t mc = live ? m : p.M - 1;
@@ -462,16 +498,31 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     hraw[l][mb][g] = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.hsave[l]) + mc * HID + 32 * mb + 8 * g + 4 * h);
-        // ---- dz of the output layer -> bf16 B fragments zb[] (k-steps of the first backward MFMA chain)
-        bf16x8 zb[2 * OBMAX];
+        // ---- dz of the output layer -> bf16 B fragments (k-steps of the first backward MFMA chain W_L^T . dz_L)
+        bf16x8 zb[OBMAX > 2 ? 2 : 2 * OBMAX];          // wide heads consume each block's two fragments immediately
+        f32x16 acc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
         const bool tile_full = (tile + 1) * 32 <= p.M;      // wave-uniform: only the last tile has dead lanes
-        auto finish_block = [&](int ob, f32x16 &zz) {      // zero dead lanes, store dz, pack
+        auto finish_block = [&](int ob, f32x16 &zz) __attribute__((always_inline)) {      // zero dead lanes, store dz, pack
             if (!tile_full) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) zz[q] = live ? zz[q] : 0.0f;
             }
-            pack_block(zz, zb[2 * ob], zb[2 * ob + 1]);
+            const int zi = OBMAX > 2 ? 0 : 2 * ob;
+            pack_block(zz, zb[zi], zb[zi + 1]);
             if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, zz, p.out_dim, vec_out);
+            if constexpr (OBMAX > 2) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * (2 * ob + half) + 8 * h);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[half], acc[mb], 0, 0, 0);
+                    }
+            }
         };
         if constexpr (PREFETCH) {
             f32x16 z[OBMAX];
@@ -526,20 +577,19 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
             const OutT *yop = outp + mc * p.out_dim;
             float dot = 0.0f;
             if (p.act == PAG_ACT_SOFTMAX) {
-#pragma unroll
-                for (int ob = 0; ob < OBMAX; ++ob)
-                    if (ob < OB) {
+                for (int ob = 0; ob < OB; ++ob) {
+                    {
                         RawO rz1[4], ry1[4];
                         load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
                         load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
 #pragma unroll
                         for (int q = 0; q < 16; ++q) dot += (float)rz1[q >> 2][q & 3] * (float)ry1[q >> 2][q & 3];
                     }
+                }
                 dot += __shfl_xor(dot, 32);
             }
-#pragma unroll
-            for (int ob = 0; ob < OBMAX; ++ob) {
-                if (ob < OB) {
+            for (int ob = 0; ob < OB; ++ob) {
+                {
                     RawO rz1[4], ry1[4];
                     f32x16 zz;
                     load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
@@ -556,24 +606,21 @@ __global__ __launch_bounds__(256) void mlp_bwd_mfma(BwdParams p) {
                         for (int q = 0; q < 16; ++q) zz[q] = (float)ry1[q >> 2][q & 3] * (zz[q] - dot);
                     }
                     finish_block(ob, zz);
-                } else {
-                    zb[2 * ob] = zero8();
-                    zb[2 * ob + 1] = zero8();
                 }
             }
         }
-        // ---- back through the output layer: dA = W_L^T . dz_L, masked by the saved ReLU output
-        f32x16 acc[2];
+        // ---- back through the output layer: dA = W_L^T . dz_L (already accumulated per block for wide heads),
+        //      masked by the saved ReLU output
         bf16x8 hb[4];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
+            if constexpr (OBMAX <= 2) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 2 * OBMAX; ++s) {
-                if (s < 2 * OB) {
-                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * s + 8 * h);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[s], acc[mb], 0, 0, 0);
+                for (int s = 0; s < 2 * OBMAX; ++s) {
+                    if (s < 2 * OB) {
+                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * s + 8 * h);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[s], acc[mb], 0, 0, 0);
+                    }
                 }
             }
             f32x16 hv;

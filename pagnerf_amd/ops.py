@@ -87,7 +87,6 @@ def _layout_args(t):
 
 
 def _encode_fwd(spec, xyz, tables, feat_scale, out):
-    lib = L.load()
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
     sm, sc, lay = _layout_args(out)
@@ -190,7 +189,6 @@ class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb):
         _check_gpu(x1, x2, x2_index, *wb)
-        lib = L.load()
         n_layers = len(wb) // 2
         Ws, bs = wb[:n_layers], wb[n_layers:]
         if grouped is not None:
@@ -323,7 +321,6 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     (ridx i32[M], pidx i32[M], samples f32[M,3], depths f32[M], deltas f32[M], boundary bool[M],
      pack_start i64[P+1], ray_of_pack i32[P])."""
     _check_gpu(origins, dirs)
-    lib = L.load()
     dev = origins.device
     N, S = origins.shape[0], int(num_samples)
     origins = origins.detach().contiguous().float()
@@ -409,7 +406,6 @@ class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sigma, rgb, deltas, depths, pack_start, ray_of_pack, N, bg_white):
         _check_gpu(sigma, deltas)
-        lib = L.load()
         dev = sigma.device
         M = sigma.shape[0]
         P = ray_of_pack.shape[0]
@@ -433,7 +429,6 @@ class _Composite(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_alpha, _g_hit, g_rgb, g_depth, _g_w):
-        lib = L.load()
         sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha = ctx.saved_tensors
         M, P = sigma.shape[0], ray_of_pack.shape[0]
         mk = torch.empty if P else torch.zeros          # all samples are covered by packs: kernels write every element
@@ -458,7 +453,6 @@ class _CompositeFeats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weights, alpha, pack_start, ray_of_pack, N):
         _check_gpu(feats, weights, alpha)
-        lib = L.load()
         feats = feats.detach().contiguous()
         if feats.dtype not in (torch.float32, torch.bfloat16):
             feats = feats.float()
@@ -476,7 +470,6 @@ class _CompositeFeats(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = L.load()
         weights, alpha, pack_start, ray_of_pack = ctx.saved_tensors
         M, C = ctx.shape
         P = ray_of_pack.shape[0]

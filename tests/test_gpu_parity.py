@@ -410,13 +410,6 @@ def test_voxel_mode_end_to_end_after_prune(gpu_device):
         np.testing.assert_allclose(getattr(rb, ch).cpu().numpy(), comp[ch].numpy(), rtol=2e-4, atol=2e-5, err_msg=ch)
 
 
-def _composite_gpu(ops, dev, g, prefix, bg, N, with_panoptic=True):
-    t = lambda k: torch.from_numpy(g[k])
-    ridx, boundary = t(prefix + "ridx").to(dev), t(prefix + "boundary").to(dev)
-    ps, rp = ops.packs_from_boundary(ridx.int(), boundary)
-    return ps, rp
-
-
 def test_g4_tracer_composite_against_reference_golden(gpu_device):
     ops, L = _ops()
     g = golden("g4_tracer.npz")
