@@ -238,6 +238,86 @@ __device__ __forceinline__ void raw_to_block(const V (&raw)[4], f32x16 &acc) {
         for (int j = 0; j < 4; ++j) acc[4 * g + j] = (float)raw[g][j];
 }
 
+// ---------------------------------------------------------------------------------------- LDS staging
+// In the accumulator layout every lane owns ONE sample row, so a direct global access touches 32 different rows per
+// wave-instruction: rocprofv3 showed the texture-address unit busy 75-85 % of these kernels' time (TA_BUSY_avr vs
+// GRBM_GUI_ACTIVE).  Row-major [M,64] bf16 tiles (32 rows = 4 KiB contiguous) and 32-column blocks of the wide
+// [M,W] tensors therefore go through a wave-private LDS buffer: global side = fully coalesced 16-byte-per-lane
+// accesses, register side = ds_read/ds_write_b64 in accumulator layout.
+constexpr int ST_RS = 72;                         // staging row stride in bf16 (144 B: conflict-light for b64 and b128)
+constexpr int ST_BYTES = 32 * ST_RS * 2;          // 4608 B per wave
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// accumulator blocks acc[0..1] (64 columns) of a 32-row tile -> row-major [M,64] bf16 at gtile (= tensor + tile*32*64)
+__device__ __forceinline__ void tile64_store(bf16_t *stg, bf16_t *gtile, int rows_valid, int lane, int r, int h, const f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v = {(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
+            *reinterpret_cast<bf16x4 *>(stg + r * ST_RS + 32 * mb + 8 * g + 4 * h) = v;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        bf16x8 v = *reinterpret_cast<const bf16x8 *>(stg + row * ST_RS + c);
+        if (row < rows_valid) *reinterpret_cast<bf16x8 *>(gtile + row * HID + c) = v;
+    }
+    wave_lds_sync();
+}
+// row-major [M,64] bf16 tile -> accumulator-layout raw pieces raw[mb][g]
+__device__ __forceinline__ void tile64_load(bf16_t *stg, const bf16_t *gtile, int rows_valid, int lane, int r, int h, bf16x4 (&raw)[2][4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        bf16x8 v = zero8();
+        if (row < rows_valid) v = *reinterpret_cast<const bf16x8 *>(gtile + row * HID + c);
+        *reinterpret_cast<bf16x8 *>(stg + row * ST_RS + c) = v;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) raw[mb][g] = *reinterpret_cast<const bf16x4 *>(stg + r * ST_RS + 32 * mb + 8 * g + 4 * h);
+    wave_lds_sync();
+}
+// columns [col0, col0+32) of rows [0,32) of a row-major [M,W] bf16 tensor (W % 8 == 0) at gtile (= tensor + tile*32*W):
+// staged into LDS columns [lcol, lcol+32) (two tensors can share the buffer: lcol = 0 / 32)
+__device__ __forceinline__ void block32_stage_in(bf16_t *stg, int lcol, const bf16_t *gtile, int W, int col0, int rows_valid, int lane) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + (lane >> 2), c = (lane & 3) * 8;
+        bf16x8 v = zero8();
+        if (row < rows_valid && col0 + c < W) v = *reinterpret_cast<const bf16x8 *>(gtile + (int64_t)row * W + col0 + c);
+        *reinterpret_cast<bf16x8 *>(stg + row * ST_RS + lcol + c) = v;
+    }
+}
+__device__ __forceinline__ void block32_read(const bf16_t *stg, int lcol, int r, int h, bf16x4 (&raw)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) raw[g] = *reinterpret_cast<const bf16x4 *>(stg + r * ST_RS + lcol + 8 * g + 4 * h);
+}
+// accumulator block -> columns [col0, col0+32) of the row-major [M,W] bf16 tensor
+__device__ __forceinline__ void block32_store(bf16_t *stg, bf16_t *gtile, int W, int col0, int rows_valid, int lane, int r, int h, const f32x16 &acc) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 v = {(bf16_t)acc[4 * g], (bf16_t)acc[4 * g + 1], (bf16_t)acc[4 * g + 2], (bf16_t)acc[4 * g + 3]};
+        *reinterpret_cast<bf16x4 *>(stg + r * ST_RS + 8 * g + 4 * h) = v;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + (lane >> 2), c = (lane & 3) * 8;
+        bf16x8 v = *reinterpret_cast<const bf16x8 *>(stg + row * ST_RS + c);
+        if (row < rows_valid && col0 + c < W) *reinterpret_cast<bf16x8 *>(gtile + (int64_t)row * W + col0 + c) = v;
+    }
+    wave_lds_sync();
+}
+
 // hidden layer: acc[2] = bias + W(64 x K) . frags ; K = 16 * nks
 template <int NKS>
 __device__ __forceinline__ void hidden_layer(const bf16_t *Ws, const float *bs, const bf16x8 (&frag)[NKS], int nks, int r, int h,
@@ -267,6 +347,7 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
     float *b0s = reinterpret_cast<float *>(WLs + OB * 32 * RS);
     float *b1s = b0s + 64;
     float *bLs = b1s + 64;
+    bf16_t *stg = reinterpret_cast<bf16_t *>(bLs + OB * 32) + (threadIdx.x >> 6) * (ST_BYTES / 2);      // wave-private staging tile
 
     stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
     if (NL == 3) stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
@@ -327,8 +408,9 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = fmaxf(acc[mb][q], 0.0f);
             pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
-            if (p.hsave[0] && live) store_block_full(reinterpret_cast<bf16_t *>(p.hsave[0]) + m * HID, 32 * mb, h, acc[mb]);
         }
+        const int rows_valid = (int)min((int64_t)32, p.M - tile * 32);
+        if (p.hsave[0]) tile64_store(stg, reinterpret_cast<bf16_t *>(p.hsave[0]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
         if (NL == 3) {
             hidden_layer<4>(W1s, b1s, hb, 4, r, h, acc);
 #pragma unroll
@@ -336,8 +418,8 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mb][q] = fmaxf(acc[mb][q], 0.0f);
                 pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
-                if (p.hsave[1] && live) store_block_full(reinterpret_cast<bf16_t *>(p.hsave[1]) + m * HID, 32 * mb, h, acc[mb]);
             }
+            if (p.hsave[1]) tile64_store(stg, reinterpret_cast<bf16_t *>(p.hsave[1]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
         }
         // ---- output layer
         auto out_block = [&](int ob, f32x16 &o) __attribute__((always_inline)) {      // bias + W_L[32ob .. 32ob+31, :] . h : 4 MFMAs
@@ -391,7 +473,14 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
 #pragma unroll
                     for (int q = 0; q < 16; ++q) o[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * o[q]));
                 }
-                if (live) store_block(out + m * p.out_dim, 32 * ob, h, o, p.out_dim, vec_out);
+                if constexpr (sizeof(OutT) == 2) {
+                    if ((p.out_dim & 7) == 0)
+                        block32_store(stg, reinterpret_cast<bf16_t *>(p.out) + tile * 32 * p.out_dim, p.out_dim, 32 * ob, rows_valid, lane, r, h, o);
+                    else if (live)
+                        store_block(out + m * p.out_dim, 32 * ob, h, o, p.out_dim, vec_out);
+                } else {
+                    if (live) store_block(out + m * p.out_dim, 32 * ob, h, o, p.out_dim, vec_out);
+                }
             }
         } else {
             f32x16 o[OBMAX];
@@ -456,6 +545,7 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
     stage_weight_t(WLt, RSL, 64, OB * 32, p.W[NL - 1], p.out_dim, HID);
     if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
     if (p.dx1) stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
+    bf16_t *stg = W0t + 64 * RS + (threadIdx.x >> 6) * (ST_BYTES / 2);      // wave-private staging tile
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -490,14 +580,11 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
         const bool live = m < p.M;
         const int64_t mc = live ? m : p.M - 1;
         // ReLU masks of the hidden layers: requested first, consumed after the first MFMA chain
+        const int rows_valid = (int)min((int64_t)32, p.M - tile * 32);
         bf16x4 hraw[NL - 1][2][4];
 #pragma unroll
         for (int l = 0; l < NL - 1; ++l)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    hraw[l][mb][g] = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const bf16_t *>(p.hsave[l]) + mc * HID + 32 * mb + 8 * g + 4 * h);
+            tile64_load(stg, reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rows_valid, lane, r, h, hraw[l]);
         // ---- dz of the output layer -> bf16 B fragments (k-steps of the first backward MFMA chain W_L^T . dz_L)
         bf16x8 zb[OBMAX > 2 ? 2 : 2 * OBMAX];          // wide heads consume each block's two fragments immediately
         f32x16 acc[2];
@@ -513,7 +600,10 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
             }
             const int zi = OBMAX > 2 ? 0 : 2 * ob;
             pack_block(zz, zb[zi], zb[zi + 1]);
-            if (live) store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, zz, p.out_dim, vec_out);
+            if (OBMAX > 2 && (p.out_dim & 7) == 0)
+                block32_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + tile * 32 * p.out_dim, p.out_dim, 32 * ob, rows_valid, lane, r, h, zz);
+            else if (live)
+                store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, zz, p.out_dim, vec_out);
             if constexpr (OBMAX > 2) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -575,13 +665,29 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
             // block live at a time instead of all of them (256 VGPRs -> 1 wave per SIMD before)
             const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
             const OutT *yop = outp + mc * p.out_dim;
+            const bf16_t *gtile_g = reinterpret_cast<const bf16_t *>(p.grad_out) + tile * 32 * p.out_dim;
+            const bf16_t *gtile_y = reinterpret_cast<const bf16_t *>(p.out) + tile * 32 * p.out_dim;
             float dot = 0.0f;
             if (p.act == PAG_ACT_SOFTMAX) {
                 for (int ob = 0; ob < OB; ++ob) {
                     {
                         RawO rz1[4], ry1[4];
-                        load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
-                        load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+                        if constexpr (sizeof(OutT) == 2) {
+                            if ((p.out_dim & 7) == 0) {
+                                block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
+                                block32_stage_in(stg, 32, gtile_y, p.out_dim, 32 * ob, rows_valid, lane);
+                                wave_lds_sync();
+                                block32_read(stg, 0, r, h, rz1);
+                                block32_read(stg, 32, r, h, ry1);
+                                wave_lds_sync();
+                            } else {
+                                load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
+                                load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+                            }
+                        } else {
+                            load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
+                            load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+                        }
 #pragma unroll
                         for (int q = 0; q < 16; ++q) dot += (float)rz1[q >> 2][q & 3] * (float)ry1[q >> 2][q & 3];
                     }
@@ -592,8 +698,22 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
                 {
                     RawO rz1[4], ry1[4];
                     f32x16 zz;
-                    load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
-                    if (p.act != PAG_ACT_NONE) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+                    bool staged = false;
+                    if constexpr (sizeof(OutT) == 2) {
+                        if ((p.out_dim & 7) == 0) {
+                            block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
+                            if (p.act != PAG_ACT_NONE) block32_stage_in(stg, 32, gtile_y, p.out_dim, 32 * ob, rows_valid, lane);
+                            wave_lds_sync();
+                            block32_read(stg, 0, r, h, rz1);
+                            if (p.act != PAG_ACT_NONE) block32_read(stg, 32, r, h, ry1);
+                            wave_lds_sync();
+                            staged = true;
+                        }
+                    }
+                    if (!staged) {
+                        load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
+                        if (p.act != PAG_ACT_NONE) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+                    }
                     raw_to_block(rz1, zz);
                     if (p.act == PAG_ACT_SIGMOID) {
 #pragma unroll
@@ -628,8 +748,8 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
             pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
-            if (live) store_block_full(reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + m * HID, 32 * mb, h, acc[mb]);
         }
+        tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
         if (NL == 3) {
             bf16x8 hb2[4];
 #pragma unroll
@@ -646,8 +766,8 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
                 pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
-                if (live) store_block_full(reinterpret_cast<bf16_t *>(p.dz[0]) + m * HID, 32 * mb, h, acc[mb]);
             }
+            tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[0]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
         }
@@ -1019,7 +1139,7 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;
-        const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + OB * 32) * RS * sizeof(bf16_t) + (128 + OB * 32) * sizeof(float);
+        const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + OB * 32) * RS * sizeof(bf16_t) + (128 + OB * 32) * sizeof(float) + 4 * ST_BYTES;
         if (a->x1_dtype == PAG_F32 && a->out_dtype == PAG_F32) MLP_FWD_NL(float, float);
         else if (a->x1_dtype == PAG_F32) MLP_FWD_NL(float, bf16_t);
         else if (a->out_dtype == PAG_F32) MLP_FWD_NL(bf16_t, float);
@@ -1098,7 +1218,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     const bool dx_f32 = a->dx1 == nullptr || a->dx1_dtype == PAG_F32;
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;
-        const size_t lds = (size_t)(64 * (OB * 32 + 8) + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t);
+        const size_t lds = (size_t)(64 * (OB * 32 + 8) + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t) + 4 * ST_BYTES;
         if (out_f32 && dx_f32) MLP_BWD_NL(float, float);
         else if (out_f32) MLP_BWD_NL(float, bf16_t);
         else if (dx_f32) MLP_BWD_NL(bf16_t, float);
