@@ -147,6 +147,11 @@ typedef struct {
     void *dz[3];
     void *dx1; int dx1_dtype;
     int mode;
+    /* Optional rank-1 upstream gradient (MFMA mode): grad_out[m][c] = g_scale[m] * g_ray[g_index[m]][c] with
+     * g_ray f32 [N, out_dim].  This is exactly d(feats) of tracers/panoptic_packed_rf_tracer.py:197-205
+     * (alpha * w_m * d out[ray]) - passing it in this form means the [M, out_dim] gradient of the composited
+     * semantic / instance probabilities is never materialised.  grad_out may then be NULL. */
+    const float *g_ray; const float *g_scale; const int32_t *g_index;
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 

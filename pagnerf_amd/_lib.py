@@ -42,7 +42,8 @@ class MlpBwdArgs(ctypes.Structure):
                 ("hidden_save", c_vp * 2),
                 ("dz", c_vp * 3),
                 ("dx1", c_vp), ("dx1_dtype", c_i32),
-                ("mode", c_i32)]
+                ("mode", c_i32),
+                ("g_ray", c_vp), ("g_scale", c_vp), ("g_index", c_vp)]
 
 
 _SIGS = {

@@ -58,7 +58,11 @@ struct FwdParams {
 };
 
 struct BwdParams {
-    const void *grad_out;      // same dtype as `out` (autograd hands back the output's dtype)
+    const void *grad_out;      // same dtype as `out` (autograd hands back the output's dtype); unused in rank-1 mode
+    // rank-1 upstream gradient (composited panoptic heads): g[m][c] = g_scale[m] * g_ray[g_index[m]][c]
+    const float *g_ray;
+    const float *g_scale;
+    const int32_t *g_index;
     const void *out;
     int k1, in_dim, in_pad, out_dim, act;
     const float *W[3];
@@ -318,6 +322,41 @@ __device__ __forceinline__ void block32_store(bf16_t *stg, bf16_t *gtile, int W,
     wave_lds_sync();
 }
 
+// upstream gradient block in rank-1 form: z[q] = scale * g_row[32ob + rho(q,h)] (g_row = this sample's ray row, f32 [n])
+__device__ __forceinline__ void rank1_block(const float *g_row, float scale, int ch_base, int h, int n_valid, f32x16 &z) {
+    const bool vec = (n_valid & 3) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = ch_base + 8 * g + 4 * h;
+        if (vec) {
+            const bool ok = c0 < n_valid;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(g_row + (ok ? c0 : 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[4 * g + j] = ok ? scale * v[j] : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[4 * g + j] = (c0 + j < n_valid) ? scale * g_row[c0 + j] : 0.0f;
+        }
+    }
+}
+
+// same, when every lane of the wave belongs to ONE ray: the row pointer is wave-uniform, so the 8 floats of a group
+// (both lane halves) come from scalar loads and each lane picks its half - no vector-memory traffic at all
+__device__ __forceinline__ void rank1_block_uniform(const float *g_row_u, float scale, int ch_base, int h, int n_valid, f32x16 &z) {
+    // read-only for the whole launch: address space 4 (constant) lets the compiler use s_load for the uniform address
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat *gc = (cfloat *)(uintptr_t)g_row_u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = ch_base + 8 * g;                     // uniform
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c0 + j < n_valid) ? gc[c0 + j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[4 * g + j] = scale * (h ? v[4 + j] : v[j]);
+    }
+}
+
 // hidden layer: acc[2] = bias + W(64 x K) . frags ; K = 16 * nks
 template <int NKS>
 __device__ __forceinline__ void hidden_layer(const bf16_t *Ws, const float *bs, const bf16x8 (&frag)[NKS], int nks, int r, int h,
@@ -560,9 +599,11 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
         const int64_t m = tile * 32 + r;
         const int64_t mc = (tile < ntiles && m < p.M) ? m : p.M - 1;
         const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
+        if (!p.g_ray) {
 #pragma unroll
-        for (int ob = 0; ob < OBMAX; ++ob)
-            if (ob < OB) load_block_raw(gop, 32 * ob, h, rz[ob], p.out_dim, vec_out);
+            for (int ob = 0; ob < OBMAX; ++ob)
+                if (ob < OB) load_block_raw(gop, 32 * ob, h, rz[ob], p.out_dim, vec_out);
+        }
         if (p.act != PAG_ACT_NONE) {
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
@@ -628,6 +669,21 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
 #pragma unroll
             for (int ob = 0; ob < OBMAX; ++ob)
                 if (ob < OB) raw_to_block(rz[ob], z[ob]);
+            if (p.g_ray) {
+                const int gi = p.g_index[mc], gi0 = __builtin_amdgcn_readfirstlane(gi);
+                const float sc = p.g_scale[mc];
+                if (__all(gi == gi0)) {
+                    const float *g_row_u = p.g_ray + (int64_t)gi0 * p.out_dim;
+#pragma unroll
+                    for (int ob = 0; ob < OBMAX; ++ob)
+                        if (ob < OB) rank1_block_uniform(g_row_u, sc, 32 * ob, h, p.out_dim, z[ob]);
+                } else {
+                    const float *g_row = p.g_ray + (int64_t)gi * p.out_dim;
+#pragma unroll
+                    for (int ob = 0; ob < OBMAX; ++ob)
+                        if (ob < OB) rank1_block(g_row, sc, 32 * ob, h, p.out_dim, z[ob]);
+                }
+            }
             if (p.act == PAG_ACT_SIGMOID) {
 #pragma unroll
                 for (int ob = 0; ob < OBMAX; ++ob)
@@ -667,11 +723,36 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
             const OutT *yop = outp + mc * p.out_dim;
             const bf16_t *gtile_g = reinterpret_cast<const bf16_t *>(p.grad_out) + tile * 32 * p.out_dim;
             const bf16_t *gtile_y = reinterpret_cast<const bf16_t *>(p.out) + tile * 32 * p.out_dim;
+            const int g_idx1 = p.g_ray ? p.g_index[mc] : 0;
+            const int g_idx0 = __builtin_amdgcn_readfirstlane(g_idx1);
+            const bool g_uni = __all(g_idx1 == g_idx0);      // whole tile inside one ray (the common case)
+            const float *g_row1 = p.g_ray ? p.g_ray + (int64_t)g_idx1 * p.out_dim : nullptr;
+            const float *g_row_u = p.g_ray ? p.g_ray + (int64_t)g_idx0 * p.out_dim : nullptr;
+            const float g_sc1 = p.g_ray ? p.g_scale[mc] : 0.0f;
             float dot = 0.0f;
             if (p.act == PAG_ACT_SOFTMAX) {
                 for (int ob = 0; ob < OB; ++ob) {
                     {
                         RawO rz1[4], ry1[4];
+                        if (p.g_ray) {       // rank-1 gradient: only the probabilities are read
+                            f32x16 gz;
+                            if (g_uni) rank1_block_uniform(g_row_u, g_sc1, 32 * ob, h, p.out_dim, gz);
+                            else rank1_block(g_row1, g_sc1, 32 * ob, h, p.out_dim, gz);
+                            bool st2 = false;
+                            if constexpr (sizeof(OutT) == 2) {
+                                if ((p.out_dim & 7) == 0) {
+                                    block32_stage_in(stg, 32, gtile_y, p.out_dim, 32 * ob, rows_valid, lane);
+                                    wave_lds_sync();
+                                    block32_read(stg, 32, r, h, ry1);
+                                    wave_lds_sync();
+                                    st2 = true;
+                                }
+                            }
+                            if (!st2) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) dot += gz[q] * (float)ry1[q >> 2][q & 3];
+                            continue;
+                        }
                         if constexpr (sizeof(OutT) == 2) {
                             if ((p.out_dim & 7) == 0) {
                                 block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
@@ -699,22 +780,25 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
                     RawO rz1[4], ry1[4];
                     f32x16 zz;
                     bool staged = false;
+                    const bool r1 = p.g_ray != nullptr;
                     if constexpr (sizeof(OutT) == 2) {
                         if ((p.out_dim & 7) == 0) {
-                            block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
+                            if (!r1) block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
                             if (p.act != PAG_ACT_NONE) block32_stage_in(stg, 32, gtile_y, p.out_dim, 32 * ob, rows_valid, lane);
                             wave_lds_sync();
-                            block32_read(stg, 0, r, h, rz1);
+                            if (!r1) block32_read(stg, 0, r, h, rz1);
                             if (p.act != PAG_ACT_NONE) block32_read(stg, 32, r, h, ry1);
                             wave_lds_sync();
                             staged = true;
                         }
                     }
                     if (!staged) {
-                        load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
+                        if (!r1) load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
                         if (p.act != PAG_ACT_NONE) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
                     }
-                    raw_to_block(rz1, zz);
+                    if (r1 && g_uni) rank1_block_uniform(g_row_u, g_sc1, 32 * ob, h, p.out_dim, zz);
+                    else if (r1) rank1_block(g_row1, g_sc1, 32 * ob, h, p.out_dim, zz);
+                    else raw_to_block(rz1, zz);
                     if (p.act == PAG_ACT_SIGMOID) {
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
@@ -1188,11 +1272,15 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a->dx1 == nullptr || a->dx1_dtype == PAG_F32 || a->dx1_dtype == PAG_BF16, "pag_mlp_bwd: dx1 dtype must be F32 or BF16");
     PAG_CHECK_ARG(a->mode == PAG_MLP_MFMA_BF16 || a->mode == PAG_MLP_FP32, "pag_mlp_bwd: bad mode %d", a->mode);
     if (M == 0) return PAG_OK;
-    PAG_CHECK_ARG(a->grad_out, "pag_mlp_bwd: NULL grad_out");
+    PAG_CHECK_ARG(a->grad_out || (a->g_ray && a->g_scale && a->g_index), "pag_mlp_bwd: NULL grad_out (and no rank-1 gradient)");
+    PAG_CHECK_ARG(!a->g_ray || (a->mode == PAG_MLP_MFMA_BF16 && a->out), "pag_mlp_bwd: rank-1 gradients need MFMA mode and the saved output");
     for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && a->dz[l], "pag_mlp_bwd: NULL weight/dz of layer %d", l);
     for (int l = 0; l + 1 < a->n_layers; ++l) PAG_CHECK_ARG(a->hidden_save[l], "pag_mlp_bwd: NULL hidden_save[%d]", l);
     BwdParams p;
-    p.grad_out = a->grad_out;
+    p.g_ray = a->g_ray;
+    p.g_scale = a->g_scale;
+    p.g_index = a->g_index;
+    p.grad_out = a->grad_out ? a->grad_out : (const void *)a->out;      // never dereferenced in rank-1 mode
     p.out = a->out ? a->out : (const void *)a->grad_out;
     p.k1 = a->k1;
     p.in_dim = a->in_dim;

@@ -188,6 +188,7 @@ class PanopticDeltaNeF(nn.Module):
             raise NotImplementedError("multiscale_type 'sum' with fused decoders")
         mode = self.mlp_mode
         feats = self._interp(self.grid, coords)                                       # :170-171
+        self._feat_cache = (coords, feats.detach())           # reused by panoptic_composited() for the same samples
         grp = self._grouped()
         density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
         density = torch.relu(density_feats[:, 0:1].float()).reshape(batch, num_samples, 1)   # :188
@@ -228,6 +229,36 @@ class PanopticDeltaNeF(nn.Module):
                     e = e / self.inst_soft_temperature if self.inst_soft_temperature > 0.0 else e
                     e = F.softmax(e, dim=-1) if self.inst_softmax else e
                 out["inst_embedding"] = e
+        return out
+
+    def can_fuse_panoptic(self, channels):
+        """True when the semantic / instance heads can run as decoder + compositing in one autograd node."""
+        if self.precision != "bf16" or self._grouped() is None:
+            return False
+        ok = True
+        if "semantics" in channels:
+            ok &= self.sem_softmax and not (self.sem_sigmoid or self.sem_normalize)
+        if "inst_embedding" in channels:
+            ok &= self.inst_softmax and not (self.inst_sigmoid or self.inst_normalize or self.inst_soft_temperature > 0.0)
+        return bool(ok)
+
+    def panoptic_composited(self, coords, channels, w, alpha, ridx, pack_start, ray_of_pack, N):
+        """Composited panoptic channels [N, C] for the packed samples `coords` ([M,1,3] or [M',k,3]): same arithmetic as
+        rgb_semantics() :210-255 followed by tracer :197-205, but each head + its per-ray weighted sum is one autograd
+        node whose backward feeds the decoder a rank-1 gradient (ops.head_composite)."""
+        cache = getattr(self, "_feat_cache", None)
+        feats = cache[1] if cache is not None and cache[0] is coords else self._interp(self.grid, coords).detach()
+        t = self.panoptic_features_type
+        if t in ("delta", "separate", None):
+            delta = self._interp(self.delta_grid, coords.detach())
+        pan = feats + delta if t in ("delta", None) else (delta if t == "separate" else feats)
+        grp = self._grouped()
+        out = {}
+        for ch, dec in (("semantics", self.decoder_semantics), ("inst_embedding", self.decoder_inst)):
+            if ch in channels:
+                W, b = dec.weights()
+                out[ch] = ops.head_composite(pan, W, b, w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=dec.input_dim,
+                                             out_act=L.ACT_SOFTMAX, out_dtype=self.feat_dtype, x1_grouped=grp)
         return out
 
     # ---------------------------------------------------------------------------------------- prune

@@ -232,6 +232,11 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        return _FusedMLP._backward_impl(ctx, g, None)
+
+    @staticmethod
+    def _backward_impl(ctx, g, rank1):
+        """rank1 = (g_ray f32 [N,out], g_scale f32 [M], g_index i32 [M]) replaces the dense upstream gradient g."""
         lib = L.load()
         in_dim, out_act, mode, n_layers, k1, grouped = ctx.cfg
         saved = ctx.saved_tensors
@@ -245,9 +250,14 @@ class _FusedMLP(torch.autograd.Function):
         dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
         need_dx = ctx.needs_input_grad[0]
         dx1 = torch.empty(x1.shape, device=dev, dtype=x1.dtype) if need_dx else None
-        g = g.contiguous().to(out.dtype)       # grad_out travels in the output's dtype
         a = L.MlpBwdArgs()
-        a.grad_out, a.out, a.out_dtype, a.out_act = L.ptr(g), L.ptr(out), L.dtype_code(out), out_act
+        if rank1 is None:
+            g = g.contiguous().to(out.dtype)       # grad_out travels in the output's dtype
+            a.grad_out = L.ptr(g)
+        else:
+            g_ray, g_scale, g_index = rank1
+            a.g_ray, a.g_scale, a.g_index = L.ptr(g_ray), L.ptr(g_scale), L.ptr(g_index)
+        a.out, a.out_dtype, a.out_act = L.ptr(out), L.dtype_code(out), out_act
         a.k1, a.in_dim, a.n_layers, a.out_dim = k1, in_dim, n_layers, out_dim
         if grouped is not None:
             a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
@@ -484,3 +494,40 @@ class _CompositeFeats(torch.autograd.Function):
 def composite_feats(feats, weights, alpha, pack_start, ray_of_pack, N):
     """out[ray] = alpha[ray] * sum_i w_i feats[i]  (weights/alpha detached; tracer :148-155,:197-205)."""
     return _CompositeFeats.apply(feats, weights, alpha, pack_start, ray_of_pack, N)
+
+
+class _HeadComposite(_FusedMLP):
+    """decoder (+ softmax) followed by the per-ray weighted sum of tracer :197-205, as ONE autograd node: the
+    backward hands the decoder the gradient in rank-1 form (alpha * w_m * d out[ray]) so neither the [M,C] gradient
+    nor a separate composite-backward launch exists."""
+
+    @staticmethod
+    def forward(ctx, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dim, out_act, out_dtype, grouped, *wb):
+        probs = _FusedMLP.forward(ctx, x1, None, None, in_dim, out_act, L.MLP_MFMA_BF16, out_dtype, grouped, *wb)
+        C = probs.shape[1]
+        P = ray_of_pack.shape[0]
+        out = torch.zeros(N, C, device=probs.device)
+        weights_w = weights_w.detach().contiguous()
+        alpha = alpha.detach().contiguous()
+        if P:
+            _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights_w), L.ptr(alpha),
+                  L.ptr(probs), L.dtype_code(probs), C, L.ptr(out), L.stream())
+        ctx.hc = (weights_w, alpha, ridx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weights_w, alpha, ridx = ctx.hc
+        scale = weights_w * alpha[ridx.long()]                       # alpha * w_m per sample (detached, :148-155)
+        grads = _FusedMLP._backward_impl(ctx, None, (g.contiguous().float(), scale.contiguous(), ridx.contiguous()))
+        dx1, gwb = grads[0], grads[8:]
+        return (dx1, None, None, None, None, None, None, None, None, None, None, *gwb)
+
+
+def head_composite(x1, weights, biases, w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=None, out_act=L.ACT_NONE,
+                   out_dtype=torch.bfloat16, x1_grouped=None):
+    """alpha[ray] * sum_i w_i * act(decoder(x1))[i]  ->  f32 [N, out_dim]; ridx i32 [M] = ray of each sample."""
+    if in_dim is None:
+        in_dim = weights[0].shape[1]
+    return _HeadComposite.apply(x1, w, alpha, ridx, pack_start, ray_of_pack, N, int(in_dim), out_act, out_dtype, x1_grouped,
+                                *weights, *biases)

@@ -95,6 +95,12 @@ class PanopticPackedRFTracer(nn.Module):
         outputs = {}
         sample_channels = set(channels - self.render_channels)                             # :121-124
         sample_channels.update(["density"])
+        # The panoptic channels use detached weights (:148-155), so they can be evaluated AFTER compositing, fused with
+        # their per-ray weighted sum (nef.panoptic_composited): the [M, C] probabilities' gradient is never materialised.
+        pan_req = [c for c in channels if c in self.panoptic_channels]
+        fuse_pan = bool(pan_req) and getattr(nef, "accepts_ray_index", False) and nef.can_fuse_panoptic(pan_req)
+        if fuse_pan:
+            sample_channels -= self.panoptic_channels
         if getattr(nef, "accepts_ray_index", False):      # per-ray view embedding gathered through ridx (no [M,3] dirs)
             feats = nef(coords=samples, ridx=ridx32, ray_dirs=rays.dirs, pidx=pidx, lod_idx=lod_idx, channels=sample_channels)
         else:                                              # :117,:124
@@ -116,8 +122,11 @@ class PanopticPackedRFTracer(nn.Module):
         if dep is not None:
             outputs["depth"] = out_depth[:, None]
         alpha_d = alpha.detach()
-        for ch in [c for c in channels if c in self.panoptic_channels]:                     # :148-155,:178-182
-            outputs[ch] = ops.composite_feats(feats[ch].reshape(-1, feats[ch].shape[-1]), w, alpha_d, pack_start, ray_of_pack, N)
+        if fuse_pan:
+            outputs.update(nef.panoptic_composited(samples, pan_req, w, alpha_d, ridx32, pack_start, ray_of_pack, N))
+        else:
+            for ch in pan_req:                                                              # :148-155,:178-182
+                outputs[ch] = ops.composite_feats(feats[ch].reshape(-1, feats[ch].shape[-1]), w, alpha_d, pack_start, ray_of_pack, N)
         extra_outputs = {}
         for ch in extra_channels:                                                          # :184-192
             f = nef(coords=samples, ray_d=rays.dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx, channels=ch)

@@ -151,6 +151,49 @@ def test_xcd8_layout_encode_and_decoder_match_strided(gpu_device):
             assert _rel_l2(b_.cpu(), a_.cpu()) < 2e-3, (Lv, F, _rel_l2(b_.cpu(), a_.cpu()))
 
 
+def test_head_composite_matches_unfused_path(gpu_device):
+    """decoder + softmax + per-ray weighted sum as one autograd node (rank-1 upstream gradient inside the decoder
+    backward) vs the two-node path (fused_mlp -> composite_feats): same outputs, same gradients."""
+    ops, L = _ops()
+    rs = np.random.RandomState(21)
+    N, Lv, F, M = 70, 24, 2, 70 * 40 + 13
+    counts = rs.multinomial(M, np.ones(N) / N)
+    counts[5] = 0
+    counts[6] += M - counts.sum()
+    ridx = torch.from_numpy(np.repeat(np.arange(N), counts).astype(np.int32)).to(gpu_device)
+    M = ridx.shape[0]
+    csum = np.cumsum(counts)
+    pack_start = torch.from_numpy(np.concatenate([[0], csum]).astype(np.int64)).to(gpu_device)
+    ray_of_pack = torch.arange(N, dtype=torch.int32, device=gpu_device)
+    w = torch.from_numpy(rs.uniform(0, 0.05, size=M).astype(np.float32)).to(gpu_device)
+    alpha = torch.from_numpy(rs.uniform(0.1, 1, size=N).astype(np.float32)).to(gpu_device)
+    for dims, grp in (((48, 64, 64, 200), (Lv, F)), ((48, 64, 6), (Lv, F))):
+        W, b = _rand_mlp(rs, dims)
+        x = torch.randn(8, M, 8, device=gpu_device).bfloat16()
+        cols = ops.xcd8_columns(Lv, F)
+        pad = torch.tensor([c < 0 for c in cols], device=gpu_device)
+        x.reshape(8, M, 8).permute(1, 0, 2).reshape(M, 64)[:, pad] = 0          # padding positions hold zeros
+        gout = torch.from_numpy(rs.standard_normal(size=(N, dims[-1])).astype(np.float32)).to(gpu_device)
+        res = []
+        for fused in (True, False):
+            Wg = [t.to(gpu_device).requires_grad_(True) for t in W]
+            bg = [t.to(gpu_device).requires_grad_(True) for t in b]
+            xg = x.clone().requires_grad_(True)
+            if fused:
+                out = ops.head_composite(xg, Wg, bg, w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=dims[0],
+                                         out_act=L.ACT_SOFTMAX, x1_grouped=grp)
+            else:
+                pr = ops.fused_mlp(xg, Wg, bg, in_dim=dims[0], out_act=L.ACT_SOFTMAX, out_dtype=torch.bfloat16, x1_grouped=grp)
+                out = ops.composite_feats(pr, w, alpha, pack_start, ray_of_pack, N)
+            (out * gout).sum().backward()
+            res.append((out.detach(), xg.grad.float(), [t.grad for t in Wg], [t.grad for t in bg]))
+        (o1, x1g, w1, b1), (o2, x2g, w2, b2) = res
+        assert torch.equal(o1, o2)
+        assert float(o1[5].abs().max()) == 0.0                      # empty ray
+        for a_, b_ in [(x1g, x2g)] + list(zip(w1, w2)) + list(zip(b1, b2)):
+            assert _rel_l2(a_.cpu(), b_.cpu()) < 1e-2, (dims, _rel_l2(a_.cpu(), b_.cpu()))   # unfused path rounds d_feats to bf16
+
+
 # ------------------------------------------------------------------------------------------------- MLP
 def _rand_mlp(rs, dims):
     W = [torch.from_numpy((rs.standard_normal(size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(len(dims) - 1)]
