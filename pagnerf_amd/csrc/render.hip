@@ -330,9 +330,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const fl
     }
 }
 
-// out[ray, c] = alpha[ray] * sum_i w_i f[i, c]; one workgroup (4 waves) per ray, channel on the lane,
-// the ray's samples split in 4 contiguous quarters, partials combined through LDS in wave order.
-template <typename FT>
+// out[ray, c] = alpha[ray] * sum_i w_i f[i, c]; one workgroup (4 waves) per ray, the ray's samples split in 4 contiguous
+// quarters, partials combined through LDS in wave order.  VEC: lane l owns channels 4l..4l+3 (one 8/16-byte load per
+// lane and sample row - a 2-byte-per-lane load per channel group kept the texture-address unit busy instead of HBM).
+template <typename FT, bool VEC>
 __global__ __launch_bounds__(256) void composite_feats_fwd_kernel(const int64_t *pack_start, const int32_t *ray_of_pack,
                                                                   const float *weights, const float *alpha, const FT *feats, int C,
                                                                   float *out) {
@@ -343,23 +344,85 @@ __global__ __launch_bounds__(256) void composite_feats_fwd_kernel(const int64_t 
     const int64_t n = end - beg, q = (n + 3) / 4;
     const int64_t lo = beg + wave * q, hi = min(end, lo + q);
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int64_t i = lo; i < hi; ++i) {
-        const float w = weights[i];
-        const FT *row = feats + i * C;
+    if (VEC) {
+        typedef FT vec4 __attribute__((ext_vector_type(4)));
+        const bool on = 4 * lane < C;
+        int64_t i = lo;
+        for (; i + 4 <= hi; i += 4) {
+            float wv[4];
+            vec4 fv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = lane + 64 * k;
-            if (c < C) acc[k] += w * pag_ld(row + c);
+            for (int u = 0; u < 4; ++u) {
+                wv[u] = weights[i + u];
+                if (on) fv[u] = *reinterpret_cast<const vec4 *>(feats + (i + u) * C + 4 * lane);
+            }
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] += wv[u] * (float)fv[u][k];
+            }
         }
-    }
+        for (; i < hi; ++i) {
+            if (on) {
+                const float w = weights[i];
+                const vec4 f = *reinterpret_cast<const vec4 *>(feats + i * C + 4 * lane);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) part[wave][lane + 64 * k] = acc[k];
+                for (int k = 0; k < 4; ++k) acc[k] += w * (float)f[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[wave][(4 * lane + k) & 255] = acc[k];
+    } else {
+        for (int64_t i = lo; i < hi; ++i) {
+            const float w = weights[i];
+            const FT *row = feats + i * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = lane + 64 * k;
+                if (c < C) acc[k] += w * pag_ld(row + c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[wave][lane + 64 * k] = acc[k];
+    }
     __syncthreads();
     const int c = threadIdx.x;
     if (c < C) {
         const int64_t ray = ray_of_pack[pk];
         const float s = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
         out[ray * C + c] = alpha[ray] * s;
+    }
+}
+
+// narrow features (C <= 16, e.g. the semantic classes): one WAVE per ray with the SAMPLE on the lane - a workgroup per
+// ray with the channel on the lane would leave 250 of 256 lanes idle and walk the ray one dependent load at a time
+template <typename FT>
+__global__ __launch_bounds__(256) void composite_feats_small_fwd_kernel(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
+                                                                        const float *weights, const float *alpha, const FT *feats,
+                                                                        int C, float *out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pk >= P) return;
+    const int64_t beg = pack_start[pk], end = pack_start[pk + 1];
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    for (int64_t i = beg + lane; i < end; i += 64) {
+        const float w = weights[i];
+        const FT *row = feats + i * C;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) acc[c] += w * pag_ld(row + c);
+    }
+    const int64_t ray = ray_of_pack[pk];
+    const float al = alpha[ray];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < C) {
+            const float s = wave_sum(acc[c]);
+            if (lane == 0) out[ray * C + c] = al * s;
+        }
     }
 }
 
@@ -466,12 +529,27 @@ extern "C" int pag_composite_feats_fwd(const int64_t *pack_start, const int32_t 
     PAG_CHECK_ARG(feat_dtype == PAG_F32 || feat_dtype == PAG_BF16, "pag_composite_feats_fwd: feats dtype must be F32 or BF16");
     if (P == 0) return PAG_OK;
     PAG_CHECK_ARG(pack_start && ray_of_pack && weights && alpha && feats && out, "pag_composite_feats_fwd: NULL input");
-    if (feat_dtype == PAG_F32)
-        hipLaunchKernelGGL((composite_feats_fwd_kernel<float>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start,
-                           ray_of_pack, weights, alpha, (const float *)feats, C, out);
-    else
-        hipLaunchKernelGGL((composite_feats_fwd_kernel<bf16_t>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start,
-                           ray_of_pack, weights, alpha, (const bf16_t *)feats, C, out);
+    if (C <= 16) {
+        const dim3 g((unsigned)((P + 3) / 4));
+        if (feat_dtype == PAG_F32)
+            hipLaunchKernelGGL((composite_feats_small_fwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, pack_start, ray_of_pack, P,
+                               weights, alpha, (const float *)feats, C, out);
+        else
+            hipLaunchKernelGGL((composite_feats_small_fwd_kernel<bf16_t>), g, dim3(256), 0, (hipStream_t)stream, pack_start, ray_of_pack, P,
+                               weights, alpha, (const bf16_t *)feats, C, out);
+    } else {
+        const bool vec = (C % 4) == 0;
+        const dim3 g((unsigned)P);
+        hipStream_t st = (hipStream_t)stream;
+        if (feat_dtype == PAG_F32 && vec)
+            hipLaunchKernelGGL((composite_feats_fwd_kernel<float, true>), g, dim3(256), 0, st, pack_start, ray_of_pack, weights, alpha, (const float *)feats, C, out);
+        else if (feat_dtype == PAG_F32)
+            hipLaunchKernelGGL((composite_feats_fwd_kernel<float, false>), g, dim3(256), 0, st, pack_start, ray_of_pack, weights, alpha, (const float *)feats, C, out);
+        else if (vec)
+            hipLaunchKernelGGL((composite_feats_fwd_kernel<bf16_t, true>), g, dim3(256), 0, st, pack_start, ray_of_pack, weights, alpha, (const bf16_t *)feats, C, out);
+        else
+            hipLaunchKernelGGL((composite_feats_fwd_kernel<bf16_t, false>), g, dim3(256), 0, st, pack_start, ray_of_pack, weights, alpha, (const bf16_t *)feats, C, out);
+    }
     PAG_CHECK_LAUNCH("pag_composite_feats_fwd");
     return PAG_OK;
 }
