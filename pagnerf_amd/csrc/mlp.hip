@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
 
 // ----------------------------------------------------------------------------------------- backward
 template <typename OutT, typename DxT, int NL, int OBMAX>
-__global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdParams p) {
+__global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.out_dim + 31) / 32;
     const int RSL = OB * 32 + 8;
@@ -717,99 +717,106 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_bwd_mfma(BwdPara
                 }
             }
         } else {
-            // wide heads: two passes over the (L2-resident) gradient / probability rows keep only ONE 32-channel
-            // block live at a time instead of all of them (256 VGPRs -> 1 wave per SIMD before)
-            const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
-            const OutT *yop = outp + mc * p.out_dim;
-            const bf16_t *gtile_g = reinterpret_cast<const bf16_t *>(p.grad_out) + tile * 32 * p.out_dim;
-            const bf16_t *gtile_y = reinterpret_cast<const bf16_t *>(p.out) + tile * 32 * p.out_dim;
+            // wide heads: two passes over the gradient / probability rows (dot product for the softmax backward, then dz)
+            // keep only ONE 32-channel block live at a time instead of all of them (256 VGPRs -> 1 wave per SIMD before).
+            // The passes form one software pipeline over 2*OB steps: the global loads of step s+1 (16 bytes per lane,
+            // fully coalesced) are in flight while step s goes through the LDS staging tile and the MFMAs - profiling
+            // showed this kernel parked on memory 69 % of the time with one exposed round trip per block.
             const int g_idx1 = p.g_ray ? p.g_index[mc] : 0;
             const int g_idx0 = __builtin_amdgcn_readfirstlane(g_idx1);
             const bool g_uni = __all(g_idx1 == g_idx0);      // whole tile inside one ray (the common case)
             const float *g_row1 = p.g_ray ? p.g_ray + (int64_t)g_idx1 * p.out_dim : nullptr;
             const float *g_row_u = p.g_ray ? p.g_ray + (int64_t)g_idx0 * p.out_dim : nullptr;
             const float g_sc1 = p.g_ray ? p.g_scale[mc] : 0.0f;
+            const bool r1 = p.g_ray != nullptr;
+            const bool need_y = p.act != PAG_ACT_NONE;
+            const int n1 = p.act == PAG_ACT_SOFTMAX ? OB : 0, n_steps = n1 + OB;
             float dot = 0.0f;
-            if (p.act == PAG_ACT_SOFTMAX) {
-                for (int ob = 0; ob < OB; ++ob) {
-                    {
-                        RawO rz1[4], ry1[4];
-                        if (p.g_ray) {       // rank-1 gradient: only the probabilities are read
-                            f32x16 gz;
-                            if (g_uni) rank1_block_uniform(g_row_u, g_sc1, 32 * ob, h, p.out_dim, gz);
-                            else rank1_block(g_row1, g_sc1, 32 * ob, h, p.out_dim, gz);
-                            bool st2 = false;
-                            if constexpr (sizeof(OutT) == 2) {
-                                if ((p.out_dim & 7) == 0) {
-                                    block32_stage_in(stg, 32, gtile_y, p.out_dim, 32 * ob, rows_valid, lane);
-                                    wave_lds_sync();
-                                    block32_read(stg, 32, r, h, ry1);
-                                    wave_lds_sync();
-                                    st2 = true;
-                                }
-                            }
-                            if (!st2) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+            bool fast = false;
+            if constexpr (sizeof(OutT) == 2) fast = (p.out_dim & 7) == 0;
+            if (fast) {
+                const bf16_t *gtile_g = reinterpret_cast<const bf16_t *>(p.grad_out) + tile * 32 * p.out_dim;
+                const bf16_t *gtile_y = reinterpret_cast<const bf16_t *>(p.out) + tile * 32 * p.out_dim;
+                bf16x8 cz[2], cy[2], nzr[2], nyr[2];
+                auto gfetch = [&](int ob, bf16x8 (&fz)[2], bf16x8 (&fy)[2]) __attribute__((always_inline)) {
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) dot += gz[q] * (float)ry1[q >> 2][q & 3];
-                            continue;
-                        }
-                        if constexpr (sizeof(OutT) == 2) {
-                            if ((p.out_dim & 7) == 0) {
-                                block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
-                                block32_stage_in(stg, 32, gtile_y, p.out_dim, 32 * ob, rows_valid, lane);
-                                wave_lds_sync();
-                                block32_read(stg, 0, r, h, rz1);
-                                block32_read(stg, 32, r, h, ry1);
-                                wave_lds_sync();
-                            } else {
-                                load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
-                                load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
-                            }
-                        } else {
-                            load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
-                            load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
-                        }
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) dot += (float)rz1[q >> 2][q & 3] * (float)ry1[q >> 2][q & 3];
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 16 + (lane >> 2), c = 32 * ob + (lane & 3) * 8;
+                        const bool ok = row < rows_valid && c < p.out_dim;
+                        fz[it] = (ok && !r1) ? *reinterpret_cast<const bf16x8 *>(gtile_g + (int64_t)row * p.out_dim + c) : zero8();
+                        fy[it] = (ok && need_y) ? *reinterpret_cast<const bf16x8 *>(gtile_y + (int64_t)row * p.out_dim + c) : zero8();
                     }
-                }
-                dot += __shfl_xor(dot, 32);
-            }
-            for (int ob = 0; ob < OB; ++ob) {
-                {
-                    RawO rz1[4], ry1[4];
+                };
+                gfetch(0, cz, cy);
+                for (int step = 0; step < n_steps; ++step) {
+                    const int ob = step < n1 ? step : step - n1;
+                    if (step + 1 < n_steps) gfetch(step + 1 < n1 ? step + 1 : step + 1 - n1, nzr, nyr);
+                    bf16x4 rz1[4], ry1[4];
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 16 + (lane >> 2), c = (lane & 3) * 8;
+                        *reinterpret_cast<bf16x8 *>(stg + row * ST_RS + c) = cz[it];
+                        *reinterpret_cast<bf16x8 *>(stg + row * ST_RS + 32 + c) = cy[it];
+                    }
+                    wave_lds_sync();
+                    block32_read(stg, 0, r, h, rz1);
+                    block32_read(stg, 32, r, h, ry1);
+                    wave_lds_sync();
                     f32x16 zz;
-                    bool staged = false;
-                    const bool r1 = p.g_ray != nullptr;
-                    if constexpr (sizeof(OutT) == 2) {
-                        if ((p.out_dim & 7) == 0) {
-                            if (!r1) block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
-                            if (p.act != PAG_ACT_NONE) block32_stage_in(stg, 32, gtile_y, p.out_dim, 32 * ob, rows_valid, lane);
-                            wave_lds_sync();
-                            if (!r1) block32_read(stg, 0, r, h, rz1);
-                            if (p.act != PAG_ACT_NONE) block32_read(stg, 32, r, h, ry1);
-                            wave_lds_sync();
-                            staged = true;
-                        }
-                    }
-                    if (!staged) {
-                        if (!r1) load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
-                        if (p.act != PAG_ACT_NONE) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
-                    }
                     if (r1 && g_uni) rank1_block_uniform(g_row_u, g_sc1, 32 * ob, h, p.out_dim, zz);
                     else if (r1) rank1_block(g_row1, g_sc1, 32 * ob, h, p.out_dim, zz);
                     else raw_to_block(rz1, zz);
-                    if (p.act == PAG_ACT_SIGMOID) {
+                    if (step < n1) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float y = (float)ry1[q >> 2][q & 3];
-                            zz[q] = zz[q] * y * (1.0f - y);
+                        for (int q = 0; q < 16; ++q) dot += zz[q] * (float)ry1[q >> 2][q & 3];
+                        if (step == n1 - 1) dot += __shfl_xor(dot, 32);
+                    } else {
+                        if (p.act == PAG_ACT_SIGMOID) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) {
+                                const float y = (float)ry1[q >> 2][q & 3];
+                                zz[q] = zz[q] * y * (1.0f - y);
+                            }
+                        } else if (p.act == PAG_ACT_SOFTMAX) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) zz[q] = (float)ry1[q >> 2][q & 3] * (zz[q] - dot);
                         }
-                    } else if (p.act == PAG_ACT_SOFTMAX) {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) zz[q] = (float)ry1[q >> 2][q & 3] * (zz[q] - dot);
+                        finish_block(ob, zz);
                     }
-                    finish_block(ob, zz);
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        cz[it] = nzr[it];
+                        cy[it] = nyr[it];
+                    }
+                }
+            } else {      // generic wide path (fp32 outputs or out_dim % 8 != 0): direct per-lane row accesses
+                const OutT *gop = reinterpret_cast<const OutT *>(p.grad_out) + mc * p.out_dim;
+                const OutT *yop = outp + mc * p.out_dim;
+                for (int step = 0; step < n_steps; ++step) {
+                    const int ob = step < n1 ? step : step - n1;
+                    RawO rz1[4], ry1[4];
+                    if (!r1) load_block_raw(gop, 32 * ob, h, rz1, p.out_dim, vec_out);
+                    if (need_y) load_block_raw(yop, 32 * ob, h, ry1, p.out_dim, vec_out);
+                    f32x16 zz;
+                    if (r1) rank1_block(g_row1, g_sc1, 32 * ob, h, p.out_dim, zz);
+                    else raw_to_block(rz1, zz);
+                    if (step < n1) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) dot += zz[q] * (float)ry1[q >> 2][q & 3];
+                        if (step == n1 - 1) dot += __shfl_xor(dot, 32);
+                    } else {
+                        if (p.act == PAG_ACT_SIGMOID) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) {
+                                const float y = (float)ry1[q >> 2][q & 3];
+                                zz[q] = zz[q] * y * (1.0f - y);
+                            }
+                        } else if (p.act == PAG_ACT_SOFTMAX) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) zz[q] = (float)ry1[q >> 2][q & 3] * (zz[q] - dot);
+                        }
+                        finish_block(ob, zz);
+                    }
                 }
             }
         }
