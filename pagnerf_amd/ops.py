@@ -271,9 +271,10 @@ class _FusedMLP(torch.autograd.Function):
         gW, gb = [], []
         if mode == L.MLP_MFMA_BF16 and M:
             # weight gradients on the matrix cores: per-workgroup fp32 slabs, summed here (deterministic)
-            nblk = lib.pag_mlp_wgrad_blocks(M)
+            nblk_max = lib.pag_mlp_wgrad_blocks(M)
             for l in range(n_layers):
                 n_out = Wc[l].shape[0]
+                nblk = nblk_max if n_out <= 64 else min(nblk_max, 512)      # wide layers: fewer, larger slabs to sum
                 slabs = torch.empty(nblk, (n_out + 31) // 32 * 32, 96, device=dev)
                 if l == 0 and grouped is not None:
                     _call("pag_mlp_wgrad", L.ptr(dz[0]), dz[0].shape[1], n_out, L.ptr(x1), L.BF16, L.LAYOUT_XCD8, 64, None, 0, None,
