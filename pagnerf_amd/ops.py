@@ -429,7 +429,7 @@ class _Composite(torch.autograd.Function):
         hit = torch.zeros(N, device=dev, dtype=torch.uint8)
         out_rgb = (torch.ones if bg_white else torch.zeros)(N, 3, device=dev) if rgb is not None else None
         out_depth = torch.zeros(N, device=dev) if depths is not None else None
-        if P:
+        if P and M:                     # M == 0: every pack is empty, the outputs already hold the background
             _call("pag_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
                                           L.ptr(rgbc), L.BG_WHITE if bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
                                           L.ptr(out_rgb), L.ptr(out_depth), L.ptr(hit), L.stream())
@@ -442,12 +442,12 @@ class _Composite(torch.autograd.Function):
     def backward(ctx, g_alpha, _g_hit, g_rgb, g_depth, _g_w):
         sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha = ctx.saved_tensors
         M, P = sigma.shape[0], ray_of_pack.shape[0]
-        mk = torch.empty if P else torch.zeros          # all samples are covered by packs: kernels write every element
+        mk = torch.empty if P and M else torch.zeros          # all samples are covered by packs: kernels write every element
         d_sigma = mk(M, device=sigma.device)
         d_rgb = mk(M, 3, device=sigma.device) if rgbc is not None else None
         gc = lambda t: t.contiguous().float() if t is not None else None
         g_alpha, g_rgb, g_depth = gc(g_alpha), gc(g_rgb), gc(g_depth)
-        if P:
+        if P and M:
             _call("pag_composite_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
                                           L.ptr(rgbc), L.BG_WHITE if ctx.bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
                                           L.ptr(g_rgb), L.ptr(g_depth), L.ptr(g_alpha), L.ptr(d_sigma), L.ptr(d_rgb),
@@ -472,7 +472,7 @@ class _CompositeFeats(torch.autograd.Function):
         out = torch.zeros(N, C, device=feats.device)
         weights = weights.detach().contiguous()
         alpha = alpha.detach().contiguous()
-        if P:
+        if P and feats.shape[0]:
             _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
                                                 L.ptr(feats), L.dtype_code(feats), C, L.ptr(out), L.stream())
         ctx.save_for_backward(weights, alpha, pack_start, ray_of_pack)
@@ -486,7 +486,7 @@ class _CompositeFeats(torch.autograd.Function):
         P = ray_of_pack.shape[0]
         # every packed sample belongs to a pack, so the kernel writes every row: no zero fill of the [M,C] buffer
         d = torch.empty(M, C, device=weights.device, dtype=ctx.fdtype) if P else torch.zeros(M, C, device=weights.device, dtype=ctx.fdtype)
-        if P:
+        if P and M:
             _call("pag_composite_feats_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
                   L.ptr(g.contiguous().float()), C, L.ptr(d), L.dtype_code(d), L.stream())
         return d, None, None, None, None, None
@@ -510,7 +510,7 @@ class _HeadComposite(_FusedMLP):
         out = torch.zeros(N, C, device=probs.device)
         weights_w = weights_w.detach().contiguous()
         alpha = alpha.detach().contiguous()
-        if P:
+        if P and probs.shape[0]:
             _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights_w), L.ptr(alpha),
                   L.ptr(probs), L.dtype_code(probs), C, L.ptr(out), L.stream())
         ctx.hc = (weights_w, alpha, ridx)

@@ -1,0 +1,99 @@
+"""Edge cases the reference's code paths hit: empty inputs (grids/permuto_grid.py:68-69), rays without samples
+(tracer :140-146,:164-176), single-sample and very long packs, ragged tails that are not multiples of the tile sizes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_inputs_everywhere(gpu_device):
+    import pagnerf_amd
+    from pagnerf_amd import ops, _lib as L
+    dev = gpu_device
+    spec = ops.hash_spec([16.0, 32.0], 8, 2)
+    tab = torch.randn(2, 256, 2, device=dev, requires_grad=True)
+    out = ops.encode(torch.zeros(0, 3, device=dev), tab, spec)
+    assert out.shape == (0, 4)
+    out.sum().backward()
+    assert float(tab.grad.abs().sum()) == 0.0
+    W = [torch.randn(64, 48, device=dev), torch.randn(16, 64, device=dev)]
+    b = [torch.zeros(64, device=dev), torch.zeros(16, device=dev)]
+    assert ops.fused_mlp(torch.zeros(0, 48, device=dev), W, b).shape == (0, 16)
+    # no ray hits the cube: zero packed samples, every output keeps its background
+    g = pagnerf_amd.PermutoGridHIP(2, capacity_log_2=8, num_lods=4, finest_scale=0.01, blas_level=3)
+    g.init_from_scales()
+    g = g.to(dev)
+    assert g.interpolate(torch.zeros(0, 1, 3, device=dev)).shape == (0, 1, 8)          # permuto_grid.py:68-69
+    nef = pagnerf_amd.PanopticDeltaNeF(grid_type="PermutoGrid", num_lods=24, feature_dim=2, num_classes=6, num_instances=200,
+                                       inst_num_layers=2, sem_num_layers=1, sem_softmax=True, inst_softmax=True,
+                                       panoptic_features_type="delta", capacity_log_2=8, delta_capacity_log_2=8, blas_level=3)
+    nef.grid.init_from_scales()
+    nef.delta_grid.init_from_scales()
+    nef = nef.to(dev)
+    tracer = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=16, bg_color="white")
+    rays = pagnerf_amd.Rays(torch.full((7, 3), 5.0, device=dev), torch.tensor([[1.0, 0, 0]], device=dev).repeat(7, 1), 0.0, 2.0)
+    for mode in ("ray", "voxel"):
+        tracer.raymarch_type = mode
+        rb = tracer(nef, channels={"rgb", "depth", "semantics", "inst_embedding"}, rays=rays)
+        assert torch.equal(rb.rgb, torch.ones(7, 3, device=dev)) and float(rb.alpha.abs().sum()) == 0 and not bool(rb.hit.any())
+        assert float(rb.depth.abs().sum()) == 0 and float(rb.inst_embedding.abs().sum()) == 0 and rb.inst_embedding.shape == (7, 200)
+    tracer.bg_color = "black"
+    tracer.raymarch_type = "ray"
+    assert float(tracer(nef, channels={"rgb"}, rays=rays).rgb.abs().sum()) == 0
+
+
+def test_ragged_packs_single_and_long(gpu_device):
+    """packs of 0, 1, 63, 64, 65 and 5000 samples; M not a multiple of 32 / 64 / 1024."""
+    from pagnerf_amd import ops
+    from oracle import render as orr
+    dev = gpu_device
+    rs = np.random.RandomState(5)
+    counts = np.array([0, 1, 63, 64, 65, 0, 5000, 2, 1, 0, 129, 7])
+    N = len(counts)
+    ridx = torch.from_numpy(np.repeat(np.arange(N), counts)).long()
+    M = ridx.shape[0]
+    boundary = orr.mark_pack_boundaries(ridx)
+    mk = lambda *s: torch.from_numpy(rs.uniform(0, 1, size=s).astype(np.float32))
+    sigma, rgb, deltas, depths = mk(M) * 5, mk(M, 3), mk(M) * 0.01, mk(M)
+    feat = torch.softmax(torch.from_numpy(rs.standard_normal(size=(M, 200)).astype(np.float32)), -1)
+    ref = orr.composite(N, ridx, boundary, sigma, deltas[:, None], depths=depths, rgb=rgb, inst=feat)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    pack_start = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    ray_of_pack = torch.arange(N, dtype=torch.int32, device=dev)
+    alpha, hit, orgb, odepth, w = ops.composite(sigma.to(dev), rgb.to(dev), deltas.to(dev), depths.to(dev), pack_start, ray_of_pack, N)
+    np.testing.assert_allclose(orgb.cpu().numpy(), ref["rgb"].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref["alpha"].numpy()[:, 0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(odepth.cpu().numpy(), ref["depth"].numpy()[:, 0], rtol=1e-5, atol=1e-6)
+    assert torch.equal(hit.bool().cpu(), ref["hit"])
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        out = ops.composite_feats(feat.to(dev).to(dt), w, alpha, pack_start, ray_of_pack, N)
+        np.testing.assert_allclose(out.cpu().numpy(), ref["inst_embedding"].numpy(), rtol=tol, atol=tol * 1e-1)
+    # kaolin-style packs (non-empty only) give the same buffers
+    ps2, rp2 = ops.packs_from_boundary(ridx.int().to(dev), boundary.to(dev))
+    a2, _, rgb2, _, _ = ops.composite(sigma.to(dev), rgb.to(dev), deltas.to(dev), depths.to(dev), ps2, rp2, N)
+    assert torch.equal(a2, alpha) and torch.equal(rgb2, orgb)
+
+
+def test_permuto_fp16_tables_and_odd_sizes(gpu_device):
+    from pagnerf_amd import ops
+    from oracle import permuto_encode as op
+    dev = gpu_device
+    rs = np.random.RandomState(8)
+    for M in (1, 31, 33, 1023, 1025, 2049):
+        Lv, F, cap = 24, 2, 4099          # prime capacity: modulo path, ragged last slice
+        sf = op.scale_factors(np.geomspace(1.0, 1e-4, Lv))
+        shifts = (rs.standard_normal(size=(Lv, 3)) * 10).astype(np.float32)
+        x = rs.uniform(-1, 1, size=(M, 3)).astype(np.float32)
+        tab = rs.standard_normal(size=(Lv, cap, F)).astype(np.float32)
+        spec = ops.permuto_spec(sf, shifts, cap, F)
+        t16 = torch.from_numpy(tab).half().to(dev).requires_grad_(True)
+        ref, _, _ = op.permuto_encode(x, t16.detach().float().cpu().numpy(), shifts, sf)
+        out = ops.encode(torch.from_numpy(x).to(dev), t16, spec)
+        assert np.array_equal(out.detach().cpu().numpy(), ref), M
+        go = rs.standard_normal(size=ref.shape).astype(np.float32)
+        out.backward(torch.from_numpy(go).to(dev))
+        gref = op.permuto_encode_bwd(x, go, cap, shifts, sf)
+        np.testing.assert_allclose(t16.grad.float().cpu().numpy(), gref, rtol=2e-3, atol=2e-3)     # fp16 gradient storage
+        xc = ops.encode(torch.from_numpy(x).to(dev), t16.detach(), spec, layout="xcd8")
+        assert xc.shape == (8, M, 8)
