@@ -206,6 +206,15 @@ int pag_raymarch_voxel_pack(const float *origins, const float *dirs, int64_t N, 
                             float *samples, float *depths, float *deltas, uint8_t *boundary,
                             void *stream);
 
+/* Occupancy update of pc_nerf/panoptic_delta_nef.py:63-104 (prune), one launch:
+ *   occupancy[i] <- max(density[i * density_stride], occupancy[i] * decay)     (:74, :90)
+ *   bit i of occupancy_bits <- occupancy[i] > min_density                      (:75, :98-104)
+ * density f32 (one value per dense cell, x slowest), occupancy f32 [num_cells] (in/out),
+ * occupancy_bits u32 [ceil(num_cells/32)] (out) - the bitfield pag_raymarch_* consume. */
+int pag_occupancy_update(const float *density, int64_t density_stride, float *occupancy,
+                         uint32_t *occupancy_bits, int64_t num_cells, float decay,
+                         float min_density, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Alpha compositing - kaolin spc_render.exponential_integration / sum_reduce as used at
  * tracers/panoptic_packed_rf_tracer.py:134-182,197-205

@@ -600,3 +600,36 @@ extern "C" int pag_raymarch_voxel_pack(const float *origins, const float *dirs, 
     PAG_CHECK_LAUNCH("pag_raymarch_voxel_pack");
     return PAG_OK;
 }
+
+// ------------------------------------------------------------------------------------------- occupancy update (prune)
+// panoptic_delta_nef.py:74-75,90-104: occupancy <- max(density, occupancy * decay); cell kept iff occupancy > min_density.
+// One lane per cell; a wave's ballot is two words of the bitfield the march kernels read.
+__global__ __launch_bounds__(256) void occupancy_update_kernel(const float *__restrict__ density, int64_t density_stride,
+                                                               float *__restrict__ occupancy, uint32_t *__restrict__ bits,
+                                                               int64_t num_cells, float decay, float min_density) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < num_cells) {
+        float o = fmaxf(density[i * density_stride], occupancy[i] * decay);
+        occupancy[i] = o;
+        keep = o > min_density;
+    }
+    uint64_t m = __ballot(keep);
+    int lane = threadIdx.x & 63;
+    int64_t word = (i - lane) >> 5;
+    int64_t words = (num_cells + 31) >> 5;
+    if (lane == 0 && word < words) bits[word] = (uint32_t)m;
+    if (lane == 32 && word + 1 < words) bits[word + 1] = (uint32_t)(m >> 32);
+}
+
+extern "C" int pag_occupancy_update(const float *density, int64_t density_stride, float *occupancy, uint32_t *occupancy_bits,
+                                    int64_t num_cells, float decay, float min_density, void *stream) {
+    PAG_CHECK_ARG(num_cells >= 0, "pag_occupancy_update: num_cells < 0");
+    PAG_CHECK_ARG(density_stride >= 1, "pag_occupancy_update: density_stride < 1");
+    if (num_cells == 0) return PAG_OK;
+    PAG_CHECK_ARG(density && occupancy && occupancy_bits, "pag_occupancy_update: NULL input/output");
+    hipLaunchKernelGGL(occupancy_update_kernel, dim3((unsigned)((num_cells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, density,
+                       density_stride, occupancy, occupancy_bits, num_cells, decay, min_density);
+    PAG_CHECK_LAUNCH("pag_occupancy_update");
+    return PAG_OK;
+}

@@ -56,6 +56,13 @@ class OccupancyBLAS(nn.Module):
         self.blas_bits = w.to(self.blas_bits.device)
         self._all_occupied = bool(mask.all())
 
+    def blas_init_bits(self, bits):
+        """Adopt a packed bitfield produced on the device (ops.occupancy_update)."""
+        assert bits.dtype == torch.int32 and bits.numel() == self.blas_bits.numel()
+        self.blas_bits = bits.clone()
+        full = self.num_cells if self.num_cells < 32 else 32
+        self._all_occupied = bool((bits == -1).all()) if full == 32 else False
+
     def occupancy_mask(self):
         bits = self.blas_bits.long() & 0xFFFFFFFF
         m = ((bits[:, None] >> torch.arange(32, device=bits.device)) & 1).bool().reshape(-1)

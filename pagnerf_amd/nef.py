@@ -272,7 +272,6 @@ class PanopticDeltaNeF(nn.Module):
         min_density = (0.01 * 512) / np.sqrt(3)
         dev = self.device
         g = self.grid
-        g.occupancy = g.occupancy.to(dev) * density_decay
         points = g.dense_points.to(dev)
         res = 2.0 ** g.blas_level
         if jitter is None:
@@ -281,7 +280,8 @@ class PanopticDeltaNeF(nn.Module):
         views = torch.zeros(points.shape[0], 3, device=dev)
         views[:, 2] = 1.0
         density = self.forward(coords=samples[:, None], ray_d=views, channels="density")
-        g.occupancy = torch.stack([density[:, 0, 0], g.occupancy], -1).max(dim=-1)[0]
-        mask = g.occupancy > min_density
+        g.occupancy = g.occupancy.to(dev).float().contiguous()
+        bits = torch.empty(max(1, (g.num_cells + 31) // 32), dtype=torch.int32, device=dev)
+        ops.occupancy_update(density.reshape(-1), g.occupancy, bits, density_decay, min_density)   # EMA-max + threshold + pack
         for grid in [self.grid] + ([self.delta_grid] if hasattr(self, "delta_grid") else []):
-            grid.blas_init(mask)
+            grid.blas_init_bits(bits)

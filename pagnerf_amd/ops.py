@@ -412,6 +412,19 @@ def packs_from_boundary(ridx, boundary):
     return torch.cat([starts, end]).contiguous(), ridx[starts].int().contiguous()
 
 
+def occupancy_update(density, occupancy, bits, decay, min_density):
+    """In place: occupancy <- max(density, occupancy*decay); bits <- occupancy > min_density  (prune, nef :74-104).
+    density f32 [cells] (any stride over dim 0), occupancy f32 [cells], bits i32 [ceil(cells/32)]."""
+    _check_gpu(density, occupancy, bits)
+    cells = occupancy.shape[0]
+    density = density.detach()
+    if density.dim() != 1 or density.dtype != torch.float32:
+        density = density.reshape(cells, -1)[:, 0].float()
+    assert occupancy.is_contiguous() and bits.is_contiguous() and bits.numel() * 32 >= cells
+    _call("pag_occupancy_update", density.data_ptr(), density.stride(0), L.ptr(occupancy), L.ptr(bits), cells, float(decay),
+          float(min_density), L.stream())
+
+
 # ----------------------------------------------------------------------------------------- composite
 class _Composite(torch.autograd.Function):
     @staticmethod

@@ -97,3 +97,22 @@ def test_permuto_fp16_tables_and_odd_sizes(gpu_device):
         np.testing.assert_allclose(t16.grad.float().cpu().numpy(), gref, rtol=2e-3, atol=2e-3)     # fp16 gradient storage
         xc = ops.encode(torch.from_numpy(x).to(dev), t16.detach(), spec, layout="xcd8")
         assert xc.shape == (8, M, 8)
+
+
+def test_occupancy_update_bit_exact(gpu_device):
+    """pag_occupancy_update vs the torch sequence of panoptic_delta_nef.py:74-75,90-104 (two prunes: EMA-max carries over)."""
+    from pagnerf_amd import ops
+    dev = gpu_device
+    rs = np.random.RandomState(2)
+    for cells in (8, 64, 4096, 16 ** 3 + 0, 100000):          # 8 = blas_level 1 (one partial word)
+        occ_ref = torch.zeros(cells)
+        occ = torch.zeros(cells, device=dev)
+        bits = torch.empty(max(1, (cells + 31) // 32), dtype=torch.int32, device=dev)
+        for it in range(2):
+            dens = torch.from_numpy((rs.standard_normal(size=(cells, 1, 1)) * 3 + 2).astype(np.float32))
+            occ_ref = torch.stack([dens[:, 0, 0], occ_ref * 0.6], -1).max(dim=-1)[0]
+            mask = occ_ref > (0.01 * 512) / np.sqrt(3)
+            ops.occupancy_update(dens.to(dev), occ, bits, 0.6, (0.01 * 512) / np.sqrt(3))
+            assert torch.equal(occ.cpu(), occ_ref)
+            got = ((bits.cpu().long()[:, None] >> torch.arange(32)) & 1).bool().reshape(-1)[:cells]
+            assert torch.equal(got, mask), (cells, it)
