@@ -91,6 +91,25 @@ int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, in
                            const float *shift_host, const float *feat_scale_host,
                            float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* d loss / d xyz of the two encoders (camera pose optimisation, pc_nerf/ba_pipeline.py:85-92: the
+ * samples o + t*d depend on the learnable extrinsics).  The reference gets this from autograd through
+ * grids/hash_grid_torch.py:69-108 (hash) and from permutohedral_encoding's position gradient
+ * (permuto); within a cell / simplex the features are (tri)linear in xyz.
+ *   tables     as in *_encode_fwd (F32 or F16);  grad_out / strides / layout as in *_encode_bwd
+ *   d_xyz      f32 [M,3] (out, overwritten)
+ *   workspace  >= 8*M*3 floats: per-XCD-group partial sums, added deterministically */
+int pag_hash_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, int table_dtype,
+                            const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                            int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T,
+                            const float *resolutions_host, const float *feat_scale_host,
+                            float *d_xyz, void *workspace, int64_t workspace_bytes, void *stream);
+int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, int table_dtype,
+                               const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                               int64_t g_stride_c, int layout, int n_levels, int n_feat,
+                               uint32_t capacity, const float *scale_factor_host,
+                               const float *shift_host, const float *feat_scale_host, float *d_xyz,
+                               void *workspace, int64_t workspace_bytes, void *stream);
+
 /* Scratch size for the atomic-free ("binned") backward of either encoder: n_vertices = 8 (hash) or
  * 4 (permuto), rows_per_level = 2^log2_T or capacity.  The caller allocates it (device memory) and
  * passes it as `workspace`; with workspace == NULL the backward falls back to per-vertex fp32

@@ -92,3 +92,13 @@ def hash_encode_bwd(xyz, grad_out, n_entries, resolutions, log2_T):
             wc = (w[:, 0] if i else 1 - w[:, 0]) * (w[:, 1] if j else 1 - w[:, 1]) * (w[:, 2] if k else 1 - w[:, 2])
             g[lvl].index_add_(0, torch.from_numpy(idx[:, c].astype(np.int64)), go * wc[:, None])
     return g.float()
+
+
+def hash_encode_bwd_xyz(xyz, tables, grad_out, resolutions, log2_T):
+    """d loss / d xyz f32 [M,3]: autograd through hash_encode, exactly what the reference's autograd yields through
+    grids/hash_grid_torch.py:69-108 (the cell lookup is integer, only the weights w = (x - vmin)/(vmax - vmin) carry
+    a gradient; pinned by tests/golden/g7_hash_grad.npz)."""
+    x = xyz.detach().float().clone().requires_grad_(True)
+    out, _ = hash_encode(x, tables.detach(), resolutions, log2_T)
+    out.backward(grad_out)
+    return x.grad

@@ -134,3 +134,76 @@ def permuto_encode_bwd(xyz, grad_out, T, shifts, sf):
         for r in range(4):
             np.add.at(g[l], idx[:, r], go * bary[:, r:r + 1].astype(np.float64))
     return g.astype(F32)
+
+
+def permuto_encode_bwd_xyz(xyz, tables, grad_out, shifts, sf):
+    """d loss / d xyz f64->f32 [M,3].  Inside a simplex the barycentric weights are affine in the elevated point E:
+    coordinate a adds +delta_a to bary[3-rank_a] and -delta_a to bary[4-rank_a] (bary[4] folds into bary[0]),
+    delta_a = (E_a - rem0_a)/4, and E = (cf0+cf1+cf2, cf1+cf2-cf0, cf2-2cf1, -3cf2), cf = (x + shift)*sf
+    (lattice_simplex above).  PARITY UNPINNED like the forward (third-party position gradient of
+    permutohedral_encoding); tests check this closed form against central differences of a float64 restatement."""
+    xyz = np.ascontiguousarray(xyz, dtype=F32)
+    tables = np.asarray(tables, dtype=np.float64)
+    L, T, F = tables.shape
+    M = xyz.shape[0]
+    dx = np.zeros((M, 3), dtype=np.float64)
+    rows = np.arange(M)
+    for l in range(L):
+        rem0, rank, _ = lattice_simplex(xyz, shifts[l].astype(F32), sf[l].astype(F32))
+        idx = vertex_indices(rem0, rank, T)
+        go = grad_out[:, l * F:(l + 1) * F].astype(np.float64)
+        gb = np.zeros((M, 5))
+        for r in range(4):
+            gb[:, r] = (tables[l][idx[:, r]] * go).sum(1)
+        gb[:, 4] = gb[:, 0]
+        gE = np.empty((M, 4))
+        for a in range(4):
+            slot = 3 - rank[:, a]
+            gE[:, a] = 0.25 * (gb[rows, slot] - gb[rows, slot + 1])
+        s = sf[l].astype(np.float64)
+        dx[:, 0] += (gE[:, 0] - gE[:, 1]) * s[0]
+        dx[:, 1] += (gE[:, 0] + gE[:, 1] - 2.0 * gE[:, 2]) * s[1]
+        dx[:, 2] += (gE[:, 0] + gE[:, 1] + gE[:, 2] - 3.0 * gE[:, 3]) * s[2]
+    return dx.astype(F32)
+
+
+def permuto_encode_f64(xyz, tables, shifts, sf):
+    """float64 restatement of permuto_encode (no fp32 rounding) for finite-difference checks of the position
+    gradient; not bit-comparable with the fp32 definition near simplex faces."""
+    x = np.asarray(xyz, dtype=np.float64)
+    tables = np.asarray(tables, dtype=np.float64)
+    L, T, F = tables.shape
+    M = x.shape[0]
+    out = np.empty((M, L * F))
+    rows = np.arange(M)
+    for l in range(L):
+        cf = (x + shifts[l].astype(np.float64)) * sf[l].astype(np.float64)
+        E = np.stack([cf[:, 0] + cf[:, 1] + cf[:, 2], cf[:, 2] + cf[:, 1] - cf[:, 0], cf[:, 2] - 2 * cf[:, 1], -3 * cf[:, 2]], 1)
+        v = E * 0.25
+        up, dn = np.ceil(v) * 4, np.floor(v) * 4
+        rem0 = np.where((up - E) < (E - dn), up, dn).astype(np.int64)
+        s = rem0.sum(1) // 4
+        resid = E - rem0
+        rank = np.zeros((M, 4), dtype=np.int64)
+        for i in range(3):
+            for j in range(i + 1, 4):
+                lt = resid[:, i] < resid[:, j]
+                rank[:, i] += lt
+                rank[:, j] += ~lt
+        rank += s[:, None]
+        low, high = rank < 0, rank > 3
+        rank = np.where(low, rank + 4, np.where(high, rank - 4, rank))
+        rem0 = np.where(low, rem0 + 4, np.where(high, rem0 - 4, rem0))
+        bary = np.zeros((M, 5))
+        for i in range(4):
+            delta = (E[:, i] - rem0[:, i]) * 0.25
+            a = 3 - rank[:, i]
+            np.add.at(bary, (rows, a), delta)
+            np.add.at(bary, (rows, a + 1), -delta)
+        bary[:, 0] += 1.0 + bary[:, 4]
+        idx = vertex_indices(rem0.astype(np.int32), rank.astype(np.int32), T)
+        acc = np.zeros((M, F))
+        for r in range(4):
+            acc += tables[l][idx[:, r]] * bary[:, r:r + 1]
+        out[:, l * F:(l + 1) * F] = acc
+    return out

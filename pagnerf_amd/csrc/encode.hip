@@ -184,6 +184,124 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(const float *__restric
 }
 
 
+// ------------------------------------------------------------------------ d loss / d xyz (pose optimisation)
+// pc_nerf/ba_pipeline.py:85-92 makes the ray origins/directions functions of the camera extrinsics, so the samples
+// o + t*d carry a gradient and the encoders must return d loss / d xyz.  Within a cell / simplex the features are
+// (tri)linear in xyz, so the kernel is a second gather pass with the forward's geometry: per (sample, level) it
+// fetches the same 8 / 4 rows, contracts them with the incoming gradient and chains through the weight
+// derivatives.  Same XCD-pinned launch as the forward; group g writes its partial sum to part[g][m][3] and a tiny
+// second kernel adds the 8 groups (deterministic, no atomics).
+template <int KIND /*0 hash, 1 permuto*/, typename TableT, typename GradT, int F, int LPX>
+__global__ __launch_bounds__(256) void xyz_grad_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables,
+                                                       const GradT *__restrict__ go, int64_t sm, int64_t sc, int grouped,
+                                                       HashParams hp, PermutoParams pp, float *__restrict__ part) {
+    constexpr int NV = KIND == 0 ? 8 : 4;
+    const int g = blockIdx.x & 7;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int L = KIND == 0 ? hp.L : pp.L;
+    const float *scale = KIND == 0 ? hp.scale : pp.scale;
+    const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
+    const int64_t rows = KIND == 0 ? ((int64_t)1 << hp.log2T) : (int64_t)pp.capacity;
+    float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    float gpiece[8];
+    if (grouped) {
+        typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t t = *reinterpret_cast<const bf16x8_t *>(reinterpret_cast<const bf16_t *>(go) + ((int64_t)g * M + i) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gpiece[e] = (float)t[e];
+    }
+    float e[LPX][NV][F];
+    float w[LPX][4];         // hash: wx, wy, wz, -   permuto: unused
+    float dw[LPX][3];        // hash: d w / d x per axis
+    int slot[LPX][4];        // permuto: 3 - rank
+#pragma unroll
+    for (int j = 0; j < LPX; ++j) {
+        const int l = g + 8 * j;
+        const int le = l < L ? l : L - 1;
+        const TableT *tab = tables + (int64_t)le * rows * F;
+        if constexpr (KIND == 0) {
+            uint32_t idx[8];
+            float w3[3];
+            hash_cell(x, hp.res[le], hp.log2T, idx, w3, dw[j]);
+            w[j][0] = w3[0], w[j][1] = w3[1], w[j][2] = w3[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gather<F>(tab + (int64_t)idx[k] * F, e[j][k]);
+        } else {
+            uint32_t idx[4];
+            float bary[4];
+            permuto_simplex(x, pp.shift[le], pp.sf[le], pp.capacity, pp.pow2mask, idx, bary, slot[j]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gather<F>(tab + (int64_t)idx[k] * F, e[j][k]);
+        }
+    }
+    float dx[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < LPX; ++j) {
+        const int l = g + 8 * j;
+        if (l >= L) break;
+        float gv[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            gv[f] = grouped ? gpiece[(j * F + f) & 7] : pag_ld(go + i * sm + (int64_t)(l * F + f) * sc);
+            if (has_scale) gv[f] *= scale[l * F + f];
+        }
+        if constexpr (KIND == 0) {
+            const float wx = w[j][0], wy = w[j][1], wz = w[j][2];
+            const float ox = 1.0f - wx, oy = 1.0f - wy, oz = 1.0f - wz;
+            float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float e0 = e[j][0][f], e1 = e[j][1][f], e2 = e[j][2][f], e3 = e[j][3][f];
+                const float e4 = e[j][4][f], e5 = e[j][5][f], e6 = e[j][6][f], e7 = e[j][7][f];
+                const float c00 = e0 * ox + e4 * wx, c01 = e1 * ox + e5 * wx, c10 = e2 * ox + e6 * wx, c11 = e3 * ox + e7 * wx;
+                const float c0 = c00 * oy + c10 * wy, c1 = c01 * oy + c11 * wy;
+                gx += gv[f] * (oz * (oy * (e4 - e0) + wy * (e6 - e2)) + wz * (oy * (e5 - e1) + wy * (e7 - e3)));
+                gy += gv[f] * (oz * (c10 - c00) + wz * (c11 - c01));
+                gz += gv[f] * (c1 - c0);
+            }
+            dx[0] += gx * dw[j][0];
+            dx[1] += gy * dw[j][1];
+            dx[2] += gz * dw[j][2];
+        } else {
+            float gb[5];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = 0.0f;
+#pragma unroll
+                for (int f = 0; f < F; ++f) a += gv[f] * e[j][k][f];
+                gb[k] = a;
+            }
+            gb[4] = gb[0];
+            float gE[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float hi = 0.0f, lo = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {     // predicated select: no runtime-indexed private array
+                    hi = (k == slot[j][a]) ? gb[k] : hi;
+                    lo = (k == slot[j][a]) ? gb[k + 1] : lo;
+                }
+                gE[a] = 0.25f * (hi - lo);
+            }
+            // E0 = cf0+cf1+cf2, E1 = cf2+cf1-cf0, E2 = cf2-2cf1, E3 = -3cf2
+            dx[0] += (gE[0] - gE[1]) * pp.sf[l][0];
+            dx[1] += (gE[0] + gE[1] - 2.0f * gE[2]) * pp.sf[l][1];
+            dx[2] += (gE[0] + gE[1] + gE[2] - 3.0f * gE[3]) * pp.sf[l][2];
+        }
+    }
+    float *o = part + ((int64_t)g * M + i) * 3;
+    o[0] = dx[0], o[1] = dx[1], o[2] = dx[2];
+}
+
+__global__ __launch_bounds__(256) void xyz_grad_sum_kernel(const float *__restrict__ part, int64_t n, int groups, float *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float a = 0.0f;
+    for (int g = 0; g < groups; ++g) a += part[(int64_t)g * n + t];
+    out[t] = a;
+}
+
 // ------------------------------------------------------------------- binned (atomic-free) backward
 // d loss / d tables without global atomics.  Scattered fp32 global atomics run at ~6 G adds/s on
 // MI355X (they execute at the memory side, one 64-B request per lane), which made the scatter 77 % of
@@ -767,6 +885,74 @@ extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *g
     PAG_CHECK_ARG(launched, "pag_permuto_encode_bwd: unsupported (n_feat=%d, n_levels=%d)", n_feat, n_levels);
     PAG_CHECK_LAUNCH("pag_permuto_encode_bwd");
     return PAG_OK;
+}
+
+template <int KIND>
+static int launch_xyz_grad(const char *name, const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out,
+                           int grad_dtype, int64_t sm, int64_t sc, int layout, int n_levels, int n_feat, const HashParams &hp,
+                           const PermutoParams &pp, float *d_xyz, void *workspace, int64_t workspace_bytes, hipStream_t st) {
+    PAG_CHECK_ARG(table_dtype == PAG_F32 || table_dtype == PAG_F16, "%s: table dtype must be F32 or F16", name);
+    PAG_CHECK_ARG(grad_dtype == PAG_F32 || grad_dtype == PAG_BF16, "%s: grad dtype must be F32 or BF16", name);
+    const int grouped = layout == PAG_LAYOUT_XCD8;
+    PAG_CHECK_ARG(!grouped || (grad_dtype == PAG_BF16 && ((n_levels + 7) / 8) * n_feat <= 8),
+                  "%s: XCD8 layout needs bf16 gradients and ceil(L/8)*F <= 8", name);
+    if (M == 0) return PAG_OK;
+    PAG_CHECK_ARG(tables && grad_out && d_xyz && workspace, "%s: NULL tables/grad_out/d_xyz/workspace", name);
+    const int groups = n_levels < 8 ? n_levels : 8;
+    PAG_CHECK_ARG(workspace_bytes >= (int64_t)8 * M * 3 * (int64_t)sizeof(float), "%s: workspace smaller than 8*M*3 floats", name);
+    float *part = (float *)workspace;
+    const int lpx = (n_levels + 7) / 8;
+    dim3 grid(encode_grid(M)), block(256);
+    bool launched = false;
+    if (table_dtype == PAG_F32 && grad_dtype == PAG_F32) {
+        PAG_DISPATCH_ALL((xyz_grad_kernel<KIND, float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, (const float *)grad_out, sm, sc, grouped, hp, pp, part)))
+    } else if (table_dtype == PAG_F32 && grad_dtype == PAG_BF16) {
+        PAG_DISPATCH_ALL((xyz_grad_kernel<KIND, float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, (const bf16_t *)grad_out, sm, sc, grouped, hp, pp, part)))
+    } else if (table_dtype == PAG_F16 && grad_dtype == PAG_F32) {
+        PAG_DISPATCH_ALL((xyz_grad_kernel<KIND, __half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, (const float *)grad_out, sm, sc, grouped, hp, pp, part)))
+    } else {
+        PAG_DISPATCH_ALL((xyz_grad_kernel<KIND, __half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, (const bf16_t *)grad_out, sm, sc, grouped, hp, pp, part)))
+    }
+    PAG_CHECK_ARG(launched, "%s: unsupported (n_feat=%d, n_levels=%d)", name, n_feat, n_levels);
+    const int64_t n = M * 3;
+    xyz_grad_sum_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(part, n, groups, d_xyz);
+    PAG_CHECK_LAUNCH(name);
+    return PAG_OK;
+}
+
+extern "C" int pag_hash_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out,
+                                       int grad_dtype, int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
+                                       int log2_T, const float *resolutions_host, const float *feat_scale_host, float *d_xyz,
+                                       void *workspace, int64_t workspace_bytes, void *stream) {
+    int rc = check_common("pag_hash_encode_bwd_xyz", xyz, M, n_levels, n_feat);
+    if (rc) return rc;
+    PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_bwd_xyz: log2_T %d not in [1,30]", log2_T);
+    PAG_CHECK_ARG(resolutions_host, "pag_hash_encode_bwd_xyz: resolutions_host is NULL");
+    HashParams p;
+    p.L = n_levels;
+    p.log2T = log2_T;
+    p.has_scale = feat_scale_host != nullptr;
+    for (int l = 0; l < n_levels; ++l) p.res[l] = resolutions_host[l];
+    for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
+    PermutoParams unused{};
+    return launch_xyz_grad<0>("pag_hash_encode_bwd_xyz", xyz, M, tables, table_dtype, grad_out, grad_dtype, g_stride_m, g_stride_c, layout,
+                              n_levels, n_feat, p, unused, d_xyz, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out,
+                                          int grad_dtype, int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels,
+                                          int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
+                                          const float *feat_scale_host, float *d_xyz, void *workspace, int64_t workspace_bytes,
+                                          void *stream) {
+    int rc = check_common("pag_permuto_encode_bwd_xyz", xyz, M, n_levels, n_feat);
+    if (rc) return rc;
+    PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_bwd_xyz: capacity is 0");
+    PAG_CHECK_ARG(scale_factor_host && shift_host, "pag_permuto_encode_bwd_xyz: NULL scale_factor/shift");
+    PermutoParams p;
+    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host);
+    HashParams unused{};
+    return launch_xyz_grad<1>("pag_permuto_encode_bwd_xyz", xyz, M, tables, table_dtype, grad_out, grad_dtype, g_stride_m, g_stride_c,
+                              layout, n_levels, n_feat, unused, p, d_xyz, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int n_vertices, int64_t rows_per_level) {

@@ -44,7 +44,9 @@ template <int F> __device__ __forceinline__ void gather(const __half *row, float
 
 // ------------------------------------------------------------------------------------ hash grid
 // grids/hash_grid_torch.py:26-46 (cell lookup) and :69-77 (weights), one level.
-__device__ __forceinline__ void hash_cell(const float (&x)[3], float res, int log2T, uint32_t (&idx)[8], float (&w)[3]) {
+// dwdx[a] = d w[a] / d x[a] = 1 / (vmax - vmin)  (the clamp of :34-36 is local to the cell lookup, :100,105)
+__device__ __forceinline__ void hash_cell(const float (&x)[3], float res, int log2T, uint32_t (&idx)[8], float (&w)[3],
+                                          float (&dwdx)[3]) {
     const float cell = __fdiv_rn(2.0f, res);
     uint32_t c[3];
 #pragma unroll
@@ -55,6 +57,7 @@ __device__ __forceinline__ void hash_cell(const float (&x)[3], float res, int lo
         float vmin = __fadd_rn(__fmul_rn((float)bl, cell), -1.0f);
         float vmax = __fadd_rn(vmin, cell);
         w[a] = __fdiv_rn(__fsub_rn(x[a], vmin), __fsub_rn(vmax, vmin));
+        dwdx[a] = __fdiv_rn(1.0f, __fsub_rn(vmax, vmin));
         c[a] = (uint32_t)bl;
     }
     const uint32_t mask = (1u << log2T) - 1u;
@@ -65,14 +68,22 @@ __device__ __forceinline__ void hash_cell(const float (&x)[3], float res, int lo
     }
 }
 
+__device__ __forceinline__ void hash_cell(const float (&x)[3], float res, int log2T, uint32_t (&idx)[8], float (&w)[3]) {
+    float unused[3];
+    hash_cell(x, res, log2T, idx, w, unused);
+}
+
 __device__ __forceinline__ float lerp_ref(float a, float b, float w, float omw) {
     return __fadd_rn(__fmul_rn(a, omw), __fmul_rn(b, w));
 }
 
 // --------------------------------------------------------------------------- permutohedral lattice
 // oracle/permuto_encode.py lattice_simplex() + vertex_indices(), one level, d = 3.
+// slot[a] = 3 - rank[a]: coordinate a of the elevated point adds +delta_a to bary[slot] and -delta_a to bary[slot+1]
+// (bary[4] folds into bary[0]) - what d bary / d x needs.
 __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float (&sh)[3], const float (&sf)[3],
-                                                uint32_t capacity, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4]) {
+                                                uint32_t capacity, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4],
+                                                int (&slot_out)[4]) {
     float cf[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) cf[a] = __fmul_rn(__fadd_rn(x[a], sh[a]), sf[a]);
@@ -123,6 +134,7 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
     for (int a = 0; a < 4; ++a) {
         float delta = __fsub_rn(E[a], (float)rem0[a]) * 0.25f;
         int slot = 3 - rank[a];
+        slot_out[a] = slot;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {   // predicated: no runtime-indexed private array
             b5[k] = (k == slot) ? __fadd_rn(b5[k], delta) : b5[k];
@@ -143,5 +155,10 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
     }
 }
 
+__device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float (&sh)[3], const float (&sf)[3],
+                                                uint32_t capacity, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4]) {
+    int unused[4];
+    permuto_simplex(x, sh, sf, capacity, pow2mask, idx, bary, unused);
+}
 
 }  // namespace pag_enc

@@ -119,6 +119,23 @@ def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
               spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
 
 
+def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale):
+    """d loss / d xyz f32 [M,3] (pose optimisation: ba_pipeline.py:85-92)."""
+    M = xyz.shape[0]
+    fs = L.host_floats(feat_scale)
+    sm, sc, lay = _layout_args(grad_out)
+    d_xyz = torch.empty(M, 3, device=xyz.device)
+    ws = torch.empty(8 * M * 3, device=xyz.device)
+    if spec.kind == "hash":
+        _call("pag_hash_encode_bwd_xyz", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), grad_out.data_ptr(), L.dtype_code(grad_out),
+              sm, sc, lay, spec.L, spec.F, spec.log2_T, spec.res, fs, L.ptr(d_xyz), L.ptr(ws), ws.numel() * 4, L.stream())
+    else:
+        _call("pag_permuto_encode_bwd_xyz", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), grad_out.data_ptr(),
+              L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F, spec.capacity, spec.sf, spec.shift, fs, L.ptr(d_xyz), L.ptr(ws),
+              ws.numel() * 4, L.stream())
+    return d_xyz
+
+
 class _Encode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, tables, spec, feat_scale, out_dtype, feature_major):
@@ -133,29 +150,39 @@ class _Encode(torch.autograd.Function):
             out = torch.empty(C, M, device=xyz.device, dtype=out_dtype).t()
         else:
             out = torch.empty(M, C, device=xyz.device, dtype=out_dtype)
+        tc = tables.detach().contiguous()
         if M:
-            _encode_fwd(spec, xyz, tables.detach().contiguous(), feat_scale, out)
+            _encode_fwd(spec, xyz, tc, feat_scale, out)
         ctx.spec, ctx.feat_scale = spec, feat_scale
-        ctx.save_for_backward(xyz)
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(xyz, tc)           # d/d xyz needs the table rows again
+        else:
+            ctx.save_for_backward(xyz)
         ctx.tshape, ctx.tdtype = tables.shape, tables.dtype
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (xyz,) = ctx.saved_tensors
-        gt = torch.zeros(ctx.tshape, device=xyz.device, dtype=torch.float32)
-        if xyz.shape[0]:
-            if g.dtype not in (torch.float32, torch.bfloat16):
-                g = g.float()
-            if g.dim() == 3:
-                g = g.contiguous()
-            _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt)
-        return None, gt.to(ctx.tdtype), None, None, None, None
+        xyz = ctx.saved_tensors[0]
+        need_t, need_x = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
+        gt = d_xyz = None
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        if g.dim() == 3:
+            g = g.contiguous()
+        if need_t:
+            gt = torch.zeros(ctx.tshape, device=xyz.device, dtype=torch.float32)
+            if xyz.shape[0]:
+                _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt)
+            gt = gt.to(ctx.tdtype)
+        if need_x:
+            d_xyz = _encode_bwd_xyz(ctx.spec, xyz, ctx.saved_tensors[1], g, ctx.feat_scale) if xyz.shape[0] else torch.zeros_like(xyz)
+        return d_xyz, gt, None, None, None, None
 
 
 def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None):
     """Grid features [M, L*F] (column = level*F + f); layout="xcd8" returns the bf16 [8, M, 8] XCD-grouped tensor the
-    fused decoders consume directly.  d/d tables is supported, d/d xyz is not."""
+    fused decoders consume directly.  Differentiable w.r.t. tables and (when xyz.requires_grad) xyz."""
     return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major)
 
 

@@ -437,13 +437,39 @@ def g6(reg):
                         sparsity=reg.sigma_sparsity_loss(torch.from_numpy(s)).numpy())
 
 
+def g7(hgt):
+    """Autograd through the reference's HashGridTorch: d loss / d coords (what pose optimisation back-propagates,
+    pc_nerf/ba_pipeline.py:85-92) and d loss / d tables, for a seeded upstream gradient."""
+    rs = np.random.RandomState(17)
+    log2T, L = 12, 8
+    grid = hgt.HashGridTorch(2, codebook_bitwidth=log2T)
+    with torch.no_grad():
+        grid.init_from_resolutions([16] * (L - 1) + [512])
+        tab = table_from_seed(100 + log2T, (L, 2 ** log2T, 2), "normal")
+        for i in range(L):
+            grid.embedder.embeddings[i].weight.copy_(torch.from_numpy(tab[i]))
+    x = torch.from_numpy(sample_points(rs, 500)).requires_grad_(True)
+    go = torch.from_numpy(rs.standard_normal(size=(x.shape[0], L * 2)).astype(np.float32))
+    feats = grid.interpolate(x[None], L - 1)
+    feats.backward(go)
+    dtab = np.stack([grid.embedder.embeddings[i].weight.grad.numpy() for i in range(L)])
+    res = [float(torch.floor(grid.embedder.base_resolution * grid.embedder.b ** i)) for i in range(L)]
+    np.savez_compressed(os.path.join(HERE, "g7_hash_grad.npz"), x=x.detach().numpy(), go=go.numpy(), dx=x.grad.numpy(),
+                        dtables=dtab, feats=feats.detach().numpy(), res=np.array(res, np.float32), log2T=log2T, seed=100 + log2T,
+                        kind="normal")
+
+
 def main():
     install_stubs()
     torch.set_num_threads(1)
     import importlib
     with _CudaToCpu():
         hgt = importlib.import_module("grids.hash_grid_torch")
+    if "--only-g7" in sys.argv:
+        g7(hgt)
+        return
     g1_g2(hgt)
+    g7(hgt)
     with _CudaToCpu():
         delta_mod = importlib.import_module("pc_nerf.panoptic_delta_nef")
     g3(delta_mod)

@@ -650,3 +650,53 @@ def test_properties_at_full_size(gpu_device):
         t1, t2 = g.tables.detach(), torch.randn_like(g.tables)
         e = lambda t: ops.encode(x, t, g._spec)
         np.testing.assert_allclose(e(2 * t1 + t2).cpu().numpy(), (2 * e(t1) + e(t2)).cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_encode_position_gradients(gpu_device):
+    """d loss / d xyz of both encoders (pose optimisation, ba_pipeline.py:85-92): hash vs autograd through the reference
+    (golden g7), permuto vs the oracle's closed form; fp32 [M,C] gradients and the bf16 XCD-grouped layout."""
+    from pagnerf_amd import ops
+    from oracle import permuto_encode as op
+    dev = gpu_device
+    g = golden("g7_hash_grad.npz")
+    res, log2T = [float(r) for r in g["res"]], int(g["log2T"])
+    tab = torch.from_numpy(table_from_seed(int(g["seed"]), (len(res), 2 ** log2T, 2), str(g["kind"]))).to(dev).requires_grad_(True)
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    spec = ops.hash_spec(res, log2T, 2)
+    out = ops.encode(x, tab, spec)
+    assert np.array_equal(out.detach().cpu().numpy(), g["feats"])
+    out.backward(torch.from_numpy(g["go"]).to(dev))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx"], rtol=1e-4, atol=2e-3)        # |dx| ~ 1e2..1e3 at res 512
+    np.testing.assert_allclose(tab.grad.cpu().numpy(), g["dtables"], rtol=1e-4, atol=1e-4)
+
+    rs = np.random.RandomState(12)
+    for M, Lv, cap in ((3000, 24, 4099), (777, 5, 256)):
+        F = 2
+        sf = op.scale_factors(np.geomspace(1.0, 1e-2, Lv))
+        shifts = (rs.standard_normal(size=(Lv, 3)) * 10).astype(np.float32)
+        xs = rs.uniform(-1, 1, size=(M, 3)).astype(np.float32)
+        tb = rs.standard_normal(size=(Lv, cap, F)).astype(np.float32)
+        go = rs.standard_normal(size=(M, Lv * F)).astype(np.float32)
+        scale = rs.uniform(0.5, 1.5, size=Lv * F).astype(np.float32)
+        ref = op.permuto_encode_bwd_xyz(xs, tb, go * scale[None], shifts, sf)
+        spec = ops.permuto_spec(sf, shifts, cap, F)
+        x = torch.from_numpy(xs).to(dev).requires_grad_(True)
+        t = torch.from_numpy(tb).to(dev)
+        ops.encode(x, t, spec, torch.from_numpy(scale)).backward(torch.from_numpy(go).to(dev))
+        assert _rel_l2(x.grad.cpu(), torch.from_numpy(ref)) < 1e-5, (M, Lv)
+        if ops.xcd8_supported(Lv, F):
+            x2 = torch.from_numpy(xs).to(dev).requires_grad_(True)
+            o = ops.encode(x2, t, spec, torch.from_numpy(scale), layout="xcd8")
+            cols = ops.xcd8_columns(Lv, F)
+            gg = torch.zeros(64, M)
+            for p, c in enumerate(cols):
+                if c >= 0:
+                    gg[p] = torch.from_numpy(go[:, c])
+            gg = gg.reshape(8, 8, M).permute(0, 2, 1).contiguous().bfloat16()
+            o.backward(gg.to(dev))
+            gob = np.zeros_like(go)
+            for p, c in enumerate(cols):
+                if c >= 0:
+                    gob[:, c] = gg[p // 8, :, p % 8].float().numpy()
+            ref2 = op.permuto_encode_bwd_xyz(xs, tb, gob * scale[None], shifts, sf)
+            assert _rel_l2(x2.grad.cpu(), torch.from_numpy(ref2)) < 1e-5, (M, Lv)

@@ -123,3 +123,45 @@ def test_g6_sigma_sparsity():
     g = golden("g6_reg.npz")
     s = torch.from_numpy(g["sigma"])
     np.testing.assert_allclose(torch.log(1.0 + 2 * s ** 2).numpy(), g["sparsity"], rtol=1e-6)
+
+
+def test_g7_hash_input_and_table_gradients():
+    """oracle d/d xyz and d/d tables of the hash encoder vs autograd through the reference's HashGridTorch."""
+    import torch
+    from oracle import hash_encode as oh
+    g = golden("g7_hash_grad.npz")
+    res, log2T = [float(r) for r in g["res"]], int(g["log2T"])
+    tab = torch.from_numpy(table_from_seed(int(g["seed"]), (len(res), 2 ** log2T, 2), str(g["kind"])))
+    x, go = torch.from_numpy(g["x"]), torch.from_numpy(g["go"])
+    feats, _ = oh.hash_encode(x, tab, res, log2T)
+    assert np.array_equal(feats.numpy(), g["feats"])
+    dx = oh.hash_encode_bwd_xyz(x, tab, go, res, log2T)
+    np.testing.assert_allclose(dx.numpy(), g["dx"], rtol=1e-5, atol=1e-4)
+    dt = oh.hash_encode_bwd(x, go, 2 ** log2T, res, log2T)
+    np.testing.assert_allclose(dt.numpy(), g["dtables"], rtol=1e-5, atol=1e-5)
+
+
+def test_permuto_position_gradient_matches_finite_differences():
+    """closed-form d/d xyz of the permutohedral oracle vs central differences of its float64 restatement."""
+    from oracle import permuto_encode as op
+    rs = np.random.RandomState(4)
+    Lv, F, cap, M = 6, 2, 512, 400
+    sf = op.scale_factors(np.geomspace(1.0, 0.05, Lv))
+    shifts = (rs.standard_normal(size=(Lv, 3)) * 10).astype(np.float32)
+    tab = rs.standard_normal(size=(Lv, cap, F)).astype(np.float32)
+    x = rs.uniform(-1, 1, size=(M, 3)).astype(np.float32)
+    go = rs.standard_normal(size=(M, Lv * F)).astype(np.float32)
+    f32, _, _ = op.permuto_encode(x, tab, shifts, sf)
+    np.testing.assert_allclose(op.permuto_encode_f64(x, tab, shifts, sf), f32, rtol=0, atol=2e-4)
+    dx = op.permuto_encode_bwd_xyz(x, tab, go, shifts, sf)
+    h = 1e-6
+    fd = np.zeros((M, 3))
+    for a in range(3):
+        e = np.zeros(3)
+        e[a] = h
+        fp = op.permuto_encode_f64(x.astype(np.float64) + e, tab, shifts, sf)
+        fm = op.permuto_encode_f64(x.astype(np.float64) - e, tab, shifts, sf)
+        fd[:, a] = ((fp - fm) * go).sum(1) / (2 * h)
+    # points within h of a simplex face see two different affine pieces: drop the few outliers, demand the rest match
+    err = np.abs(fd - dx).max(1) / (1.0 + np.abs(fd).max(1))
+    assert np.mean(err < 1e-3) > 0.99, np.sort(err)[-10:]
