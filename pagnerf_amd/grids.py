@@ -19,6 +19,24 @@ import torch.nn as nn
 from . import ops
 
 
+class _VoxelSamples(torch.autograd.Function):
+    """Voxel-mode counterpart of ops.ray_samples: samples [M',k,3] of nugget i belong to ray ridx[i]."""
+
+    @staticmethod
+    def forward(ctx, origins, dirs, samples, depths, ridx):
+        ctx.save_for_backward(depths, ridx)
+        ctx.N = origins.shape[0]
+        return samples.view_as(samples)
+
+    @staticmethod
+    def backward(ctx, g):
+        depths, ridx = ctx.saved_tensors
+        g = g.float()
+        per = torch.cat([g.sum(1), (g * depths[..., None]).sum(1)], dim=1)             # [M',6] per nugget
+        seg = torch.zeros(ctx.N, 6, device=g.device).index_add_(0, ridx.long(), per)
+        return seg[:, :3], seg[:, 3:], None, None, None
+
+
 class OccupancyBLAS(nn.Module):
     """Dense occupancy bitfield standing in for wisp's OctreeAS (grids/occtree.py:54-67 is the
     in-tree description of that contract).  Bit (x*R + y)*R + z of `blas_bits`."""
@@ -79,6 +97,8 @@ class OccupancyBLAS(nn.Module):
             ridx, pidx, samples, depths, deltas, boundary = ops.raymarch_voxel(
                 rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, bits, self.blas_level)
             self._pack_cache = None
+            if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
+                samples = _VoxelSamples.apply(rays.origins, rays.dirs, samples, depths, ridx)   # pose gradient
             return ridx.long(), pidx, samples, depths[..., None], deltas[:, None], boundary
         if raymarch_type != "ray":
             raise NotImplementedError("raymarch_type '%s'" % raymarch_type)
@@ -86,6 +106,8 @@ class OccupancyBLAS(nn.Module):
             rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, jitter, bits, self.blas_level)
         ridx64 = ridx.long()
         self._pack_cache = (ridx64, ridx, pack_start, ray_of_pack)
+        if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
+            samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack)   # pose gradient
         return ridx64, pidx, samples[:, None], depths[:, None], deltas[:, None], boundary
 
 

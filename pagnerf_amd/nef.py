@@ -45,10 +45,10 @@ class BasicDecoder(nn.Module):
         return [l.weight for l in lins], [l.bias for l in lins]
 
     def forward(self, x1, x2=None, x2_index=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16, out_dtype=torch.float32,
-                x1_grouped=None):
+                x1_grouped=None, x2_packs=None):
         W, b = self.weights()
         return ops.fused_mlp(x1, W, b, x2=x2, x2_index=x2_index, in_dim=self.input_dim, out_act=out_act, mode=mode,
-                             out_dtype=out_dtype, x1_grouped=x1_grouped)
+                             out_dtype=out_dtype, x1_grouped=x1_grouped, x2_packs=x2_packs)
 
 
 def positional_embed(x, num_freq):
@@ -177,7 +177,8 @@ class PanopticDeltaNeF(nn.Module):
         lw = None if bool((self.lod_weights == 1).all()) else self.lod_weights
         return grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None)
 
-    def rgb_semantics(self, coords, ray_d=None, compute_channels=None, pidx=None, lod_idx=None, ridx=None, ray_dirs=None):
+    def rgb_semantics(self, coords, ray_d=None, compute_channels=None, pidx=None, lod_idx=None, ridx=None, ray_dirs=None,
+                      ray_packs=None):
         out = {}
         if not compute_channels:
             return out
@@ -198,7 +199,8 @@ class PanopticDeltaNeF(nn.Module):
             if num_samples != 1 and ridx is None:                                  # one direction per pack entry -> per sample
                 ray_d = ray_d[:, None].repeat(1, num_samples, 1).reshape(-1, 3)
             pe, index = self._view_embedding(ray_d, ridx, ray_dirs)
-            rgb = self.decoder_color(density_feats, x2=pe, x2_index=index, out_act=L.ACT_SIGMOID, mode=mode)
+            rgb = self.decoder_color(density_feats, x2=pe, x2_index=index, out_act=L.ACT_SIGMOID, mode=mode,
+                                     x2_packs=ray_packs if ridx is not None else None)
             out["rgb"] = rgb.reshape(batch, num_samples, 3)
         if "semantics" in compute_channels or "inst_embedding" in compute_channels:    # :210-236
             t = self.panoptic_features_type

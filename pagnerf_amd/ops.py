@@ -229,7 +229,7 @@ class _FusedMLP(torch.autograd.Function):
             x1 = x1.float()
         out_dim = Ws[-1].shape[0]
         out = torch.empty(M, out_dim, device=x1.device, dtype=out_dtype)
-        need_grad = any(t.requires_grad for t in wb) or ctx.needs_input_grad[0]
+        need_grad = any(t.requires_grad for t in wb) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         hdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
         hidden = [torch.empty(M, 64, device=x1.device, dtype=hdt) for _ in range(n_layers - 1)] if need_grad else []
         a = L.MlpFwdArgs()
@@ -253,6 +253,7 @@ class _FusedMLP(torch.autograd.Function):
         if M:
             _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
         ctx.cfg = (in_dim, out_act, mode, n_layers, k1, grouped)
+        ctx.x2_packs = None
         ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc)
         ctx.n_hidden = len(hidden)
         return out
@@ -340,17 +341,35 @@ class _FusedMLP(torch.autograd.Function):
                     w = _mm_f32(z.t(), hidden[l - 1])
                 gW.append(w)
                 gb.append(z.sum(0, dtype=torch.float32))
-        return (dx1, None, None, None, None, None, None, None, *gW, *gb)
+        dx2 = None
+        if ctx.needs_input_grad[1] and x2 is not None:
+            # d x2[r] = (sum of dz_0 over the samples that gathered row r) @ W_0[:, k1:]  - the per-ray view embedding's
+            # gradient (pose optimisation: the view direction depends on the camera rotation, ba_pipeline.py:89-90)
+            R = x2.shape[0]
+            if M == 0:
+                seg = torch.zeros(R, dz[0].shape[1], device=dev)
+            elif ctx.x2_packs is not None:                 # rows gathered pack by pack: one segmented-sum launch
+                pack_start, ray_of_pack = ctx.x2_packs
+                seg = composite_feats(dz[0], torch.ones(M, device=dev), torch.ones(R, device=dev), pack_start, ray_of_pack, R)
+            else:
+                seg = torch.zeros(R, dz[0].shape[1], device=dev).index_add_(0, x2_index.long(), dz[0].float())
+            w_tail = Wc[0][:, k1:in_dim]
+            dx2 = torch.zeros_like(x2)
+            dx2[:, :in_dim - k1] = seg @ w_tail
+        return (dx1, dx2, None, None, None, None, None, None, *gW, *gb)
 
 
 def fused_mlp(x1, weights, biases, x2=None, x2_index=None, in_dim=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16,
-              out_dtype=torch.float32, x1_grouped=None):
+              out_dtype=torch.float32, x1_grouped=None, x2_packs=None):
     """wisp BasicDecoder (Linear+ReLU ... Linear) [+ sigmoid/softmax] in one launch.
     x1 [M,k1] (+ optional per-ray x2 [R,k2p] gathered by x2_index [M]); weights[i] is [out,in].
     x1_grouped=(levels, feats): x1 is the encoders' bf16 [8, M, 8] XCD-grouped tensor."""
     if in_dim is None:
         in_dim = weights[0].shape[1]
-    return _FusedMLP.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, x1_grouped, *weights, *biases)
+    out = _FusedMLP.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, x1_grouped, *weights, *biases)
+    if x2_packs is not None and x2 is not None and x2.requires_grad and out.grad_fn is not None:
+        out.grad_fn.x2_packs = x2_packs      # (pack_start, ray_of_pack): x2_index is constant inside each pack (d/d x2 only)
+    return out
 
 
 # ------------------------------------------------------------------------------------------ ray march
@@ -391,6 +410,34 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     ray_of_pack = torch.arange(N, device=dev, dtype=torch.int32)
     pack_start = torch.cat([offsets, csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)
     return ridx, pidx, samples, depths, deltas, boundary.bool(), pack_start.contiguous(), ray_of_pack
+
+
+class _RaySamples(torch.autograd.Function):
+    """samples = origins[ray] + dirs[ray] * depth with the march kernel's values as the forward result (bit-identical to
+    the non-differentiable path) and d/d origins, d/d dirs as per-ray segmented sums - what autograd gives through
+    wisp's `torch.addcmul(origins[ridx], dirs[ridx], depth)` when the rays come from learnable extrinsics
+    (ba_pipeline.py:85-92)."""
+
+    @staticmethod
+    def forward(ctx, origins, dirs, samples, depths, pack_start, ray_of_pack):
+        ctx.save_for_backward(depths, pack_start, ray_of_pack)
+        ctx.N = origins.shape[0]
+        return samples.view_as(samples)
+
+    @staticmethod
+    def backward(ctx, g):
+        depths, pack_start, ray_of_pack = ctx.saved_tensors
+        N = ctx.N
+        g = g.reshape(-1, 3).float()
+        M = g.shape[0]
+        both = torch.cat([g, g * depths.reshape(-1, 1)], dim=1).contiguous()           # [M,6]: d/d origin | d/d dir
+        seg = composite_feats(both, torch.ones(M, device=g.device), torch.ones(N, device=g.device), pack_start, ray_of_pack, N)
+        return seg[:, :3], seg[:, 3:], None, None, None, None
+
+
+def ray_samples(origins, dirs, samples, depths, pack_start, ray_of_pack):
+    """Attach the pose gradient to march-kernel samples (samples [M,3] or [M',k,3], depths alike, one pack per ray)."""
+    return _RaySamples.apply(origins, dirs, samples, depths, pack_start, ray_of_pack)
 
 
 _TVALS = {}

@@ -102,7 +102,8 @@ class PanopticPackedRFTracer(nn.Module):
         if fuse_pan:
             sample_channels -= self.panoptic_channels
         if getattr(nef, "accepts_ray_index", False):      # per-ray view embedding gathered through ridx (no [M,3] dirs)
-            feats = nef(coords=samples, ridx=ridx32, ray_dirs=rays.dirs, pidx=pidx, lod_idx=lod_idx, channels=sample_channels)
+            feats = nef(coords=samples, ridx=ridx32, ray_dirs=rays.dirs, pidx=pidx, lod_idx=lod_idx, channels=sample_channels,
+                        ray_packs=(pack_start, ray_of_pack))
         else:                                              # :117,:124
             feats = nef(coords=samples, ray_d=rays.dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx,
                         channels=sample_channels)

@@ -700,3 +700,122 @@ def test_encode_position_gradients(gpu_device):
                     gob[:, c] = gg[p // 8, :, p % 8].float().numpy()
             ref2 = op.permuto_encode_bwd_xyz(xs, tb, gob * scale[None], shifts, sf)
             assert _rel_l2(x2.grad.cpu(), torch.from_numpy(ref2)) < 1e-5, (M, Lv)
+
+
+def _look_at_views(C, gen):
+    """C world->camera matrices around the origin (rotation rows orthonormal)."""
+    views = []
+    for _ in range(C):
+        q = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0]
+        if torch.det(q) < 0:
+            q[2] = -q[2]
+        V = torch.eye(4)
+        V[:3, :3] = q
+        V[:3, 3] = (torch.rand(3, generator=gen) - 0.5) * 0.4
+        views.append(V)
+    return torch.stack(views)
+
+
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_pose_gradients_vs_oracle(gpu_device, mode):
+    """BAPipeline (ba_pipeline.py:64-92): d loss / d camera_extrinsics through ray transform -> packed samples -> encoder
+    position gradient + view embedding -> decoders -> compositing, vs torch autograd over the CPU oracle chain."""
+    import pagnerf_amd
+    from oracle import permuto_encode as op, decoders as od, render as orr
+    dev = gpu_device
+    N, S = 128, 32
+    nef, tracer, _, occ, jitter = _make_scene(dev, "fp32", L_perm=8, cap_log2=12, N=N, S=S, level=4)
+    for grid in (nef.grid, nef.delta_grid):                      # moderate finest scale: smooth enough for a stable comparison
+        grid.finest_scale = 0.05
+        grid.init_from_scales(random_shift=grid.random_shift_per_level, tables=grid.tables.detach() * 1.0)
+    nef = nef.to(dev)
+    gen = torch.Generator().manual_seed(5)
+    views = _look_at_views(2, gen)
+    pipe = pagnerf_amd.BAPipeline(nef, views, tracer, anchor_frame_idxs=[]).to(dev)
+    base_o = torch.zeros(N, 3)
+    base_d = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1)
+    base = pagnerf_amd.Rays(base_o.to(dev), base_d.to(dev), 0.0, 2.0)
+    G = torch.randn(N, 3, generator=gen)
+    Gd = torch.randn(N, 1, generator=gen)
+    chans = {"rgb", "depth"}
+    if mode == "ray":
+        rb = pipe(rays=base, cam_ids=[0, 1], channels=chans, jitter=jitter[:N, :S].to(dev), stage="train",
+                  raymarch_type="ray", num_steps=S)
+    else:
+        tracer.ray_max_travel = 10.0
+        rb = pipe(rays=base, cam_ids=[0, 1], channels=chans, stage="train", raymarch_type="voxel", num_steps=3)
+    loss = (rb.rgb * G.to(dev)).sum() + (rb.depth * Gd.to(dev)).sum()
+    loss.backward()
+    got = pipe.camera_extrinsics.grad.cpu()
+
+    # ---- oracle chain on the CPU
+    prm = pipe.camera_extrinsics.detach().cpu().clone().requires_grad_(True)
+    from pagnerf_amd.ba_pipeline import rotation_6d_to_matrix
+    R = rotation_6d_to_matrix(prm[:, :6])
+    o = torch.matmul(base_o.reshape(2, -1, 3) - prm[:, None, 6:], R).reshape(-1, 3)
+    d = torch.matmul(base_d.reshape(2, -1, 3), R)
+    d = (d / torch.linalg.norm(d, dim=-1, keepdim=True)).reshape(-1, 3)
+    if mode == "ray":
+        ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_ray(o, d, 0.0, 2.0, S, jitter[:N, :S], occ, 4)
+        rk = ridx
+    else:
+        with torch.no_grad():
+            ridx, pidx, s0, depths, deltas, boundary = orr.raymarch_voxel(o.detach(), d.detach(), 0.0, 2.0, 3, occ, 4)
+        samples = torch.addcmul(o[ridx][:, None], d[ridx][:, None], depths)           # wisp: o + d * depth, depth constant
+        assert torch.allclose(samples.detach(), s0, atol=1e-6)
+        rk = ridx.repeat_interleave(3)
+    sf = {id(g): g.scale_factors(g.resolutions).numpy() for g in (nef.grid, nef.delta_grid)}
+
+    class Enc(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, xyz, grid):
+            ctx.grid, ctx.xyz = grid, xyz.detach().numpy()
+            f, _, _ = op.permuto_encode(ctx.xyz, grid.tables.detach().cpu().numpy(), grid.random_shift_per_level.cpu().numpy(), sf[id(grid)])
+            return torch.from_numpy(f)
+
+        @staticmethod
+        def backward(ctx, g):
+            grid = ctx.grid
+            return torch.from_numpy(op.permuto_encode_bwd_xyz(ctx.xyz, grid.tables.detach().cpu().numpy(), g.numpy(),
+                                                              grid.random_shift_per_level.cpu().numpy(), sf[id(grid)])), None
+    xyz = samples.reshape(-1, 3)
+    params = {}
+    for short in ("density", "color", "semantics", "inst"):
+        W, b = getattr(nef, "decoder_" + short).weights()
+        params[short] = ([w.detach().cpu() for w in W], [v.detach().cpu() for v in b])
+    out = od.nef_forward(Enc.apply(xyz, nef.grid), Enc.apply(xyz.detach(), nef.delta_grid), d[rk], params, {"rgb"},
+                         lod_weights=nef.lod_weights)
+    comp = orr.composite(N, rk, boundary, out["density"], deltas.reshape(-1, 1), depths=depths.reshape(-1, 1), rgb=out["rgb"],
+                         bg_color="white")
+    np.testing.assert_allclose(rb.rgb.detach().cpu().numpy(), comp["rgb"].detach().numpy(), rtol=2e-4, atol=2e-5)
+    ref_loss = (comp["rgb"] * G).sum() + (comp["depth"] * Gd).sum()
+    ref_loss.backward()
+    assert float(prm.grad.abs().max()) > 1e-3
+    assert _rel_l2(got, prm.grad) < 2e-3, (got, prm.grad)
+
+
+def test_pose_gradients_bf16_path_tracks_fp32(gpu_device):
+    """Production bf16 path (XCD-grouped features, MFMA decoders, rank-1 head gradients) delivers the same pose gradient as
+    the fp32 parity path up to bf16 rounding."""
+    import pagnerf_amd
+    dev = gpu_device
+    N, S = 256, 32
+    grads = {}
+    for precision in ("fp32", "bf16"):
+        nef, tracer, _, occ, jitter = _make_scene(dev, precision, L_perm=24, cap_log2=12, N=N, S=S, level=4)
+        for grid in (nef.grid, nef.delta_grid):
+            grid.finest_scale = 0.05
+            grid.init_from_scales(random_shift=grid.random_shift_per_level, tables=grid.tables.detach() * 1.0)
+        nef = nef.to(dev)
+        gen = torch.Generator().manual_seed(5)
+        pipe = pagnerf_amd.BAPipeline(nef, _look_at_views(4, gen), tracer, anchor_frame_idxs=[0]).to(dev)
+        base = pagnerf_amd.Rays(torch.zeros(N, 3, device=dev),
+                                torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1).to(dev), 0.0, 2.0)
+        G = torch.randn(N, 3, generator=gen).to(dev)
+        rb = pipe(rays=base, cam_ids=[0, 1, 2, 3], channels={"rgb", "semantics", "inst_embedding"}, jitter=jitter[:N, :S].to(dev),
+                  stage="train", raymarch_type="ray", num_steps=S)
+        ((rb.rgb * G).sum() + rb.semantics[:, 0].sum() + rb.inst_embedding[:, 3].sum()).backward()
+        grads[precision] = pipe.camera_extrinsics.grad.cpu()
+        assert float(grads[precision][0].abs().sum()) == 0.0            # anchor frame: masked (ba_pipeline.py:56-60)
+        assert nef.grid.tables.grad is not None and nef.delta_grid.tables.grad is not None
+    assert _rel_l2(grads["bf16"], grads["fp32"]) < 0.1, grads
