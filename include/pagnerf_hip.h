@@ -271,6 +271,21 @@ int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t *ray_of_pac
                             const float *weights, const float *alpha, const float *g_out, int C,
                             void *d_feats, int feat_dtype, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Linear-assignment instance loss, device half (loss/lin_assignment_things.py:23-54,
+ * loss/lin_assignment.py:16-26, utils/outlier_rejection.py:56-71)
+ * ------------------------------------------------------------------------------------------ */
+
+/* sums[k, c] = sum over rays p with labels_gt[p] == label_list[k] (and row_mask[p] != 0 when given)
+ *              of values[p, col0 + c];   counts[k] = number of such rays.
+ *   values [P, row_stride] (PAG_F32 or PAG_BF16), labels_gt i64 [P], row_mask u8 [P] or NULL,
+ *   label_list i64 [K] (device), sums f32 [K, C], counts i32 [K].
+ * fp32 accumulation in ray order (the order of a sequential sum over dim 0); the caller forms
+ * cost = -(sums / (counts + 1e-4)) (:33) and runs the Hungarian solver on the host. */
+int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_stride, int col0, int C,
+                   const int64_t *labels_gt, const uint8_t *row_mask, const int64_t *label_list, int K,
+                   float *sums, int32_t *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ _SIGS = {
     "pag_raymarch_voxel_count": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),
     "pag_raymarch_voxel_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_occupancy_update": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
+    "pag_label_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "pag_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_composite_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_composite_feats_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),

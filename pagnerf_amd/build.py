@@ -24,6 +24,7 @@ SOURCES = {
     "encode.hip": ["-ffp-contract=off"],
     "render.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
+    "assign.hip": ["-ffp-contract=off"],
 }
 
 

@@ -1,0 +1,135 @@
+"""Linear-assignment instance losses on the rendered `inst_embedding` (the consumer directly after the
+hot path), with the cost matrix built on the GPU.
+
+  LinAssignmentThingsLoss  <- loss/lin_assignment_things.py::LinAssignmentThingsLoss
+  LinAssignmentLoss        <- loss/lin_assignment.py::LinAssignmentLoss
+
+The reference builds cost[l, :] = -(sum of the probabilities of the rays labelled l) / (count + 1e-4)
+with one masked sum + one device-to-host copy per label (lin_assignment_things.py:31-33).  Here ONE
+launch (pag_label_sums) produces all per-label sums and counts where the probabilities already are;
+only the [K, I] matrix goes to the host, where SciPy's Hungarian solver runs exactly as in the
+reference (:45), and the relabelling (:47-53) is a table lookup on the device.  The optional ID-range
+cost (utils/outlier_rejection.py:8-51) needs per-id 3-D centres (:56-71): the same kernel on the
+[P,3] points.
+"""
+import numpy as np
+import scipy.optimize
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+def label_sums(values, labels_gt, label_list, col0=0, row_mask=None):
+    """-> (sums f32 [K, C-col0], counts i32 [K]) of `values` [P,C] rows grouped by labels_gt == label_list[k]."""
+    ops._check_gpu(values, labels_gt)
+    dev = values.device
+    if values.dtype not in (torch.float32, torch.bfloat16):
+        values = values.float()
+    values = values.detach()
+    if values.stride(-1) != 1:
+        values = values.contiguous()
+    P, C = values.shape
+    labels_gt = labels_gt.detach().contiguous().long()
+    lab = torch.as_tensor(label_list, dtype=torch.int64, device=dev).contiguous()
+    K = lab.shape[0]
+    sums = torch.zeros(K, C - col0, device=dev)
+    counts = torch.zeros(K, device=dev, dtype=torch.int32)
+    mask = row_mask.detach().contiguous().to(torch.uint8) if row_mask is not None else None
+    if K and P:
+        ops._call("pag_label_sums", values.data_ptr(), L.dtype_code(values), P, values.stride(0), col0, C - col0, L.ptr(labels_gt),
+                  L.ptr(mask), L.ptr(lab), K, L.ptr(sums), L.ptr(counts), L.stream())
+    return sums, counts
+
+
+def cost_matrix(prob, labels_gt, labels, col0=0):
+    """float64 [K, C-col0] numpy cost matrix: -(per-label fp32 sum / (count + 1e-4)), as :31-33 builds it."""
+    sums, counts = label_sums(prob, labels_gt, labels, col0=col0)
+    cost = -(sums / (counts.long() + 1e-4)[:, None])             # int64 + python float -> fp32, as in the reference
+    return cost.cpu().numpy().astype(np.float64)
+
+
+def id_range_cost(cost, centers_x, frame_min_length=0.3, max_num_inst_at_x=30, id_margin=30):
+    """utils/outlier_rejection.py:8-51: ids outside [lo(x), lo(x)+margin] of an instance's x position cost 10000.
+    cost float64 [K,num_ids] (modified in place), centers_x f32 tensor [K]."""
+    num_ids = cost.shape[1]
+    slope = (max_num_inst_at_x + id_margin) / frame_min_length
+    x_limit = (num_ids - id_margin) / slope
+    x = (-centers_x + 1) / 2
+    lo = torch.clamp(slope * (x % x_limit), 0, num_ids - 1).long()
+    hi = torch.clamp(lo + id_margin, 0, num_ids - 1)
+    ids = torch.arange(num_ids, device=centers_x.device)[None, :]
+    allowed = (lo[:, None] <= ids) & (ids <= hi[:, None])
+    cost[~allowed.cpu().numpy()] = 10000
+    return cost
+
+
+def _lookup(labels_gt, labels, targets, default):
+    """per-ray relabelling: labels[i] -> targets[i], every other value -> default (a device table lookup)."""
+    lo, hi = int(min(labels)), int(max(labels))
+    lut = torch.full((hi - lo + 1,), default, dtype=labels_gt.dtype)
+    lut[torch.tensor([l - lo for l in labels], dtype=torch.long)] = torch.as_tensor(targets, dtype=labels_gt.dtype)
+    lut = lut.to(labels_gt.device)
+    inside = (labels_gt >= lo) & (labels_gt <= hi)
+    return torch.where(inside, lut[(labels_gt - lo).clamp(0, hi - lo)], torch.full_like(labels_gt, default))
+
+
+class LinAssignmentThingsLoss(nn.Module):
+    def __init__(self, outlier_rejection=False, min_distance=0.2, max_distance=0.5, *args, **kwargs):
+        super().__init__()
+        self.outlier_rejection = outlier_rejection
+        self.min_distance, self.max_distance = min_distance, max_distance
+
+    @torch.no_grad()
+    def create_virtual_gt_with_linear_assignment(self, inst_probabilities, labels_gt, points_3d=None):
+        """[P,I] probabilities, [P] gt ids (0 = stuff) -> [P] virtual labels (:23-54).  Rows with gt <= 0 get 0."""
+        things = labels_gt > 0
+        n_ids = inst_probabilities.shape[-1] - 1                                            # column 0 is stuff (:27)
+        labels = sorted(torch.unique(labels_gt[things]).cpu().tolist())[:n_ids]            # :29
+        if not labels:
+            return torch.zeros_like(labels_gt)
+        cost = cost_matrix(inst_probabilities, labels_gt, labels, col0=1)                   # :30-33
+        assert (self.outlier_rejection and points_3d is not None) or not self.outlier_rejection, \
+            "Outlier rejection requires 3d points"                                          # :36-37
+        if self.outlier_rejection:                                                           # :38-43
+            s, c = label_sums(points_3d.float(), labels_gt, labels)
+            cost = id_range_cost(cost, s[:, 0] / c.float())
+        rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))              # :45
+        # things rays: assigned column + 1; things whose label got no column keep 0 + 1 (:47-53)
+        new = _lookup(labels_gt, [labels[r] for r in rows], [int(c) + 1 for c in cols], 1)
+        return torch.where(things, new, torch.zeros_like(labels_gt))
+
+    def forward(self, inst_probabilities, labels_gt, stuff_mask, points_3d=None, *args, **kwargs):
+        loss = []
+        for i, (p, gt, m) in enumerate(zip(inst_probabilities, labels_gt, stuff_mask)):
+            valid = torch.logical_or(m, gt > 0)                                             # :60
+            gt_v = torch.where(valid, gt, torch.zeros_like(gt))
+            virt = self.create_virtual_gt_with_linear_assignment(p, gt_v, points_3d[i] if points_3d is not None else None)
+            wrong = ((virt != p.argmax(dim=-1)) & valid).any()                              # :69,:79
+            nll = -torch.log(p.gather(1, virt[:, None])[:, 0] + 1e-27)                      # :80
+            loss.append(torch.where(valid & wrong, nll, torch.zeros_like(nll)))
+        return torch.stack(loss)
+
+
+class LinAssignmentLoss(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    @torch.no_grad()
+    def create_virtual_gt_with_linear_assignment(self, labels_gt, predicted_scores):
+        """:16-26 (softmax of the scores inside, every gt label takes part)."""
+        labels = sorted(torch.unique(labels_gt).cpu().tolist())[:predicted_scores.shape[-1]]
+        prob = torch.softmax(predicted_scores, dim=-1)
+        cost = cost_matrix(prob, labels_gt, labels)
+        rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))
+        return _lookup(labels_gt, [labels[r] for r in rows], [int(c) for c in cols], 0)
+
+    def forward(self, inst_embeddings, labels_gt, *args, **kwargs):
+        loss = torch.zeros(1, device=labels_gt.device)
+        for s, gt in zip(inst_embeddings, labels_gt):
+            virt = self.create_virtual_gt_with_linear_assignment(gt, s)
+            wrong = (virt != s.argmax(dim=-1)).any()                                        # :32
+            nll = -torch.log(s.gather(1, virt[:, None])[:, 0] + 1e-27).mean()               # :33
+            loss = loss + torch.where(wrong, nll, torch.zeros_like(nll))
+        return loss / inst_embeddings.shape[0]
