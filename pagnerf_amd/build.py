@@ -17,7 +17,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpagnerf_hip.so")
 ARCH = "gfx950"
 
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value"]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value"] + \
+    os.environ.get("PAG_EXTRA_FLAGS", "").split()          # kernel experiments only (e.g. -DPAG_DBG_...)
 # encode / render reproduce the oracle's fp32 op order: no FMA contraction there
 SOURCES = {
     "api.cpp": ["-x", "hip"],

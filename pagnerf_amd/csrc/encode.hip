@@ -133,6 +133,16 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
         uint32_t idx[4];
         permuto_simplex(x, p.shift[le], p.sf[le], p.capacity, p.pow2mask, idx, bary[j]);
         const TableT *tab = tables + (int64_t)le * p.capacity * F;
+#ifdef PAG_DBG_HOTIDX      // experiment: all gathers hit 256 hot rows (isolates the arithmetic + store cost)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) idx[r] &= 0xFFu;
+#endif
+#ifdef PAG_DBG_CHEAPIDX    // experiment: random rows from a 2-instruction hash (isolates the gather cost)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) idx[r] = (((uint32_t)i * 4u + r + le * 77u) * 2654435761u) >> 14;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bary[j][r] = 0.25f;
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) gather<F>(tab + (int64_t)idx[r] * F, e[j][r]);
     }
@@ -322,12 +332,25 @@ constexpr int NS_MAX = 256;       // slices per level supported (T <= 2^21)
 
 struct BinLayout {
     uint32_t *keys;      // [L][ntiles][TS*NV]      row index inside its slice
-    float *vals;         // [L][ntiles][TS*NV][F]
+    float *vals;         // [L][ntiles][TS*NV][F]   (PACK: u64 [L][ntiles][TS*NV], see pack_entry)
     uint32_t *header;    // [L][NS+1][ntiles]       exclusive offsets of each slice inside the tile region
     uint32_t *tile_max;  // [L][ntiles] bit pattern of max |gradient| of each (level, tile): no atomics, pass 2 reduces it
     int64_t ntiles;
     int NS, shift;
 };
+
+// bf16 gradients with F = 2 (the production path): one 8-byte entry = 12-bit row | 2 x 26-bit floats (fp32 with the low
+// 6 mantissa bits rounded away - 2^-18 relative, far below the bf16 inputs' 2^-9) instead of a 4-byte key + 8-byte
+// value: a third less pass-1 -> pass-2 traffic and one store / load per entry instead of two.
+__device__ __forceinline__ uint64_t pack_entry(uint32_t key12, float v0, float v1) {
+    const uint64_t a = (uint64_t)((__float_as_uint(v0) + 0x20u) >> 6), b = (uint64_t)((__float_as_uint(v1) + 0x20u) >> 6);
+    return (uint64_t)key12 | (a << 12) | (b << 38);
+}
+__device__ __forceinline__ void unpack_entry(uint64_t e, uint32_t &key12, float &v0, float &v1) {
+    key12 = (uint32_t)e & 0xFFFu;
+    v0 = __uint_as_float(((uint32_t)(e >> 12) & 0x3FFFFFFu) << 6);
+    v1 = __uint_as_float((uint32_t)(e >> 38) << 6);
+}
 
 // merge runs of equal keys in adjacent lanes: on return `emit` is set on the last lane of every run
 // and that lane's v[] holds the run's sum.  Skipped (wave-uniformly) when the wave has few repeats.
@@ -373,7 +396,7 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[
     emit = live && (lane == 63 || !next_same);
 }
 
-template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX>
+template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool PACK>
 __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
                                                  int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
@@ -489,9 +512,13 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
             if (emit[j][k]) {
                 const uint32_t s = idx[j][k] >> lay.shift;
                 const int64_t pos = region + offs[j][s] + rank[j][k];
-                lay.keys[pos] = idx[j][k] & ((1u << lay.shift) - 1u);
+                if constexpr (PACK) {
+                    reinterpret_cast<uint64_t *>(lay.vals)[pos] = pack_entry(idx[j][k] & ((1u << lay.shift) - 1u), ev[j][k][0], ev[j][k][F - 1]);
+                } else {
+                    lay.keys[pos] = idx[j][k] & ((1u << lay.shift) - 1u);
 #pragma unroll
-                for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[j][k][f];
+                    for (int f = 0; f < F; ++f) lay.vals[pos * F + f] = ev[j][k][f];
+                }
             }
         }
         for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[j][s];
@@ -530,7 +557,18 @@ __device__ __forceinline__ void lds_accumulate(unsigned long long *acc, uint32_t
     }
 }
 
-template <int F, int NV>
+template <int F, bool PACK>
+__device__ __forceinline__ void load_entry(const BinLayout &lay, int64_t pos, uint32_t &key, float (&val)[F]) {
+    if constexpr (PACK) {
+        unpack_entry(reinterpret_cast<const uint64_t *>(lay.vals)[pos], key, val[0], val[F - 1]);
+    } else {
+        key = lay.keys[pos];
+#pragma unroll
+        for (int f = 0; f < F; ++f) val[f] = lay.vals[pos * F + f];
+    }
+}
+
+template <int F, int NV, bool PACK>
 __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [2^shift][F] fixed point
     const int level = blockIdx.x / lay.NS, slice = blockIdx.x % lay.NS;
@@ -569,11 +607,7 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
             const uint32_t b = __shfl(mb, 0), e = __shfl(me, 0);
             const int64_t region = ((int64_t)level * lay.ntiles + t0) * (TS * NV);
             ok_n = b + lane < e;
-            if (ok_n) {
-                key_n = lay.keys[region + b + lane];
-#pragma unroll
-                for (int f = 0; f < F; ++f) val_n[f] = lay.vals[(region + b + lane) * F + f];
-            }
+            if (ok_n) load_entry<F, PACK>(lay, region + b + lane, key_n, val_n);
         }
         for (int j = 0; j < nt; ++j) {
             const uint32_t key = key_n;
@@ -587,11 +621,7 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
                 const uint32_t b2 = __shfl(mb, j + 1), e2 = __shfl(me, j + 1);
                 const int64_t region2 = region + TS * NV;
                 ok_n = b2 + lane < e2;
-                if (ok_n) {
-                    key_n = lay.keys[region2 + b2 + lane];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) val_n[f] = lay.vals[(region2 + b2 + lane) * F + f];
-                }
+                if (ok_n) load_entry<F, PACK>(lay, region2 + b2 + lane, key_n, val_n);
             }
             lds_accumulate<F>(acc, key, val, ok, lane);
             for (uint32_t q0 = b + 64; q0 < e; q0 += 64) {       // long segments
@@ -602,9 +632,10 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
 #pragma unroll
                 for (int f = 0; f < F; ++f) vq[f] = 0ll;
                 if (okq) {
-                    kq = lay.keys[region + q];
+                    float fq[F];
+                    load_entry<F, PACK>(lay, region + q, kq, fq);
 #pragma unroll
-                    for (int f = 0; f < F; ++f) vq[f] = __float2ll_rn(ldexpf(lay.vals[(region + q) * F + f], S));
+                    for (int f = 0; f < F; ++f) vq[f] = __float2ll_rn(ldexpf(fq[f], S));
                 }
                 lds_accumulate<F>(acc, kq, vq, okq, lane);
             }
@@ -660,14 +691,14 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
     const size_t lds = ((size_t)1 << b.shift) * F * sizeof(unsigned long long);
     const int lpx = grouped ? (L + 7) / 8 : 1;
 #define BIN_LAUNCH1(GT, F_, LPX_)                                                                                       \
-    hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay)
+    hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_, (sizeof(GT) == 2 && F_ == 2)>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay)
 #define BIN_LAUNCH(GT, F_)                                                                                              \
     do {                                                                                                                \
         if (lpx == 1) BIN_LAUNCH1(GT, F_, 1);                                                                           \
         else if (lpx == 2) BIN_LAUNCH1(GT, F_, 2);                                                                      \
         else if (lpx == 3) BIN_LAUNCH1(GT, F_, 3);                                                                      \
         else BIN_LAUNCH1(GT, F_, 4);                                                                                    \
-        hipLaunchKernelGGL((reduce_kernel<F_, NV>), g2, dim3(1024), lds, st, lay, rows, gtab);                         \
+        hipLaunchKernelGGL((reduce_kernel<F_, NV, (sizeof(GT) == 2 && F_ == 2)>), g2, dim3(1024), lds, st, lay, rows, gtab); \
     } while (0)
     if (grad_dtype == PAG_F32) {
         if (F == 2) BIN_LAUNCH(float, 2);

@@ -118,40 +118,52 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
             rank[a] += lt;
             rank[b] += 1 - lt;
         }
+    // rank += sum, wrapped into 0..3 with rem0 moved by the same amount.  |sum| <= 2 (four roundings of < 2 each on
+    // coordinates that add up to 0), so rank + sum lies in [-2, 5] and one +-4 step is the whole wrap: t & 3.
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        rank[a] += sum;
-        if (rank[a] < 0) {
-            rank[a] += 4;
-            rem0[a] += 4;
-        } else if (rank[a] > 3) {
-            rank[a] -= 4;
-            rem0[a] -= 4;
-        }
+        const int t = rank[a] + sum;
+        rank[a] = t & 3;
+        rem0[a] += rank[a] - t;
     }
-    float b5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // Barycentric weights.  The oracle adds +delta_a to slot 3-rank_a and -delta_a to slot 4-rank_a in coordinate order;
+    // the ranks are a permutation of 0..3, so every slot receives exactly one +delta and/or one -delta and the first of
+    // the two lands on 0.0 exactly: slot s = fl(delta[rank 3-s] - delta[rank 4-s]) whatever the order, and
+    // slot 0 = fl(delta[rank 3] + fl(1 - delta[rank 0])).  Sorting the four deltas by rank (16 selects) replaces the
+    // 40 predicated slot updates and is bit-identical (the kernels were VALU-bound: 86 % VALUBusy on the forward).
+    float d[4], dr[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        float delta = __fsub_rn(E[a], (float)rem0[a]) * 0.25f;
-        int slot = 3 - rank[a];
-        slot_out[a] = slot;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {   // predicated: no runtime-indexed private array
-            b5[k] = (k == slot) ? __fadd_rn(b5[k], delta) : b5[k];
-            b5[k] = (k == slot + 1) ? __fsub_rn(b5[k], delta) : b5[k];
-        }
+        d[a] = __fsub_rn(E[a], (float)rem0[a]) * 0.25f;
+        slot_out[a] = 3 - rank[a];
     }
-    b5[0] = __fadd_rn(b5[0], __fadd_rn(1.0f, b5[4]));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bary[r] = b5[r];
-        uint32_t k = 0;
+    for (int r = 0; r < 4; ++r) dr[r] = rank[0] == r ? d[0] : (rank[1] == r ? d[1] : (rank[2] == r ? d[2] : d[3]));
+    bary[0] = __fadd_rn(dr[3], __fsub_rn(1.0f, dr[0]));
+    bary[1] = __fsub_rn(dr[2], dr[3]);
+    bary[2] = __fsub_rn(dr[1], dr[2]);
+    bary[3] = __fsub_rn(dr[0], dr[1]);
+    // Vertex hashes.  k = ((key0*m + key1)*m + key2)*m is linear in the keys (mod 2^32) and
+    // key_a(r) = rem0_a + r - 4*[rank_a > 3-r], so k(r) = k(rem0) + r*(m^3+m^2+m) - sum_a [rank_a >= 4-r] * 4*m^(3-a):
+    // three multiplies per level instead of twelve.
+    constexpr uint32_t m1 = 2531011u, m2 = m1 * m1, m3 = m2 * m1;
+    constexpr uint32_t step = m3 + m2 + m1;
+    constexpr uint32_t A[3] = {4u * m3, 4u * m2, 4u * m1};
+    const uint32_t h0 = (((uint32_t)rem0[0] * m1 + (uint32_t)rem0[1]) * m1 + (uint32_t)rem0[2]) * m1;
+    // the sets {a: rank_a >= 4-r} are nested in r and at most one coordinate holds each rank: B[q] = 4*m^(3-a) of the
+    // coordinate a < 3 with rank q (the compares are the ones the delta sort above already made)
+    uint32_t B[4];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            int key = rem0[a] + r - ((rank[a] > 3 - r) ? 4 : 0);
-            k = (k + (uint32_t)key) * 2531011u;
-        }
-        idx[r] = pow2mask ? (k & pow2mask) : (k % capacity);
+    for (int q = 1; q < 4; ++q) B[q] = rank[0] == q ? A[0] : (rank[1] == q ? A[1] : (rank[2] == q ? A[2] : 0u));
+    idx[0] = h0;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) idx[r] = idx[r - 1] + (step - B[4 - r]);
+    if (pow2mask) {      // one wave-uniform branch for the four vertices
+#pragma unroll
+        for (int r = 0; r < 4; ++r) idx[r] &= pow2mask;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) idx[r] %= capacity;
     }
 }
 
