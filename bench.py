@@ -215,7 +215,8 @@ def main():
     # units, FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes) - measured offline on this exact configuration and
     # committed under profiles/; null for any other configuration.
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01f_pmc_traffic_per_launch.json")
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_per_launch.json"))
+    tf = os.path.join(ROOT, "profiles", cands[-1]) if cands else ""      # newest committed PMC pass (profiles/README.md)
     if os.path.exists(tf) and (args.grid, args.rays, args.samples, args.precision) == ("permuto", 4096, 512, "bf16"):
         for k, v in json.load(open(tf)).items():
             if "permuto_fwd_kernel" in k:
