@@ -1098,40 +1098,93 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
     const A1T *a1 = reinterpret_cast<const A1T *>(p.a1);
     const bool dz_vec = (p.dz_cols % 8) == 0;
     const int64_t nchunks = (p.M + 63) / 64;
-    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // global -> register fetch of one 8-column piece of this lane's sample row (dz tile / input tile)
+    auto fetch_z = [&](int64_t chunk, int cg) __attribute__((always_inline)) {
         const int64_t m = chunk * 64 + lane;
         const bool live = m < p.M;
         const int64_t mc = live ? m : p.M - 1;
-        // ---- dz tile, transposed: Zt[col][sample]
-        for (int cg = wave; cg < OB * 4; cg += 4) {
-            const int c0 = 8 * cg;
-            bf16x8 v = zero8();
-            if (live && c0 < p.dz_cols) {
-                if (dz_vec) {
-                    v = load8(p.dz + mc * p.dz_cols + c0);
-                } else {
+        const int c0 = 8 * cg;
+        bf16x8 v = zero8();
+        if (live && c0 < p.dz_cols) {
+            if (dz_vec) {
+                v = load8(p.dz + mc * p.dz_cols + c0);
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (c0 + j < p.dz_cols) v[j] = p.dz[mc * p.dz_cols + c0 + j];
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < p.dz_cols) v[j] = p.dz[mc * p.dz_cols + c0 + j];
+            }
+        }
+        return v;
+    };
+    auto fetch_a = [&](int64_t chunk, int cg) __attribute__((always_inline)) {
+        const int64_t m = chunk * 64 + lane;
+        const bool live = m < p.M;
+        const int64_t mc = live ? m : p.M - 1;
+        const int c0 = 8 * cg;
+        bf16x8 v = zero8();
+        if (live && p.a1_grouped)
+            v = load8(reinterpret_cast<const bf16_t *>(p.a1) + ((int64_t)cg * p.M + mc) * 8);
+        else if (live && c0 < p.k1)
+            v = load8(a1 + mc * p.k1 + c0);
+        else if (live && p.a2 && c0 < p.k1 + p.k2p)
+            v = load8(p.a2 + (int64_t)p.a2_index[mc] * p.k2p + (c0 - p.k1));
+        return v;
+    };
+    // APW == 2 (<= 64 x 64 layers, 76 VGPRs): the next chunk's four 16-byte pieces are fetched into registers while the
+    // current chunk goes through LDS and the MFMAs - the kernel sat waiting on memory 77 % of its wave cycles (SQ_WAIT_ANY)
+    // with nothing in flight between the two barriers.  The wide variant has no registers to spare for this.
+    constexpr bool PF = APW == 2;
+    bf16x8 pz[2], pa[2];
+    if constexpr (PF) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cg = wave + 4 * i;
+            pz[i] = (blockIdx.x < nchunks && cg < OB * 4) ? fetch_z(blockIdx.x, cg) : zero8();
+            pa[i] = (blockIdx.x < nchunks && cg < IB * 4) ? fetch_a(blockIdx.x, cg) : zero8();
+        }
+    }
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // ---- dz tile, transposed: Zt[col][sample]
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int cg = wave + 4 * i, c0 = 8 * cg;
+                if (cg < OB * 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Zt[(c0 + j) * WG_RS + lane] = pz[i][j];
+                }
+                if (cg < IB * 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) At[(c0 + j) * WG_RS + lane] = (c0 + j < p.n_in) ? pa[i][j] : (bf16_t)0.0f;
                 }
             }
+        } else {
+            for (int cg = wave; cg < OB * 4; cg += 4) {
+                const int c0 = 8 * cg;
+                const bf16x8 v = fetch_z(chunk, cg);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Zt[(c0 + j) * WG_RS + lane] = v[j];
-        }
-        // ---- input tile, transposed: At[col][sample]
-        for (int cg = wave; cg < IB * 4; cg += 4) {
-            const int c0 = 8 * cg;
-            bf16x8 v = zero8();
-            if (live && p.a1_grouped)
-                v = load8(reinterpret_cast<const bf16_t *>(p.a1) + ((int64_t)cg * p.M + mc) * 8);
-            else if (live && c0 < p.k1)
-                v = load8(a1 + mc * p.k1 + c0);
-            else if (live && p.a2 && c0 < p.k1 + p.k2p)
-                v = load8(p.a2 + (int64_t)p.a2_index[mc] * p.k2p + (c0 - p.k1));
+                for (int j = 0; j < 8; ++j) Zt[(c0 + j) * WG_RS + lane] = v[j];
+            }
+            // ---- input tile, transposed: At[col][sample]
+            for (int cg = wave; cg < IB * 4; cg += 4) {
+                const int c0 = 8 * cg;
+                const bf16x8 v = fetch_a(chunk, cg);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) At[(c0 + j) * WG_RS + lane] = (c0 + j < p.n_in) ? v[j] : (bf16_t)0.0f;
+                for (int j = 0; j < 8; ++j) At[(c0 + j) * WG_RS + lane] = (c0 + j < p.n_in) ? v[j] : (bf16_t)0.0f;
+            }
         }
         __syncthreads();
+        if constexpr (PF) {
+            const int64_t next = chunk + gridDim.x;
+            if (next < nchunks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int cg = wave + 4 * i;
+                    if (cg < OB * 4) pz[i] = fetch_z(next, cg);
+                    if (cg < IB * 4) pa[i] = fetch_a(next, cg);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int pr = wave + 4 * i;
