@@ -73,3 +73,44 @@ def nef_forward(feats, delta_feats, ray_d, params, channels,
             e = F.softmax(e, dim=-1) if inst_softmax else e
             out["inst_embedding"] = e
     return out
+
+
+def nef_forward_dd(feats, delta_feats, ray_d, params, channels, view_multires=4, lod_weights=None, separate_sem_grid=False,
+                   sem_softmax=True, inst_softmax=True, sem_sigmoid=False, inst_sigmoid=False,
+                   sem_normalize=False, inst_normalize=False, inst_soft_temperature=0.0):
+    """Delta-density variant: pc_nerf/panoptic_dd_nef.py:130-275.  As nef_forward() plus
+      delta_density    = decoder_delta_density(panoptic feats)                      (:236-241)
+      panoptic_density = relu(density_feats[...,0:1].detach() + delta_density)      (:243-247)
+    (separate_sem_grid: panoptic feats = delta feats alone, panoptic density = relu(delta_density)).
+    params additionally holds "delta_density"."""
+    out = {}
+    if lod_weights is not None:
+        feats = feats * lod_weights
+    dfe = mlp(feats, *params["density"])
+    out["density_feats"] = dfe
+    out["density"] = torch.relu(dfe[..., 0:1])
+    if "rgb" in channels:
+        pe = positional_embed(-ray_d, view_multires)
+        out["rgb"] = torch.sigmoid(mlp(torch.cat([dfe, pe], dim=-1), *params["color"]))
+    if any(c in channels for c in ("delta_density", "panoptic_density", "semantics", "inst_embedding")):
+        d = delta_feats * lod_weights if lod_weights is not None else delta_feats
+        pan = d if separate_sem_grid else feats.detach() + d
+        if "delta_density" in channels or "panoptic_density" in channels:
+            dd = mlp(pan, *params["delta_density"], act=lambda t: t)      # activation 'none' (panoptic_dd_nef.py:49-56)
+            out["delta_density"] = dd
+            if "panoptic_density" in channels:
+                out["panoptic_density"] = torch.relu(dd if separate_sem_grid else dfe[..., 0:1].detach() + dd)
+        if "semantics" in channels:
+            s = mlp(pan, *params["semantics"])
+            s = torch.sigmoid(s) if sem_sigmoid else s
+            s = F.normalize(s, dim=-1) if sem_normalize else s
+            s = F.softmax(s, dim=-1) if sem_softmax else s
+            out["semantics"] = s
+        if "inst_embedding" in channels:
+            e = mlp(pan, *params["inst"])
+            e = torch.sigmoid(e) if inst_sigmoid else e
+            e = F.normalize(e, dim=-1) if inst_normalize else e
+            e = e / inst_soft_temperature if inst_soft_temperature > 0.0 else e
+            e = F.softmax(e, dim=-1) if inst_softmax else e
+            out["inst_embedding"] = e
+    return out

@@ -131,6 +131,28 @@ def composite(N, ridx, boundary, density, deltas, depths=None, rgb=None, semanti
     return out
 
 
+def composite_dd(N, ridx, boundary, density, panoptic_density, deltas, depths=None, rgb=None, semantics=None, inst=None,
+                 bg_color="white", ray_sparcity_reg=0.0):
+    """Compositing half of tracers/panoptic_dd_packed_rf_tracer.py:52-177: alpha / rgb / depth use the rgb density's
+    weights (:112-160); the panoptic channels use the weights AND alpha of the panoptic density (:124-135, :162-166),
+    which - unlike the plain tracer - keep their gradient (only deltas / boundary are detached)."""
+    out = composite(N, ridx, boundary, density, deltas, depths=depths, rgb=rgb, bg_color=bg_color, ray_sparcity_reg=ray_sparcity_reg)
+    ridx_hit = ridx[boundary].long()
+    ptau = panoptic_density.reshape(-1, 1) * deltas.detach()
+    pw = exponential_integration_weights(ptau, boundary)
+    palpha = sum_reduce(pw, boundary) if pw.numel() else torch.zeros(0, 1)
+    out["panoptic_weights"] = pw
+    for name, feat in (("semantics", semantics), ("inst_embedding", inst)):
+        if feat is None:
+            continue
+        C = feat.shape[-1]
+        rf = sum_reduce(pw * feat.reshape(-1, C), boundary) if pw.numel() else torch.zeros(0, C)
+        buf = torch.zeros(N, C)
+        buf[ridx_hit] = palpha * rf
+        out[name] = buf
+    return out
+
+
 def voxel_travel_filter(ridx, depths, ray_max_travel):
     """tracer :88-108 - keep samples whose depth is < ray_max_travel past the first sample
     of their ray.  depths [M,k,1] (first column used).  Returns bool mask [M]."""

@@ -459,6 +459,93 @@ def g7(hgt):
                         kind="normal")
 
 
+def g8(dd_nef_mod, dd_tracer_mod):
+    """Delta-density variant (SURVEY 8f4): pc_nerf/panoptic_dd_nef.py::PanopticDDensityNeF.rgb_semantics on HashGridTorch
+    grids with fixed weights, and tracers/panoptic_dd_packed_rf_tracer.py::PanopticDDensityPackedRFTracer.trace() on a fixed
+    packed scene (panoptic channels composited with the panoptic density's own weights)."""
+    torch.manual_seed(8)
+    L, log2T, C, I = 8, 12, 6, 20
+    nef = dd_nef_mod.PanopticDDensityNeF(
+        grid_type='HashGridTorch', interpolation_type='linear', multiscale_type='cat', feature_dim=2, num_lods=L,
+        base_lod=2, hidden_dim=64, num_layers=1, activation_type='relu', layer_type='none', embedder_type='positional',
+        view_multires=4, pos_multires=4, position_input=False, num_classes=C, num_instances=I, sem_num_layers=1,
+        sem_hidden_dim=64, sem_softmax=True, inst_num_layers=2, inst_hidden_dim=64, inst_softmax=True,
+        delta_num_layers=1, delta_hidden_dim=64, codebook_bitwidth=log2T, delta_capacity_log_2=log2T)
+    res = [16] * (L - 1) + [256]
+    save = {}
+    with torch.no_grad():
+        for gi, g in enumerate((nef.grid, nef.delta_grid)):
+            g.init_from_resolutions(res)
+            tab = table_from_seed(800 + gi, (L, 2 ** log2T, 2), "normal") * np.float32(0.5)
+            for i in range(L):
+                g.embedder.embeddings[i].weight.copy_(torch.from_numpy(tab[i]))
+        rs = np.random.RandomState(8)
+        M = 256
+        coords = torch.from_numpy(rs.uniform(-1, 1, size=(M, 1, 3)).astype(np.float32))
+        d = rs.standard_normal(size=(M, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        ray_d = torch.from_numpy(d)
+        chans = {'density', 'rgb', 'delta_density', 'panoptic_density', 'semantics', 'inst_embedding'}
+        out = nef(coords=coords, ray_d=ray_d, pidx=None, lod_idx=None, channels=chans)
+    for name in ("decoder_density", "decoder_color", "decoder_semantics", "decoder_inst", "decoder_delta_density"):
+        dec = getattr(nef, name)
+        lins = list(dec.layers) + [dec.lout]
+        for li, lin in enumerate(lins):
+            save[f"{name}_w{li}"] = lin.weight.detach().numpy()
+            save[f"{name}_b{li}"] = lin.bias.detach().numpy()
+        save[f"{name}_n"] = len(lins)
+    save.update(coords=coords.numpy(), ray_d=ray_d.numpy(), res=np.array(res, np.float32), log2T=log2T, L=L,
+                seed_main=800, seed_delta=801, **{"nef_" + k: v.numpy() for k, v in out.items()})
+    # ---- tracer on a fixed packed scene
+    N, S = 40, 20
+    origins = torch.from_numpy(rs.uniform(-0.3, 0.3, size=(N, 3)).astype(np.float32))
+    dd = rs.standard_normal(size=(N, 3)).astype(np.float32)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    dirs = torch.from_numpy(dd)
+    jitter = torch.from_numpy(rs.uniform(0, 1, size=(N, S)).astype(np.float32))
+    occ = torch.from_numpy(rs.uniform(size=(8, 8, 8)) > 0.3)
+    ridx, pidx, samples, depths, deltas, boundary = orender.raymarch_ray(origins, dirs, 0.0, 2.0, S, jitter, occ, 3)
+    keep = ridx != 3                                                     # ray 3 has no samples
+    ridx, pidx, samples, depths, deltas = ridx[keep], pidx[keep], samples[keep], depths[keep], deltas[keep]
+    boundary = orender.mark_pack_boundaries(ridx)
+    Mt = ridx.shape[0]
+    density = torch.from_numpy((rs.gamma(1.0, 8.0, size=(Mt, 1, 1)) * (rs.uniform(size=(Mt, 1, 1)) > 0.3)).astype(np.float32))
+    pdens = torch.from_numpy((rs.gamma(1.0, 6.0, size=(Mt, 1, 1)) * (rs.uniform(size=(Mt, 1, 1)) > 0.2)).astype(np.float32))
+    rgb = torch.from_numpy(rs.uniform(size=(Mt, 1, 3)).astype(np.float32))
+    sem = torch.softmax(torch.from_numpy(rs.standard_normal(size=(Mt, C)).astype(np.float32)), -1)
+    inst = torch.softmax(torch.from_numpy(rs.standard_normal(size=(Mt, I)).astype(np.float32)), -1)
+
+    class Grid:
+        num_lods = 4
+        active_lods = [0, 1, 2, 3]
+
+        def raymarch(self, rays, level, num_samples, raymarch_type):
+            return ridx, pidx, samples, depths, deltas, boundary
+
+    class Nef:
+        grid = Grid()
+        device = 'cpu'
+
+        def __call__(self, coords, ray_d, pidx, lod_idx, channels):
+            full = {'density': density, 'rgb': rgb, 'semantics': sem, 'inst_embedding': inst, 'panoptic_density': pdens}
+            if isinstance(channels, str):
+                return full[channels]
+            return {c: full[c] for c in channels}
+
+    rays = types.SimpleNamespace(origins=origins, dirs=dirs)
+    save.update(t_N=N, t_S=S, t_ridx=ridx.numpy(), t_depths=depths.numpy(), t_deltas=deltas.numpy(), t_boundary=boundary.numpy(),
+                t_density=density.numpy(), t_panoptic_density=pdens.numpy(), t_rgb=rgb.numpy(), t_semantics=sem.numpy(),
+                t_inst_embedding=inst.numpy(), t_origins=origins.numpy(), t_dirs=dirs.numpy(), t_jitter=jitter.numpy(),
+                t_occ=occ.numpy(), t_empty_ray=3)
+    for bg in ("white", "black"):
+        tr = dd_tracer_mod.PanopticDDensityPackedRFTracer(ray_sparcity_reg=0.01, raymarch_type='ray', num_steps=S, bg_color=bg)
+        rb = tr.trace(Nef(), {'rgb', 'depth', 'semantics', 'inst_embedding'}, set(), rays, lod_idx=None,
+                      raymarch_type='ray', num_steps=S, bg_color=bg, stage='train')
+        for ch in ('rgb', 'alpha', 'hit', 'depth', 'semantics', 'inst_embedding', 'ray_sparcity_loss'):
+            save[f"t_{bg}_{ch}"] = getattr(rb, ch).numpy()
+    np.savez_compressed(os.path.join(HERE, "g8_dd.npz"), **save)
+
+
 def main():
     install_stubs()
     torch.set_num_threads(1)
@@ -467,6 +554,11 @@ def main():
         hgt = importlib.import_module("grids.hash_grid_torch")
     if "--only-g7" in sys.argv:
         g7(hgt)
+        return
+    if "--only-g8" in sys.argv:
+        with _CudaToCpu():
+            dd_nef = importlib.import_module("pc_nerf.panoptic_dd_nef")
+        g8(dd_nef, importlib.import_module("tracers.panoptic_dd_packed_rf_tracer"))
         return
     g1_g2(hgt)
     g7(hgt)
@@ -479,6 +571,9 @@ def main():
     lat = importlib.import_module("loss.lin_assignment_things")
     g5(la, lat)
     g6(importlib.import_module("loss.regularizers"))
+    with _CudaToCpu():
+        dd_nef = importlib.import_module("pc_nerf.panoptic_dd_nef")
+    g8(dd_nef, importlib.import_module("tracers.panoptic_dd_packed_rf_tracer"))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -165,3 +165,37 @@ def test_permuto_position_gradient_matches_finite_differences():
     # points within h of a simplex face see two different affine pieces: drop the few outliers, demand the rest match
     err = np.abs(fd - dx).max(1) / (1.0 + np.abs(fd).max(1))
     assert np.mean(err < 1e-3) > 0.99, np.sort(err)[-10:]
+
+
+def _g8_params(g):
+    params = {}
+    for short, name in (("density", "decoder_density"), ("color", "decoder_color"), ("semantics", "decoder_semantics"),
+                        ("inst", "decoder_inst"), ("delta_density", "decoder_delta_density")):
+        n = int(g[f"{name}_n"])
+        params[short] = ([torch.from_numpy(g[f"{name}_w{i}"]) for i in range(n)], [torch.from_numpy(g[f"{name}_b{i}"]) for i in range(n)])
+    return params
+
+
+def test_g8_delta_density_variant():
+    """oracle restatement of the delta-density nef + tracer vs the reference's pc_nerf/panoptic_dd_nef.py and
+    tracers/panoptic_dd_packed_rf_tracer.py (golden g8)."""
+    from oracle import hash_encode as oh, decoders as od, render as orr
+    g = golden("g8_dd.npz")
+    log2T, L = int(g["log2T"]), int(g["L"])
+    res = [float(r) for r in oh.level_resolutions(int(g["res"][0]), int(g["res"][-1]), L)]
+    x = torch.from_numpy(g["coords"]).reshape(-1, 3)
+    tabs = [torch.from_numpy(table_from_seed(int(g[k]), (L, 2 ** log2T, 2), "normal") * np.float32(0.5)) for k in ("seed_main", "seed_delta")]
+    f, _ = oh.hash_encode(x, tabs[0], res, log2T)
+    df, _ = oh.hash_encode(x, tabs[1], res, log2T)
+    chans = {"density", "rgb", "delta_density", "panoptic_density", "semantics", "inst_embedding"}
+    out = od.nef_forward_dd(f, df, torch.from_numpy(g["ray_d"]), _g8_params(g), chans)
+    for ch in chans:
+        np.testing.assert_allclose(out[ch].numpy().reshape(g["nef_" + ch].shape), g["nef_" + ch], rtol=1e-5, atol=1e-6, err_msg=ch)
+    N = int(g["t_N"])
+    t = lambda k: torch.from_numpy(g["t_" + k])
+    for bg in ("white", "black"):
+        comp = orr.composite_dd(N, t("ridx"), t("boundary"), t("density"), t("panoptic_density"), t("deltas"), depths=t("depths"),
+                                rgb=t("rgb"), semantics=t("semantics"), inst=t("inst_embedding"), bg_color=bg, ray_sparcity_reg=0.01)
+        for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding", "ray_sparcity_loss"):
+            np.testing.assert_allclose(comp[ch].numpy(), g[f"t_{bg}_{ch}"], rtol=1e-5, atol=1e-6, err_msg=f"{bg} {ch}")
+        assert np.array_equal(comp["hit"].numpy(), g[f"t_{bg}_hit"])
