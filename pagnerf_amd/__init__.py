@@ -5,14 +5,16 @@
     tracer: PanopticPackedRFTracer                (tracer.py)   <- tracers/panoptic_packed_rf_tracer.py
     core  : Rays, RenderBuffer, Pipeline          (core.py)     <- wisp.core / wisp.models.Pipeline
     pose  : BAPipeline (learnable extrinsics)     (ba_pipeline.py) <- pc_nerf/ba_pipeline.py
+    dd    : PanopticDDensityNeF / ...PackedRFTracer (dd.py)     <- pc_nerf/panoptic_dd_nef.py, tracers/panoptic_dd_packed_rf_tracer.py
     shard : ray sharding + RCCL gather/all-reduce (shard.py)
 
 All compute goes through libpagnerf_hip.so (include/pagnerf_hip.h); there is no CPU fallback.
 """
-from .core import Rays, RenderBuffer, Pipeline                     # noqa: F401
+from .core import Rays, RenderBuffer, Pipeline, batch_render       # noqa: F401
 from .grids import HashGridHIP, PermutoGridHIP                     # noqa: F401
 from .nef import PanopticDeltaNeF, BasicDecoder                    # noqa: F401
 from .tracer import PanopticPackedRFTracer                         # noqa: F401
 from .ba_pipeline import BAPipeline                                # noqa: F401
+from .dd import PanopticDDensityNeF, PanopticDDensityPackedRFTracer    # noqa: F401
 
 __version__ = "0.1.0"

@@ -107,3 +107,18 @@ class Pipeline(nn.Module):
         if self.tracer is not None:
             return self.tracer(self.nef, *args, **kwargs)
         return self.nef(*args, **kwargs)
+
+
+def batch_render(pipeline, rays, channels=("rgb",), render_batch=4000, cam_ids=None):
+    """Validation-time chunked render (pc_nerf/trainer.py:637-649): BAPipelines first map the base rays to world space,
+    then the rays go through the pipeline `render_batch` at a time and the RenderBuffers are concatenated with `+=`."""
+    if hasattr(pipeline, "transform_rays") and cam_ids is not None:
+        rays = pipeline.transform_rays(rays, cam_ids)
+    rb = None
+    for pack in rays.split(render_batch):
+        part = pipeline(rays=pack, lod_idx=None, channels=channels)
+        if rb is None:
+            rb = part
+        else:
+            rb += part
+    return rb

@@ -192,7 +192,8 @@ class PanopticDeltaNeF(nn.Module):
         self._feat_cache = (coords, feats.detach())           # reused by panoptic_composited() for the same samples
         grp = self._grouped()
         density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
-        density = torch.relu(density_feats[:, 0:1].float()).reshape(batch, num_samples, 1)   # :188
+        self._density_pre = density_feats[:, 0:1].float()        # pre-ReLU density (the delta-density variant adds to it)
+        density = torch.relu(self._density_pre).reshape(batch, num_samples, 1)            # :188
         if "density" in compute_channels:
             out["density"] = density
         if "rgb" in compute_channels:                                                 # :196-204

@@ -584,6 +584,71 @@ def composite_feats(feats, weights, alpha, pack_start, ray_of_pack, N):
     return _CompositeFeats.apply(feats, weights, alpha, pack_start, ray_of_pack, N)
 
 
+class _CompositeFeatsWeights(torch.autograd.Function):
+    """out[ray] = alpha_r * sum_i w_i f_i with w, alpha computed from (sigma, deltas) INSIDE the node and differentiable:
+    the delta-density tracer composites the panoptic channels with the panoptic density's own weights and keeps their
+    gradient (tracers/panoptic_dd_packed_rf_tracer.py:124-135,162-166).
+    Backward: d f_i = alpha w_i G_r (composite_feats_bwd).  For sigma, sum_c G_rc out_rc = alpha_r sum_i w_i s_i with the
+    per-sample scalar s_i = <G_r, f_i>, which is the black-background colour formula of pag_composite_bwd on the
+    one-channel "colour" s - so d sigma comes from that kernel with rgb = (s,0,0) and upstream gradient (1,0,0)."""
+
+    @staticmethod
+    def forward(ctx, sigma, deltas, feats, ridx, pack_start, ray_of_pack, N):
+        _check_gpu(sigma, deltas, feats)
+        dev = sigma.device
+        M, P = sigma.shape[0], ray_of_pack.shape[0]
+        sigma = sigma.detach().contiguous().float()
+        deltas = deltas.detach().contiguous().float()
+        feats = feats.detach().contiguous()
+        if feats.dtype not in (torch.float32, torch.bfloat16):
+            feats = feats.float()
+        C = feats.shape[1]
+        w = torch.empty(M, device=dev)
+        alpha = torch.zeros(N, device=dev)
+        hit = torch.zeros(N, device=dev, dtype=torch.uint8)
+        out = torch.zeros(N, C, device=dev)
+        if P and M:
+            _call("pag_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), None, None, L.BG_BLACK,
+                  L.ptr(w), L.ptr(alpha), None, None, L.ptr(hit), L.stream())
+            _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(w), L.ptr(alpha), L.ptr(feats),
+                  L.dtype_code(feats), C, L.ptr(out), L.stream())
+        ctx.save_for_backward(sigma, deltas, feats, ridx, pack_start, ray_of_pack, w, alpha)
+        ctx.mark_non_differentiable(alpha)
+        return out, alpha
+
+    @staticmethod
+    def backward(ctx, g, _g_alpha):
+        sigma, deltas, feats, ridx, pack_start, ray_of_pack, w, alpha = ctx.saved_tensors
+        M, C = feats.shape
+        P = ray_of_pack.shape[0]
+        dev = sigma.device
+        g = g.contiguous().float()
+        d_feats = torch.zeros(M, C, device=dev, dtype=feats.dtype)
+        d_sigma = torch.zeros(M, device=dev)
+        if P and M:
+            if ctx.needs_input_grad[2]:
+                _call("pag_composite_feats_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(w), L.ptr(alpha), L.ptr(g), C,
+                      L.ptr(d_feats), L.dtype_code(d_feats), L.stream())
+            if ctx.needs_input_grad[0]:
+                s3 = torch.zeros(M, 3, device=dev)
+                rl = ridx.long()
+                step = max(1, (1 << 24) // max(C, 1))                        # bound the [chunk, C] temporary
+                for lo in range(0, M, step):
+                    hi = min(M, lo + step)
+                    s3[lo:hi, 0] = (feats[lo:hi].float() * g[rl[lo:hi]]).sum(1)
+                ones = torch.zeros(alpha.shape[0], 3, device=dev)
+                ones[:, 0] = 1.0
+                d_rgb = torch.empty(M, 3, device=dev)
+                _call("pag_composite_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), None, L.ptr(s3),
+                      L.BG_BLACK, L.ptr(w), L.ptr(alpha), L.ptr(ones), None, None, L.ptr(d_sigma), L.ptr(d_rgb), L.stream())
+        return d_sigma, None, (d_feats if ctx.needs_input_grad[2] else None), None, None, None, None
+
+
+def composite_features(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N):
+    """-> (out f32 [N,C], alpha f32 [N]) with gradients to sigma AND feats (delta-density tracer); ridx i32 [M]."""
+    return _CompositeFeatsWeights.apply(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N)
+
+
 class _HeadComposite(_FusedMLP):
     """decoder (+ softmax) followed by the per-ray weighted sum of tracer :197-205, as ONE autograd node: the
     backward hands the decoder the gradient in rank-1 form (alpha * w_m * d out[ray]) so neither the [M,C] gradient
