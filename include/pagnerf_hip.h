@@ -148,6 +148,8 @@ typedef struct {
     void *out; int out_dtype;
     void *hidden_save[2];
     int mode;
+    float *softmax_stats;   /* optional (MFMA mode, out_act SOFTMAX): f32 [M,2] = (max logit * log2(e), 1 / sum exp) per
+                               sample, from which the backward rebuilds the probabilities instead of reading `out` */
 } pag_mlp_fwd_args;
 int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
 
@@ -171,6 +173,10 @@ typedef struct {
      * (alpha * w_m * d out[ray]) - passing it in this form means the [M, out_dim] gradient of the composited
      * semantic / instance probabilities is never materialised.  grad_out may then be NULL. */
     const float *g_ray; const float *g_scale; const int32_t *g_index;
+    /* Optional (MFMA mode, out_act SOFTMAX, out_dim > 64, bf16 out): with the forward's softmax_stats and the last layer's
+     * bias the wide-head backward recomputes the probabilities from hidden_save (4 MFMAs per 32-channel block on idle
+     * matrix cores) instead of streaming the [M, out_dim] output through twice; `out` may then be NULL. */
+    const float *softmax_stats; const float *b_last;
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 

@@ -31,7 +31,8 @@ class MlpFwdArgs(ctypes.Structure):
                 ("out_act", c_i32),
                 ("out", c_vp), ("out_dtype", c_i32),
                 ("hidden_save", c_vp * 2),
-                ("mode", c_i32)]
+                ("mode", c_i32),
+                ("softmax_stats", c_vp)]
 
 
 class MlpBwdArgs(ctypes.Structure):
@@ -43,7 +44,8 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dz", c_vp * 3),
                 ("dx1", c_vp), ("dx1_dtype", c_i32),
                 ("mode", c_i32),
-                ("g_ray", c_vp), ("g_scale", c_vp), ("g_index", c_vp)]
+                ("g_ray", c_vp), ("g_scale", c_vp), ("g_index", c_vp),
+                ("softmax_stats", c_vp), ("b_last", c_vp)]
 
 
 _SIGS = {

@@ -22,6 +22,7 @@
 // FP32 path (PAG_MLP_FP32): one lane per sample, fp32 FMA chains in k order with the weights
 // broadcast from LDS - the parity path (tolerance 1e-5 against the fp32 oracle).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -30,6 +31,9 @@ typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef PAG_WIDE_BWD_WAVES
+#define PAG_WIDE_BWD_WAVES 8      // waves per workgroup of mlp_bwd_wide_mfma (8 or 16; one workgroup per CU)
+#endif
 constexpr int RS = 72;          // LDS row stride (bf16 elements) of a 64-wide weight row: 144 B
 constexpr int HID = 64;
 
@@ -55,6 +59,7 @@ struct FwdParams {
     void *hsave[2];
     int64_t M;
     int grp_L, grp_F;      // x1 in PAG_LAYOUT_XCD8 (bf16 [8][M][8]) when grp_L > 0
+    float *stats;          // optional f32 [M,2]: (max logit * log2e, 1 / sum exp) of the output softmax
 };
 
 struct BwdParams {
@@ -71,6 +76,8 @@ struct BwdParams {
     void *dx1;
     int64_t M;
     int grp_L, grp_F;      // dx1 (and layer-0 weight columns) in PAG_LAYOUT_XCD8 order when grp_L > 0
+    const float *stats;    // forward's softmax statistics + last-layer bias: the wide kernel recomputes the probabilities
+    const float *b_last;
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
@@ -502,6 +509,10 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
                 inv = 1.0f / S_;
             }
             const float Ms = M_ * LOG2E;
+            if (p.stats && p.act == PAG_ACT_SOFTMAX && live && h == 0) {
+                float2 st2 = {Ms, inv};
+                *reinterpret_cast<float2 *>(p.stats + 2 * m) = st2;
+            }
             for (int ob = 0; ob < OB; ++ob) {
                 f32x16 o;
                 out_block(ob, o);
@@ -890,6 +901,217 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
     }
 }
 
+// ------------------------------------------------------------------- backward of wide softmax heads
+// The 200-way instance head dominated the decoder backward: its [M,200] probabilities were streamed through twice
+// (dot product of the softmax backward, then dz) - 1.7 GB per launch.  With the forward's per-sample softmax statistics
+// (max*log2e, 1/sum) the probabilities of a 32-channel block are instead REBUILT from the saved last hidden layer with
+// the forward's own instruction sequence (bias + 4 MFMAs on the idle matrix cores + exp2), so the kernel reads only the
+// two [M,64] hidden tensors.  Both layouts of W_L are needed in LDS (rows = channels for the rebuild, rows = hidden
+// units for W_L^T . dz), 62 KiB - the workgroup therefore has NW = 8 or 16 waves sharing one copy instead of two
+// 4-wave workgroups per CU.
+template <typename DxT, int NL, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int OB = (p.out_dim + 31) / 32;
+    const int RSL = OB * 32 + 8;
+    bf16_t *WLt = reinterpret_cast<bf16_t *>(smem);              // [64 hidden][RSL]   k = output channel (permuted)
+    bf16_t *WLs = WLt + 64 * RSL;                                // [OB*32 channels][RS] permuted k (forward layout)
+    bf16_t *W1t = WLs + OB * 32 * RS;                            // [64][RS]      (NL == 3)
+    bf16_t *W0t = W1t + (NL == 3 ? 64 * RS : 0);                 // [64 in-feature rows][RS]
+    float *bLs = reinterpret_cast<float *>(W0t + 64 * RS);       // [OB*32]
+    bf16_t *stg = reinterpret_cast<bf16_t *>(bLs + OB * 32) + (threadIdx.x >> 6) * (ST_BYTES / 2);
+    float *grow = reinterpret_cast<float *>(reinterpret_cast<bf16_t *>(bLs + OB * 32) + NW * (ST_BYTES / 2)) +
+                  (threadIdx.x >> 6) * (OB * 32);              // wave-private copy of the tile's upstream gradient row [OB*32]
+    stage_weight_t(WLt, RSL, 64, OB * 32, p.W[NL - 1], p.out_dim, HID);
+    stage_weight(WLs, RS, OB * 32, 64, p.W[NL - 1], p.out_dim, HID, true);
+    if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
+    if (p.dx1) stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
+    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b_last[e] : 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int r = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (p.M + 31) / 32;
+    const bool vec_out = (p.out_dim % 4) == 0;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int64_t tile_step = (int64_t)gridDim.x * NW;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += tile_step) {
+        asm volatile("" : "+v"(r), "+v"(h));      // keep lane-constant addresses from being hoisted and spilled
+        const int64_t m = tile * 32 + r;
+        const bool live = m < p.M;
+        const int64_t mc = live ? m : p.M - 1;
+        const int rows_valid = (int)min((int64_t)32, p.M - tile * 32);
+        const bool tile_full = (tile + 1) * 32 <= p.M;
+        bf16x4 hraw[NL - 1][2][4];
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l)
+            tile64_load(stg, reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rows_valid, lane, r, h, hraw[l]);
+        // the forward's B operand of the output layer: the saved bf16 activations, re-packed (exact)
+        bf16x8 hbL[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            f32x16 hv;
+            raw_to_block(hraw[NL - 2][mb], hv);
+            pack_block(hv, hbL[2 * mb], hbL[2 * mb + 1]);
+        }
+        const float2 st2 = *reinterpret_cast<const float2 *>(p.stats + 2 * mc);
+        const float Ms = st2.x, inv = st2.y;
+        auto prob_block = [&](int ob, f32x16 &o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {      // rows rho(4g..4g+3, h) = 8g + 4h + 0..3: one 16-byte LDS read
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bLs + 32 * ob + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[4 * g + j] = b4[j];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hbL[s], o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[q] = __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -Ms)) * inv;
+            if (ob == OB - 1) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) o[q] = (32 * ob + rho(q, h) < p.out_dim) ? o[q] : 0.0f;
+            }
+        };
+        // upstream gradient of the probabilities: rank-1 (scale_m * G[ray_m]) or a dense bf16 [M,out_dim] tensor
+        const bool r1 = p.g_ray != nullptr;
+        const int g_idx1 = r1 ? p.g_index[mc] : 0;
+        const int g_idx0 = __builtin_amdgcn_readfirstlane(g_idx1);
+        const bool g_uni = __all(g_idx1 == g_idx0);
+        const float *g_row1 = r1 ? p.g_ray + (int64_t)g_idx1 * p.out_dim : nullptr;
+        const float *g_row_u = r1 ? p.g_ray + (int64_t)g_idx0 * p.out_dim : nullptr;
+        const float g_sc1 = r1 ? p.g_scale[mc] : 0.0f;
+        const bf16_t *gtile_g = reinterpret_cast<const bf16_t *>(p.grad_out) + tile * 32 * p.out_dim;
+        if (r1 && g_uni) {      // whole tile inside one ray (the common case): its gradient row goes to LDS once - the
+            // per-block scalar loads of rank1_block_uniform each exposed a full round trip with 2 waves per SIMD
+            for (int c = lane; c < OB * 32; c += 64) grow[c] = c < p.out_dim ? g_row_u[c] : 0.0f;
+            wave_lds_sync();
+        }
+        auto grad_block = [&](int ob, f32x16 &z) __attribute__((always_inline)) {
+            if (r1 && g_uni) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(grow + 32 * ob + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[4 * g + j] = g_sc1 * v[j];
+                }
+            } else if (r1) {
+                rank1_block(g_row1, g_sc1, 32 * ob, h, p.out_dim, z);
+            } else {
+                bf16x4 rz[4];
+                block32_stage_in(stg, 0, gtile_g, p.out_dim, 32 * ob, rows_valid, lane);
+                wave_lds_sync();
+                block32_read(stg, 0, r, h, rz);
+                wave_lds_sync();
+                raw_to_block(rz, z);
+            }
+        };
+        // pass 1 keeps the rebuilt probability blocks in registers (7 x 16 floats: the 8-wave workgroup runs 2 waves per
+        // SIMD, i.e. a 256-VGPR budget) - the exp2 of the rebuild is a quarter-rate instruction and was the largest item
+        float dot = 0.0f;
+        f32x16 pr[7];
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob) {
+            if (ob < OB) {
+                f32x16 z;
+                prob_block(ob, pr[ob]);
+                grad_block(ob, z);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dot += pr[ob][q] * z[q];
+            }
+        }
+        dot += __shfl_xor(dot, 32);
+        f32x16 acc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob) {
+            if (ob >= OB) break;
+            f32x16 zz, z;
+            grad_block(ob, z);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) zz[q] = pr[ob][q] * (z[q] - dot);
+            if (!tile_full) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) zz[q] = live ? zz[q] : 0.0f;
+            }
+            bf16x8 zb[2];
+            pack_block(zz, zb[0], zb[1]);
+            if ((p.out_dim & 7) == 0)
+                block32_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + tile * 32 * p.out_dim, p.out_dim, 32 * ob, rows_valid, lane, r, h, zz);
+            else if (live)
+                store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, zz, p.out_dim, vec_out);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * (2 * ob + half) + 8 * h);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[half], acc[mb], 0, 0, 0);
+                }
+        }
+        // ---- dA = W_L^T . dz_L masked by the saved ReLU output, then down the chain exactly as mlp_bwd_mfma
+        bf16x8 hb[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            f32x16 hv;
+            raw_to_block(hraw[NL - 2][mb], hv);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
+            pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
+        }
+        tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
+        if (NL == 3) {
+            bf16x8 hb2[4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(W1t + (32 * mb + r) * RS + 16 * s + 8 * h);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
+                }
+                f32x16 hv;
+                raw_to_block(hraw[0][mb], hv);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
+                pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
+            }
+            tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[0]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
+        }
+        if (p.dx1) {
+            DxT *dx = reinterpret_cast<DxT *>(p.dx1);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (32 * mb < p.k1) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(W0t + (32 * mb + r) * RS + 16 * s + 8 * h);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
+                    }
+                    if (live && !p.grp_L) store_block(dx + m * p.k1, 32 * mb, h, acc[mb], p.k1, true);
+                    if (live && p.grp_L) {
+                        bf16_t *dg = reinterpret_cast<bf16_t *>(p.dx1);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            bf16x4 v = {(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
+                            *reinterpret_cast<bf16x4 *>(dg + ((int64_t)(4 * mb + g) * p.M + m) * 8 + 4 * h) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ FP32 parity path
 // One lane per sample.  Weights transposed in LDS ([k][j]) so the 64 outputs of a layer are 16
 // broadcast ds_read_b128; the per-sample activation column lives in LDS ([k][lane]).
@@ -1264,6 +1486,7 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     p.in_pad = ((a->k1 + k2p + 15) / 16) * 16;
     p.out_dim = a->out_dim;
     p.act = a->out_act;
+    p.stats = (a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64) ? a->softmax_stats : nullptr;
     for (int l = 0; l < 3; ++l) {
         p.W[l] = l < a->n_layers ? a->W[l] : nullptr;
         p.b[l] = l < a->n_layers ? a->b[l] : nullptr;
@@ -1327,13 +1550,15 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a->in_dim > 0 && a->in_dim <= 64, "pag_mlp_bwd: in_dim %d out of range", a->in_dim);
     PAG_CHECK_ARG(a->out_dim >= 1 && a->out_dim <= 224, "pag_mlp_bwd: out_dim %d not in [1,224]", a->out_dim);
     PAG_CHECK_ARG(a->out_act >= PAG_ACT_NONE && a->out_act <= PAG_ACT_SOFTMAX, "pag_mlp_bwd: bad out_act %d", a->out_act);
-    PAG_CHECK_ARG(a->out_act == PAG_ACT_NONE || a->out, "pag_mlp_bwd: activated output needed for sigmoid/softmax");
+    PAG_CHECK_ARG(a->out_act == PAG_ACT_NONE || a->out || (a->softmax_stats && a->b_last),
+                  "pag_mlp_bwd: activated output (or softmax_stats + b_last) needed for sigmoid/softmax");
     PAG_CHECK_ARG(a->out_dtype == PAG_F32 || a->out_dtype == PAG_BF16, "pag_mlp_bwd: out dtype must be F32 or BF16");
     PAG_CHECK_ARG(a->dx1 == nullptr || a->dx1_dtype == PAG_F32 || a->dx1_dtype == PAG_BF16, "pag_mlp_bwd: dx1 dtype must be F32 or BF16");
     PAG_CHECK_ARG(a->mode == PAG_MLP_MFMA_BF16 || a->mode == PAG_MLP_FP32, "pag_mlp_bwd: bad mode %d", a->mode);
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(a->grad_out || (a->g_ray && a->g_scale && a->g_index), "pag_mlp_bwd: NULL grad_out (and no rank-1 gradient)");
-    PAG_CHECK_ARG(!a->g_ray || (a->mode == PAG_MLP_MFMA_BF16 && a->out), "pag_mlp_bwd: rank-1 gradients need MFMA mode and the saved output");
+    PAG_CHECK_ARG(!a->g_ray || (a->mode == PAG_MLP_MFMA_BF16 && (a->out || a->softmax_stats)),
+                  "pag_mlp_bwd: rank-1 gradients need MFMA mode and the saved output");
     for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && a->dz[l], "pag_mlp_bwd: NULL weight/dz of layer %d", l);
     for (int l = 0; l + 1 < a->n_layers; ++l) PAG_CHECK_ARG(a->hidden_save[l], "pag_mlp_bwd: NULL hidden_save[%d]", l);
     BwdParams p;
@@ -1364,7 +1589,32 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool out_f32 = a->out_dtype == PAG_F32;      // dtype of grad_out and of the saved activated output
     const bool dx_f32 = a->dx1 == nullptr || a->dx1_dtype == PAG_F32;
-    if (a->mode == PAG_MLP_MFMA_BF16) {
+    p.stats = a->softmax_stats;
+    p.b_last = a->b_last;
+    const bool wide_rebuild = a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64 && a->out_act == PAG_ACT_SOFTMAX && a->softmax_stats &&
+                              a->b_last && !out_f32 && (a->g_ray || (a->grad_out && a->out_dim % 8 == 0));
+    if (wide_rebuild) {
+        constexpr int NW = PAG_WIDE_BWD_WAVES;
+        const int OB = (a->out_dim + 31) / 32;
+        const size_t lds = (size_t)(64 * (OB * 32 + 8) + OB * 32 * RS + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t) +
+                           (size_t)OB * 32 * sizeof(float) + (size_t)NW * ST_BYTES + (size_t)NW * OB * 32 * sizeof(float);
+        const int64_t tiles = (M + 31) / 32;
+        const unsigned grid = (unsigned)std::min<int64_t>((tiles + NW - 1) / NW, 256);      // one workgroup per CU, tiles grid-strided
+#define MLP_BWD_WIDE(DxT, NL_)                                                                                              \
+    do {                                                                                                                    \
+        static bool attr_done = false;                                                                                      \
+        if (!attr_done) {                                                                                                   \
+            hipFuncSetAttribute((const void *)mlp_bwd_wide_mfma<DxT, NL_, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                               \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((mlp_bwd_wide_mfma<DxT, NL_, NW>), dim3(grid), dim3(NW * 64), lds, st, p);                     \
+    } while (0)
+        if (dx_f32 && a->n_layers == 2) MLP_BWD_WIDE(float, 2);
+        else if (dx_f32) MLP_BWD_WIDE(float, 3);
+        else if (a->n_layers == 2) MLP_BWD_WIDE(bf16_t, 2);
+        else MLP_BWD_WIDE(bf16_t, 3);
+#undef MLP_BWD_WIDE
+    } else if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;
         const size_t lds = (size_t)(64 * (OB * 32 + 8) + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t) + 4 * ST_BYTES;
         if (out_f32 && dx_f32) MLP_BWD_NL(float, float);

@@ -250,11 +250,19 @@ class _FusedMLP(torch.autograd.Function):
         a.out_act, a.out, a.out_dtype, a.mode = out_act, L.ptr(out), L.dtype_code(out), mode
         for i, h in enumerate(hidden):
             a.hidden_save[i] = L.ptr(h)
+        # wide softmax heads: per-sample (max*log2e, 1/sum) lets the backward rebuild the probabilities from the saved
+        # hidden layer instead of streaming `out` through twice (pag_mlp_bwd_args.softmax_stats)
+        stats = None
+        if need_grad and mode == L.MLP_MFMA_BF16 and out_act == L.ACT_SOFTMAX and out_dim > 64 and out_dtype == torch.bfloat16:
+            stats = torch.empty(M, 2, device=x1.device)
+            a.softmax_stats = L.ptr(stats)
         if M:
             _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
         ctx.cfg = (in_dim, out_act, mode, n_layers, k1, grouped)
         ctx.x2_packs = None
-        ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc)
+        ctx.has_stats = stats is not None
+        extra = (stats, bc[-1]) if stats is not None else ()
+        ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc, *extra)
         ctx.n_hidden = len(hidden)
         return out
 
@@ -270,7 +278,8 @@ class _FusedMLP(torch.autograd.Function):
         saved = ctx.saved_tensors
         x1, x2, x2_index, out = saved[:4]
         hidden = list(saved[4:4 + ctx.n_hidden])
-        Wc = list(saved[4 + ctx.n_hidden:])
+        Wc = list(saved[4 + ctx.n_hidden:4 + ctx.n_hidden + n_layers])
+        stats, b_last = (saved[-2], saved[-1]) if getattr(ctx, "has_stats", False) else (None, None)
         M = x1.shape[1] if grouped is not None else x1.shape[0]
         out_dim = Wc[-1].shape[0]
         dev = x1.device
@@ -294,6 +303,7 @@ class _FusedMLP(torch.autograd.Function):
         for i, h in enumerate(hidden):
             a.hidden_save[i] = L.ptr(h)
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
+        a.softmax_stats, a.b_last = L.ptr(stats), L.ptr(b_last)
         if M:
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
         gW, gb = [], []
