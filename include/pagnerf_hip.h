@@ -148,8 +148,9 @@ typedef struct {
     void *out; int out_dtype;
     void *hidden_save[2];
     int mode;
-    float *softmax_stats;   /* optional (MFMA mode, out_act SOFTMAX): f32 [M,2] = (max logit * log2(e), 1 / sum exp) per
-                               sample, from which the backward rebuilds the probabilities instead of reading `out` */
+    float *softmax_stats;   /* optional (MFMA mode, out_act SOFTMAX, out_dim > 64): f32 [M,2] = (max logit * log2(e),
+                               1 / sum exp) per sample, from which the backward and pag_head_composite_fwd rebuild the
+                               probabilities; `out` may then be NULL (nothing but the statistics is written) */
 } pag_mlp_fwd_args;
 int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
 
@@ -179,6 +180,16 @@ typedef struct {
     const float *softmax_stats; const float *b_last;
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
+
+/* Wide softmax head fused with the per-ray weighted sum of tracers/panoptic_packed_rf_tracer.py:197-205:
+ *   out[ray][c] = alpha[ray] * sum_{i in pack} weights[i] * softmax(W_last . hidden[i] + b_last)[c]
+ * from the forward's saved last hidden layer (bf16 [M,64]) and softmax_stats (pag_mlp_fwd with out = NULL): the
+ * [M, out_dim] probabilities are rebuilt tile by tile and never stored.  64 < out_dim <= 224; out f32 [N,out_dim]
+ * (rows of rays that have a pack are overwritten). */
+int pag_head_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
+                           const void *hidden, const float *W_last, const float *b_last, int out_dim,
+                           const float *softmax_stats, const float *weights, const float *alpha,
+                           float *out, void *stream);
 
 /* Weight and bias gradients of one Linear layer of pag_mlp_fwd (MFMA mode):
  *   dW[o][i] = sum_m dz[m][o] * a[m][i],  db[o] = sum_m dz[m][o]

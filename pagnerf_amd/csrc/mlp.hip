@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
                 float2 st2 = {Ms, inv};
                 *reinterpret_cast<float2 *>(p.stats + 2 * m) = st2;
             }
-            for (int ob = 0; ob < OB; ++ob) {
+            for (int ob = 0; ob < (p.out ? OB : 0); ++ob) {      // out == NULL: statistics only (pag_head_composite_fwd rebuilds)
                 f32x16 o;
                 out_block(ob, o);
                 if (p.act == PAG_ACT_SOFTMAX) {
@@ -1112,6 +1112,115 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
     }
 }
 
+// --------------------------------------------------- wide softmax head + per-ray weighted sum, forward
+// out[ray][c] = alpha[ray] * sum_i w_i * softmax(W_L h_i + b_L)[c]   (tracer :197-205 on the instance head) WITHOUT the
+// [M,200] probability tensor: the decoder forward only writes the per-sample softmax statistics, and this kernel -
+// one workgroup per ray, waves taking 32-sample tiles of that ray - rebuilds each tile's probabilities from the saved
+// last hidden layer exactly as mlp_bwd_wide_mfma does (same fragments, same MFMA sequence as the forward), scales
+// them by the sample weight and keeps the 7 x 16 per-lane partial sums in registers until the ray is finished.  The
+// sum over a tile's 32 samples is a sum over lanes: DPP row_shr 1/2/4/8 + row_bcast:15 put it on lanes 31 / 63, LDS
+// combines the four waves.  Reads 128 B per sample instead of 400 B, and the 839 MB tensor is never written.
+struct HeadCompParams {
+    const int64_t *pack_start;
+    const int32_t *ray_of_pack;
+    int64_t P;
+    const bf16_t *hidden;      // [M,64] last hidden layer (hidden_save of the forward)
+    const float *W, *b;        // [out_dim,64], [out_dim]
+    int out_dim;
+    const float *stats;        // [M,2]
+    const float *weights;      // [M]
+    const float *alpha;        // [N]
+    float *out;                // [N,out_dim]
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+
+__global__ __launch_bounds__(256) void head_composite_fwd_kernel(HeadCompParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int OB = (p.out_dim + 31) / 32;
+    bf16_t *WLs = reinterpret_cast<bf16_t *>(smem);                  // [OB*32][RS] permuted k (forward layout)
+    float *bLs = reinterpret_cast<float *>(WLs + OB * 32 * RS);      // [OB*32]
+    float *red = bLs + OB * 32;                                      // [4][OB*32]
+    bf16_t *stg = reinterpret_cast<bf16_t *>(red + 4 * OB * 32) + (threadIdx.x >> 6) * (ST_BYTES / 2);
+    stage_weight(WLs, RS, OB * 32, 64, p.W, p.out_dim, HID, true);
+    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b[e] : 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int r = lane & 31, h = lane >> 5;
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int64_t pk = blockIdx.x; pk < p.P; pk += gridDim.x) {
+        asm volatile("" : "+v"(r), "+v"(h));
+        const int64_t beg = p.pack_start[pk], end = p.pack_start[pk + 1];
+        const int64_t ntile = (end - beg + 31) / 32;
+        f32x16 acc[7];
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[ob][q] = 0.0f;
+        for (int64_t t = wave; t < ntile; t += 4) {
+            const int64_t base = beg + 32 * t;
+            const int rows_valid = (int)min((int64_t)32, end - base);
+            bf16x4 hraw[2][4];
+            tile64_load(stg, p.hidden + base * HID, rows_valid, lane, r, h, hraw);
+            bf16x8 hb[4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                f32x16 hv;
+                raw_to_block(hraw[mb], hv);
+                pack_block(hv, hb[2 * mb], hb[2 * mb + 1]);
+            }
+            const bool live = r < rows_valid;
+            const int64_t mc = live ? base + r : base;
+            const float2 st2 = *reinterpret_cast<const float2 *>(p.stats + 2 * mc);
+            const float Ms = st2.x, sw = live ? st2.y * p.weights[mc] : 0.0f;       // 1/sum folded into the sample weight
+#pragma unroll
+            for (int ob = 0; ob < 7; ++ob) {
+                if (ob < OB) {
+                    f32x16 o;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bLs + 32 * ob + 8 * g + 4 * h);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[4 * g + j] = b4[j];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], o, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[ob][q] = fmaf(sw, __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -Ms)), acc[ob][q]);
+                }
+            }
+        }
+        // ---- sum over the 32 sample lanes of each half, then over the four waves
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob) {
+            if (ob < OB) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float v = acc[ob][q];
+                    v = dpp_add<0x111, 0xF>(v);      // row_shr:1
+                    v = dpp_add<0x112, 0xF>(v);      // row_shr:2
+                    v = dpp_add<0x114, 0xF>(v);      // row_shr:4
+                    v = dpp_add<0x118, 0xF>(v);      // row_shr:8   -> lane 15 of every 16-lane row holds the row sum
+                    v = dpp_add<0x142, 0xA>(v);      // row_bcast:15 into rows 1, 3 -> lanes 31 / 63 hold the half's sum
+                    if (r == 31) red[wave * OB * 32 + 32 * ob + rho(q, h)] = v;
+                }
+            }
+        }
+        __syncthreads();
+        const int32_t ray = p.ray_of_pack[pk];
+        const float al = p.alpha[ray];
+        for (int c = threadIdx.x; c < p.out_dim; c += blockDim.x)
+            p.out[(int64_t)ray * p.out_dim + c] = al * (red[c] + red[OB * 32 + c] + red[2 * OB * 32 + c] + red[3 * OB * 32 + c]);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------ FP32 parity path
 // One lane per sample.  Weights transposed in LDS ([k][j]) so the 64 outputs of a layer are 16
 // broadcast ds_read_b128; the per-sample activation column lives in LDS ([k][lane]).
@@ -1475,7 +1584,9 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a->mode == PAG_MLP_MFMA_BF16 || a->mode == PAG_MLP_FP32, "pag_mlp_fwd: bad mode %d", a->mode);
     if (M == 0) return PAG_OK;
     for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && a->b[l], "pag_mlp_fwd: NULL weight/bias of layer %d", l);
-    PAG_CHECK_ARG(a->x1 && a->out, "pag_mlp_fwd: NULL x1/out");
+    PAG_CHECK_ARG(a->x1, "pag_mlp_fwd: NULL x1");
+    PAG_CHECK_ARG(a->out || (a->softmax_stats && a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64 && a->out_act == PAG_ACT_SOFTMAX),
+                  "pag_mlp_fwd: NULL out (allowed only for wide softmax heads that write softmax_stats)");
     FwdParams p;
     p.x1 = a->x1;
     p.x2 = a->x2;
@@ -1672,5 +1783,22 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
         else hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 6>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
     }
     PAG_CHECK_LAUNCH("pag_mlp_wgrad");
+    return PAG_OK;
+}
+
+extern "C" int pag_head_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const void *hidden,
+                                      const float *W_last, const float *b_last, int out_dim, const float *softmax_stats,
+                                      const float *weights, const float *alpha, float *out, void *stream) {
+    PAG_CHECK_ARG(P >= 0, "pag_head_composite_fwd: P < 0");
+    PAG_CHECK_ARG(out_dim > 64 && out_dim <= 224, "pag_head_composite_fwd: out_dim %d not in (64,224]", out_dim);
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(pack_start && ray_of_pack && hidden && W_last && b_last && softmax_stats && weights && alpha && out,
+                  "pag_head_composite_fwd: NULL input/output");
+    HeadCompParams p{pack_start, ray_of_pack, P, (const bf16_t *)hidden, W_last, b_last, out_dim, softmax_stats, weights, alpha, out};
+    const int OB = (out_dim + 31) / 32;
+    const size_t lds = (size_t)OB * 32 * RS * sizeof(bf16_t) + (size_t)5 * OB * 32 * sizeof(float) + 4 * ST_BYTES;
+    const unsigned grid = (unsigned)std::min<int64_t>(P, 512);
+    hipLaunchKernelGGL(head_composite_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    PAG_CHECK_LAUNCH("pag_head_composite_fwd");
     return PAG_OK;
 }

@@ -98,6 +98,8 @@ def _encode_fwd(spec, xyz, tables, feat_scale, out):
               spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, L.stream())
 
 
+_DTYPE_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
+
 BWD_ALGO = "binned"     # "binned": atomic-free two-pass scatter (default); "atomic": per-vertex fp32 global atomics
 
 
@@ -228,10 +230,12 @@ class _FusedMLP(torch.autograd.Function):
         if x1.dtype not in (torch.float32, torch.bfloat16):
             x1 = x1.float()
         out_dim = Ws[-1].shape[0]
-        out = torch.empty(M, out_dim, device=x1.device, dtype=out_dtype)
         need_grad = any(t.requires_grad for t in wb) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        wide_softmax = mode == L.MLP_MFMA_BF16 and out_act == L.ACT_SOFTMAX and out_dim > 64 and out_dtype == torch.bfloat16
+        stats_only = bool(getattr(ctx, "stats_only", False)) and wide_softmax       # _HeadComposite: no [M,out] tensor at all
+        out = None if stats_only else torch.empty(M, out_dim, device=x1.device, dtype=out_dtype)
         hdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
-        hidden = [torch.empty(M, 64, device=x1.device, dtype=hdt) for _ in range(n_layers - 1)] if need_grad else []
+        hidden = [torch.empty(M, 64, device=x1.device, dtype=hdt) for _ in range(n_layers - 1)] if (need_grad or stats_only) else []
         a = L.MlpFwdArgs()
         a.x1, a.x1_dtype, a.k1 = L.ptr(x1), L.dtype_code(x1), k1
         if grouped is not None:
@@ -247,13 +251,13 @@ class _FusedMLP(torch.autograd.Function):
         bc = [b.detach().contiguous().float() for b in bs]
         for i in range(n_layers):
             a.W[i], a.b[i] = L.ptr(Wc[i]), L.ptr(bc[i])
-        a.out_act, a.out, a.out_dtype, a.mode = out_act, L.ptr(out), L.dtype_code(out), mode
+        a.out_act, a.out, a.out_dtype, a.mode = out_act, L.ptr(out), _DTYPE_CODE[out_dtype], mode
         for i, h in enumerate(hidden):
             a.hidden_save[i] = L.ptr(h)
         # wide softmax heads: per-sample (max*log2e, 1/sum) lets the backward rebuild the probabilities from the saved
         # hidden layer instead of streaming `out` through twice (pag_mlp_bwd_args.softmax_stats)
         stats = None
-        if need_grad and mode == L.MLP_MFMA_BF16 and out_act == L.ACT_SOFTMAX and out_dim > 64 and out_dtype == torch.bfloat16:
+        if wide_softmax and (need_grad or stats_only):
             stats = torch.empty(M, 2, device=x1.device)
             a.softmax_stats = L.ptr(stats)
         if M:
@@ -261,9 +265,12 @@ class _FusedMLP(torch.autograd.Function):
         ctx.cfg = (in_dim, out_act, mode, n_layers, k1, grouped)
         ctx.x2_packs = None
         ctx.has_stats = stats is not None
+        ctx.out_dtype = out_dtype
         extra = (stats, bc[-1]) if stats is not None else ()
         ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc, *extra)
         ctx.n_hidden = len(hidden)
+        if stats_only:
+            ctx.fwd_state = (hidden[-1], Wc[-1], bc[-1], stats)
         return out
 
     @staticmethod
@@ -285,16 +292,17 @@ class _FusedMLP(torch.autograd.Function):
         dev = x1.device
         zdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
         dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
+        out_dtype = ctx.out_dtype
         need_dx = ctx.needs_input_grad[0]
         dx1 = torch.empty(x1.shape, device=dev, dtype=x1.dtype) if need_dx else None
         a = L.MlpBwdArgs()
         if rank1 is None:
-            g = g.contiguous().to(out.dtype)       # grad_out travels in the output's dtype
+            g = g.contiguous().to(out_dtype)       # grad_out travels in the output's dtype
             a.grad_out = L.ptr(g)
         else:
             g_ray, g_scale, g_index = rank1
             a.g_ray, a.g_scale, a.g_index = L.ptr(g_ray), L.ptr(g_scale), L.ptr(g_index)
-        a.out, a.out_dtype, a.out_act = L.ptr(out), L.dtype_code(out), out_act
+        a.out, a.out_dtype, a.out_act = L.ptr(out), _DTYPE_CODE[out_dtype], out_act
         a.k1, a.in_dim, a.n_layers, a.out_dim = k1, in_dim, n_layers, out_dim
         if grouped is not None:
             a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
@@ -659,6 +667,9 @@ def composite_features(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N):
     return _CompositeFeatsWeights.apply(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N)
 
 
+HEAD_REBUILD = True      # wide softmax heads under head_composite(): statistics-only forward + rebuilt probabilities
+
+
 class _HeadComposite(_FusedMLP):
     """decoder (+ softmax) followed by the per-ray weighted sum of tracer :197-205, as ONE autograd node: the
     backward hands the decoder the gradient in rank-1 form (alpha * w_m * d out[ray]) so neither the [M,C] gradient
@@ -666,13 +677,23 @@ class _HeadComposite(_FusedMLP):
 
     @staticmethod
     def forward(ctx, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dim, out_act, out_dtype, grouped, *wb):
+        ctx.stats_only = HEAD_REBUILD
         probs = _FusedMLP.forward(ctx, x1, None, None, in_dim, out_act, L.MLP_MFMA_BF16, out_dtype, grouped, *wb)
-        C = probs.shape[1]
+        C = wb[len(wb) // 2 - 1].shape[0]
         P = ray_of_pack.shape[0]
-        out = torch.zeros(N, C, device=probs.device)
+        M = x1.shape[1] if grouped is not None else x1.shape[0]
+        out = torch.zeros(N, C, device=x1.device)
         weights_w = weights_w.detach().contiguous()
         alpha = alpha.detach().contiguous()
-        if P and probs.shape[0]:
+        if probs is None:
+            # wide softmax head: the forward wrote only the softmax statistics; the per-ray sums are formed from
+            # probabilities rebuilt on the fly (pag_head_composite_fwd) - the [M, C] tensor never exists
+            hidden_last, W_last, b_last, stats = ctx.fwd_state
+            ctx.fwd_state = None
+            if P and M:
+                _call("pag_head_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(hidden_last), L.ptr(W_last),
+                      L.ptr(b_last), C, L.ptr(stats), L.ptr(weights_w), L.ptr(alpha), L.ptr(out), L.stream())
+        elif P and M:
             _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights_w), L.ptr(alpha),
                   L.ptr(probs), L.dtype_code(probs), C, L.ptr(out), L.stream())
         ctx.hc = (weights_w, alpha, ridx)

@@ -188,7 +188,12 @@ def test_head_composite_matches_unfused_path(gpu_device):
             (out * gout).sum().backward()
             res.append((out.detach(), xg.grad.float(), [t.grad for t in Wg], [t.grad for t in bg]))
         (o1, x1g, w1, b1), (o2, x2g, w2, b2) = res
-        assert torch.equal(o1, o2)
+        # narrow heads: same kernels on both paths, bit-equal; wide heads: the fused path sums fp32 probabilities rebuilt
+        # from the hidden layer (pag_head_composite_fwd), the unfused one their bf16-rounded copy
+        if dims[-1] <= 64:
+            assert torch.equal(o1, o2)
+        else:
+            np.testing.assert_allclose(o1.cpu().numpy(), o2.cpu().numpy(), rtol=4e-3, atol=1e-6)
         assert float(o1[5].abs().max()) == 0.0                      # empty ray
         for a_, b_ in [(x1g, x2g)] + list(zip(w1, w2)) + list(zip(b1, b2)):
             assert _rel_l2(a_.cpu(), b_.cpu()) < 1e-2, (dims, _rel_l2(a_.cpu(), b_.cpu()))   # unfused path rounds d_feats to bf16
