@@ -568,6 +568,16 @@ __device__ __forceinline__ void load_entry(const BinLayout &lay, int64_t pos, ui
     }
 }
 
+// value -> 2^-S fixed point.  Exact 64-bit conversion on the fp32-gradient path; on the packed bf16 path (entries already
+// rounded to 18 mantissa bits) a 32-bit convert of v * 2^(S-14) followed by a 14-bit shift: the quantum becomes
+// max|g| * 2^-24 per addend - far below the inputs' bf16 noise - and the software float -> int64 sequence, a third of this
+// kernel's VALU instructions, disappears.
+template <bool PACK>
+__device__ __forceinline__ long long to_fixed(float v, int S) {
+    if constexpr (PACK) return (long long)__float2int_rn(ldexpf(v, S - 14)) << 14;
+    else return __float2ll_rn(ldexpf(v, S));
+}
+
 template <int F, int NV, bool PACK>
 __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [2^shift][F] fixed point
@@ -613,7 +623,7 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
             const uint32_t key = key_n;
             long long val[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) val[f] = ok_n ? __float2ll_rn(ldexpf(val_n[f], S)) : 0ll;
+            for (int f = 0; f < F; ++f) val[f] = ok_n ? to_fixed<PACK>(val_n[f], S) : 0ll;
             const bool ok = ok_n;
             const uint32_t b = __shfl(mb, j), e = __shfl(me, j);
             const int64_t region = ((int64_t)level * lay.ntiles + (t0 + j)) * (TS * NV);
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
                     float fq[F];
                     load_entry<F, PACK>(lay, region + q, kq, fq);
 #pragma unroll
-                    for (int f = 0; f < F; ++f) vq[f] = __float2ll_rn(ldexpf(fq[f], S));
+                    for (int f = 0; f < F; ++f) vq[f] = to_fixed<PACK>(fq[f], S);
                 }
                 lds_accumulate<F>(acc, kq, vq, okq, lane);
             }
