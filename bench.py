@@ -96,7 +96,7 @@ def make_optimizer(nef):
         return torch.optim.Adam(groups, eps=1e-15)
 
 
-def train_step(nef, tracer, opt, rays, gt, channels, world):
+def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None):
     opt.zero_grad(set_to_none=True)
     rb = tracer(nef, channels=channels, rays=rays, stage="train")
     loss = 10.0 * torch.abs(rb.rgb - gt["rgb"]).mean()                                 # trainer.py:443-446, best.yaml:116
@@ -106,8 +106,7 @@ def train_step(nef, tracer, opt, rays, gt, channels, world):
         loss = loss + 1000.0 * (-torch.log(rb.inst_embedding[idx, gt["inst"]] + 1e-27)).mean()
     loss.backward()
     if world > 1:
-        from pagnerf_amd import shard
-        shard.allreduce_grads(nef.parameters())     # one flat RCCL all-reduce (pagnerf_amd/shard.py)
+        sync.finish()       # delta-table all-reduce was launched from the backward; the rest goes as one flat RCCL all-reduce
     opt.step()
     return loss
 
@@ -179,6 +178,11 @@ def main():
     nef, tracer = make_model(args, dev, seed=0)                 # same seed everywhere: replicated parameters
     rays, gt = make_rays(args.rays, dev, seed=1000 + rank)      # per-rank ray shard
     opt = make_optimizer(nef)
+    sync = None
+    if world > 1:
+        from pagnerf_amd import shard
+        early = [nef.delta_grid.tables] if hasattr(nef, "delta_grid") else []
+        sync = shard.GradSync(list(nef.parameters()), early=early)
     channels = {"rgb", "depth", "semantics", "inst_embedding"} if args.channels == "all" else {"rgb"}
 
     def barrier():
@@ -192,7 +196,7 @@ def main():
             ops.profile_start()
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            train_step(nef, tracer, opt, rays, gt, chans, world)
+            train_step(nef, tracer, opt, rays, gt, chans, world, sync)
         barrier()
         dt = time.perf_counter() - t0
         prof = ops.profile_stop() if profile else None
@@ -203,7 +207,7 @@ def main():
         return dt, prof
 
     for _ in range(args.warmup):
-        train_step(nef, tracer, opt, rays, gt, channels, world)
+        train_step(nef, tracer, opt, rays, gt, channels, world, sync)
     dt, prof = timed(args.steps, channels, profile=True)
 
     M = args.rays * args.samples
@@ -237,7 +241,7 @@ def main():
     aux = None
     if not args.no_aux and args.channels == "all":
         for _ in range(2):
-            train_step(nef, tracer, opt, rays, gt, {"rgb"}, world)
+            train_step(nef, tracer, opt, rays, gt, {"rgb"}, world, sync)
         dt_rgb, _ = timed(max(3, args.steps // 2), {"rgb"})
         n_aux = max(3, args.steps // 2)
         aux = dict(workload="same scene, channels {rgb} only (epochs < 601, best.yaml:89)",

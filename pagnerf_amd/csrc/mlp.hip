@@ -1797,7 +1797,10 @@ extern "C" int pag_head_composite_fwd(const int64_t *pack_start, const int32_t *
     HeadCompParams p{pack_start, ray_of_pack, P, (const bf16_t *)hidden, W_last, b_last, out_dim, softmax_stats, weights, alpha, out};
     const int OB = (out_dim + 31) / 32;
     const size_t lds = (size_t)OB * 32 * RS * sizeof(bf16_t) + (size_t)5 * OB * 32 * sizeof(float) + 4 * ST_BYTES;
-    const unsigned grid = (unsigned)std::min<int64_t>(P, 512);
+#ifndef PAG_HC_GRID
+#define PAG_HC_GRID 512
+#endif
+    const unsigned grid = (unsigned)std::min<int64_t>(P, PAG_HC_GRID);
     hipLaunchKernelGGL(head_composite_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     PAG_CHECK_LAUNCH("pag_head_composite_fwd");
     return PAG_OK;

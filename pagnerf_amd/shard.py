@@ -5,7 +5,8 @@ The reference is single-GPU; this is the build's own addi
 independent, so the hot path shards with no data-path exchange: every rank marches a contiguous block
 of rays against replicated tables / decoders / occupancy.  Two collectives exist around it:
   * rendering: ONE all_gather of the per-rank [n_local, C] buffer (all channels packed side by side);
-  * training:  ONE flat all_reduce of the gradients per step (2 x 50.3 MB tables + 0.14 MB decoders).
+  * training:  the delta grid's table gradient (50.3 MB, complete early in the backward) is all-reduced asynchronously
+    from a post-accumulate hook, the rest (50.3 MB main table + 0.14 MB decoders) as ONE flat all_reduce (GradSync).
 Both are single large messages - on MI355X's point-to-point xGMI mesh a ring is bound by one link, so
 fewer, larger collectives let RCCL spread traffic over all 7 links.
 """
@@ -80,6 +81,47 @@ def allreduce_grads(params, average=True):
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))
         off += g.numel()
+
+
+class GradSync:
+    """Gradient exchange of a training step with the early part overlapped with the rest of the backward.
+
+    `early` parameters (the delta grid's table: its gradient is complete after the panoptic heads' backward, before the
+    colour / density decoders and the main grid run theirs) are all-reduced asynchronously from a post-accumulate hook;
+    finish() waits for them, exchanges everything else as one flat all-reduce and averages.  On the xGMI mesh the 50 MB
+    early message therefore travels while the GPU still computes; only the main table (produced last) is exposed."""
+
+    def __init__(self, params, early=()):
+        self.params = list(params)
+        self.early = [p for p in early]
+        self._early_ids = {id(p) for p in self.early}
+        self._handles = []
+        self._hooks = []
+        _, world = world_info()
+        if world > 1:
+            for p in self.early:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._launch))
+
+    def _launch(self, p):
+        if p.grad is not None:
+            self._handles.append((p, dist.all_reduce(p.grad, async_op=True)))
+
+    def finish(self, average=True):
+        _, world = world_info()
+        if world == 1:
+            return
+        rest = [p for p in self.params if id(p) not in self._early_ids or not any(q is p for q, _ in self._handles)]
+        allreduce_grads(rest, average=average)
+        for p, h in self._handles:
+            h.wait()
+            if average:
+                p.grad /= world
+        self._handles = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def render_sharded(pipeline, rays, channels, **kwargs):

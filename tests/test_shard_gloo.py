@@ -52,6 +52,20 @@ def _worker(rank, world, port, n, q):
         mean = sum(range(1, world + 1)) / world
         assert torch.allclose(p1.grad, torch.full((5, 3), mean)) and torch.allclose(p2.grad, torch.arange(7.0) * mean)
         assert p3.grad is None
+        # GradSync: the early parameter is exchanged from its post-accumulate hook while the backward continues
+        a, b, c = (torch.nn.Parameter(torch.ones(4, 2)), torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2)))
+        sync = shard.GradSync([a, b, c], early=[a])
+        for step in range(2):
+            for prm in (a, b, c):
+                prm.grad = None
+            loss = (a * (rank + 1)).sum() * (step + 1) + (b * (rank + 2)).sum()          # c gets no gradient
+            loss.backward()
+            sync.finish()
+            mean_a = sum(r + 1 for r in range(world)) / world * (step + 1)
+            mean_b = sum(r + 2 for r in range(world)) / world
+            assert torch.allclose(a.grad, torch.full((4, 2), mean_a)) and torch.allclose(b.grad, torch.full((3,), mean_b)), step
+            assert c.grad is None
+        sync.remove()
         q.put((rank, "ok"))
     except Exception as e:          # surface the failure in the parent
         q.put((rank, repr(e)))
