@@ -203,6 +203,22 @@ def xcd8_columns(n_levels, n_feat):
     return cols
 
 
+_XCD8_POS = {}
+
+
+def _xcd8_positions(grouped, dev):
+    """i64 [levels*feats]: staged position of every feature column (cached per layout and device)."""
+    key = (tuple(grouped), str(dev))
+    if key not in _XCD8_POS:
+        cols = xcd8_columns(*grouped)
+        inv = [0] * (grouped[0] * grouped[1])
+        for p, c in enumerate(cols):
+            if c >= 0:
+                inv[c] = p
+        _XCD8_POS[key] = torch.tensor(inv, dtype=torch.int64, device=dev)
+    return _XCD8_POS[key]
+
+
 # ---------------------------------------------------------------------------------------------- MLP
 def _mm_f32(a, b):
     """a^T-free helper: a [K,M] @ b [M,N] with fp32 result (bf16 inputs accumulate in fp32)."""
@@ -336,12 +352,8 @@ class _FusedMLP(torch.autograd.Function):
                     n_in = 64
                 red = slabs.sum(0)
                 w = red[:n_out, :n_in]
-                if l == 0 and grouped is not None:      # staged XCD8 positions -> feature columns
-                    cols = xcd8_columns(*grouped)
-                    pos = [p for p, c in enumerate(cols) if c >= 0]
-                    full = torch.zeros(n_out, in_dim, device=dev)
-                    full[:, torch.tensor([cols[p] for p in pos], device=dev)] = w[:, torch.tensor(pos, device=dev)]
-                    w = full
+                if l == 0 and grouped is not None:      # staged XCD8 positions -> feature columns (one gather)
+                    w = w.index_select(1, _xcd8_positions(grouped, dev))
                 gW.append(w.contiguous())
                 gb.append(red[:n_out, 64].contiguous())
         else:
