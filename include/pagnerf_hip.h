@@ -85,6 +85,17 @@ int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int 
                            const float *feat_scale_host, void *out, int out_dtype,
                            int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream);
 
+/* Same encoders writing  out = bf16(addend + bf16(features))  in the XCD8 layout (addend, out: bf16 [8][M][8]).
+ * pc_nerf/panoptic_delta_nef.py:226 forms the panoptic features as `feats.detach() + delta`; with the main grid's
+ * features as addend the delta grid's encoder emits that sum directly (bit-identical to the separate bf16 add). */
+int pag_hash_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype,
+                            int n_levels, int n_feat, int log2_T, const float *resolutions_host,
+                            const float *feat_scale_host, const void *addend, void *out, void *stream);
+int pag_permuto_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype,
+                               int n_levels, int n_feat, uint32_t capacity,
+                               const float *scale_factor_host, const float *shift_host,
+                               const float *feat_scale_host, const void *addend, void *out, void *stream);
+
 int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
                            int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                            uint32_t capacity, const float *scale_factor_host,

@@ -23,12 +23,19 @@ namespace {
 // (zero padded): each lane stores ONE aligned 16-byte piece holding all the levels it computed, a wave
 // stores 1 KiB contiguously - instead of LPX*F scattered 2-byte pieces per sample in a [M, L*F] row
 // (measured 8x write amplification).  The decoders read the same pieces as MFMA B fragments.
+// addend (optional, same layout): the piece stored is bf16(addend + bf16(value)) - exactly what a separate bf16 tensor add
+// of the two feature tensors yields (pc_nerf/panoptic_delta_nef.py:226 `feats.detach() + delta`), without the pass.
 template <int N>
-__device__ __forceinline__ void store_grouped(bf16_t *out, int64_t M, int g, int64_t i, const float (&v)[N]) {
+__device__ __forceinline__ void store_grouped(bf16_t *out, int64_t M, int g, int64_t i, const float (&v)[N], const bf16_t *addend) {
     typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
     bf16x8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(e < N ? v[e < N ? e : 0] : 0.0f);
+    if (addend) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(addend + ((int64_t)g * M + i) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)o[e]);
+    }
     *reinterpret_cast<bf16x8_t *>(out + ((int64_t)g * M + i) * 8) = o;
 }
 __device__ __forceinline__ void store_grouped(float *, int64_t, int, int64_t, ...) {}
@@ -36,7 +43,8 @@ __device__ __forceinline__ void store_grouped(float *, int64_t, int, int64_t, ..
 template <typename TableT, typename OutT, int F, int LPX>
 __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                        const TableT *__restrict__ tables, HashParams p,
-                                                       OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped) {
+                                                       OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped,
+                                                       const bf16_t *__restrict__ addend) {
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
         }
     }
     if constexpr (LPX * F <= 8 && sizeof(OutT) == 2)
-        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals);
+        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals, addend);
 }
 
 template <typename GradT, int F, int LPX>
@@ -116,7 +124,8 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(const float *__restrict__
 template <typename TableT, typename OutT, int F, int LPX>
 __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                           const TableT *__restrict__ tables, PermutoParams p,
-                                                          OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped) {
+                                                          OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped,
+                                                          const bf16_t *__restrict__ addend) {
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
         }
     }
     if constexpr (LPX * F <= 8 && sizeof(OutT) == 2)
-        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals);
+        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals, addend);
 }
 
 template <typename GradT, int F, int LPX>
@@ -759,9 +768,12 @@ int check_common(const char *name, const void *xyz, int64_t M, int n_levels, int
 
 }  // namespace
 
-extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
-                                   int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
-                                   void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream) {
+static int hash_encode_fwd_impl(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
+                                int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
+                                void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, int layout,
+                                const void *addend_p, void *stream) {
+    const bf16_t *addend = (const bf16_t *)addend_p;
+    PAG_CHECK_ARG(!addend || layout == PAG_LAYOUT_XCD8, "pag_hash_encode_fwd_add: the addend needs the XCD8 layout");
     int rc = check_common("pag_hash_encode_fwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_fwd: log2_T %d not in [1,30]", log2_T);
@@ -784,17 +796,31 @@ extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tabl
     dim3 grid(encode_grid(M)), block(256);
     bool launched = false;
     if (table_dtype == PAG_F32 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else if (table_dtype == PAG_F32 && out_dtype == PAG_BF16) {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else if (table_dtype == PAG_F16 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else {
-        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((hash_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend)))
     }
     PAG_CHECK_ARG(launched, "pag_hash_encode_fwd: unsupported (n_feat=%d, n_levels=%d)", n_feat, n_levels);
     PAG_CHECK_LAUNCH("pag_hash_encode_fwd");
     return PAG_OK;
+}
+
+extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
+                                   int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
+                                   void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream) {
+    return hash_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, log2_T, resolutions_host, feat_scale_host, out, out_dtype,
+                                out_stride_m, out_stride_c, layout, nullptr, stream);
+}
+
+extern "C" int pag_hash_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
+                                       int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
+                                       const void *addend, void *out, void *stream) {
+    return hash_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, log2_T, resolutions_host, feat_scale_host, out, PAG_BF16, 0,
+                                0, PAG_LAYOUT_XCD8, addend, stream);
 }
 
 extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
@@ -855,10 +881,12 @@ static int fill_permuto(PermutoParams &p, int n_levels, int n_feat, uint32_t cap
     return 0;
 }
 
-extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
-                                      int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
-                                      const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
-                                      int64_t out_stride_c, int layout, void *stream) {
+static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
+                                   int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
+                                   const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
+                                   int64_t out_stride_c, int layout, const void *addend_p, void *stream) {
+    const bf16_t *addend = (const bf16_t *)addend_p;
+    PAG_CHECK_ARG(!addend || layout == PAG_LAYOUT_XCD8, "pag_permuto_encode_fwd_add: the addend needs the XCD8 layout");
     int rc = check_common("pag_permuto_encode_fwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_fwd: capacity is 0");
@@ -877,17 +905,32 @@ extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *t
     dim3 grid(encode_grid(M)), block(256);
     bool launched = false;
     if (table_dtype == PAG_F32 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else if (table_dtype == PAG_F32 && out_dtype == PAG_BF16) {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else if (table_dtype == PAG_F16 && out_dtype == PAG_F32) {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else {
-        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped)))
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend)))
     }
     PAG_CHECK_ARG(launched, "pag_permuto_encode_fwd: unsupported (n_feat=%d, n_levels=%d)", n_feat, n_levels);
     PAG_CHECK_LAUNCH("pag_permuto_encode_fwd");
     return PAG_OK;
+}
+
+extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
+                                      int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
+                                      const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
+                                      int64_t out_stride_c, int layout, void *stream) {
+    return permuto_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host,
+                                   out, out_dtype, out_stride_m, out_stride_c, layout, nullptr, stream);
+}
+
+extern "C" int pag_permuto_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
+                                          int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
+                                          const float *feat_scale_host, const void *addend, void *out, void *stream) {
+    return permuto_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host,
+                                   out, PAG_BF16, 0, 0, PAG_LAYOUT_XCD8, addend, stream);
 }
 
 extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,

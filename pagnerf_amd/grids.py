@@ -137,10 +137,10 @@ class _GridBase(OccupancyBLAS):
     def _coords(self, coords):
         return coords.reshape(-1, 3)
 
-    def interpolate_scaled(self, coords, feat_scale=None, out_dtype=torch.float32, layout=None):
+    def interpolate_scaled(self, coords, feat_scale=None, out_dtype=torch.float32, layout=None, addend=None):
         """interpolate() with the nef's lod_weights folded into the kernel; layout="xcd8" returns the bf16
-        [8, M, 8] XCD-grouped features the fused decoders consume (ops.encode)."""
-        return ops.encode(self._coords(coords), self.tables, self._spec, feat_scale, out_dtype, False, layout=layout)
+        [8, M, 8] XCD-grouped features the fused decoders consume (ops.encode); addend: see ops.encode."""
+        return ops.encode(self._coords(coords), self.tables, self._spec, feat_scale, out_dtype, False, layout=layout, addend=addend)
 
 
 class HashGridHIP(_GridBase):

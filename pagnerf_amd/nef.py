@@ -173,9 +173,22 @@ class PanopticDeltaNeF(nn.Module):
             return (self.num_lods, self.feature_dim)
         return None
 
-    def _interp(self, grid, coords):
+    def _interp(self, grid, coords, addend=None):
         lw = None if bool((self.lod_weights == 1).all()) else self.lod_weights
-        return grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None)
+        return grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None,
+                                       addend=addend)
+
+    def _panoptic_feats(self, feats_detached, coords):
+        """:210-236 - `feats.detach() + delta` ('delta'), delta alone ('separate') or the main features ('appearance').
+        On the grouped bf16 path the sum is formed inside the delta grid's encode launch (same rounding as the tensor add)."""
+        t = self.panoptic_features_type
+        if t == "appearance":
+            return feats_detached
+        if t == "separate":
+            return self._interp(self.delta_grid, coords.detach())
+        if self._grouped() is not None:
+            return self._interp(self.delta_grid, coords.detach(), addend=feats_detached)
+        return feats_detached + self._interp(self.delta_grid, coords.detach())
 
     def rgb_semantics(self, coords, ray_d=None, compute_channels=None, pidx=None, lod_idx=None, ridx=None, ray_dirs=None,
                       ray_packs=None):
@@ -204,15 +217,7 @@ class PanopticDeltaNeF(nn.Module):
                                      x2_packs=ray_packs if ridx is not None else None)
             out["rgb"] = rgb.reshape(batch, num_samples, 3)
         if "semantics" in compute_channels or "inst_embedding" in compute_channels:    # :210-236
-            t = self.panoptic_features_type
-            if t in ("delta", "separate", None):
-                delta = self._interp(self.delta_grid, coords.detach())
-            if t in ("delta", None):
-                pan = feats.detach() + delta
-            elif t == "separate":
-                pan = delta
-            else:
-                pan = feats.detach()
+            pan = self._panoptic_feats(feats.detach(), coords)
             if "semantics" in compute_channels:                                        # :238-244
                 plain = not (self.sem_sigmoid or self.sem_normalize)
                 act = L.ACT_SOFTMAX if (self.sem_softmax and plain) else L.ACT_NONE
@@ -251,10 +256,7 @@ class PanopticDeltaNeF(nn.Module):
         node whose backward feeds the decoder a rank-1 gradient (ops.head_composite)."""
         cache = getattr(self, "_feat_cache", None)
         feats = cache[1] if cache is not None and cache[0] is coords else self._interp(self.grid, coords).detach()
-        t = self.panoptic_features_type
-        if t in ("delta", "separate", None):
-            delta = self._interp(self.delta_grid, coords.detach())
-        pan = feats + delta if t in ("delta", None) else (delta if t == "separate" else feats)
+        pan = self._panoptic_feats(feats, coords)
         grp = self._grouped()
         out = {}
         for ch, dec in (("semantics", self.decoder_semantics), ("inst_embedding", self.decoder_inst)):

@@ -86,10 +86,19 @@ def _layout_args(t):
     return t.stride(0), t.stride(1), L.LAYOUT_STRIDED
 
 
-def _encode_fwd(spec, xyz, tables, feat_scale, out):
+def _encode_fwd(spec, xyz, tables, feat_scale, out, addend=None):
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
     sm, sc, lay = _layout_args(out)
+    if addend is not None:                    # out = bf16(addend + bf16(features)), XCD8 layout only
+        assert lay == L.LAYOUT_XCD8 and addend.shape == out.shape and addend.dtype == torch.bfloat16 and addend.is_contiguous()
+        if spec.kind == "hash":
+            _call("pag_hash_encode_fwd_add", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T, spec.res, fs,
+                  L.ptr(addend), out.data_ptr(), L.stream())
+        else:
+            _call("pag_permuto_encode_fwd_add", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity, spec.sf,
+                  spec.shift, fs, L.ptr(addend), out.data_ptr(), L.stream())
+        return
     if spec.kind == "hash":
         _call("pag_hash_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
               spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, L.stream())
@@ -140,7 +149,7 @@ def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale):
 
 class _Encode(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, tables, spec, feat_scale, out_dtype, feature_major):
+    def forward(ctx, xyz, tables, spec, feat_scale, out_dtype, feature_major, addend=None):
         _check_gpu(xyz, tables)
         xyz = xyz.detach().contiguous().float()
         M, C = xyz.shape[0], spec.L * spec.F
@@ -154,7 +163,7 @@ class _Encode(torch.autograd.Function):
             out = torch.empty(M, C, device=xyz.device, dtype=out_dtype)
         tc = tables.detach().contiguous()
         if M:
-            _encode_fwd(spec, xyz, tc, feat_scale, out)
+            _encode_fwd(spec, xyz, tc, feat_scale, out, addend.detach() if addend is not None else None)
         ctx.spec, ctx.feat_scale = spec, feat_scale
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(xyz, tc)           # d/d xyz needs the table rows again
@@ -179,13 +188,14 @@ class _Encode(torch.autograd.Function):
             gt = gt.to(ctx.tdtype)
         if need_x:
             d_xyz = _encode_bwd_xyz(ctx.spec, xyz, ctx.saved_tensors[1], g, ctx.feat_scale) if xyz.shape[0] else torch.zeros_like(xyz)
-        return d_xyz, gt, None, None, None, None
+        return d_xyz, gt, None, None, None, None, None
 
 
-def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None):
+def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None, addend=None):
     """Grid features [M, L*F] (column = level*F + f); layout="xcd8" returns the bf16 [8, M, 8] XCD-grouped tensor the
-    fused decoders consume directly.  Differentiable w.r.t. tables and (when xyz.requires_grad) xyz."""
-    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major)
+    fused decoders consume directly.  Differentiable w.r.t. tables and (when xyz.requires_grad) xyz.
+    addend (xcd8 only, treated as a constant): the result is bf16(addend + bf16(features)) in the same launch."""
+    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major, addend)
 
 
 def xcd8_supported(n_levels, n_feat):

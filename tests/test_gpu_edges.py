@@ -116,3 +116,27 @@ def test_occupancy_update_bit_exact(gpu_device):
             assert torch.equal(occ.cpu(), occ_ref)
             got = ((bits.cpu().long()[:, None] >> torch.arange(32)) & 1).bool().reshape(-1)[:cells]
             assert torch.equal(got, mask), (cells, it)
+
+
+def test_encode_with_addend_equals_separate_bf16_add(gpu_device):
+    """pag_*_encode_fwd_add: bf16(addend + bf16(features)) in one launch == the tensor add of panoptic_delta_nef.py:226."""
+    from pagnerf_amd import ops
+    from oracle import permuto_encode as op
+    dev = gpu_device
+    rs = np.random.RandomState(31)
+    M = 5000
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(M, 3)).astype(np.float32)).to(dev)
+    addend = torch.randn(8, M, 8, device=dev).bfloat16()
+    sf = op.scale_factors(np.geomspace(1.0, 1e-3, 24))
+    shifts = (rs.standard_normal(size=(24, 3)) * 10).astype(np.float32)
+    pspec = ops.permuto_spec(sf, shifts, 1 << 12, 2)
+    hspec = ops.hash_spec([16.0 * 1.4 ** i for i in range(16)], 12, 2)
+    for spec, Lv in ((pspec, 24), (hspec, 16)):
+        tab = torch.randn(Lv, 1 << 12, 2, device=dev).requires_grad_(True)
+        plain = ops.encode(x, tab, spec, layout="xcd8")
+        fused = ops.encode(x, tab, spec, layout="xcd8", addend=addend)
+        assert torch.equal(fused, addend + plain)
+        g = torch.randn_like(fused)
+        (g1,) = torch.autograd.grad(fused, tab, g)
+        (g2,) = torch.autograd.grad(addend + plain, tab, g)
+        assert torch.equal(g1, g2)
