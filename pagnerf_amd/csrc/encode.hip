@@ -25,18 +25,26 @@ namespace {
 // (measured 8x write amplification).  The decoders read the same pieces as MFMA B fragments.
 // addend (optional, same layout): the piece stored is bf16(addend + bf16(value)) - exactly what a separate bf16 tensor add
 // of the two feature tensors yields (pc_nerf/panoptic_delta_nef.py:226 `feats.detach() + delta`), without the pass.
+typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+// the addend piece is requested at the top of the kernel so that its latency hides under the lattice arithmetic
+__device__ __forceinline__ bf16x8_t load_addend(const bf16_t *addend, int64_t M, int g, int64_t i) {
+    bf16x8_t a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (bf16_t)0.0f;
+    if (addend) a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t *>(addend + ((int64_t)g * M + i) * 8));   // streamed once: keep the tables in L2
+    return a;
+}
 template <int N>
-__device__ __forceinline__ void store_grouped(bf16_t *out, int64_t M, int g, int64_t i, const float (&v)[N], const bf16_t *addend) {
-    typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void store_grouped(bf16_t *out, int64_t M, int g, int64_t i, const float (&v)[N], bool has_addend,
+                                              const bf16x8_t &a) {
     bf16x8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(e < N ? v[e < N ? e : 0] : 0.0f);
-    if (addend) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(addend + ((int64_t)g * M + i) * 8);
+    if (has_addend) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)o[e]);
     }
-    *reinterpret_cast<bf16x8_t *>(out + ((int64_t)g * M + i) * 8) = o;
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8_t *>(out + ((int64_t)g * M + i) * 8));
 }
 __device__ __forceinline__ void store_grouped(float *, int64_t, int, int64_t, ...) {}
 
@@ -49,6 +57,7 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
     float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    const bf16x8_t addv = load_addend(addend, M, g, i);
     const int64_t T = (int64_t)1 << p.log2T;
     float e[LPX][8][F];
     float w[LPX][3];
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
         }
     }
     if constexpr (LPX * F <= 8 && sizeof(OutT) == 2)
-        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals, addend);
+        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals, addend != nullptr, addv);
 }
 
 template <typename GradT, int F, int LPX>
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
     float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    const bf16x8_t addv = load_addend(addend, M, g, i);
     float e[LPX][4][F];
     float bary[LPX][4];
     float gvals[LPX * F <= 8 ? LPX * F : 1];
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
         }
     }
     if constexpr (LPX * F <= 8 && sizeof(OutT) == 2)
-        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals, addend);
+        if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals, addend != nullptr, addv);
 }
 
 template <typename GradT, int F, int LPX>
