@@ -189,6 +189,8 @@ typedef struct {
      * bias the wide-head backward recomputes the probabilities from hidden_save (4 MFMAs per 32-channel block on idle
      * matrix cores) instead of streaming the [M, out_dim] output through twice; `out` may then be NULL. */
     const float *softmax_stats; const float *b_last;
+    int dx1_accumulate;   /* XCD8 dx1 only: add this decoder's input gradient to what dx1 already holds (two heads on the
+                             same panoptic features - saves the separate gradient-sum pass) */
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 

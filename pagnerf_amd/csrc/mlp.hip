@@ -78,6 +78,7 @@ struct BwdParams {
     int grp_L, grp_F;      // dx1 (and layer-0 weight columns) in PAG_LAYOUT_XCD8 order when grp_L > 0
     const float *stats;    // forward's softmax statistics + last-layer bias: the wide kernel recomputes the probabilities
     const float *b_last;
+    int dx1_acc;           // XCD8 dx1: add to the existing contents instead of overwriting
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
@@ -637,6 +638,16 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
 #pragma unroll
         for (int l = 0; l < NL - 1; ++l)
             tile64_load(stg, reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rows_valid, lane, r, h, hraw[l]);
+        // dx1_accumulate: the other decoder's gradient pieces are requested now and added at the end of the tile
+        bf16x4 oldx[2][4];
+        if (p.dx1_acc) {
+            const bf16_t *dg = reinterpret_cast<const bf16_t *>(p.dx1);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    oldx[mb][g] = *reinterpret_cast<const bf16x4 *>(dg + ((int64_t)(4 * mb + g) * p.M + mc) * 8 + 4 * h);
+        }
         // ---- dz of the output layer -> bf16 B fragments (k-steps of the first backward MFMA chain W_L^T . dz_L)
         bf16x8 zb[OBMAX > 2 ? 2 : 2 * OBMAX];          // wide heads consume each block's two fragments immediately
         f32x16 acc[2];
@@ -891,8 +902,13 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
                         bf16_t *dg = reinterpret_cast<bf16_t *>(p.dx1);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
+                            bf16x4 *dst = reinterpret_cast<bf16x4 *>(dg + ((int64_t)(4 * mb + g) * p.M + m) * 8 + 4 * h);
+                            if (p.dx1_acc) {      // second decoder on the same input: add to the first one's gradient in place
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] += (float)oldx[mb][g][j];
+                            }
                             bf16x4 v = {(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
-                            *reinterpret_cast<bf16x4 *>(dg + ((int64_t)(4 * mb + g) * p.M + m) * 8 + 4 * h) = v;
+                            *dst = v;
                         }
                     }
                 }
@@ -1102,8 +1118,14 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
                         bf16_t *dg = reinterpret_cast<bf16_t *>(p.dx1);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
+                            bf16x4 *dst = reinterpret_cast<bf16x4 *>(dg + ((int64_t)(4 * mb + g) * p.M + m) * 8 + 4 * h);
+                            if (p.dx1_acc) {
+                                const bf16x4 o = *dst;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] += (float)o[j];
+                            }
                             bf16x4 v = {(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
-                            *reinterpret_cast<bf16x4 *>(dg + ((int64_t)(4 * mb + g) * p.M + m) * 8 + 4 * h) = v;
+                            *dst = v;
                         }
                     }
                 }
@@ -1702,6 +1724,8 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     const bool dx_f32 = a->dx1 == nullptr || a->dx1_dtype == PAG_F32;
     p.stats = a->softmax_stats;
     p.b_last = a->b_last;
+    p.dx1_acc = a->dx1_accumulate;
+    PAG_CHECK_ARG(!a->dx1_accumulate || (p.grp_L && a->dx1), "pag_mlp_bwd: dx1_accumulate needs an XCD8 dx1");
     const bool wide_rebuild = a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64 && a->out_act == PAG_ACT_SOFTMAX && a->softmax_stats &&
                               a->b_last && !out_f32 && (a->g_ray || (a->grad_out && a->out_dim % 8 == 0));
     if (wide_rebuild) {

@@ -259,6 +259,12 @@ class PanopticDeltaNeF(nn.Module):
         pan = self._panoptic_feats(feats, coords)
         grp = self._grouped()
         out = {}
+        if "semantics" in channels and "inst_embedding" in channels and grp is not None:
+            # both heads read the same features: one autograd node, the input gradient is summed inside the kernels
+            heads = tuple((*dec.weights(), dec.input_dim) for dec in (self.decoder_inst, self.decoder_semantics))
+            out["inst_embedding"], out["semantics"] = ops.head_composite_pair(pan, heads, w, alpha, ridx, pack_start, ray_of_pack, N,
+                                                                              out_dtype=self.feat_dtype, x1_grouped=grp)
+            return out
         for ch, dec in (("semantics", self.decoder_semantics), ("inst_embedding", self.decoder_inst)):
             if ch in channels:
                 W, b = dec.weights()

@@ -304,8 +304,9 @@ class _FusedMLP(torch.autograd.Function):
         return _FusedMLP._backward_impl(ctx, g, None)
 
     @staticmethod
-    def _backward_impl(ctx, g, rank1):
-        """rank1 = (g_ray f32 [N,out], g_scale f32 [M], g_index i32 [M]) replaces the dense upstream gradient g."""
+    def _backward_impl(ctx, g, rank1, dx1_into=None):
+        """rank1 = (g_ray f32 [N,out], g_scale f32 [M], g_index i32 [M]) replaces the dense upstream gradient g.
+        dx1_into: an XCD8 gradient tensor of another decoder on the same input - this one's d x1 is added to it in place."""
         lib = L.load()
         in_dim, out_act, mode, n_layers, k1, grouped = ctx.cfg
         saved = ctx.saved_tensors
@@ -320,7 +321,7 @@ class _FusedMLP(torch.autograd.Function):
         dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
         out_dtype = ctx.out_dtype
         need_dx = ctx.needs_input_grad[0]
-        dx1 = torch.empty(x1.shape, device=dev, dtype=x1.dtype) if need_dx else None
+        dx1 = (dx1_into if dx1_into is not None else torch.empty(x1.shape, device=dev, dtype=x1.dtype)) if need_dx else None
         a = L.MlpBwdArgs()
         if rank1 is None:
             g = g.contiguous().to(out_dtype)       # grad_out travels in the output's dtype
@@ -338,6 +339,7 @@ class _FusedMLP(torch.autograd.Function):
             a.hidden_save[i] = L.ptr(h)
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
         a.softmax_stats, a.b_last = L.ptr(stats), L.ptr(b_last)
+        a.dx1_accumulate = 1 if (need_dx and dx1_into is not None) else 0
         if M:
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
         gW, gb = [], []
@@ -723,11 +725,58 @@ class _HeadComposite(_FusedMLP):
 
     @staticmethod
     def backward(ctx, g):
+        dx1, gwb = _HeadComposite._backward_pair(ctx, g, None)
+        return (dx1, None, None, None, None, None, None, None, None, None, None, *gwb)
+
+    @staticmethod
+    def _backward_pair(ctx, g, dx1_into):
         weights_w, alpha, ridx = ctx.hc
         scale = weights_w * alpha[ridx.long()]                       # alpha * w_m per sample (detached, :148-155)
-        grads = _FusedMLP._backward_impl(ctx, None, (g.contiguous().float(), scale.contiguous(), ridx.contiguous()))
-        dx1, gwb = grads[0], grads[8:]
-        return (dx1, None, None, None, None, None, None, None, None, None, None, *gwb)
+        grads = _FusedMLP._backward_impl(ctx, None, (g.contiguous().float(), scale.contiguous(), ridx.contiguous()), dx1_into)
+        return grads[0], grads[8:]
+
+
+class _SubCtx:
+    """Per-head stand-in for the autograd ctx inside _HeadCompositePair."""
+
+    def __init__(self, needs_x1):
+        self.needs_input_grad = (needs_x1, False)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _HeadCompositePair(torch.autograd.Function):
+    """Two head_composite() decoders on the SAME grouped input (semantic + instance heads on the panoptic features) as one
+    autograd node: the second decoder's backward adds its input gradient into the first one's tensor in place
+    (pag_mlp_bwd_args.dx1_accumulate) instead of autograd summing two [8,M,8] tensors in a separate pass."""
+
+    @staticmethod
+    def forward(ctx, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dims, out_dtype, grouped, n_a, *wb):
+        subs, outs = [], []
+        for i, part in enumerate((wb[:n_a], wb[n_a:])):
+            sub = _SubCtx(ctx.needs_input_grad[0])
+            outs.append(_HeadComposite.forward(sub, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dims[i], L.ACT_SOFTMAX,
+                                               out_dtype, grouped, *part))
+            subs.append(sub)
+        ctx.subs, ctx.n_a = subs, n_a
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        sub_a, sub_b = ctx.subs
+        # wide head first (it writes dx1), the narrow one accumulates
+        ga = _HeadComposite._backward_pair(sub_a, g_a, None)
+        gb = _HeadComposite._backward_pair(sub_b, g_b, ga[0])
+        return (ga[0], None, None, None, None, None, None, None, None, None, None, *ga[1], *gb[1])
+
+
+def head_composite_pair(x1, heads, w, alpha, ridx, pack_start, ray_of_pack, N, out_dtype=torch.bfloat16, x1_grouped=None):
+    """heads = ((weights, biases, in_dim), (weights, biases, in_dim)) -> (out_a, out_b), each as head_composite()."""
+    (wa, ba, ia), (wb_, bb, ib) = heads
+    return _HeadCompositePair.apply(x1, w, alpha, ridx, pack_start, ray_of_pack, N, (int(ia), int(ib)), out_dtype, x1_grouped,
+                                    len(wa) + len(ba), *wa, *ba, *wb_, *bb)
 
 
 def head_composite(x1, weights, biases, w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=None, out_act=L.ACT_NONE,

@@ -9,7 +9,7 @@ from pagnerf_amd import ops, grids  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 21)
-L, F, cap = 24, 2, 1 << 18
+L, F, cap = (int(sys.argv[2]) if len(sys.argv) > 2 else 24), 2, 1 << 18
 torch.manual_seed(0)
 # ray-like sample order: 512 samples along each of M/512 rays
 o = (torch.rand(M // 512, 1, 3, device=dev) - 0.5) * 0.2

@@ -824,3 +824,44 @@ def test_pose_gradients_bf16_path_tracks_fp32(gpu_device):
         assert float(grads[precision][0].abs().sum()) == 0.0            # anchor frame: masked (ba_pipeline.py:56-60)
         assert nef.grid.tables.grad is not None and nef.delta_grid.tables.grad is not None
     assert _rel_l2(grads["bf16"], grads["fp32"]) < 0.1, grads
+
+
+def test_head_composite_pair_equals_two_nodes(gpu_device):
+    """semantic + instance heads as ONE autograd node with in-kernel accumulation of the input gradient (dx1_accumulate) vs two
+    head_composite() nodes whose input gradients autograd adds."""
+    ops, L = _ops()
+    rs = np.random.RandomState(23)
+    N, Lv, F = 50, 24, 2
+    counts = rs.randint(1, 90, size=N)
+    counts[7] = 0
+    M = int(counts.sum())
+    ridx = torch.from_numpy(np.repeat(np.arange(N), counts).astype(np.int32)).to(gpu_device)
+    pack_start = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(gpu_device)
+    ray_of_pack = torch.arange(N, dtype=torch.int32, device=gpu_device)
+    w = torch.from_numpy(rs.uniform(0, 0.05, size=M).astype(np.float32)).to(gpu_device)
+    alpha = torch.from_numpy(rs.uniform(0.1, 1, size=N).astype(np.float32)).to(gpu_device)
+    x = torch.randn(8, M, 8, device=gpu_device).bfloat16()
+    cols = ops.xcd8_columns(Lv, F)
+    pad = torch.tensor([c < 0 for c in cols], device=gpu_device)
+    x.permute(1, 0, 2).reshape(M, 64)[:, pad] = 0
+    dims_a, dims_b = (48, 64, 64, 200), (48, 64, 6)
+    Wa, ba = _rand_mlp(rs, dims_a)
+    Wb, bb = _rand_mlp(rs, dims_b)
+    ga = torch.from_numpy(rs.standard_normal(size=(N, 200)).astype(np.float32)).to(gpu_device)
+    gb = torch.from_numpy(rs.standard_normal(size=(N, 6)).astype(np.float32)).to(gpu_device)
+    res = []
+    for pair in (True, False):
+        P = [[t.to(gpu_device).requires_grad_(True) for t in lst] for lst in (Wa, ba, Wb, bb)]
+        xg = x.clone().requires_grad_(True)
+        if pair:
+            oa, ob = ops.head_composite_pair(xg, ((P[0], P[1], 48), (P[2], P[3], 48)), w, alpha, ridx, pack_start, ray_of_pack, N,
+                                             x1_grouped=(Lv, F))
+        else:
+            oa = ops.head_composite(xg, P[0], P[1], w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=48, out_act=L.ACT_SOFTMAX, x1_grouped=(Lv, F))
+            ob = ops.head_composite(xg, P[2], P[3], w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=48, out_act=L.ACT_SOFTMAX, x1_grouped=(Lv, F))
+        ((oa * ga).sum() + (ob * gb).sum()).backward()
+        res.append((oa.detach(), ob.detach(), xg.grad.float(), [t.grad for lst in P for t in lst]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert _rel_l2(res[0][2].cpu(), res[1][2].cpu()) < 6e-3          # one bf16 rounding of the sum instead of two + one
+    for g1, g2 in zip(res[0][3], res[1][3]):
+        assert torch.equal(g1, g2)
