@@ -298,6 +298,29 @@ __device__ __forceinline__ void tile64_load(bf16_t *stg, const bf16_t *gtile, in
         for (int g = 0; g < 4; ++g) raw[mb][g] = *reinterpret_cast<const bf16x4 *>(stg + r * ST_RS + 32 * mb + 8 * g + 4 * h);
     wave_lds_sync();
 }
+// tile64_load in two phases so that the global request of the NEXT tile can be in flight during the current tile's work
+// (these kernels run 2 waves per SIMD: an exposed round trip per tile costs more than anything else in them)
+__device__ __forceinline__ void tile64_fetch(const bf16_t *gtile, int rows_valid, int lane, bf16x8 (&v)[4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        v[it] = zero8();
+        if (row < rows_valid) v[it] = *reinterpret_cast<const bf16x8 *>(gtile + row * HID + c);
+    }
+}
+__device__ __forceinline__ void tile64_unstage(bf16_t *stg, const bf16x8 (&v)[4], int lane, int r, int h, bf16x4 (&raw)[2][4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        *reinterpret_cast<bf16x8 *>(stg + row * ST_RS + c) = v[it];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) raw[mb][g] = *reinterpret_cast<const bf16x4 *>(stg + r * ST_RS + 32 * mb + 8 * g + 4 * h);
+    wave_lds_sync();
+}
 // columns [col0, col0+32) of rows [0,32) of a row-major [M,W] bf16 tensor (W % 8 == 0) at gtile (= tensor + tile*32*W):
 // staged into LDS columns [lcol, lcol+32) (two tensors can share the buffer: lcol = 0 / 32)
 __device__ __forceinline__ void block32_stage_in(bf16_t *stg, int lcol, const bf16_t *gtile, int W, int col0, int rows_valid, int lane) {
@@ -625,6 +648,16 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
     const int64_t tile_step = (int64_t)gridDim.x * 4;
     RawO nz[PREFETCH ? OBMAX : 1][4], ny[PREFETCH ? OBMAX : 1][4];
     if constexpr (PREFETCH) load_g((int64_t)blockIdx.x * 4 + wave, nz, ny);
+    bf16x8 hnext[PREFETCH ? NL - 1 : 1][4];      // next tile's hidden rows, in flight during the current tile
+    auto fetch_h = [&](int64_t tile, bf16x8 (&hn)[PREFETCH ? NL - 1 : 1][4]) __attribute__((always_inline)) {
+        if (tile < ntiles) {
+            const int rv = (int)min((int64_t)32, p.M - tile * 32);
+#pragma unroll
+            for (int l = 0; l < NL - 1; ++l)
+                tile64_fetch(reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rv, lane, hn[l]);
+        }
+    };
+    if constexpr (PREFETCH) fetch_h((int64_t)blockIdx.x * 4 + wave, hnext);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
         if constexpr (OBMAX > 2) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
             asm volatile("" : "+v"(r), "+v"(h));
@@ -635,9 +668,15 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
         // ReLU masks of the hidden layers: requested first, consumed after the first MFMA chain
         const int rows_valid = (int)min((int64_t)32, p.M - tile * 32);
         bf16x4 hraw[NL - 1][2][4];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int l = 0; l < NL - 1; ++l)
-            tile64_load(stg, reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rows_valid, lane, r, h, hraw[l]);
+            for (int l = 0; l < NL - 1; ++l) tile64_unstage(stg, hnext[l], lane, r, h, hraw[l]);
+            fetch_h(tile + tile_step, hnext);
+        } else {
+#pragma unroll
+            for (int l = 0; l < NL - 1; ++l)
+                tile64_load(stg, reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rows_valid, lane, r, h, hraw[l]);
+        }
         // dx1_accumulate: the other decoder's gradient pieces are requested now and added at the end of the tile
         bf16x4 oldx[2][4];
         if (p.dx1_acc) {
