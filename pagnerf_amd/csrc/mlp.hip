@@ -1221,11 +1221,26 @@ __global__ __launch_bounds__(256) void head_composite_fwd_kernel(HeadCompParams 
         for (int ob = 0; ob < 7; ++ob)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[ob][q] = 0.0f;
+        bf16x8 hnext[4];
+        float2 stn = {0.0f, 0.0f};
+        float wn = 0.0f;
+        auto fetch = [&](int64_t t) __attribute__((always_inline)) {      // next tile's rows / statistics / weight: in flight during this tile
+            if (t < ntile) {
+                const int64_t base = beg + 32 * t;
+                const int rv = (int)min((int64_t)32, end - base);
+                tile64_fetch(p.hidden + base * HID, rv, lane, hnext);
+                const int64_t mc = r < rv ? base + r : base;
+                stn = *reinterpret_cast<const float2 *>(p.stats + 2 * mc);
+                wn = r < rv ? p.weights[mc] : 0.0f;
+            }
+        };
+        fetch(wave);
         for (int64_t t = wave; t < ntile; t += 4) {
-            const int64_t base = beg + 32 * t;
-            const int rows_valid = (int)min((int64_t)32, end - base);
             bf16x4 hraw[2][4];
-            tile64_load(stg, p.hidden + base * HID, rows_valid, lane, r, h, hraw);
+            tile64_unstage(stg, hnext, lane, r, h, hraw);
+            const float2 st2 = stn;
+            const float wcur = wn;
+            fetch(t + 4);
             bf16x8 hb[4];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1233,10 +1248,7 @@ __global__ __launch_bounds__(256) void head_composite_fwd_kernel(HeadCompParams 
                 raw_to_block(hraw[mb], hv);
                 pack_block(hv, hb[2 * mb], hb[2 * mb + 1]);
             }
-            const bool live = r < rows_valid;
-            const int64_t mc = live ? base + r : base;
-            const float2 st2 = *reinterpret_cast<const float2 *>(p.stats + 2 * mc);
-            const float Ms = st2.x, sw = live ? st2.y * p.weights[mc] : 0.0f;       // 1/sum folded into the sample weight
+            const float Ms = st2.x, sw = st2.y * wcur;       // 1/sum folded into the sample weight (0 for lanes past the pack's end)
 #pragma unroll
             for (int ob = 0; ob < 7; ++ob) {
                 if (ob < OB) {
