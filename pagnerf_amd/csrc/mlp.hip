@@ -990,6 +990,18 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
     const bool vec_out = (p.out_dim % 4) == 0;
     constexpr float LOG2E = 1.4426950408889634f;
     const int64_t tile_step = (int64_t)gridDim.x * NW;
+    // the next tile's hidden rows are requested as soon as the probability blocks of the current one are dead (after the
+    // second pass), so their round trip hides under the rest of the layer chain instead of opening the next tile
+    bf16x8 hnext[NL - 1][4];
+    auto fetch_h = [&](int64_t tile) __attribute__((always_inline)) {
+        if (tile < ntiles) {
+            const int rv = (int)min((int64_t)32, p.M - tile * 32);
+#pragma unroll
+            for (int l = 0; l < NL - 1; ++l)
+                tile64_fetch(reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rv, lane, hnext[l]);
+        }
+    };
+    fetch_h((int64_t)blockIdx.x * NW + wave);
     for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += tile_step) {
         asm volatile("" : "+v"(r), "+v"(h));      // keep lane-constant addresses from being hoisted and spilled
         const int64_t m = tile * 32 + r;
@@ -999,8 +1011,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
         const bool tile_full = (tile + 1) * 32 <= p.M;
         bf16x4 hraw[NL - 1][2][4];
 #pragma unroll
-        for (int l = 0; l < NL - 1; ++l)
-            tile64_load(stg, reinterpret_cast<const bf16_t *>(p.hsave[l]) + tile * 32 * HID, rows_valid, lane, r, h, hraw[l]);
+        for (int l = 0; l < NL - 1; ++l) tile64_unstage(stg, hnext[l], lane, r, h, hraw[l]);
         // the forward's B operand of the output layer: the saved bf16 activations, re-packed (exact)
         bf16x8 hbL[4];
 #pragma unroll
@@ -1066,15 +1077,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
         // pass 1 keeps the rebuilt probability blocks in registers (7 x 16 floats: the 8-wave workgroup runs 2 waves per
         // SIMD, i.e. a 256-VGPR budget) - the exp2 of the rebuild is a quarter-rate instruction and was the largest item
         float dot = 0.0f;
-        f32x16 pr[7];
+        bf16x8 pr[7][2];      // kept as bf16 (the precision the stored probabilities had): 56 registers instead of 112
 #pragma unroll
         for (int ob = 0; ob < 7; ++ob) {
             if (ob < OB) {
-                f32x16 z;
-                prob_block(ob, pr[ob]);
+                f32x16 z, pf;
+                prob_block(ob, pf);
                 grad_block(ob, z);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) dot += pr[ob][q] * z[q];
+                for (int q = 0; q < 16; ++q) dot += pf[q] * z[q];
+                pack_block(pf, pr[ob][0], pr[ob][1]);
             }
         }
         dot += __shfl_xor(dot, 32);
@@ -1089,7 +1101,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
             f32x16 zz, z;
             grad_block(ob, z);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) zz[q] = pr[ob][q] * (z[q] - dot);
+            for (int q = 0; q < 16; ++q) zz[q] = (float)pr[ob][q >> 3][q & 7] * (z[q] - dot);
             if (!tile_full) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) zz[q] = live ? zz[q] : 0.0f;
@@ -1108,6 +1120,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
                     acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[half], acc[mb], 0, 0, 0);
                 }
         }
+        fetch_h(tile + tile_step);
         // ---- dA = W_L^T . dz_L masked by the saved ReLU output, then down the chain exactly as mlp_bwd_mfma
         bf16x8 hb[4];
 #pragma unroll
