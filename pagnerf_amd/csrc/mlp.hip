@@ -1002,6 +1002,31 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
         }
     };
     fetch_h((int64_t)blockIdx.x * NW + wave);
+    // ... and so are its per-sample scalars and (when the tile lies inside one ray) the ray's gradient row
+    const bool r1 = p.g_ray != nullptr;
+    float2 st_n = {0.0f, 1.0f};
+    int gi_n = 0;
+    float gs_n = 0.0f, grow_n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool uni_n = false;
+    auto fetch_s = [&](int64_t tile) __attribute__((always_inline)) {
+        if (tile < ntiles) {
+            const int64_t m_ = tile * 32 + r;
+            const int64_t mc_ = m_ < p.M ? m_ : p.M - 1;
+            st_n = *reinterpret_cast<const float2 *>(p.stats + 2 * mc_);
+            if (r1) {
+                gi_n = p.g_index[mc_];
+                gs_n = p.g_scale[mc_];
+                const int g0 = __builtin_amdgcn_readfirstlane(gi_n);
+                uni_n = __all(gi_n == g0);
+                if (uni_n) {
+                    const float *row = p.g_ray + (int64_t)g0 * p.out_dim;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) grow_n[k] = (lane + 64 * k < p.out_dim) ? row[lane + 64 * k] : 0.0f;
+                }
+            }
+        }
+    };
+    fetch_s((int64_t)blockIdx.x * NW + wave);
     for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += tile_step) {
         asm volatile("" : "+v"(r), "+v"(h));      // keep lane-constant addresses from being hoisted and spilled
         const int64_t m = tile * 32 + r;
@@ -1020,8 +1045,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
             raw_to_block(hraw[NL - 2][mb], hv);
             pack_block(hv, hbL[2 * mb], hbL[2 * mb + 1]);
         }
-        const float2 st2 = *reinterpret_cast<const float2 *>(p.stats + 2 * mc);
-        const float Ms = st2.x, inv = st2.y;
+        const float Ms = st_n.x, inv = st_n.y;
         auto prob_block = [&](int ob, f32x16 &o) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {      // rows rho(4g..4g+3, h) = 8g + 4h + 0..3: one 16-byte LDS read
@@ -1042,17 +1066,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
             }
         };
         // upstream gradient of the probabilities: rank-1 (scale_m * G[ray_m]) or a dense bf16 [M,out_dim] tensor
-        const bool r1 = p.g_ray != nullptr;
-        const int g_idx1 = r1 ? p.g_index[mc] : 0;
-        const int g_idx0 = __builtin_amdgcn_readfirstlane(g_idx1);
-        const bool g_uni = __all(g_idx1 == g_idx0);
+        const int g_idx1 = gi_n;
+        const bool g_uni = uni_n;
         const float *g_row1 = r1 ? p.g_ray + (int64_t)g_idx1 * p.out_dim : nullptr;
-        const float *g_row_u = r1 ? p.g_ray + (int64_t)g_idx0 * p.out_dim : nullptr;
-        const float g_sc1 = r1 ? p.g_scale[mc] : 0.0f;
+        const float g_sc1 = gs_n;
         const bf16_t *gtile_g = reinterpret_cast<const bf16_t *>(p.grad_out) + tile * 32 * p.out_dim;
         if (r1 && g_uni) {      // whole tile inside one ray (the common case): its gradient row goes to LDS once - the
             // per-block scalar loads of rank1_block_uniform each exposed a full round trip with 2 waves per SIMD
-            for (int c = lane; c < OB * 32; c += 64) grow[c] = c < p.out_dim ? g_row_u[c] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lane + 64 * k < OB * 32) grow[lane + 64 * k] = grow_n[k];
             wave_lds_sync();
         }
         auto grad_block = [&](int ob, f32x16 &z) __attribute__((always_inline)) {
@@ -1121,6 +1144,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
                 }
         }
         fetch_h(tile + tile_step);
+        fetch_s(tile + tile_step);
         // ---- dA = W_L^T . dz_L masked by the saved ReLU output, then down the chain exactly as mlp_bwd_mfma
         bf16x8 hb[4];
 #pragma unroll
