@@ -1519,7 +1519,8 @@ constexpr int WG_RS = 72;       // LDS row stride (bf16) of the transposed tiles
 constexpr int WG_SLAB_COLS = 96;
 
 template <typename A1T, int APW /* accumulator blocks per wave: 2 (<= 8 block pairs) or 6 */>
-__global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradParams p) {
+// narrow variant: asking for 5 workgroups per CU keeps every accumulator in VGPRs (no AGPR copies) under 102 registers
+__global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.n_out + 31) / 32;
     const int IB = (p.n_in + 31) / 32;                 // 1 or 2
