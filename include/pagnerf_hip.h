@@ -219,6 +219,11 @@ int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1
                   int a1_layout, int k1, const float *a2, int k2p, const int32_t *a2_index, int n_in,
                   float *slabs, int n_blocks, int64_t M, void *stream);
 
+/* Deterministic sum of those slabs into the final gradients: dW f32 [n_out, n_in] (for XCD8 inputs the staged
+ * positions are mapped back to feature columns level*F + f) and db f32 [n_out]. */
+int pag_mlp_wgrad_finish(const float *slabs, int n_blocks, int n_out, int n_in, int a1_layout,
+                         int a1_levels, int a1_feats, float *dW, float *db, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray march (wisp OctreeAS.raymarch, 'ray' mode) - tracers/panoptic_packed_rf_tracer.py:85-86
  * ------------------------------------------------------------------------------------------ */

@@ -1899,6 +1899,53 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
     return PAG_OK;
 }
 
+// Sum the per-workgroup slabs of pag_mlp_wgrad into the final dW [n_out][n_in] / db [n_out] (fixed order: deterministic).
+// One workgroup per output row, 4 slab quarters x 96 columns; XCD8 inputs: slab column p is a staged position and lands in
+// feature column grp_col(p).
+constexpr int WF_SPLITS = 10;      // slab range split over 10 x 96 threads of the row's workgroup
+__global__ __launch_bounds__(WF_SPLITS * WG_SLAB_COLS) void wgrad_finish_kernel(const float *__restrict__ slabs, int n_blocks, int rows_pad, int n_in,
+                                                           int grp_L, int grp_F, float *__restrict__ dW, float *__restrict__ db) {
+    __shared__ float part[WF_SPLITS][WG_SLAB_COLS];
+    const int o = blockIdx.x, c = threadIdx.x % WG_SLAB_COLS, q = threadIdx.x / WG_SLAB_COLS;
+    const int64_t stride = (int64_t)rows_pad * WG_SLAB_COLS;
+    const float *src = slabs + (int64_t)o * WG_SLAB_COLS + c;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int b = q;
+    for (; b + 3 * WF_SPLITS < n_blocks; b += 4 * WF_SPLITS) {
+        a0 += src[(int64_t)b * stride];
+        a1 += src[(int64_t)(b + WF_SPLITS) * stride];
+        a2 += src[(int64_t)(b + 2 * WF_SPLITS) * stride];
+        a3 += src[(int64_t)(b + 3 * WF_SPLITS) * stride];
+    }
+    for (; b < n_blocks; b += WF_SPLITS) a0 += src[(int64_t)b * stride];
+    part[q][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WF_SPLITS; ++k) v += part[k][c];
+        if (c == 64) {
+            db[o] = v;
+        } else if (c < 64) {
+            const int col = grp_L ? grp_col(c, grp_L, grp_F) : c;
+            if (col >= 0 && col < n_in) dW[(int64_t)o * n_in + col] = v;
+        }
+    }
+}
+
+extern "C" int pag_mlp_wgrad_finish(const float *slabs, int n_blocks, int n_out, int n_in, int a1_layout, int a1_levels, int a1_feats,
+                                    float *dW, float *db, void *stream) {
+    PAG_CHECK_ARG(n_blocks >= 1 && n_out >= 1 && n_out <= 224 && n_in >= 1 && n_in <= 64, "pag_mlp_wgrad_finish: size out of range");
+    PAG_CHECK_ARG(slabs && dW && db, "pag_mlp_wgrad_finish: NULL slabs/dW/db");
+    const int grouped = a1_layout == PAG_LAYOUT_XCD8;
+    PAG_CHECK_ARG(!grouped || (a1_levels >= 1 && a1_feats >= 1 && a1_levels * a1_feats == n_in && ((a1_levels + 7) / 8) * a1_feats <= 8),
+                  "pag_mlp_wgrad_finish: XCD8 needs n_in = levels*feats");
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(n_out), dim3(WF_SPLITS * WG_SLAB_COLS), 0, (hipStream_t)stream, slabs, n_blocks, (n_out + 31) / 32 * 32, n_in,
+                       grouped ? a1_levels : 0, a1_feats, dW, db);
+    PAG_CHECK_LAUNCH("pag_mlp_wgrad_finish");
+    return PAG_OK;
+}
+
 extern "C" int pag_head_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const void *hidden,
                                       const float *W_last, const float *b_last, int out_dim, const float *softmax_stats,
                                       const float *weights, const float *alpha, float *out, void *stream) {

@@ -362,12 +362,13 @@ class _FusedMLP(torch.autograd.Function):
                     _call("pag_mlp_wgrad", L.ptr(dz[l]), dz[l].shape[1], n_out, L.ptr(hidden[l - 1]), L.BF16, L.LAYOUT_STRIDED, 64,
                           None, 0, None, 64, L.ptr(slabs), nblk, M, L.stream())
                     n_in = 64
-                red = slabs.sum(0)
-                w = red[:n_out, :n_in]
-                if l == 0 and grouped is not None:      # staged XCD8 positions -> feature columns (one gather)
-                    w = w.index_select(1, _xcd8_positions(grouped, dev))
-                gW.append(w.contiguous())
-                gb.append(red[:n_out, 64].contiguous())
+                w = torch.empty(n_out, in_dim if l == 0 else 64, device=dev)
+                bgrad = torch.empty(n_out, device=dev)
+                is_grp = l == 0 and grouped is not None
+                _call("pag_mlp_wgrad_finish", L.ptr(slabs), nblk, n_out, w.shape[1], L.LAYOUT_XCD8 if is_grp else L.LAYOUT_STRIDED,
+                      grouped[0] if is_grp else 0, grouped[1] if is_grp else 0, L.ptr(w), L.ptr(bgrad), L.stream())
+                gW.append(w)
+                gb.append(bgrad)
         else:
             # fp32 parity path: dz_l^T @ input_l as plain fp32 GEMMs (BLAS)
             for l in range(n_layers):
