@@ -624,50 +624,47 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
     __syncthreads();
     const uint32_t *hb = lay.header + ((int64_t)level * (lay.NS + 1) + slice) * lay.ntiles;
     const uint32_t *he = hb + lay.ntiles;
+    // A (tile, slice) segment holds ~20 entries on average (the fine levels fill all 64 slices evenly), so walking one
+    // segment per wave-iteration left two thirds of the lanes idle.  Instead the segments of 64 consecutive tiles are
+    // treated as ONE concatenated stream: lane l takes stream element 64*c + l, finds its tile by a 6-step binary search
+    // over the wave's exclusive prefix of segment lengths (shuffles) and reads that tile's region at the right offset.
     for (int64_t t0 = (int64_t)wave * 64; t0 < lay.ntiles; t0 += (int64_t)nwaves * 64) {
         const int64_t tl = t0 + lane;
         const uint32_t mb = tl < lay.ntiles ? hb[tl] : 0u, me = tl < lay.ntiles ? he[tl] : 0u;
-        const int nt = (int)min((int64_t)64, lay.ntiles - t0);
-        // software pipeline: the first 64 entries of tile j+1 are in flight while tile j is accumulated
+        uint32_t incl = me - mb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t excl = incl - (me - mb);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        const int64_t region0 = ((int64_t)level * lay.ntiles + t0) * (TS * NV);
+        auto fetch = [&](uint32_t c0, uint32_t &key, float (&val)[F]) __attribute__((always_inline)) {
+            const uint32_t i = c0 + lane;
+            const bool ok = i < total;
+            int t = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int cand = t + step;
+                const uint32_t pe = (uint32_t)__shfl((int)excl, cand & 63);
+                if (pe <= i) t = cand;                       // cand <= 63 always: t + step never exceeds 63
+            }
+            const uint32_t bt = (uint32_t)__shfl((int)mb, t), et = (uint32_t)__shfl((int)excl, t);
+            if (ok) load_entry<F, PACK>(lay, region0 + (int64_t)t * (TS * NV) + bt + (i - et), key, val);
+            return ok;
+        };
         uint32_t key_n = 0;
         float val_n[F];
-        bool ok_n = false;
-        {
-            const uint32_t b = __shfl(mb, 0), e = __shfl(me, 0);
-            const int64_t region = ((int64_t)level * lay.ntiles + t0) * (TS * NV);
-            ok_n = b + lane < e;
-            if (ok_n) load_entry<F, PACK>(lay, region + b + lane, key_n, val_n);
-        }
-        for (int j = 0; j < nt; ++j) {
+        bool ok_n = total ? fetch(0, key_n, val_n) : false;
+        for (uint32_t c0 = 0; c0 < total; c0 += 64) {
             const uint32_t key = key_n;
             long long val[F];
 #pragma unroll
             for (int f = 0; f < F; ++f) val[f] = ok_n ? to_fixed<PACK>(val_n[f], S) : 0ll;
             const bool ok = ok_n;
-            const uint32_t b = __shfl(mb, j), e = __shfl(me, j);
-            const int64_t region = ((int64_t)level * lay.ntiles + (t0 + j)) * (TS * NV);
-            if (j + 1 < nt) {
-                const uint32_t b2 = __shfl(mb, j + 1), e2 = __shfl(me, j + 1);
-                const int64_t region2 = region + TS * NV;
-                ok_n = b2 + lane < e2;
-                if (ok_n) load_entry<F, PACK>(lay, region2 + b2 + lane, key_n, val_n);
-            }
+            ok_n = (c0 + 64 < total) ? fetch(c0 + 64, key_n, val_n) : false;      // next chunk in flight during the accumulate
             lds_accumulate<F>(acc, key, val, ok, lane);
-            for (uint32_t q0 = b + 64; q0 < e; q0 += 64) {       // long segments
-                const uint32_t q = q0 + lane;
-                const bool okq = q < e;
-                uint32_t kq = 0;
-                long long vq[F];
-#pragma unroll
-                for (int f = 0; f < F; ++f) vq[f] = 0ll;
-                if (okq) {
-                    float fq[F];
-                    load_entry<F, PACK>(lay, region + q, kq, fq);
-#pragma unroll
-                    for (int f = 0; f < F; ++f) vq[f] = to_fixed<PACK>(fq[f], S);
-                }
-                lds_accumulate<F>(acc, kq, vq, okq, lane);
-            }
         }
     }
     __syncthreads();
