@@ -1538,7 +1538,7 @@ __global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(Wgra
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)(r == 0 ? 1.0f : 0.0f);
     const A1T *a1 = reinterpret_cast<const A1T *>(p.a1);
-    const bool dz_vec = (p.dz_cols % 8) == 0;
+    const bool dz_vec = (p.dz_cols % 8) == 0 && (p.n_out % 8) == 0;
     const int64_t nchunks = (p.M + 63) / 64;
     // global -> register fetch of one 8-column piece of this lane's sample row (dz tile / input tile)
     auto fetch_z = [&](int64_t chunk, int cg) __attribute__((always_inline)) {
@@ -1547,13 +1547,13 @@ __global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(Wgra
         const int64_t mc = live ? m : p.M - 1;
         const int c0 = 8 * cg;
         bf16x8 v = zero8();
-        if (live && c0 < p.dz_cols) {
+        if (live && c0 < p.n_out) {      // n_out <= dz_cols: dz may point at a band of columns of a wider row
             if (dz_vec) {
                 v = load8(p.dz + mc * p.dz_cols + c0);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (c0 + j < p.dz_cols) v[j] = p.dz[mc * p.dz_cols + c0 + j];
+                    if (c0 + j < p.n_out) v[j] = p.dz[mc * p.dz_cols + c0 + j];
             }
         }
         return v;
