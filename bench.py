@@ -162,8 +162,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PAG_BENCH_SHARE_GPU=1 (testing only): every rank uses cuda:0 and the collectives go through gloo, so the multi-process
+    # code path can be exercised on a one-GPU box; the real launch is one rank per GPU over RCCL ("nccl" on ROCm).
+    share = os.environ.get("PAG_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
