@@ -167,7 +167,8 @@ def test_head_composite_matches_unfused_path(gpu_device):
     ray_of_pack = torch.arange(N, dtype=torch.int32, device=gpu_device)
     w = torch.from_numpy(rs.uniform(0, 0.05, size=M).astype(np.float32)).to(gpu_device)
     alpha = torch.from_numpy(rs.uniform(0.1, 1, size=N).astype(np.float32)).to(gpu_device)
-    for dims, grp in (((48, 64, 64, 200), (Lv, F)), ((48, 64, 6), (Lv, F))):
+    # wide 3-layer head (best.yaml), narrow head, wide 2-layer head, wide head whose width is not a multiple of 8
+    for dims, grp in (((48, 64, 64, 200), (Lv, F)), ((48, 64, 6), (Lv, F)), ((48, 64, 200), (Lv, F)), ((48, 64, 64, 100), (Lv, F))):
         W, b = _rand_mlp(rs, dims)
         x = torch.randn(8, M, 8, device=gpu_device).bfloat16()
         cols = ops.xcd8_columns(Lv, F)
