@@ -213,22 +213,6 @@ def xcd8_columns(n_levels, n_feat):
     return cols
 
 
-_XCD8_POS = {}
-
-
-def _xcd8_positions(grouped, dev):
-    """i64 [levels*feats]: staged position of every feature column (cached per layout and device)."""
-    key = (tuple(grouped), str(dev))
-    if key not in _XCD8_POS:
-        cols = xcd8_columns(*grouped)
-        inv = [0] * (grouped[0] * grouped[1])
-        for p, c in enumerate(cols):
-            if c >= 0:
-                inv[c] = p
-        _XCD8_POS[key] = torch.tensor(inv, dtype=torch.int64, device=dev)
-    return _XCD8_POS[key]
-
-
 # ---------------------------------------------------------------------------------------------- MLP
 def _mm_f32(a, b):
     """a^T-free helper: a [K,M] @ b [M,N] with fp32 result (bf16 inputs accumulate in fp32)."""
