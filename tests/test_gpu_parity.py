@@ -866,3 +866,36 @@ def test_head_composite_pair_equals_two_nodes(gpu_device):
     assert _rel_l2(res[0][2].cpu(), res[1][2].cpu()) < 6e-3          # one bf16 rounding of the sum instead of two + one
     for g1, g2 in zip(res[0][3], res[1][3]):
         assert torch.equal(g1, g2)
+
+
+def test_short_training_run_converges_and_bf16_tracks_fp32(gpu_device):
+    """60 Adam steps on a small synthetic scene through the whole path (march -> grids -> decoders -> compositing -> losses ->
+    backward through every fused node -> Adam): the loss must fall, and the bf16 production path must follow the fp32 parity
+    path (same initial weights, same targets)."""
+    dev = gpu_device
+    losses = {}
+    for precision in ("fp32", "bf16"):
+        nef, tracer, rays, occ, jitter = _make_scene(dev, precision, seed=3, L_perm=24, cap_log2=12, N=256, S=48, level=4)
+        gen = torch.Generator().manual_seed(11)
+        gt_rgb = torch.rand(256, 3, generator=gen).to(dev) * 0.5 + 0.25
+        gt_sem = torch.randint(0, 6, (256,), generator=gen).to(dev)
+        gt_inst = torch.randint(0, 200, (256,), generator=gen).to(dev)
+        idx = torch.arange(256, device=dev)
+        groups = [{"params": [p for n, p in nef.named_parameters() if "grid" in n], "lr": 3e-2},
+                  {"params": [p for n, p in nef.named_parameters() if "grid" not in n], "lr": 3e-3}]
+        opt = torch.optim.Adam(groups, eps=1e-15)
+        hist = []
+        for step in range(60):
+            opt.zero_grad(set_to_none=True)
+            rb = tracer(nef, channels={"rgb", "depth", "semantics", "inst_embedding"}, rays=rays, jitter=jitter.to(dev), stage="train")
+            loss = ((rb.rgb - gt_rgb).abs().mean() + 0.1 * (-torch.log(rb.semantics[idx, gt_sem] + 1e-6)).mean()
+                    + 0.1 * (-torch.log(rb.inst_embedding[idx, gt_inst] + 1e-6)).mean())
+            loss.backward()
+            opt.step()
+            hist.append(float(loss.detach()))
+        assert all(np.isfinite(hist)), hist
+        losses[precision] = hist
+    for precision, hist in losses.items():
+        assert hist[-1] < 0.8 * hist[0], (precision, hist[0], hist[-1])
+    assert abs(losses["bf16"][0] - losses["fp32"][0]) < 0.02 * losses["fp32"][0]
+    assert abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.1 * losses["fp32"][-1], (losses["bf16"][-1], losses["fp32"][-1])
