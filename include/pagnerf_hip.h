@@ -191,6 +191,9 @@ typedef struct {
     const float *softmax_stats; const float *b_last;
     int dx1_accumulate;   /* XCD8 dx1 only: add this decoder's input gradient to what dx1 already holds (two heads on the
                              same panoptic features - saves the separate gradient-sum pass) */
+    const float *dx1_col0_add;   /* optional f32 [M] (strided dx1, MFMA mode, out_dim <= 64): added to column 0 of dx1 - the
+                                    gradient of the density that pc_nerf/panoptic_delta_nef.py:188 reads off column 0 of the
+                                    density decoder's output, which is also this (colour) decoder's x1 */
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 

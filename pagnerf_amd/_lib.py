@@ -45,7 +45,7 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dx1", c_vp), ("dx1_dtype", c_i32),
                 ("mode", c_i32),
                 ("g_ray", c_vp), ("g_scale", c_vp), ("g_index", c_vp),
-                ("softmax_stats", c_vp), ("b_last", c_vp), ("dx1_accumulate", c_i32)]
+                ("softmax_stats", c_vp), ("b_last", c_vp), ("dx1_accumulate", c_i32), ("dx1_col0_add", c_vp)]
 
 
 _SIGS = {

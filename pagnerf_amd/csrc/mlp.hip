@@ -79,6 +79,7 @@ struct BwdParams {
     const float *stats;    // forward's softmax statistics + last-layer bias: the wide kernel recomputes the probabilities
     const float *b_last;
     int dx1_acc;           // XCD8 dx1: add to the existing contents instead of overwriting
+    const float *dx_col0;  // strided dx1: f32 [M] added to column 0
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
@@ -936,7 +937,12 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
                         bf16x8 a = *reinterpret_cast<const bf16x8 *>(W0t + (32 * mb + r) * RS + 16 * s + 8 * h);
                         acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
                     }
-                    if (live && !p.grp_L) store_block(dx + m * p.k1, 32 * mb, h, acc[mb], p.k1, true);
+                    if (live && !p.grp_L) {
+                        // extra gradient of input column 0 (the density read off the density decoder's first output,
+                        // pc_nerf/panoptic_delta_nef.py:188): added here instead of a zero-padded [M,k1] tensor + add pass
+                        if (p.dx_col0 && mb == 0 && h == 0) acc[0][0] += p.dx_col0[m];
+                        store_block(dx + m * p.k1, 32 * mb, h, acc[mb], p.k1, true);
+                    }
                     if (live && p.grp_L) {      // XCD8: row 32mb + 8g + 4h + j of dx^T -> piece [4mb + g][m][4h + j]
                         bf16_t *dg = reinterpret_cast<bf16_t *>(p.dx1);
 #pragma unroll
@@ -1814,6 +1820,9 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     p.stats = a->softmax_stats;
     p.b_last = a->b_last;
     p.dx1_acc = a->dx1_accumulate;
+    p.dx_col0 = a->dx1_col0_add;
+    PAG_CHECK_ARG(!a->dx1_col0_add || (a->dx1 && !p.grp_L && a->mode == PAG_MLP_MFMA_BF16 && a->out_dim <= 64),
+                  "pag_mlp_bwd: dx1_col0_add needs a strided dx1, MFMA mode and out_dim <= 64");
     PAG_CHECK_ARG(!a->dx1_accumulate || (p.grp_L && a->dx1), "pag_mlp_bwd: dx1_accumulate needs an XCD8 dx1");
     const bool wide_rebuild = a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64 && a->out_act == PAG_ACT_SOFTMAX && a->softmax_stats &&
                               a->b_last && !out_f32 && (a->g_ray || (a->grad_out && a->out_dim % 8 == 0));

@@ -85,7 +85,7 @@ class PanopticDDensityNeF(PanopticDeltaNeF):
             if "delta_density" in extra:
                 out["delta_density"] = dd
             if "panoptic_density" in extra:                                                  # :243-247
-                pre = self._density_pre.detach().reshape(batch, num_samples, 1)
+                pre = self._density_feats.detach()[:, 0:1].float().reshape(batch, num_samples, 1)
                 out["panoptic_density"] = torch.relu(dd if self.separate_sem_grid else pre + dd)
         if compute_channels is not None and "density" not in compute_channels:
             out.pop("density", None)

@@ -205,17 +205,21 @@ class PanopticDeltaNeF(nn.Module):
         self._feat_cache = (coords, feats.detach())           # reused by panoptic_composited() for the same samples
         grp = self._grouped()
         density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
-        self._density_pre = density_feats[:, 0:1].float()        # pre-ReLU density (the delta-density variant adds to it)
-        density = torch.relu(self._density_pre).reshape(batch, num_samples, 1)            # :188
-        if "density" in compute_channels:
-            out["density"] = density
-        if "rgb" in compute_channels:                                                 # :196-204
+        self._density_feats = density_feats                      # the delta-density variant adds to its column 0 (pre-ReLU)
+        if "rgb" in compute_channels:                                                 # :188, :196-204
             if num_samples != 1 and ridx is None:                                  # one direction per pack entry -> per sample
                 ray_d = ray_d[:, None].repeat(1, num_samples, 1).reshape(-1, 3)
             pe, index = self._view_embedding(ray_d, ridx, ray_dirs)
-            rgb = self.decoder_color(density_feats, x2=pe, x2_index=index, out_act=L.ACT_SIGMOID, mode=mode,
-                                     x2_packs=ray_packs if ridx is not None else None)
+            W, b = self.decoder_color.weights()
+            # colour decoder and the density column of its input as one node (ops._ColourDensity)
+            rgb, sigma = ops.colour_and_density(density_feats, W, b, pe, index, self.decoder_color.input_dim, out_act=L.ACT_SIGMOID,
+                                                mode=mode, x2_packs=ray_packs if ridx is not None else None)
+            density = sigma.reshape(batch, num_samples, 1)
             out["rgb"] = rgb.reshape(batch, num_samples, 3)
+        else:
+            density = torch.relu(density_feats[:, 0:1].float()).reshape(batch, num_samples, 1)   # :188
+        if "density" in compute_channels:
+            out["density"] = density
         if "semantics" in compute_channels or "inst_embedding" in compute_channels:    # :210-236
             pan = self._panoptic_feats(feats.detach(), coords)
             if "semantics" in compute_channels:                                        # :238-244

@@ -288,7 +288,7 @@ class _FusedMLP(torch.autograd.Function):
         return _FusedMLP._backward_impl(ctx, g, None)
 
     @staticmethod
-    def _backward_impl(ctx, g, rank1, dx1_into=None):
+    def _backward_impl(ctx, g, rank1, dx1_into=None, col0_add=None):
         """rank1 = (g_ray f32 [N,out], g_scale f32 [M], g_index i32 [M]) replaces the dense upstream gradient g.
         dx1_into: an XCD8 gradient tensor of another decoder on the same input - this one's d x1 is added to it in place."""
         lib = L.load()
@@ -324,8 +324,13 @@ class _FusedMLP(torch.autograd.Function):
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
         a.softmax_stats, a.b_last = L.ptr(stats), L.ptr(b_last)
         a.dx1_accumulate = 1 if (need_dx and dx1_into is not None) else 0
+        fuse_col0 = col0_add is not None and need_dx and grouped is None and mode == L.MLP_MFMA_BF16 and out_dim <= 64
+        if fuse_col0:
+            a.dx1_col0_add = L.ptr(col0_add)
         if M:
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
+        if col0_add is not None and need_dx and not fuse_col0:
+            dx1[:, 0] += col0_add.to(dx1.dtype)          # parity path: same sum with torch ops
         gW, gb = [], []
         if mode == L.MLP_MFMA_BF16 and M:
             # weight gradients on the matrix cores: per-workgroup fp32 slabs, summed here (deterministic)
@@ -384,6 +389,36 @@ class _FusedMLP(torch.autograd.Function):
             dx2 = torch.zeros_like(x2)
             dx2[:, :in_dim - k1] = seg @ w_tail
         return (dx1, dx2, None, None, None, None, None, None, *gW, *gb)
+
+
+class _ColourDensity(_FusedMLP):
+    """The colour decoder on cat(density_feats, PE) AND the density sigma = relu(density_feats[:, 0]) that
+    pc_nerf/panoptic_delta_nef.py:188 reads off its x1, as one autograd node: the gradient of sigma is added to column 0 of
+    the decoder's d x1 inside the backward kernel - no zero-padded [M,16] gradient, slice / cast / relu backward or add pass."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb):
+        rgb = _FusedMLP.forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb)
+        pre = x1.detach()[:, 0].float()
+        ctx.pre = pre
+        return rgb, torch.relu(pre)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sigma):
+        saved_out = ctx.saved_tensors[3]
+        if g_rgb is None:
+            g_rgb = torch.zeros_like(saved_out)
+        add = (g_sigma.float() * (ctx.pre > 0)).contiguous() if g_sigma is not None else None
+        return _FusedMLP._backward_impl(ctx, g_rgb, None, col0_add=add)
+
+
+def colour_and_density(x1, weights, biases, x2, x2_index, in_dim, out_act=L.ACT_SIGMOID, mode=L.MLP_MFMA_BF16,
+                       out_dtype=torch.float32, x2_packs=None):
+    """-> (rgb [M,3], sigma f32 [M] = relu(x1[:,0])); x1 = the density decoder's [M,16] output (see _ColourDensity)."""
+    rgb, sigma = _ColourDensity.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
+    if x2_packs is not None and x2 is not None and x2.requires_grad and rgb.grad_fn is not None:
+        rgb.grad_fn.x2_packs = x2_packs
+    return rgb, sigma
 
 
 def fused_mlp(x1, weights, biases, x2=None, x2_index=None, in_dim=None, out_act=L.ACT_NONE, mode=L.MLP_MFMA_BF16,
