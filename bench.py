@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -101,9 +102,10 @@ def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None):
     rb = tracer(nef, channels=channels, rays=rays, stage="train")
     loss = 10.0 * torch.abs(rb.rgb - gt["rgb"]).mean()                                 # trainer.py:443-446, best.yaml:116
     if "semantics" in channels:
-        idx = torch.arange(gt["sem"].shape[0], device=rb.rgb.device)
-        loss = loss + 0.1 * (-torch.log(rb.semantics[idx, gt["sem"]] + 1e-27)).mean()   # trainer.py:454-480
-        loss = loss + 1000.0 * (-torch.log(rb.inst_embedding[idx, gt["inst"]] + 1e-27)).mean()
+        # trainer.py:465-467: nll_loss(log(p + 1e-27), gt); the instance term stands for the per-image linear-assignment NLL
+        # (trainer.py:499-520 -> loss/lin_assignment_things.py:80), same arithmetic on a fixed target
+        loss = loss + 0.1 * F.nll_loss(torch.log(rb.semantics + 1e-27), gt["sem"], reduction="mean")
+        loss = loss + 1000.0 * F.nll_loss(torch.log(rb.inst_embedding + 1e-27), gt["inst"], reduction="mean")
     loss.backward()
     if world > 1:
         sync.finish()       # delta-table all-reduce was launched from the backward; the rest goes as one flat RCCL all-reduce
