@@ -1524,9 +1524,11 @@ struct WgradParams {
 constexpr int WG_RS = 72;       // LDS row stride (bf16) of the transposed tiles: 64 samples + 8 pad
 constexpr int WG_SLAB_COLS = 96;
 
-template <typename A1T, int APW /* accumulator blocks per wave: 2 (<= 8 block pairs) or 6 */>
-// narrow variant: asking for 5 workgroups per CU keeps every accumulator in VGPRs (no AGPR copies) under 102 registers
-__global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(WgradParams p) {
+template <typename A1T, int APW /* accumulator blocks per wave */, int NWV = 4 /* waves per workgroup */>
+// narrow variant (APW 2, 4 waves): asking for 5 waves per SIMD keeps every accumulator in VGPRs (no AGPR copies) under 102
+// registers.  Wide layers (up to 224 outputs = 21 block pairs): 8 waves x 3 pairs instead of 4 x 6 - 48 accumulator
+// registers per wave leave room for the prefetch and for 4 waves per SIMD (the 4 x 6 form ran 2 waves per SIMD, no prefetch).
+__global__ __launch_bounds__(NWV * 64, (APW == 2 ? 5 : (APW == 3 ? 4 : 1))) void mlp_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.n_out + 31) / 32;
     const int IB = (p.n_in + 31) / 32;                 // 1 or 2
@@ -1581,13 +1583,18 @@ __global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(Wgra
     // APW == 2 (<= 64 x 64 layers, 76 VGPRs): the next chunk's four 16-byte pieces are fetched into registers while the
     // current chunk goes through LDS and the MFMAs - the kernel sat waiting on memory 77 % of its wave cycles (SQ_WAIT_ANY)
     // with nothing in flight between the two barriers.  The wide variant has no registers to spare for this.
-    constexpr bool PF = APW == 2;
-    bf16x8 pz[2], pa[2];
+    constexpr bool PF = APW <= 3;
+    constexpr int ZG = (NWV == 8) ? 4 : 2, AG = (NWV == 8) ? 1 : 2;      // 16-byte pieces per wave: dz (<= 224 / 64 cols), input (64 cols)
+    bf16x8 pz[ZG], pa[AG];
     if constexpr (PF) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cg = wave + 4 * i;
+        for (int i = 0; i < ZG; ++i) {
+            const int cg = wave + NWV * i;
             pz[i] = (blockIdx.x < nchunks && cg < OB * 4) ? fetch_z(blockIdx.x, cg) : zero8();
+        }
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            const int cg = wave + NWV * i;
             pa[i] = (blockIdx.x < nchunks && cg < IB * 4) ? fetch_a(blockIdx.x, cg) : zero8();
         }
     }
@@ -1595,26 +1602,30 @@ __global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(Wgra
         // ---- dz tile, transposed: Zt[col][sample]
         if constexpr (PF) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int cg = wave + 4 * i, c0 = 8 * cg;
+            for (int i = 0; i < ZG; ++i) {
+                const int cg = wave + NWV * i, c0 = 8 * cg;
                 if (cg < OB * 4) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) Zt[(c0 + j) * WG_RS + lane] = pz[i][j];
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < AG; ++i) {
+                const int cg = wave + NWV * i, c0 = 8 * cg;
                 if (cg < IB * 4) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) At[(c0 + j) * WG_RS + lane] = (c0 + j < p.n_in) ? pa[i][j] : (bf16_t)0.0f;
                 }
             }
         } else {
-            for (int cg = wave; cg < OB * 4; cg += 4) {
+            for (int cg = wave; cg < OB * 4; cg += NWV) {
                 const int c0 = 8 * cg;
                 const bf16x8 v = fetch_z(chunk, cg);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Zt[(c0 + j) * WG_RS + lane] = v[j];
             }
             // ---- input tile, transposed: At[col][sample]
-            for (int cg = wave; cg < IB * 4; cg += 4) {
+            for (int cg = wave; cg < IB * 4; cg += NWV) {
                 const int c0 = 8 * cg;
                 const bf16x8 v = fetch_a(chunk, cg);
 #pragma unroll
@@ -1626,16 +1637,20 @@ __global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(Wgra
             const int64_t next = chunk + gridDim.x;
             if (next < nchunks) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int cg = wave + 4 * i;
+                for (int i = 0; i < ZG; ++i) {
+                    const int cg = wave + NWV * i;
                     if (cg < OB * 4) pz[i] = fetch_z(next, cg);
+                }
+#pragma unroll
+                for (int i = 0; i < AG; ++i) {
+                    const int cg = wave + NWV * i;
                     if (cg < IB * 4) pa[i] = fetch_a(next, cg);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
-            const int pr = wave + 4 * i;
+            const int pr = wave + NWV * i;
             if (pr < npairs) {
                 const int ob = pr / (IB + 1), ib = pr - ob * (IB + 1);
 #pragma unroll
@@ -1652,7 +1667,7 @@ __global__ __launch_bounds__(256, (APW == 2 ? 5 : 1)) void mlp_wgrad_kernel(Wgra
     float *slab = p.slabs + (int64_t)blockIdx.x * OB * 32 * WG_SLAB_COLS;
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
-        const int pr = wave + 4 * i;
+        const int pr = wave + NWV * i;
         if (pr < npairs) {
             const int ob = pr / (IB + 1), ib = pr - ob * (IB + 1);
 #pragma unroll
@@ -1902,7 +1917,7 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
         else hipLaunchKernelGGL((mlp_wgrad_kernel<float, 6>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
     } else {
         if (small) hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 2>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 6>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 3, 8>), dim3(n_blocks), dim3(512), lds, (hipStream_t)stream, p);
     }
     PAG_CHECK_LAUNCH("pag_mlp_wgrad");
     return PAG_OK;
