@@ -65,22 +65,31 @@ def all_gather_render(rb, n_total, channels=None):
     return RenderBuffer(**res)
 
 
-def allreduce_grads(params, average=True):
-    """One flat all_reduce over every gradient (bucket = everything: ~100 MB fp32)."""
+def allreduce_grads(params, average=True, big=1 << 20):
+    """Gradients of >= `big` elements (the tables, ~50 MB each) are all-reduced in place, one message each; everything
+    smaller (decoders, poses: ~0.14 MB) travels as ONE flat all_reduce.  No staging copy of the large tensors."""
     rank, world = world_info()
     if world == 1:
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
-    flat = torch.cat([g.reshape(-1).float() for g in grads])
-    dist.all_reduce(flat)
-    if average:
-        flat /= world
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    large = [g for g in grads if g.numel() >= big and g.is_contiguous()]
+    small = [g for g in grads if not (g.numel() >= big and g.is_contiguous())]
+    handles = [dist.all_reduce(g, async_op=True) for g in large]
+    if small:
+        flat = torch.cat([g.reshape(-1).float() for g in small])
+        dist.all_reduce(flat)
+        if average:
+            flat /= world
+        off = 0
+        for g in small:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    for g, h in zip(large, handles):
+        h.wait()
+        if average:
+            g /= world
 
 
 class GradSync:

@@ -52,6 +52,13 @@ def _worker(rank, world, port, n, q):
         mean = sum(range(1, world + 1)) / world
         assert torch.allclose(p1.grad, torch.full((5, 3), mean)) and torch.allclose(p2.grad, torch.arange(7.0) * mean)
         assert p3.grad is None
+        # large gradients (tables) go in place, one message each; small ones flat - same result either way
+        p1.grad = torch.full((5, 3), float(rank + 1))
+        p2.grad = torch.arange(7.0) * (rank + 1)
+        p2_storage = p2.grad.data_ptr()
+        shard.allreduce_grads([p1, p2, p3], big=7)
+        assert torch.allclose(p1.grad, torch.full((5, 3), mean)) and torch.allclose(p2.grad, torch.arange(7.0) * mean)
+        assert p2.grad.data_ptr() == p2_storage
         # GradSync: the early parameter is exchanged from its post-accumulate hook while the backward continues
         a, b, c = (torch.nn.Parameter(torch.ones(4, 2)), torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2)))
         sync = shard.GradSync([a, b, c], early=[a])
