@@ -456,22 +456,27 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
                                        float(dist_max), occ, blas_level, L.ptr(counts), st)
     csum = torch.cumsum(counts.long(), 0)
     offsets = csum - counts
-    M = int(csum[-1].item()) if N else 0
-    ridx = torch.empty(M, device=dev, dtype=torch.int32)
-    pidx = torch.empty(M, device=dev, dtype=torch.int32)
-    samples = torch.empty(M, 3, device=dev)
-    depths = torch.empty(M, device=dev)
-    deltas = torch.empty(M, device=dev)
-    boundary = torch.empty(M, device=dev, dtype=torch.uint8)
-    if M:
+    # The pack kernel takes its write offsets from the device, so it (and the per-ray pack tables) are queued BEFORE the
+    # host learns the sample count: buffers are sized for the N * S upper bound and trimmed to M afterwards.  The GPU then
+    # idles only for the read-back itself instead of read-back + six allocations + four launches (0.11 ms per step).
+    cap = N * S
+    ridx = torch.empty(cap, device=dev, dtype=torch.int32)
+    pidx = torch.empty(cap, device=dev, dtype=torch.int32)
+    samples = torch.empty(cap, 3, device=dev)
+    depths = torch.empty(cap, device=dev)
+    deltas = torch.empty(cap, device=dev)
+    boundary = torch.empty(cap, device=dev, dtype=torch.uint8)
+    if cap:
         _call("pag_raymarch_pack", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
                                       float(dist_max), occ, blas_level, L.ptr(offsets), L.ptr(ridx), L.ptr(pidx),
                                       L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), st)
     # one pack per RAY (empty packs allowed): no nonzero() / second host sync.  A ray without samples composites to the
     # background with alpha = depth = 0 and hit = False, exactly what the pre-filled buffers hold (Appendix E.10).
     ray_of_pack = torch.arange(N, device=dev, dtype=torch.int32)
-    pack_start = torch.cat([offsets, csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)
-    return ridx, pidx, samples, depths, deltas, boundary.bool(), pack_start.contiguous(), ray_of_pack
+    pack_start = (torch.cat([offsets, csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)).contiguous()
+    boundary = boundary.bool()
+    M = int(csum[-1].item()) if N else 0
+    return ridx[:M], pidx[:M], samples[:M], depths[:M], deltas[:M], boundary[:M], pack_start, ray_of_pack
 
 
 class _RaySamples(torch.autograd.Function):
