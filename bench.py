@@ -100,12 +100,20 @@ def make_optimizer(nef):
 def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None):
     opt.zero_grad(set_to_none=True)
     rb = tracer(nef, channels=channels, rays=rays, stage="train")
-    loss = 10.0 * torch.abs(rb.rgb - gt["rgb"]).mean()                                 # trainer.py:443-446, best.yaml:116
-    if "semantics" in channels:
-        # trainer.py:465-467: nll_loss(log(p + 1e-27), gt); the instance term stands for the per-image linear-assignment NLL
-        # (trainer.py:499-520 -> loss/lin_assignment_things.py:80), same arithmetic on a fixed target
-        loss = loss + 0.1 * F.nll_loss(torch.log(rb.semantics + 1e-27), gt["sem"], reduction="mean")
-        loss = loss + 1000.0 * F.nll_loss(torch.log(rb.inst_embedding + 1e-27), gt["inst"], reduction="mean")
+    # trainer.py:443-446 / best.yaml:116 rgb L1; trainer.py:465-467 nll_loss(log(p + 1e-27), gt); the instance term stands for the
+    # per-image linear-assignment NLL (trainer.py:499-520 -> loss/lin_assignment_things.py:80), same arithmetic on a fixed target.
+    # pagnerf_amd.loss.render_loss evaluates exactly that sum in one launch (and its gradients in one more).
+    from pagnerf_amd.loss import render_loss, NllTerm
+    if os.environ.get("PAG_BENCH_TORCH_LOSS"):
+        loss = 10.0 * torch.abs(rb.rgb - gt["rgb"]).mean()
+        if "semantics" in channels:
+            loss = loss + 0.1 * F.nll_loss(torch.log(rb.semantics + 1e-27), gt["sem"], reduction="mean")
+            loss = loss + 1000.0 * F.nll_loss(torch.log(rb.inst_embedding + 1e-27), gt["inst"], reduction="mean")
+    elif "semantics" in channels:
+        loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1),
+                              NllTerm(rb.inst_embedding, gt["inst"], weight=1000.0))
+    else:
+        loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0)
     loss.backward()
     if world > 1:
         sync.finish()       # delta-table all-reduce was launched from the backward; the rest goes as one flat RCCL all-reduce

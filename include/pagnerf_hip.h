@@ -324,6 +324,41 @@ int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_s
                    const int64_t *labels_gt, const uint8_t *row_mask, const int64_t *label_list, int K,
                    float *sums, int32_t *counts, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-ray training loss of the rendered buffers (pc_nerf/trainer.py:443-446 rgb, :459-465 semantics,
+ * loss/lin_assignment_things.py:80 instance term after the assignment) - one launch forward, one backward
+ * ------------------------------------------------------------------------------------------ */
+
+/* loss = rgb_weight * mean|rgb - rgb_gt|
+ *      + sum over the (up to two) NLL terms t of  weight_t * sum_n l_tn / denom_t,
+ *        l_tn = -log(prob_t[n, target_t[n]] + eps) * inv_temp_t * (conf_t[n] if conf_t else 1)
+ *        for rows with 0 <= target < C_t (others - F.nll_loss's ignore_index included - contribute nothing);
+ *        denom_t = N if all_t (reduction 'none' then .mean(), trainer.py:459-465) else the number of valid rows
+ *        (F.nll_loss reduction 'mean').
+ *   rgb, rgb_gt f32 [N,3] (both NULL: no rgb term); prob_t f32 [N, C_t] contiguous (NULL: term absent);
+ *   target_t i64 [N]; conf_t f32 [N] or NULL.
+ *   workspace: pag_render_loss_workspace_bytes() bytes, ZEROED ONCE by the caller and then reused as is.
+ *   out f32 [6]: total, rgb term, term A, term B, denom A, denom B.
+ * Deterministic (fixed-order block partials, the last block adds them in block order). */
+int64_t pag_render_loss_workspace_bytes(void);
+int pag_render_loss_fwd(const float *rgb, const float *rgb_gt, int64_t N, float rgb_weight,
+                        const float *prob_a, int C_a, const int64_t *target_a, const float *conf_a, float weight_a,
+                        float inv_temp_a, int all_a,
+                        const float *prob_b, int C_b, const int64_t *target_b, const float *conf_b, float weight_b,
+                        float inv_temp_b, int all_b,
+                        float eps, void *workspace, float *out, void *stream);
+
+/* Gradients of the above times the upstream scalar *g (device pointer; NULL = 1): d_rgb [N,3] = g rgb_weight sgn(rgb-gt)/(3N),
+ * d_t [N, C_t] dense: -g weight_t inv_temp_t conf / (denom_t (p + eps)) in the target column of valid rows, 0 elsewhere
+ * (every element is written).  fwd_out = the forward's `out`.  Any of d_rgb / d_a / d_b may be NULL. */
+int pag_render_loss_bwd(const float *g, const float *fwd_out, const float *rgb, const float *rgb_gt, int64_t N,
+                        float rgb_weight,
+                        const float *prob_a, int C_a, const int64_t *target_a, const float *conf_a, float weight_a,
+                        float inv_temp_a, int all_a,
+                        const float *prob_b, int C_b, const int64_t *target_b, const float *conf_b, float weight_b,
+                        float inv_temp_b, int all_b,
+                        float eps, float *d_rgb, float *d_a, float *d_b, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ SOURCES = {
     "render.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
     "assign.hip": ["-ffp-contract=off"],
+    "loss.hip": ["-ffp-contract=off"],
 }
 
 

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
+from .ops import render_loss, NllTerm          # noqa: F401  (the trainer's per-ray objective as two launches)
 
 
 def label_sums(values, labels_gt, label_list, col0=0, row_mask=None):

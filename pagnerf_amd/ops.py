@@ -811,3 +811,71 @@ def head_composite(x1, weights, biases, w, alpha, ridx, pack_start, ray_of_pack,
         in_dim = weights[0].shape[1]
     return _HeadComposite.apply(x1, w, alpha, ridx, pack_start, ray_of_pack, N, int(in_dim), out_act, out_dtype, x1_grouped,
                                 *weights, *biases)
+
+
+# --------------------------------------------------------------------------------------- render loss
+_LOSS_WS = {}
+
+
+class NllTerm:
+    """One `weight * mean(-log(prob[n, target_n] + eps) / temperature * conf_n)` term of render_loss."""
+
+    def __init__(self, prob, target, weight=1.0, temperature=1.0, conf=None, mean_over="valid"):
+        assert mean_over in ("valid", "all")
+        self.prob, self.target, self.weight, self.temperature, self.conf, self.mean_over = prob, target, weight, temperature, conf, mean_over
+
+
+class _RenderLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, prob_a, prob_b, rgb_gt, rgb_weight, term_a, term_b, eps):
+        src = rgb if rgb is not None else (prob_a if prob_a is not None else prob_b)
+        _check_gpu(src)
+        dev = src.device
+        N = src.shape[0]
+        f = lambda t: t.detach().contiguous().float() if t is not None else None
+        rgb_c, gt_c = f(rgb), f(rgb_gt)
+        if rgb_c is not None:
+            rgb_c, gt_c = rgb_c.reshape(N, 3), gt_c.reshape(N, 3)
+        targs, keep = [], [rgb_c, gt_c]
+        for prob, t in ((prob_a, term_a), (prob_b, term_b)):
+            if prob is None:
+                targs += [None, 0, None, None, 0.0, 1.0, 0]
+                continue
+            p = f(prob).reshape(N, -1)
+            tg = t.target.detach().reshape(-1).long().contiguous()
+            cf = f(t.conf).reshape(-1) if t.conf is not None else None
+            keep += [p, tg, cf]
+            targs += [L.ptr(p), p.shape[1], L.ptr(tg), L.ptr(cf), float(t.weight), 1.0 / float(t.temperature), int(t.mean_over == "all")]
+        key = (dev.type, dev.index)
+        if key not in _LOSS_WS:
+            _LOSS_WS[key] = torch.zeros(L.load().pag_render_loss_workspace_bytes(), device=dev, dtype=torch.uint8)
+        out = torch.empty(6, device=dev)
+        head = [L.ptr(rgb_c), L.ptr(gt_c), N, float(rgb_weight)]
+        _call("pag_render_loss_fwd", *head, *targs, float(eps), L.ptr(_LOSS_WS[key]), L.ptr(out), L.stream())
+        ctx.call = (head, targs, float(eps))
+        ctx.keep = keep                      # plain tensors (detached copies / inputs), not autograd-tracked
+        ctx.out = out
+        ctx.shapes = tuple(None if t is None else (t.shape, t.dtype) for t in (rgb, prob_a, prob_b))
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g, _g_terms):
+        head, targs, eps = ctx.call
+        dev = ctx.out.device
+        grads = []
+        for need, sh in zip(ctx.needs_input_grad[:3], ctx.shapes):
+            grads.append(torch.empty(sh[0], device=dev) if (need and sh is not None) else None)
+        g = g.detach().float().contiguous()
+        _call("pag_render_loss_bwd", L.ptr(g), L.ptr(ctx.out), *head, *targs, eps, L.ptr(grads[0]), L.ptr(grads[1]), L.ptr(grads[2]), L.stream())
+        grads = [None if d is None else (d if sh[1] == torch.float32 else d.to(sh[1])) for d, sh in zip(grads, ctx.shapes)]
+        return grads[0], grads[1], grads[2], None, None, None, None, None
+
+
+def render_loss(rgb=None, rgb_gt=None, rgb_weight=1.0, term_a=None, term_b=None, eps=1e-27):
+    """-> (loss 0-dim, terms f32 [6] = total, rgb, A, B, denom A, denom B - detached).  The trainer's per-ray objective
+    (pc_nerf/trainer.py:443-446, :459-465, loss/lin_assignment_things.py:80) as one launch forward and one backward."""
+    if rgb is None and term_a is None and term_b is None:
+        raise ValueError("render_loss needs at least one term")
+    return _RenderLoss.apply(rgb, term_a.prob if term_a is not None else None, term_b.prob if term_b is not None else None,
+                             rgb_gt, rgb_weight, term_a, term_b, eps)

@@ -60,3 +60,57 @@ def test_g5_virtual_labels_and_losses(gpu_device):
         np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"loss_{tag}"], rtol=1e-5, atol=1e-6)
         out.sum().backward()
         assert torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+
+
+def test_render_loss_matches_trainer_formulas(gpu_device):
+    """pag_render_loss_fwd / _bwd against the reference trainer's arithmetic written as plain tensor ops in float64
+    (pc_nerf/trainer.py:443-446 rgb L1; :459-465 semantics: nll 'none' / temperature * conf, mean over all rays;
+    loss/lin_assignment_things.py:80 instance NLL; F.nll_loss 'mean' = mean over the rows whose target is not ignored).
+    Tolerance: fp32 sums of <= 1e5 terms against float64 - 2e-6 relative on the loss, 1e-6 relative on gradients."""
+    import torch.nn.functional as F
+    from pagnerf_amd import loss as pl
+    dev = gpu_device
+    g = torch.Generator().manual_seed(5)
+    for N, Cs, Ci in ((1, 3, 4), (300, 7, 200), (4096, 7, 200), (100000, 5, 33)):
+        rgb = torch.rand(N, 3, generator=g)
+        gt = torch.rand(N, 3, generator=g)
+        gt[::7] = rgb[::7]                                                   # exact zeros: sgn(0) = 0
+        sem = torch.softmax(torch.randn(N, Cs, generator=g) * 3, -1)
+        inst = torch.softmax(torch.randn(N, Ci, generator=g) * 6, -1)
+        sem_t = torch.randint(0, Cs, (N,), generator=g)
+        inst_t = torch.randint(0, Ci, (N,), generator=g)
+        inst_t[::5] = -100                                                   # ignore_index rows
+        conf = torch.rand(N, generator=g)
+        for use_conf, temp, sem_mode in ((False, 1.0, "valid"), (True, 0.7, "all")):
+            leaves = [t.clone().to(dev).requires_grad_(True) for t in (rgb, sem, inst)]
+            loss, terms = pl.render_loss(leaves[0], gt.to(dev), 10.0,
+                                         pl.NllTerm(leaves[1], sem_t.to(dev), weight=0.1, temperature=temp,
+                                                    conf=conf.to(dev) if use_conf else None, mean_over=sem_mode),
+                                         pl.NllTerm(leaves[2], inst_t.to(dev), weight=1000.0))
+            (loss * 0.5).backward()                                          # upstream gradient read on the device
+            ref_leaves = [t.clone().double().requires_grad_(True) for t in (rgb, sem, inst)]
+            r_rgb = 10.0 * torch.abs(ref_leaves[0] - gt.double()).mean()
+            nll = F.nll_loss(torch.log(ref_leaves[1] + 1e-27) / temp, sem_t, reduction="none")
+            if use_conf:
+                nll = nll * conf.double()
+            r_sem = 0.1 * (nll.mean() if sem_mode == "all" else nll.sum() / N)          # no ignored rows here: same thing
+            r_inst = 1000.0 * F.nll_loss(torch.log(ref_leaves[2] + 1e-27), inst_t, reduction="mean")
+            ref = r_rgb + r_sem + r_inst
+            (ref * 0.5).backward()
+            t = terms.cpu().double()
+            for got, want in ((loss.item(), ref.item()), (t[1].item(), r_rgb.item()), (t[2].item(), r_sem.item()), (t[3].item(), r_inst.item())):
+                if want != want:                 # N = 1: the only row is ignored -> 0/0 = NaN, as F.nll_loss gives
+                    assert got != got
+                    continue
+                assert abs(got - want) <= 2e-6 * abs(want) + 1e-9, (N, got, want)
+            assert t[5].item() == float((inst_t >= 0).sum())
+            for a, b in zip(leaves, ref_leaves):
+                ga, gb = a.grad.cpu().double(), b.grad
+                assert torch.equal(ga == 0, gb == 0)
+                assert torch.allclose(ga, gb, rtol=1e-5, atol=0.0, equal_nan=True), (N, (ga - gb).abs().max())
+    # determinism (fixed-order partials): same bits on a second call; single terms work alone
+    a = pl.render_loss(rgb.to(dev), gt.to(dev), 10.0, pl.NllTerm(sem.to(dev), sem_t.to(dev)), None)[0]
+    b = pl.render_loss(rgb.to(dev), gt.to(dev), 10.0, pl.NllTerm(sem.to(dev), sem_t.to(dev)), None)[0]
+    assert torch.equal(a, b)
+    only = pl.render_loss(term_a=pl.NllTerm(inst.to(dev), inst_t.to(dev)))[0]
+    assert abs(only.item() - F.nll_loss(torch.log(inst.double() + 1e-27), inst_t).item()) < 1e-5 * abs(only.item())
