@@ -239,6 +239,16 @@ int pag_raymarch_count(const float *origins, const float *dirs, int64_t N, int S
                        const float *tvals, const float *jitter, float dist_min, float dist_max,
                        const uint32_t *occupancy_bits, int blas_level, int32_t *counts,
                        void *stream);
+/* pack_start i64 [N+1]: exclusive prefix sums of counts i32 [N] (pack_start[N] = total number of samples) - the write
+ * offsets pag_raymarch_pack takes and the per-ray pack table of the compositing kernels (kaolin's
+ * mark_pack_boundaries / cumsum bookkeeping, tracers/panoptic_packed_rf_tracer.py:114).  One workgroup. */
+int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, void *stream);
+
+/* View-direction embedding of the colour decoder (wisp PositionalEmbedder on -ray_d, pc_nerf/panoptic_delta_nef.py:196-200):
+ * out f32 [R, width] = (-d, sin(-d 2^k) for k < n_freq, cos(-d 2^k) for k < n_freq), frequency-major, zero padded;
+ * dirs f32 [R,3], width >= 3 + 6 n_freq. */
+int pag_view_embed(const float *dirs, int64_t R, int n_freq, int width, float *out, void *stream);
+
 /* Pass 2: pack.  offsets i64 [N] = exclusive prefix sum of counts.
  *   ridx i32 [M], pidx i32 [M] (linear cell id), samples f32 [M,3], depths f32 [M],
  *   deltas f32 [M], boundary u8 [M] (1 at the first sample of each ray) */

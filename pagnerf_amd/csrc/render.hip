@@ -476,6 +476,78 @@ extern "C" int pag_raymarch_count(const float *origins, const float *dirs, int64
     return PAG_OK;
 }
 
+namespace {
+// pack_start[i] = sum of counts[0..i), pack_start[N] = total: ONE workgroup, every thread owns a contiguous chunk (sum, block
+// scan of the 1024 chunk sums, prefix write).  Replaces the cast / scan-init / scan / subtract / concatenate launches the same
+// result costs as tensor ops at the head of every training step (N = 4096 rays: 4 counts per thread).
+__global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__restrict__ counts, int64_t N, int64_t *__restrict__ pack_start) {
+    __shared__ int64_t wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t chunk = (N + 1023) / 1024;
+    const int64_t lo = tid * chunk, hi = lo + chunk < N ? lo + chunk : N;
+    int64_t sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += counts[i];
+    int64_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int64_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += w < wave ? wave_tot[w] : 0;
+        total += wave_tot[w];
+    }
+    int64_t run = base + incl - sum;
+    for (int64_t i = lo; i < hi; ++i) {
+        pack_start[i] = run;
+        run += counts[i];
+    }
+    if (tid == 0) pack_start[N] = total;
+}
+
+// wisp PositionalEmbedder on the NEGATED ray directions (pc_nerf/panoptic_delta_nef.py:196-200): out[r] = (-d, sin(-d 2^k) k<F,
+// cos(-d 2^k) k<F), frequency-major, zero padded to `width` columns.  One launch instead of the ten of the tensor-op form.
+__global__ __launch_bounds__(256) void view_embed_kernel(const float *__restrict__ dirs, int64_t R, int n_freq, int width,
+                                                         float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * width) return;
+    const int64_t r = i / width;
+    const int c = (int)(i - r * width);
+    const int used = 3 + 6 * n_freq;
+    float v = 0.0f;
+    if (c < 3) {
+        v = -dirs[r * 3 + c];
+    } else if (c < used) {
+        const int q = c - 3, is_cos = q >= 3 * n_freq;
+        const int k = (is_cos ? q - 3 * n_freq : q) / 3, ax = (is_cos ? q - 3 * n_freq : q) % 3;
+        const float w = -dirs[r * 3 + ax] * (float)(1 << k);          // exact scaling: same argument as x * 2.0^k
+        v = is_cos ? cosf(w) : sinf(w);
+    }
+    out[i] = v;
+}
+}  // namespace
+
+extern "C" int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, void *stream) {
+    PAG_CHECK_ARG(N >= 0 && pack_start && (N == 0 || counts), "pag_pack_offsets: bad arguments");
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, pack_start);
+    PAG_CHECK_LAUNCH("pag_pack_offsets");
+    return PAG_OK;
+}
+
+extern "C" int pag_view_embed(const float *dirs, int64_t R, int n_freq, int width, float *out, void *stream) {
+    PAG_CHECK_ARG(R >= 0 && n_freq >= 0 && n_freq <= 16 && width >= 3 + 6 * n_freq, "pag_view_embed: n_freq %d / width %d out of range", n_freq, width);
+    if (R == 0) return PAG_OK;
+    PAG_CHECK_ARG(dirs && out, "pag_view_embed: NULL input/output");
+    const int64_t items = R * width;
+    hipLaunchKernelGGL(view_embed_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dirs, R, n_freq, width, out);
+    PAG_CHECK_LAUNCH("pag_view_embed");
+    return PAG_OK;
+}
+
 extern "C" int pag_raymarch_pack(const float *origins, const float *dirs, int64_t N, int S, const float *tvals,
                                  const float *jitter, float dist_min, float dist_max, const uint32_t *occupancy_bits,
                                  int blas_level, const int64_t *offsets, int32_t *ridx, int32_t *pidx, float *samples,

@@ -54,7 +54,7 @@ class BasicDecoder(nn.Module):
 def positional_embed(x, num_freq):
     """wisp PositionalEmbedder: cat(x, sin(x*2^k), cos(x*2^k)), frequency-major."""
     bands = 2.0 ** torch.linspace(0.0, num_freq - 1, num_freq, device=x.device)
-    w = (x[:, None, :] * bands[None, :, None]).reshape(x.shape[0], -1)
+    w = (x[:, None, :] * bands[None, :, None]).reshape(x.shape[0], num_freq * x.shape[-1])
     return torch.cat([x, torch.sin(w), torch.cos(w)], dim=-1)
 
 
@@ -164,6 +164,9 @@ class PanopticDeltaNeF(nn.Module):
             src, index = ray_dirs, ridx
         else:
             src, index = ray_d, torch.arange(ray_d.shape[0], device=ray_d.device, dtype=torch.int32)
+        if self.embedder_type == "positional" and src.is_cuda and not (src.requires_grad and torch.is_grad_enabled()):
+            width = 3 + 6 * self.view_multires
+            return ops.view_embed(src, self.view_multires, width + (-width) % 8), index      # one launch (pag_view_embed)
         pe = positional_embed(-src.float(), self.view_multires) if self.embedder_type == "positional" else -src.float()
         return F.pad(pe, (0, (-pe.shape[1]) % 8)).contiguous(), index
 

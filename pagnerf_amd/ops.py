@@ -454,11 +454,11 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     if N:
         _call("pag_raymarch_count", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
                                        float(dist_max), occ, blas_level, L.ptr(counts), st)
-    csum = torch.cumsum(counts.long(), 0)
-    offsets = csum - counts
-    # The pack kernel takes its write offsets from the device, so it (and the per-ray pack tables) are queued BEFORE the
-    # host learns the sample count: buffers are sized for the N * S upper bound and trimmed to M afterwards.  The GPU then
-    # idles only for the read-back itself instead of read-back + six allocations + four launches (0.11 ms per step).
+    pack_start = torch.empty(N + 1, device=dev, dtype=torch.int64)      # [i] = first sample of ray i, [N] = M
+    _call("pag_pack_offsets", L.ptr(counts), N, L.ptr(pack_start), st)
+    # The pack kernel takes its write offsets from the device, so it is queued BEFORE the host learns the sample count:
+    # buffers are sized for the N * S upper bound and trimmed to M afterwards.  The GPU then idles only for the read-back
+    # itself instead of read-back + six allocations + four launches (0.11 ms per step).
     cap = N * S
     ridx = torch.empty(cap, device=dev, dtype=torch.int32)
     pidx = torch.empty(cap, device=dev, dtype=torch.int32)
@@ -468,15 +468,36 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     boundary = torch.empty(cap, device=dev, dtype=torch.uint8)
     if cap:
         _call("pag_raymarch_pack", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
-                                      float(dist_max), occ, blas_level, L.ptr(offsets), L.ptr(ridx), L.ptr(pidx),
+                                      float(dist_max), occ, blas_level, L.ptr(pack_start), L.ptr(ridx), L.ptr(pidx),
                                       L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), st)
     # one pack per RAY (empty packs allowed): no nonzero() / second host sync.  A ray without samples composites to the
     # background with alpha = depth = 0 and hit = False, exactly what the pre-filled buffers hold (Appendix E.10).
-    ray_of_pack = torch.arange(N, device=dev, dtype=torch.int32)
-    pack_start = (torch.cat([offsets, csum[-1:]]) if N else torch.zeros(1, device=dev, dtype=torch.int64)).contiguous()
-    boundary = boundary.bool()
-    M = int(csum[-1].item()) if N else 0
-    return ridx[:M], pidx[:M], samples[:M], depths[:M], deltas[:M], boundary[:M], pack_start, ray_of_pack
+    M = int(pack_start[N].item())
+    return (ridx[:M], pidx[:M], samples[:M], depths[:M], deltas[:M], boundary[:M].view(torch.bool),   # kernel writes 0 / 1
+            pack_start, _ray_iota(N, dev))
+
+
+_IOTA = {}
+
+
+def _ray_iota(N, dev):
+    """arange(N) i32, cached per (N, device): ray_of_pack of the one-pack-per-ray layout (read-only by contract)."""
+    key = (N, str(dev))
+    if key not in _IOTA:
+        if len(_IOTA) > 16:
+            _IOTA.clear()
+        _IOTA[key] = torch.arange(N, device=dev, dtype=torch.int32)
+    return _IOTA[key]
+
+
+def view_embed(dirs, n_freq, width):
+    """f32 [R, width] = wisp PositionalEmbedder(-dirs) zero padded (pag_view_embed); no gradient (callers keep the tensor-op
+    form when the directions are learnable)."""
+    _check_gpu(dirs)
+    d = dirs.detach().contiguous().float()
+    out = torch.empty(d.shape[0], width, device=d.device)
+    _call("pag_view_embed", L.ptr(d), d.shape[0], int(n_freq), int(width), L.ptr(out), L.stream())
+    return out
 
 
 class _RaySamples(torch.autograd.Function):

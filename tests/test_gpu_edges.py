@@ -140,3 +140,28 @@ def test_encode_with_addend_equals_separate_bf16_add(gpu_device):
         (g1,) = torch.autograd.grad(fused, tab, g)
         (g2,) = torch.autograd.grad(addend + plain, tab, g)
         assert torch.equal(g1, g2)
+
+
+def test_pack_offsets_and_view_embed_kernels(gpu_device):
+    """pag_pack_offsets against torch.cumsum (integers: exact) and pag_view_embed against the tensor-op form of wisp's
+    PositionalEmbedder on -ray_d (sin / cos of the same fp32 argument: 1e-6 absolute, the argument scaling is exact)."""
+    import ctypes
+    from pagnerf_amd import ops, _lib as L
+    from pagnerf_amd.nef import positional_embed
+    dev = gpu_device
+    g = torch.Generator().manual_seed(11)
+    for N in (0, 1, 5, 1023, 1024, 1025, 4096, 100003):
+        counts = torch.randint(0, 600, (N,), generator=g, dtype=torch.int32).to(dev)
+        out = torch.empty(N + 1, device=dev, dtype=torch.int64)
+        L.check(L.load().pag_pack_offsets(L.ptr(counts) if N else None, N, L.ptr(out), L.stream()), "pag_pack_offsets")
+        ref = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts.cpu().long(), 0)])
+        assert torch.equal(out.cpu(), ref), N
+    for R, nf in ((0, 4), (1, 4), (4096, 4), (777, 0), (513, 10)):
+        d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+        width = 3 + 6 * nf
+        width += (-width) % 8
+        got = ops.view_embed(d, nf, width)
+        ref = positional_embed(-d, nf) if nf else -d
+        assert got.shape == (R, width)
+        assert torch.allclose(got[:, :ref.shape[1]], ref, rtol=0.0, atol=1e-6)
+        assert bool((got[:, ref.shape[1]:] == 0).all())
