@@ -227,6 +227,25 @@ int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void *a1, int a1
 int pag_mlp_wgrad_finish(const float *slabs, int n_blocks, int n_out, int n_in, int a1_layout,
                          int a1_levels, int a1_feats, float *dW, float *db, void *stream);
 
+/* Every weight gradient of one decoder in 2-3 launches: layers with the same kernel variant share one slab launch
+ * (grid.y = layer), one finish launch sums all of them.  Same arithmetic (and bits) as pag_mlp_wgrad +
+ * pag_mlp_wgrad_finish per layer.  Field meanings as in those two; n_layers <= 4; M >= 1. */
+typedef struct pag_wgrad_layer {
+    const void *dz;          /* bf16 [M, dz_cols] */
+    int dz_cols, n_out;
+    const void *a1;          /* layer input (a1_dtype, a1_layout, k1 columns) */
+    int a1_dtype, a1_layout, k1;
+    const float *a2;         /* gathered second input or NULL */
+    int k2p;
+    const int32_t *a2_index;
+    int n_in;
+    float *slabs;            /* f32 [n_blocks, round32(n_out), 96] */
+    int n_blocks;
+    int a1_levels, a1_feats; /* XCD8 inputs only */
+    float *dW, *db;          /* f32 [n_out, n_in] (XCD8 inputs: [n_out, a1_levels * a1_feats]), f32 [n_out] */
+} pag_wgrad_layer;
+int pag_mlp_wgrad_batch(const pag_wgrad_layer *layers, int n_layers, int64_t M, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray march (wisp OctreeAS.raymarch, 'ray' mode) - tracers/panoptic_packed_rf_tracer.py:85-86
  * ------------------------------------------------------------------------------------------ */

@@ -35,6 +35,15 @@ class MlpFwdArgs(ctypes.Structure):
                 ("softmax_stats", c_vp)]
 
 
+class WgradLayer(ctypes.Structure):
+    """pag_wgrad_layer (include/pagnerf_hip.h)."""
+    _fields_ = [("dz", c_vp), ("dz_cols", c_i32), ("n_out", c_i32),
+                ("a1", c_vp), ("a1_dtype", c_i32), ("a1_layout", c_i32), ("k1", c_i32),
+                ("a2", c_vp), ("k2p", c_i32), ("a2_index", c_vp), ("n_in", c_i32),
+                ("slabs", c_vp), ("n_blocks", c_i32), ("a1_levels", c_i32), ("a1_feats", c_i32),
+                ("dW", c_vp), ("db", c_vp)]
+
+
 class MlpBwdArgs(ctypes.Structure):
     _fields_ = [("grad_out", c_vp), ("out", c_vp), ("out_dtype", c_i32), ("out_act", c_i32),
                 ("k1", c_i32), ("in_dim", c_i32), ("n_layers", c_i32), ("out_dim", c_i32),
@@ -64,6 +73,7 @@ _SIGS = {
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
     "pag_head_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_mlp_wgrad_blocks": (c_i32, [c_i64]),
+    "pag_mlp_wgrad_batch": (c_i32, [ctypes.POINTER(WgradLayer), c_i32, c_i64, c_vp]),
     "pag_mlp_wgrad_finish": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "pag_mlp_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
     "pag_raymarch_count": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),

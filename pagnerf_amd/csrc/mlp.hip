@@ -1521,6 +1521,10 @@ struct WgradParams {
     int64_t M;
     int a1_grouped;        // a1 is bf16 [8][M][8] (PAG_LAYOUT_XCD8); slab columns are then staged positions
 };
+constexpr int WG_MAX_BATCH = 4;
+struct WgradBatch {
+    WgradParams p[WG_MAX_BATCH];
+};
 constexpr int WG_RS = 72;       // LDS row stride (bf16) of the transposed tiles: 64 samples + 8 pad
 constexpr int WG_SLAB_COLS = 96;
 
@@ -1528,7 +1532,8 @@ template <typename A1T, int APW /* accumulator blocks per wave */, int NWV = 4 /
 // narrow variant (APW 2, 4 waves): asking for 5 waves per SIMD keeps every accumulator in VGPRs (no AGPR copies) under 102
 // registers.  Wide layers (up to 224 outputs = 21 block pairs): 8 waves x 3 pairs instead of 4 x 6 - 48 accumulator
 // registers per wave leave room for the prefetch and for 4 waves per SIMD (the 4 x 6 form ran 2 waves per SIMD, no prefetch).
-__global__ __launch_bounds__(NWV * 64, (APW == 2 ? 5 : (APW == 3 ? 4 : 1))) void mlp_wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(NWV * 64, (APW == 2 ? 5 : (APW == 3 ? 4 : 1))) void mlp_wgrad_kernel(WgradBatch batch) {
+    const WgradParams &p = batch.p[blockIdx.y];       // blockIdx.y = layer: the layers of one decoder share a launch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.n_out + 31) / 32;
     const int IB = (p.n_in + 31) / 32;                 // 1 or 2
@@ -1889,6 +1894,17 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     return PAG_OK;
 }
 
+static void wgrad_launch(const WgradBatch &b, int count, bool a1_f32, bool small, int n_blocks, size_t lds, hipStream_t st) {
+    const dim3 grid(n_blocks, count);
+    if (a1_f32) {
+        if (small) hipLaunchKernelGGL((mlp_wgrad_kernel<float, 2>), grid, dim3(256), lds, st, b);
+        else hipLaunchKernelGGL((mlp_wgrad_kernel<float, 6>), grid, dim3(256), lds, st, b);
+    } else {
+        if (small) hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 2>), grid, dim3(256), lds, st, b);
+        else hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 3, 8>), grid, dim3(512), lds, st, b);
+    }
+}
+
 extern "C" int pag_mlp_wgrad_blocks(int64_t M) {
     int64_t chunks = (M + 63) / 64;
     return (int)(chunks < 1024 ? (chunks > 0 ? chunks : 1) : 1024);
@@ -1912,13 +1928,9 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
     const int OB = (n_out + 31) / 32, IB = (n_in + 31) / 32;
     const size_t lds = (size_t)(OB + IB) * 32 * WG_RS * sizeof(bf16_t);
     const bool small = OB * (IB + 1) <= 8;      // fewer accumulators -> fewer VGPRs -> more resident workgroups
-    if (a1_dtype == PAG_F32) {
-        if (small) hipLaunchKernelGGL((mlp_wgrad_kernel<float, 2>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((mlp_wgrad_kernel<float, 6>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
-    } else {
-        if (small) hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 2>), dim3(n_blocks), dim3(256), lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((mlp_wgrad_kernel<bf16_t, 3, 8>), dim3(n_blocks), dim3(512), lds, (hipStream_t)stream, p);
-    }
+    WgradBatch b{};
+    b.p[0] = p;
+    wgrad_launch(b, 1, a1_dtype == PAG_F32, small, n_blocks, lds, (hipStream_t)stream);
     PAG_CHECK_LAUNCH("pag_mlp_wgrad");
     return PAG_OK;
 }
@@ -1927,9 +1939,21 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
 // One workgroup per output row, 4 slab quarters x 96 columns; XCD8 inputs: slab column p is a staged position and lands in
 // feature column grp_col(p).
 constexpr int WF_SPLITS = 10;      // slab range split over 10 x 96 threads of the row's workgroup
-__global__ __launch_bounds__(WF_SPLITS * WG_SLAB_COLS) void wgrad_finish_kernel(const float *__restrict__ slabs, int n_blocks, int rows_pad, int n_in,
-                                                           int grp_L, int grp_F, float *__restrict__ dW, float *__restrict__ db) {
+struct FinishParams {
+    const float *slabs;
+    int n_blocks, n_out, rows_pad, n_in, grp_L, grp_F;
+    float *dW, *db;
+};
+struct FinishBatch {
+    FinishParams p[WG_MAX_BATCH];
+};
+__global__ __launch_bounds__(WF_SPLITS * WG_SLAB_COLS) void wgrad_finish_kernel(FinishBatch batch) {
     __shared__ float part[WF_SPLITS][WG_SLAB_COLS];
+    const FinishParams &fp = batch.p[blockIdx.y];     // blockIdx.y = layer
+    if ((int)blockIdx.x >= fp.n_out) return;
+    const float *__restrict__ slabs = fp.slabs;
+    float *__restrict__ dW = fp.dW, *__restrict__ db = fp.db;
+    const int n_blocks = fp.n_blocks, rows_pad = fp.rows_pad, n_in = fp.n_in, grp_L = fp.grp_L, grp_F = fp.grp_F;
     const int o = blockIdx.x, c = threadIdx.x % WG_SLAB_COLS, q = threadIdx.x / WG_SLAB_COLS;
     const int64_t stride = (int64_t)rows_pad * WG_SLAB_COLS;
     const float *src = slabs + (int64_t)o * WG_SLAB_COLS + c;
@@ -1964,9 +1988,61 @@ extern "C" int pag_mlp_wgrad_finish(const float *slabs, int n_blocks, int n_out,
     const int grouped = a1_layout == PAG_LAYOUT_XCD8;
     PAG_CHECK_ARG(!grouped || (a1_levels >= 1 && a1_feats >= 1 && a1_levels * a1_feats == n_in && ((a1_levels + 7) / 8) * a1_feats <= 8),
                   "pag_mlp_wgrad_finish: XCD8 needs n_in = levels*feats");
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(n_out), dim3(WF_SPLITS * WG_SLAB_COLS), 0, (hipStream_t)stream, slabs, n_blocks, (n_out + 31) / 32 * 32, n_in,
-                       grouped ? a1_levels : 0, a1_feats, dW, db);
+    FinishBatch fb{};
+    fb.p[0] = FinishParams{slabs, n_blocks, n_out, (n_out + 31) / 32 * 32, n_in, grouped ? a1_levels : 0, a1_feats, dW, db};
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(n_out, 1), dim3(WF_SPLITS * WG_SLAB_COLS), 0, (hipStream_t)stream, fb);
     PAG_CHECK_LAUNCH("pag_mlp_wgrad_finish");
+    return PAG_OK;
+}
+
+// All weight gradients of one decoder: the layers that share a kernel variant (input dtype, narrow / wide) go into ONE slab
+// launch (grid.y = layer) and ONE finish launch sums every layer's slabs - 2-3 launches per decoder instead of 2 per layer.
+extern "C" int pag_mlp_wgrad_batch(const pag_wgrad_layer *layers, int n_layers, int64_t M, void *stream) {
+    PAG_CHECK_ARG(layers && n_layers >= 1 && n_layers <= WG_MAX_BATCH, "pag_mlp_wgrad_batch: n_layers %d not in [1,%d]", n_layers, WG_MAX_BATCH);
+    PAG_CHECK_ARG(M >= 1, "pag_mlp_wgrad_batch: M < 1 (callers zero the gradients of an empty batch themselves)");
+    hipStream_t st = (hipStream_t)stream;
+    bool done[WG_MAX_BATCH] = {false, false, false, false};
+    FinishBatch fb{};
+    int max_out = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const pag_wgrad_layer &y = layers[l];
+        PAG_CHECK_ARG(y.n_out >= 1 && y.n_out <= 224 && y.dz_cols >= y.n_out, "pag_mlp_wgrad_batch: layer %d n_out %d / dz_cols %d out of range", l, y.n_out, y.dz_cols);
+        PAG_CHECK_ARG(y.k1 > 0 && y.k1 % 8 == 0, "pag_mlp_wgrad_batch: layer %d k1 %d must be a positive multiple of 8", l, y.k1);
+        PAG_CHECK_ARG(y.a2 == nullptr || (y.k2p > 0 && y.k2p % 8 == 0 && y.a2_index), "pag_mlp_wgrad_batch: layer %d a2 needs k2p %% 8 == 0 and a2_index", l);
+        PAG_CHECK_ARG(y.n_in >= 1 && y.n_in <= 64 && y.n_in <= y.k1 + (y.a2 ? y.k2p : 0), "pag_mlp_wgrad_batch: layer %d n_in %d out of range", l, y.n_in);
+        PAG_CHECK_ARG(y.a1_dtype == PAG_F32 || y.a1_dtype == PAG_BF16, "pag_mlp_wgrad_batch: layer %d a1 dtype must be F32 or BF16", l);
+        PAG_CHECK_ARG(y.n_blocks >= 1 && y.dz && y.a1 && y.slabs && y.dW && y.db, "pag_mlp_wgrad_batch: layer %d NULL pointer or n_blocks < 1", l);
+        const bool grouped = y.a1_layout == PAG_LAYOUT_XCD8;
+        PAG_CHECK_ARG(!grouped || (y.a1_dtype == PAG_BF16 && y.k1 == 64 && y.n_in == 64 && y.a2 == nullptr && y.a1_levels >= 1 && y.a1_feats >= 1 &&
+                                   ((y.a1_levels + 7) / 8) * y.a1_feats <= 8),
+                      "pag_mlp_wgrad_batch: layer %d XCD8 a1 needs bf16, k1 = n_in = 64 (staged positions), levels*feats <= 64 and no a2", l);
+        // XCD8: the slab columns are the 64 staged positions, dW has levels*feats feature columns
+        fb.p[l] = FinishParams{y.slabs, y.n_blocks, y.n_out, (y.n_out + 31) / 32 * 32, grouped ? y.a1_levels * y.a1_feats : y.n_in,
+                               grouped ? y.a1_levels : 0, y.a1_feats, y.dW, y.db};
+        max_out = std::max(max_out, y.n_out);
+    }
+    for (int l = 0; l < n_layers; ++l) {
+        if (done[l]) continue;
+        const pag_wgrad_layer &y = layers[l];
+        const bool f32 = y.a1_dtype == PAG_F32;
+        const bool small = ((y.n_out + 31) / 32) * ((y.n_in + 31) / 32 + 1) <= 8;
+        WgradBatch b{};
+        int count = 0;
+        size_t lds = 0;
+        for (int k = l; k < n_layers; ++k) {
+            const pag_wgrad_layer &z = layers[k];
+            const int OB = (z.n_out + 31) / 32, IB = (z.n_in + 31) / 32;
+            if (done[k] || (z.a1_dtype == PAG_F32) != f32 || (OB * (IB + 1) <= 8) != small || z.n_blocks != y.n_blocks) continue;
+            b.p[count++] = WgradParams{(const bf16_t *)z.dz, z.dz_cols, z.n_out, z.a1, z.k1, z.a2, z.a2 ? z.k2p : 0, z.a2_index, z.n_in, z.slabs, M,
+                                       z.a1_layout == PAG_LAYOUT_XCD8};
+            lds = std::max(lds, (size_t)(OB + IB) * 32 * WG_RS * sizeof(bf16_t));
+            done[k] = true;
+        }
+        wgrad_launch(b, count, f32, small, y.n_blocks, lds, st);
+        PAG_CHECK_LAUNCH("pag_mlp_wgrad_batch (slabs)");
+    }
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(max_out, n_layers), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
+    PAG_CHECK_LAUNCH("pag_mlp_wgrad_batch (finish)");
     return PAG_OK;
 }
 

@@ -335,29 +335,29 @@ class _FusedMLP(torch.autograd.Function):
         if mode == L.MLP_MFMA_BF16 and M:
             # weight gradients on the matrix cores: per-workgroup fp32 slabs, summed here (deterministic)
             nblk_max = lib.pag_mlp_wgrad_blocks(M)
+            layers = (L.WgradLayer * n_layers)()
+            keep = []
             for l in range(n_layers):
                 n_out = Wc[l].shape[0]
                 nblk = nblk_max if n_out <= 64 else min(nblk_max, 512)      # wide layers: fewer, larger slabs to sum
                 slabs = torch.empty(nblk, (n_out + 31) // 32 * 32, 96, device=dev)
+                y = layers[l]
+                y.dz, y.dz_cols, y.n_out = L.ptr(dz[l]), dz[l].shape[1], n_out
                 if l == 0 and grouped is not None:
-                    _call("pag_mlp_wgrad", L.ptr(dz[0]), dz[0].shape[1], n_out, L.ptr(x1), L.BF16, L.LAYOUT_XCD8, 64, None, 0, None,
-                          64, L.ptr(slabs), nblk, M, L.stream())
-                    n_in = 64
+                    y.a1, y.a1_dtype, y.a1_layout, y.k1, y.n_in = L.ptr(x1), L.BF16, L.LAYOUT_XCD8, 64, 64
+                    y.a1_levels, y.a1_feats = grouped
                 elif l == 0:
-                    _call("pag_mlp_wgrad", L.ptr(dz[0]), dz[0].shape[1], n_out, L.ptr(x1), L.dtype_code(x1), L.LAYOUT_STRIDED, k1,
-                          L.ptr(x2), x2.shape[1] if x2 is not None else 0, L.ptr(x2_index), in_dim, L.ptr(slabs), nblk, M, L.stream())
-                    n_in = in_dim
+                    y.a1, y.a1_dtype, y.a1_layout, y.k1, y.n_in = L.ptr(x1), L.dtype_code(x1), L.LAYOUT_STRIDED, k1, in_dim
+                    y.a2, y.k2p, y.a2_index = L.ptr(x2), (x2.shape[1] if x2 is not None else 0), L.ptr(x2_index)
                 else:
-                    _call("pag_mlp_wgrad", L.ptr(dz[l]), dz[l].shape[1], n_out, L.ptr(hidden[l - 1]), L.BF16, L.LAYOUT_STRIDED, 64,
-                          None, 0, None, 64, L.ptr(slabs), nblk, M, L.stream())
-                    n_in = 64
+                    y.a1, y.a1_dtype, y.a1_layout, y.k1, y.n_in = L.ptr(hidden[l - 1]), L.BF16, L.LAYOUT_STRIDED, 64, 64
                 w = torch.empty(n_out, in_dim if l == 0 else 64, device=dev)
                 bgrad = torch.empty(n_out, device=dev)
-                is_grp = l == 0 and grouped is not None
-                _call("pag_mlp_wgrad_finish", L.ptr(slabs), nblk, n_out, w.shape[1], L.LAYOUT_XCD8 if is_grp else L.LAYOUT_STRIDED,
-                      grouped[0] if is_grp else 0, grouped[1] if is_grp else 0, L.ptr(w), L.ptr(bgrad), L.stream())
+                y.slabs, y.n_blocks, y.dW, y.db = L.ptr(slabs), nblk, L.ptr(w), L.ptr(bgrad)
+                keep.append(slabs)
                 gW.append(w)
                 gb.append(bgrad)
+            _call("pag_mlp_wgrad_batch", layers, n_layers, M, L.stream())      # 2-3 launches for the whole decoder
         else:
             # fp32 parity path: dz_l^T @ input_l as plain fp32 GEMMs (BLAS)
             for l in range(n_layers):
