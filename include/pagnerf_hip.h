@@ -162,6 +162,9 @@ typedef struct {
     float *softmax_stats;   /* optional (MFMA mode, out_act SOFTMAX, out_dim > 64): f32 [M,2] = (max logit * log2(e),
                                1 / sum exp) per sample, from which the backward and pag_head_composite_fwd rebuild the
                                probabilities; `out` may then be NULL (nothing but the statistics is written) */
+    float *x1_col0_relu;    /* optional (MFMA mode, strided bf16 x1, out_dim <= 64): f32 [M] = relu(x1[m][0]) written by the
+                               same launch - the density pc_nerf/panoptic_delta_nef.py:188 reads off column 0 of the density
+                               decoder's output, which is this (colour) decoder's x1 */
 } pag_mlp_fwd_args;
 int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
 
@@ -194,6 +197,10 @@ typedef struct {
     const float *dx1_col0_add;   /* optional f32 [M] (strided dx1, MFMA mode, out_dim <= 64): added to column 0 of dx1 - the
                                     gradient of the density that pc_nerf/panoptic_delta_nef.py:188 reads off column 0 of the
                                     density decoder's output, which is also this (colour) decoder's x1 */
+    const float *dx1_col0_gate;  /* optional f32 [M] with dx1_col0_add: the addend is applied only where gate[m] > 0 (the relu of
+                                    that column: pass the forward's x1_col0_relu) */
+    const float *g_ray_scale;    /* optional f32 [N] with the rank-1 gradient: grad_out[m][c] = g_scale[m] * g_ray_scale[g_index[m]] *
+                                    g_ray[g_index[m]][c] (g_scale = the compositing weights w_m, g_ray_scale = the rays' alpha) */
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 

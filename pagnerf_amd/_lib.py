@@ -32,7 +32,7 @@ class MlpFwdArgs(ctypes.Structure):
                 ("out", c_vp), ("out_dtype", c_i32),
                 ("hidden_save", c_vp * 2),
                 ("mode", c_i32),
-                ("softmax_stats", c_vp)]
+                ("softmax_stats", c_vp), ("x1_col0_relu", c_vp)]
 
 
 class WgradLayer(ctypes.Structure):
@@ -54,7 +54,8 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dx1", c_vp), ("dx1_dtype", c_i32),
                 ("mode", c_i32),
                 ("g_ray", c_vp), ("g_scale", c_vp), ("g_index", c_vp),
-                ("softmax_stats", c_vp), ("b_last", c_vp), ("dx1_accumulate", c_i32), ("dx1_col0_add", c_vp)]
+                ("softmax_stats", c_vp), ("b_last", c_vp), ("dx1_accumulate", c_i32), ("dx1_col0_add", c_vp),
+                ("dx1_col0_gate", c_vp), ("g_ray_scale", c_vp)]
 
 
 _SIGS = {

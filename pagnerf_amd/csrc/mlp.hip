@@ -60,6 +60,7 @@ struct FwdParams {
     int64_t M;
     int grp_L, grp_F;      // x1 in PAG_LAYOUT_XCD8 (bf16 [8][M][8]) when grp_L > 0
     float *stats;          // optional f32 [M,2]: (max logit * log2e, 1 / sum exp) of the output softmax
+    float *col0_relu;      // optional f32 [M]: relu(x1[m][0]) (strided bf16 x1) - the density read off the colour decoder's input
 };
 
 struct BwdParams {
@@ -67,6 +68,7 @@ struct BwdParams {
     // rank-1 upstream gradient (composited panoptic heads): g[m][c] = g_scale[m] * g_ray[g_index[m]][c]
     const float *g_ray;
     const float *g_scale;
+    const float *g_ray_scale;  // optional per-ray factor: g[m][c] = g_scale[m] * g_ray_scale[g_index[m]] * g_ray[g_index[m]][c]
     const int32_t *g_index;
     const void *out;
     int k1, in_dim, in_pad, out_dim, act;
@@ -80,6 +82,7 @@ struct BwdParams {
     const float *b_last;
     int dx1_acc;           // XCD8 dx1: add to the existing contents instead of overwriting
     const float *dx_col0;  // strided dx1: f32 [M] added to column 0
+    const float *dx_col0_gate;   // optional f32 [M]: the addend counts only where gate[m] > 0 (relu of that column)
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
@@ -468,6 +471,9 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdPara
 #pragma unroll
         for (int s = 0; s < 4; ++s) xb[s] = xnext[s];
         load_x(tile + tile_step, xnext);
+        if constexpr (OBMAX <= 2) {     // narrow decoders only (the colour decoder): density = relu(column 0 of its input)
+            if (p.col0_relu && h == 0 && live) p.col0_relu[m] = fmaxf((float)xb[0][0], 0.0f);
+        }
         if constexpr (OBMAX > 2) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
             asm volatile("" : "+v"(r), "+v"(h));
         }
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
                 if (ob < OB) raw_to_block(rz[ob], z[ob]);
             if (p.g_ray) {
                 const int gi = p.g_index[mc], gi0 = __builtin_amdgcn_readfirstlane(gi);
-                const float sc = p.g_scale[mc];
+                const float sc = p.g_ray_scale ? __fmul_rn(p.g_scale[mc], p.g_ray_scale[gi]) : p.g_scale[mc];
                 if (__all(gi == gi0)) {
                     const float *g_row_u = p.g_ray + (int64_t)gi0 * p.out_dim;
 #pragma unroll
@@ -789,7 +795,7 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
             const bool g_uni = __all(g_idx1 == g_idx0);      // whole tile inside one ray (the common case)
             const float *g_row1 = p.g_ray ? p.g_ray + (int64_t)g_idx1 * p.out_dim : nullptr;
             const float *g_row_u = p.g_ray ? p.g_ray + (int64_t)g_idx0 * p.out_dim : nullptr;
-            const float g_sc1 = p.g_ray ? p.g_scale[mc] : 0.0f;
+            const float g_sc1 = p.g_ray ? (p.g_ray_scale ? __fmul_rn(p.g_scale[mc], p.g_ray_scale[g_idx1]) : p.g_scale[mc]) : 0.0f;
             const bool r1 = p.g_ray != nullptr;
             const bool need_y = p.act != PAG_ACT_NONE;
             const int n1 = p.act == PAG_ACT_SOFTMAX ? OB : 0, n_steps = n1 + OB;
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? 2 : 1)) void mlp_bwd_mfma(BwdPara
                     if (live && !p.grp_L) {
                         // extra gradient of input column 0 (the density read off the density decoder's first output,
                         // pc_nerf/panoptic_delta_nef.py:188): added here instead of a zero-padded [M,k1] tensor + add pass
-                        if (p.dx_col0 && mb == 0 && h == 0) acc[0][0] += p.dx_col0[m];
+                        if (p.dx_col0 && mb == 0 && h == 0 && (!p.dx_col0_gate || p.dx_col0_gate[m] > 0.0f)) acc[0][0] += p.dx_col0[m];
                         store_block(dx + m * p.k1, 32 * mb, h, acc[mb], p.k1, true);
                     }
                     if (live && p.grp_L) {      // XCD8: row 32mb + 8g + 4h + j of dx^T -> piece [4mb + g][m][4h + j]
@@ -1021,7 +1027,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
             st_n = *reinterpret_cast<const float2 *>(p.stats + 2 * mc_);
             if (r1) {
                 gi_n = p.g_index[mc_];
-                gs_n = p.g_scale[mc_];
+                gs_n = p.g_ray_scale ? __fmul_rn(p.g_scale[mc_], p.g_ray_scale[gi_n]) : p.g_scale[mc_];
                 const int g0 = __builtin_amdgcn_readfirstlane(gi_n);
                 uni_n = __all(gi_n == g0);
                 if (uni_n) {
@@ -1735,6 +1741,9 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     p.out_dim = a->out_dim;
     p.act = a->out_act;
     p.stats = (a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64) ? a->softmax_stats : nullptr;
+    PAG_CHECK_ARG(!a->x1_col0_relu || (a->mode == PAG_MLP_MFMA_BF16 && a->x1_dtype == PAG_BF16 && a->x1_layout != PAG_LAYOUT_XCD8 && a->out_dim <= 64),
+                  "pag_mlp_fwd: x1_col0_relu needs MFMA mode, a strided bf16 x1 and out_dim <= 64");
+    p.col0_relu = a->x1_col0_relu;
     for (int l = 0; l < 3; ++l) {
         p.W[l] = l < a->n_layers ? a->W[l] : nullptr;
         p.b[l] = l < a->n_layers ? a->b[l] : nullptr;
@@ -1812,6 +1821,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     BwdParams p;
     p.g_ray = a->g_ray;
     p.g_scale = a->g_scale;
+    p.g_ray_scale = a->g_ray_scale;
     p.g_index = a->g_index;
     p.grad_out = a->grad_out ? a->grad_out : (const void *)a->out;      // never dereferenced in rank-1 mode
     p.out = a->out ? a->out : (const void *)a->grad_out;
@@ -1841,6 +1851,8 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     p.b_last = a->b_last;
     p.dx1_acc = a->dx1_accumulate;
     p.dx_col0 = a->dx1_col0_add;
+    p.dx_col0_gate = a->dx1_col0_gate;
+    PAG_CHECK_ARG(!a->dx1_col0_gate || a->dx1_col0_add, "pag_mlp_bwd: dx1_col0_gate without dx1_col0_add");
     PAG_CHECK_ARG(!a->dx1_col0_add || (a->dx1 && !p.grp_L && a->mode == PAG_MLP_MFMA_BF16 && a->out_dim <= 64),
                   "pag_mlp_bwd: dx1_col0_add needs a strided dx1, MFMA mode and out_dim <= 64");
     PAG_CHECK_ARG(!a->dx1_accumulate || (p.grp_L && a->dx1), "pag_mlp_bwd: dx1_accumulate needs an XCD8 dx1");

@@ -270,6 +270,11 @@ class _FusedMLP(torch.autograd.Function):
         if wide_softmax and (need_grad or stats_only):
             stats = torch.empty(M, 2, device=x1.device)
             a.softmax_stats = L.ptr(stats)
+        ctx.col0_relu = None
+        if getattr(ctx, "want_col0_relu", False) and mode == L.MLP_MFMA_BF16 and grouped is None and x1.dtype == torch.bfloat16 \
+                and out_dim <= 64 and M:
+            ctx.col0_relu = torch.empty(M, device=x1.device)           # _ColourDensity: sigma from the same launch
+            a.x1_col0_relu = L.ptr(ctx.col0_relu)
         if M:
             _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
         ctx.cfg = (in_dim, out_act, mode, n_layers, k1, grouped)
@@ -288,7 +293,7 @@ class _FusedMLP(torch.autograd.Function):
         return _FusedMLP._backward_impl(ctx, g, None)
 
     @staticmethod
-    def _backward_impl(ctx, g, rank1, dx1_into=None, col0_add=None):
+    def _backward_impl(ctx, g, rank1, dx1_into=None, col0_add=None, col0_gate=None):
         """rank1 = (g_ray f32 [N,out], g_scale f32 [M], g_index i32 [M]) replaces the dense upstream gradient g.
         dx1_into: an XCD8 gradient tensor of another decoder on the same input - this one's d x1 is added to it in place."""
         lib = L.load()
@@ -311,8 +316,11 @@ class _FusedMLP(torch.autograd.Function):
             g = g.contiguous().to(out_dtype)       # grad_out travels in the output's dtype
             a.grad_out = L.ptr(g)
         else:
-            g_ray, g_scale, g_index = rank1
+            g_ray, g_scale, g_index = rank1[:3]
             a.g_ray, a.g_scale, a.g_index = L.ptr(g_ray), L.ptr(g_scale), L.ptr(g_index)
+            if len(rank1) > 3:
+                g_ray_scale = rank1[3].float()            # named: stays alive past the launch
+                a.g_ray_scale = L.ptr(g_ray_scale)
         a.out, a.out_dtype, a.out_act = L.ptr(out), _DTYPE_CODE[out_dtype], out_act
         a.k1, a.in_dim, a.n_layers, a.out_dim = k1, in_dim, n_layers, out_dim
         if grouped is not None:
@@ -325,8 +333,12 @@ class _FusedMLP(torch.autograd.Function):
         a.softmax_stats, a.b_last = L.ptr(stats), L.ptr(b_last)
         a.dx1_accumulate = 1 if (need_dx and dx1_into is not None) else 0
         fuse_col0 = col0_add is not None and need_dx and grouped is None and mode == L.MLP_MFMA_BF16 and out_dim <= 64
+        if col0_gate is not None and not fuse_col0:          # the gate only exists on the fused path's preconditions
+            col0_add, col0_gate = col0_add * (col0_gate > 0), None
         if fuse_col0:
             a.dx1_col0_add = L.ptr(col0_add)
+            if col0_gate is not None:
+                a.dx1_col0_gate = L.ptr(col0_gate)
         if M:
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
         if col0_add is not None and need_dx and not fuse_col0:
@@ -398,7 +410,11 @@ class _ColourDensity(_FusedMLP):
 
     @staticmethod
     def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb):
+        ctx.want_col0_relu = True
         rgb = _FusedMLP.forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb)
+        if ctx.col0_relu is not None:            # written by the decoder launch; the backward gates on it inside the kernel
+            ctx.pre = None
+            return rgb, ctx.col0_relu
         pre = x1.detach()[:, 0].float()
         ctx.pre = pre
         return rgb, torch.relu(pre)
@@ -408,7 +424,11 @@ class _ColourDensity(_FusedMLP):
         saved_out = ctx.saved_tensors[3]
         if g_rgb is None:
             g_rgb = torch.zeros_like(saved_out)
-        add = (g_sigma.float() * (ctx.pre > 0)).contiguous() if g_sigma is not None else None
+        if g_sigma is None:
+            return _FusedMLP._backward_impl(ctx, g_rgb, None)
+        if ctx.pre is None:
+            return _FusedMLP._backward_impl(ctx, g_rgb, None, col0_add=g_sigma.float().contiguous(), col0_gate=ctx.col0_relu)
+        add = (g_sigma.float() * (ctx.pre > 0)).contiguous()
         return _FusedMLP._backward_impl(ctx, g_rgb, None, col0_add=add)
 
 
@@ -611,6 +631,7 @@ class _Composite(torch.autograd.Function):
         ctx.save_for_backward(sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha)
         ctx.bg_white = bg_white
         ctx.mark_non_differentiable(hit, w)
+        ctx.set_materialize_grads(False)      # unused outputs (alpha, depth, hit, w) arrive as None, not as zero-filled tensors
         return alpha, hit, out_rgb, out_depth, w
 
     @staticmethod
@@ -777,8 +798,9 @@ class _HeadComposite(_FusedMLP):
     @staticmethod
     def _backward_pair(ctx, g, dx1_into):
         weights_w, alpha, ridx = ctx.hc
-        scale = weights_w * alpha[ridx.long()]                       # alpha * w_m per sample (detached, :148-155)
-        grads = _FusedMLP._backward_impl(ctx, None, (g.contiguous().float(), scale.contiguous(), ridx.contiguous()), dx1_into)
+        # upstream gradient in rank-1 form: alpha[ray] * w_m * g[ray] (detached weights, :148-155); the kernel forms the product
+        grads = _FusedMLP._backward_impl(ctx, None, (g.contiguous().float(), weights_w.contiguous(), ridx.contiguous(), alpha.contiguous()),
+                                         dx1_into)
         return grads[0], grads[8:]
 
 
@@ -878,12 +900,15 @@ class _RenderLoss(torch.autograd.Function):
         ctx.out = out
         ctx.shapes = tuple(None if t is None else (t.shape, t.dtype) for t in (rgb, prob_a, prob_b))
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
         return out[0], out
 
     @staticmethod
     def backward(ctx, g, _g_terms):
         head, targs, eps = ctx.call
         dev = ctx.out.device
+        if g is None:
+            return (None,) * 8
         grads = []
         for need, sh in zip(ctx.needs_input_grad[:3], ctx.shapes):
             grads.append(torch.empty(sh[0], device=dev) if (need and sh is not None) else None)
