@@ -349,9 +349,12 @@ class _FusedMLP(torch.autograd.Function):
             nblk_max = lib.pag_mlp_wgrad_blocks(M)
             layers = (L.WgradLayer * n_layers)()
             keep = []
+            # the narrow layers share ONE launch (grid.y = layer): split the ~1024 workgroups that fill the chip in a single
+            # wave between them (a second, partial wave of workgroups cost 10 %)
+            n_narrow = sum(1 for w_ in Wc if w_.shape[0] <= 64)
             for l in range(n_layers):
                 n_out = Wc[l].shape[0]
-                nblk = nblk_max if n_out <= 64 else min(nblk_max, 512)      # wide layers: fewer, larger slabs to sum
+                nblk = max(1, nblk_max // n_narrow) if n_out <= 64 else min(nblk_max, 512)      # wide layers: fewer, larger slabs
                 slabs = torch.empty(nblk, (n_out + 31) // 32 * 32, 96, device=dev)
                 y = layers[l]
                 y.dz, y.dz_cols, y.n_out = L.ptr(dz[l]), dz[l].shape[1], n_out
