@@ -51,6 +51,18 @@ class BasicDecoder(nn.Module):
                              out_dtype=out_dtype, x1_grouped=x1_grouped, x2_packs=x2_packs)
 
 
+_PARAM_NAMES = {}
+
+
+def _param_names(fn):
+    """Parameter names of a channel function (inspect.signature costs ~40 us per call; the functions never change)."""
+    key = getattr(fn, "__func__", fn)
+    names = _PARAM_NAMES.get(key)
+    if names is None:
+        names = _PARAM_NAMES[key] = frozenset(inspect.signature(fn).parameters)
+    return names
+
+
 def positional_embed(x, num_freq):
     """wisp PositionalEmbedder: cat(x, sin(x*2^k), cos(x*2^k)), frequency-major."""
     bands = 2.0 ** torch.linspace(0.0, num_freq - 1, num_freq, device=x.device)
@@ -147,7 +159,7 @@ class PanopticDeltaNeF(nn.Module):
         for fn, chans in self._fns:
             if not (chans & req):
                 continue
-            params = inspect.signature(fn).parameters
+            params = _param_names(fn)
             res = fn(**{k: v for k, v in kwargs.items() if k in params})
             for c in chans & req:
                 out[c] = res[c]
@@ -176,8 +188,17 @@ class PanopticDeltaNeF(nn.Module):
             return (self.num_lods, self.feature_dim)
         return None
 
+    def _lod_weights_or_none(self):
+        """None while every weight is 1 (the kernels then skip the multiply); the CPU-side check (three tensor ops, ~40 us -
+        paid while the GPU waits for the step's first encode launch) is cached against the tensor's version counter."""
+        lw = self.lod_weights
+        key = (id(lw), lw._version)
+        if getattr(self, "_lw_key", None) != key:
+            self._lw_key, self._lw_ones = key, bool((lw == 1).all())
+        return None if self._lw_ones else lw
+
     def _interp(self, grid, coords, addend=None):
-        lw = None if bool((self.lod_weights == 1).all()) else self.lod_weights
+        lw = self._lod_weights_or_none()
         return grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None,
                                        addend=addend)
 

@@ -17,6 +17,9 @@ from . import ops
 from .core import RenderBuffer
 
 
+_TRACE_PARAMS = {}      # per tracer class: trace()'s parameters (inspect.signature is ~40 us per call)
+
+
 class PanopticPackedRFTracer(nn.Module):
     def __init__(self, ray_sparcity_reg=0.0, ray_max_travel=6.0, raymarch_type="voxel", num_steps=64, step_size=1.0,
                  bg_color="white", **kwargs):
@@ -53,7 +56,10 @@ class PanopticPackedRFTracer(nn.Module):
         if unsupported:
             raise Exception("channels %s are supported by neither the tracer nor the nef" % unsupported)
         args = {}
-        for name, prm in inspect.signature(self.trace).parameters.items():
+        sig = _TRACE_PARAMS.get(type(self))
+        if sig is None:
+            sig = _TRACE_PARAMS[type(self)] = tuple(inspect.signature(self.trace).parameters.items())
+        for name, prm in sig:
             if name in ("nef", "channels", "extra_channels"):
                 continue
             if name in kwargs:
