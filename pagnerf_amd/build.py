@@ -64,14 +64,14 @@ def build(force=False, verbose=True):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         if verbose:
-            print("[pagnerf_amd.build] up to date:", LIB)
+            print("[pagnerf_amd.build] up to date:", LIB, file=sys.stderr)
         return LIB
     objs = {s: os.path.join(LIBDIR, "obj", os.path.splitext(s)[0] + ".o") for s in SOURCES}
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         futs = [ex.submit(_compile, s, f, objs[s]) for s, f in SOURCES.items()]
         for f in concurrent.futures.as_completed(futs):
             if verbose:
-                print("[pagnerf_amd.build] compiled", f.result())
+                print("[pagnerf_amd.build] compiled", f.result(), file=sys.stderr)
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + list(objs.values())
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -79,7 +79,7 @@ def build(force=False, verbose=True):
     with open(stamp, "w") as fh:
         fh.write(dig)
     if verbose:
-        print("[pagnerf_amd.build] linked", LIB)
+        print("[pagnerf_amd.build] linked", LIB, file=sys.stderr)
     return LIB
 
 
