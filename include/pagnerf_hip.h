@@ -236,7 +236,7 @@ int pag_mlp_wgrad_finish(const float *slabs, int n_blocks, int n_out, int n_in, 
 
 /* Every weight gradient of one decoder in 2-3 launches: layers with the same kernel variant share one slab launch
  * (grid.y = layer), one finish launch sums all of them.  Same arithmetic (and bits) as pag_mlp_wgrad +
- * pag_mlp_wgrad_finish per layer.  Field meanings as in those two; n_layers <= 4; M >= 1. */
+ * pag_mlp_wgrad_finish per layer.  Field meanings as in those two; n_layers <= 6; M >= 1. */
 typedef struct pag_wgrad_layer {
     const void *dz;          /* bf16 [M, dz_cols] */
     int dz_cols, n_out;

@@ -1527,7 +1527,7 @@ struct WgradParams {
     int64_t M;
     int a1_grouped;        // a1 is bf16 [8][M][8] (PAG_LAYOUT_XCD8); slab columns are then staged positions
 };
-constexpr int WG_MAX_BATCH = 4;
+constexpr int WG_MAX_BATCH = 6;
 struct WgradBatch {
     WgradParams p[WG_MAX_BATCH];
 };
@@ -2013,7 +2013,7 @@ extern "C" int pag_mlp_wgrad_batch(const pag_wgrad_layer *layers, int n_layers, 
     PAG_CHECK_ARG(layers && n_layers >= 1 && n_layers <= WG_MAX_BATCH, "pag_mlp_wgrad_batch: n_layers %d not in [1,%d]", n_layers, WG_MAX_BATCH);
     PAG_CHECK_ARG(M >= 1, "pag_mlp_wgrad_batch: M < 1 (callers zero the gradients of an empty batch themselves)");
     hipStream_t st = (hipStream_t)stream;
-    bool done[WG_MAX_BATCH] = {false, false, false, false};
+    bool done[WG_MAX_BATCH] = {};
     FinishBatch fb{};
     int max_out = 0;
     for (int l = 0; l < n_layers; ++l) {

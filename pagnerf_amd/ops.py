@@ -293,7 +293,7 @@ class _FusedMLP(torch.autograd.Function):
         return _FusedMLP._backward_impl(ctx, g, None)
 
     @staticmethod
-    def _backward_impl(ctx, g, rank1, dx1_into=None, col0_add=None, col0_gate=None):
+    def _backward_impl(ctx, g, rank1, dx1_into=None, col0_add=None, col0_gate=None, wgrad_queue=None):
         """rank1 = (g_ray f32 [N,out], g_scale f32 [M], g_index i32 [M]) replaces the dense upstream gradient g.
         dx1_into: an XCD8 gradient tensor of another decoder on the same input - this one's d x1 is added to it in place."""
         lib = L.load()
@@ -346,33 +346,26 @@ class _FusedMLP(torch.autograd.Function):
         gW, gb = [], []
         if mode == L.MLP_MFMA_BF16 and M:
             # weight gradients on the matrix cores: per-workgroup fp32 slabs, summed here (deterministic)
-            nblk_max = lib.pag_mlp_wgrad_blocks(M)
-            layers = (L.WgradLayer * n_layers)()
-            keep = []
-            # the narrow layers share ONE launch (grid.y = layer): split the ~1024 workgroups that fill the chip in a single
-            # wave between them (a second, partial wave of workgroups cost 10 %)
-            n_narrow = sum(1 for w_ in Wc if w_.shape[0] <= 64)
+            specs = []
             for l in range(n_layers):
                 n_out = Wc[l].shape[0]
-                nblk = max(1, nblk_max // n_narrow) if n_out <= 64 else min(nblk_max, 512)      # wide layers: fewer, larger slabs
-                slabs = torch.empty(nblk, (n_out + 31) // 32 * 32, 96, device=dev)
-                y = layers[l]
-                y.dz, y.dz_cols, y.n_out = L.ptr(dz[l]), dz[l].shape[1], n_out
+                sp = dict(dz=dz[l], n_out=n_out, a2=None, k2p=0, a2_index=None, levels=0, feats=0)
                 if l == 0 and grouped is not None:
-                    y.a1, y.a1_dtype, y.a1_layout, y.k1, y.n_in = L.ptr(x1), L.BF16, L.LAYOUT_XCD8, 64, 64
-                    y.a1_levels, y.a1_feats = grouped
+                    sp.update(a1=x1, a1_dtype=L.BF16, a1_layout=L.LAYOUT_XCD8, k1=64, n_in=64, levels=grouped[0], feats=grouped[1])
                 elif l == 0:
-                    y.a1, y.a1_dtype, y.a1_layout, y.k1, y.n_in = L.ptr(x1), L.dtype_code(x1), L.LAYOUT_STRIDED, k1, in_dim
-                    y.a2, y.k2p, y.a2_index = L.ptr(x2), (x2.shape[1] if x2 is not None else 0), L.ptr(x2_index)
+                    sp.update(a1=x1, a1_dtype=L.dtype_code(x1), a1_layout=L.LAYOUT_STRIDED, k1=k1, n_in=in_dim,
+                              a2=x2, k2p=(x2.shape[1] if x2 is not None else 0), a2_index=x2_index)
                 else:
-                    y.a1, y.a1_dtype, y.a1_layout, y.k1, y.n_in = L.ptr(hidden[l - 1]), L.BF16, L.LAYOUT_STRIDED, 64, 64
-                w = torch.empty(n_out, in_dim if l == 0 else 64, device=dev)
-                bgrad = torch.empty(n_out, device=dev)
-                y.slabs, y.n_blocks, y.dW, y.db = L.ptr(slabs), nblk, L.ptr(w), L.ptr(bgrad)
-                keep.append(slabs)
-                gW.append(w)
-                gb.append(bgrad)
-            _call("pag_mlp_wgrad_batch", layers, n_layers, M, L.stream())      # 2-3 launches for the whole decoder
+                    sp.update(a1=hidden[l - 1], a1_dtype=L.BF16, a1_layout=L.LAYOUT_STRIDED, k1=64, n_in=64)
+                sp["w"] = torch.empty(n_out, in_dim if l == 0 else 64, device=dev)
+                sp["b"] = torch.empty(n_out, device=dev)
+                gW.append(sp["w"])
+                gb.append(sp["b"])
+                specs.append(sp)
+            if wgrad_queue is not None:
+                wgrad_queue.extend(specs)          # the caller launches several decoders' weight gradients together
+            else:
+                _launch_wgrad(specs, M)
         else:
             # fp32 parity path: dz_l^T @ input_l as plain fp32 GEMMs (BLAS)
             for l in range(n_layers):
@@ -404,6 +397,33 @@ class _FusedMLP(torch.autograd.Function):
             dx2 = torch.zeros_like(x2)
             dx2[:, :in_dim - k1] = seg @ w_tail
         return (dx1, dx2, None, None, None, None, None, None, *gW, *gb)
+
+
+WGRAD_MAX_BATCH = 6      # WG_MAX_BATCH of csrc/mlp.hip
+
+
+def _launch_wgrad(specs, M):
+    """Weight / bias gradients of the given decoder layers (dicts built by _FusedMLP._backward_impl; all over the same M samples)
+    through pag_mlp_wgrad_batch: the narrow layers share ONE slab launch (grid.y = layer) whose ~1024 workgroups - one wave of
+    workgroups on the chip; a second, partial wave cost 10 % - are split between them; one finish launch sums every layer's slabs."""
+    lib = L.load()
+    nblk_max = lib.pag_mlp_wgrad_blocks(M)
+    for c0 in range(0, len(specs), WGRAD_MAX_BATCH):
+        part = specs[c0:c0 + WGRAD_MAX_BATCH]
+        n_narrow = max(1, sum(1 for sp in part if sp["n_out"] <= 64))
+        layers = (L.WgradLayer * len(part))()
+        keep = []
+        for y, sp in zip(layers, part):
+            n_out = sp["n_out"]
+            nblk = max(1, nblk_max // n_narrow) if n_out <= 64 else min(nblk_max, 512)      # wide layers: fewer, larger slabs
+            slabs = torch.empty(nblk, (n_out + 31) // 32 * 32, 96, device=sp["dz"].device)
+            keep.append(slabs)
+            y.dz, y.dz_cols, y.n_out = L.ptr(sp["dz"]), sp["dz"].shape[1], n_out
+            y.a1, y.a1_dtype, y.a1_layout, y.k1, y.n_in = L.ptr(sp["a1"]), sp["a1_dtype"], sp["a1_layout"], sp["k1"], sp["n_in"]
+            y.a2, y.k2p, y.a2_index = L.ptr(sp["a2"]), sp["k2p"], L.ptr(sp["a2_index"])
+            y.a1_levels, y.a1_feats = sp["levels"], sp["feats"]
+            y.slabs, y.n_blocks, y.dW, y.db = L.ptr(slabs), nblk, L.ptr(sp["w"]), L.ptr(sp["b"])
+        _call("pag_mlp_wgrad_batch", layers, len(part), M, L.stream())
 
 
 class _ColourDensity(_FusedMLP):
@@ -799,11 +819,11 @@ class _HeadComposite(_FusedMLP):
         return (dx1, None, None, None, None, None, None, None, None, None, None, *gwb)
 
     @staticmethod
-    def _backward_pair(ctx, g, dx1_into):
+    def _backward_pair(ctx, g, dx1_into, wgrad_queue=None):
         weights_w, alpha, ridx = ctx.hc
         # upstream gradient in rank-1 form: alpha[ray] * w_m * g[ray] (detached weights, :148-155); the kernel forms the product
         grads = _FusedMLP._backward_impl(ctx, None, (g.contiguous().float(), weights_w.contiguous(), ridx.contiguous(), alpha.contiguous()),
-                                         dx1_into)
+                                         dx1_into, wgrad_queue=wgrad_queue)
         return grads[0], grads[8:]
 
 
@@ -838,8 +858,11 @@ class _HeadCompositePair(torch.autograd.Function):
     def backward(ctx, g_a, g_b):
         sub_a, sub_b = ctx.subs
         # wide head first (it writes dx1), the narrow one accumulates
-        ga = _HeadComposite._backward_pair(sub_a, g_a, None)
-        gb = _HeadComposite._backward_pair(sub_b, g_b, ga[0])
+        queue = []
+        ga = _HeadComposite._backward_pair(sub_a, g_a, None, queue)
+        gb = _HeadComposite._backward_pair(sub_b, g_b, ga[0], queue)
+        if queue:                                   # both heads' weight gradients: one narrow + one wide + one finish launch
+            _launch_wgrad(queue, queue[0]["dz"].shape[0])
         return (ga[0], None, None, None, None, None, None, None, None, None, None, *ga[1], *gb[1])
 
 

@@ -865,7 +865,9 @@ def test_head_composite_pair_equals_two_nodes(gpu_device):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert _rel_l2(res[0][2].cpu(), res[1][2].cpu()) < 6e-3          # one bf16 rounding of the sum instead of two + one
     for g1, g2 in zip(res[0][3], res[1][3]):
-        assert torch.equal(g1, g2)
+        # same products, but the pair sums them over a different number of per-workgroup slabs (both heads' weight gradients
+        # share one launch): equal to fp32 summation-order noise, not bit for bit
+        assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-6 * float(g2.abs().max()))
 
 
 def test_short_training_run_converges_and_bf16_tracks_fp32(gpu_device):
