@@ -47,6 +47,20 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pag_mlp_fwd(ctypes.byref(a), 0, None) == -1 and b"n_layers" in lib.pag_last_error_string()
     a.n_layers, a.out_dim = 2, 500
     assert lib.pag_mlp_fwd(ctypes.byref(a), 0, None) == -1 and b"out_dim" in lib.pag_last_error_string()
+    # the single-launch helpers around the path
+    assert lib.pag_view_embed(None, 0, 4, 32, None, None) == 0                    # R == 0: no-op
+    assert lib.pag_view_embed(None, 8, 4, 16, None, None) == -1 and b"width" in lib.pag_last_error_string()
+    assert lib.pag_pack_offsets(None, -1, None, None) == -1
+    assert lib.pag_mlp_wgrad_batch(None, 0, 8, None) == -1 and b"n_layers" in lib.pag_last_error_string()
+    layers = (L.WgradLayer * 1)()
+    layers[0].n_out, layers[0].dz_cols = 300, 300
+    assert lib.pag_mlp_wgrad_batch(layers, 1, 8, None) == -1 and b"n_out" in lib.pag_last_error_string()
+    assert lib.pag_render_loss_workspace_bytes() >= 64
+    t = [None, 0, None, None, 0.0, 1.0, 0]
+    one = ctypes.c_void_p(16)        # a non-NULL pointer value; rejected before it is ever dereferenced
+    assert lib.pag_render_loss_fwd(one, None, 4, 1.0, *t, *t, 1e-27, one, one, None) == -1 and b"rgb_gt" in lib.pag_last_error_string()
+    assert lib.pag_render_loss_fwd(None, None, 4, 1.0, one, 0, None, None, 1.0, 1.0, 0, *t, 1e-27, one, one, None) == -1
+    assert lib.pag_render_loss_bwd(None, None, None, None, 4, 1.0, *t, *t, 1e-27, None, None, None, None) == -1
 
 
 def test_product_path_refuses_cpu_tensors():
