@@ -267,8 +267,10 @@ int pag_raymarch_count(const float *origins, const float *dirs, int64_t N, int S
                        void *stream);
 /* pack_start i64 [N+1]: exclusive prefix sums of counts i32 [N] (pack_start[N] = total number of samples) - the write
  * offsets pag_raymarch_pack takes and the per-ray pack table of the compositing kernels (kaolin's
- * mark_pack_boundaries / cumsum bookkeeping, tracers/panoptic_packed_rf_tracer.py:114).  One workgroup. */
-int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, void *stream);
+ * mark_pack_boundaries / cumsum bookkeeping, tracers/panoptic_packed_rf_tracer.py:114).  One workgroup.
+ * total_host (optional): device-accessible PINNED HOST memory that also receives pack_start[N] (system-scope release store):
+ * a host that preset it to a negative value can poll it instead of issuing a stream-synchronising read-back. */
+int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, int64_t *total_host, void *stream);
 
 /* View-direction embedding of the colour decoder (wisp PositionalEmbedder on -ray_d, pc_nerf/panoptic_delta_nef.py:196-200):
  * out f32 [R, width] = (-d, sin(-d 2^k) for k < n_freq, cos(-d 2^k) for k < n_freq), frequency-major, zero padded;

@@ -78,7 +78,7 @@ _SIGS = {
     "pag_mlp_wgrad_finish": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "pag_mlp_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
     "pag_raymarch_count": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),
-    "pag_pack_offsets": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    "pag_pack_offsets": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "pag_view_embed": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "pag_raymarch_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_raymarch_voxel_count": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),

@@ -480,7 +480,8 @@ namespace {
 // pack_start[i] = sum of counts[0..i), pack_start[N] = total: ONE workgroup, every thread owns a contiguous chunk (sum, block
 // scan of the 1024 chunk sums, prefix write).  Replaces the cast / scan-init / scan / subtract / concatenate launches the same
 // result costs as tensor ops at the head of every training step (N = 4096 rays: 4 counts per thread).
-__global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__restrict__ counts, int64_t N, int64_t *__restrict__ pack_start) {
+__global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__restrict__ counts, int64_t N, int64_t *__restrict__ pack_start,
+                                                            int64_t *total_host) {
     __shared__ int64_t wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t chunk = (N + 1023) / 1024;
@@ -506,7 +507,11 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__res
         pack_start[i] = run;
         run += counts[i];
     }
-    if (tid == 0) pack_start[N] = total;
+    if (tid == 0) {
+        pack_start[N] = total;
+        // optional host-visible copy (pinned memory): the host polls it instead of a stream-synchronising read-back
+        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // wisp PositionalEmbedder on the NEGATED ray directions (pc_nerf/panoptic_delta_nef.py:196-200): out[r] = (-d, sin(-d 2^k) k<F,
@@ -531,9 +536,9 @@ __global__ __launch_bounds__(256) void view_embed_kernel(const float *__restrict
 }
 }  // namespace
 
-extern "C" int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, void *stream) {
+extern "C" int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, int64_t *total_host, void *stream) {
     PAG_CHECK_ARG(N >= 0 && pack_start && (N == 0 || counts), "pag_pack_offsets: bad arguments");
-    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, pack_start);
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, pack_start, total_host);
     PAG_CHECK_LAUNCH("pag_pack_offsets");
     return PAG_OK;
 }

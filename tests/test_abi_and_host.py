@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu(lib):
     # the single-launch helpers around the path
     assert lib.pag_view_embed(None, 0, 4, 32, None, None) == 0                    # R == 0: no-op
     assert lib.pag_view_embed(None, 8, 4, 16, None, None) == -1 and b"width" in lib.pag_last_error_string()
-    assert lib.pag_pack_offsets(None, -1, None, None) == -1
+    assert lib.pag_pack_offsets(None, -1, None, None, None) == -1
     assert lib.pag_mlp_wgrad_batch(None, 0, 8, None) == -1 and b"n_layers" in lib.pag_last_error_string()
     layers = (L.WgradLayer * 1)()
     layers[0].n_out, layers[0].dz_cols = 300, 300

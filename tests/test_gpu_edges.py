@@ -153,7 +153,7 @@ def test_pack_offsets_and_view_embed_kernels(gpu_device):
     for N in (0, 1, 5, 1023, 1024, 1025, 4096, 100003):
         counts = torch.randint(0, 600, (N,), generator=g, dtype=torch.int32).to(dev)
         out = torch.empty(N + 1, device=dev, dtype=torch.int64)
-        L.check(L.load().pag_pack_offsets(L.ptr(counts) if N else None, N, L.ptr(out), L.stream()), "pag_pack_offsets")
+        L.check(L.load().pag_pack_offsets(L.ptr(counts) if N else None, N, L.ptr(out), None, L.stream()), "pag_pack_offsets")
         ref = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts.cpu().long(), 0)])
         assert torch.equal(out.cpu(), ref), N
     for R, nf in ((0, 4), (1, 4), (4096, 4), (777, 0), (513, 10)):
