@@ -279,12 +279,13 @@ int pag_view_embed(const float *dirs, int64_t R, int n_freq, int width, float *o
 
 /* Pass 2: pack.  offsets i64 [N] = exclusive prefix sum of counts.
  *   ridx i32 [M], pidx i32 [M] (linear cell id), samples f32 [M,3], depths f32 [M],
- *   deltas f32 [M], boundary u8 [M] (1 at the first sample of each ray) */
+ *   deltas f32 [M], boundary u8 [M] (1 at the first sample of each ray);
+ *   ridx64 i64 [M] or NULL: the ray ids once more in the int64 form wisp's raymarch returns */
 int pag_raymarch_pack(const float *origins, const float *dirs, int64_t N, int S,
                       const float *tvals, const float *jitter, float dist_min, float dist_max,
                       const uint32_t *occupancy_bits, int blas_level, const int64_t *offsets,
                       int32_t *ridx, int32_t *pidx, float *samples, float *depths, float *deltas,
-                      uint8_t *boundary, void *stream);
+                      uint8_t *boundary, int64_t *ridx64, void *stream);
 
 /* 'voxel' mode (wisp OctreeAS.raymarch after pc_nerf/trainer.py:362-366 switches the tracer): every ray is walked
  * through the 2^blas_level occupancy grid (3-D DDA); each occupied cell it crosses (a "nugget") receives

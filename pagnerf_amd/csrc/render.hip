@@ -36,6 +36,7 @@ struct MarchArgs {
     int64_t N;
     int S, level;
     float dmin, dmax;
+    int64_t *ridx64 = nullptr;      // optional second copy of the ray ids as int64 ('ray' mode pack pass)
 };
 
 __device__ __forceinline__ float march_depth(const MarchArgs &a, int64_t ray, int s) {
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a, int32_t *counts
         if (PACK && keep) {
             const int64_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
             ridx[pos] = (int32_t)ray;
+            if (a.ridx64) a.ridx64[pos] = ray;
             pidx[pos] = cell;
             samples[pos * 3 + 0] = p[0];
             samples[pos * 3 + 1] = p[1];
@@ -556,12 +558,12 @@ extern "C" int pag_view_embed(const float *dirs, int64_t R, int n_freq, int widt
 extern "C" int pag_raymarch_pack(const float *origins, const float *dirs, int64_t N, int S, const float *tvals,
                                  const float *jitter, float dist_min, float dist_max, const uint32_t *occupancy_bits,
                                  int blas_level, const int64_t *offsets, int32_t *ridx, int32_t *pidx, float *samples,
-                                 float *depths, float *deltas, uint8_t *boundary, void *stream) {
+                                 float *depths, float *deltas, uint8_t *boundary, int64_t *ridx64, void *stream) {
     int rc = march_check("pag_raymarch_pack", origins, dirs, N, S, tvals, jitter, blas_level);
     if (rc) return rc;
     if (N == 0) return PAG_OK;
     PAG_CHECK_ARG(offsets && ridx && pidx && samples && depths && deltas && boundary, "pag_raymarch_pack: NULL output");
-    MarchArgs a{origins, dirs, tvals, jitter, occupancy_bits, N, S, blas_level, dist_min, dist_max};
+    MarchArgs a{origins, dirs, tvals, jitter, occupancy_bits, N, S, blas_level, dist_min, dist_max, ridx64};
     hipLaunchKernelGGL((march_kernel<true>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, nullptr,
                        offsets, ridx, pidx, samples, depths, deltas, boundary);
     PAG_CHECK_LAUNCH("pag_raymarch_pack");

@@ -102,9 +102,8 @@ class OccupancyBLAS(nn.Module):
             return ridx.long(), pidx, samples, depths[..., None], deltas[:, None], boundary
         if raymarch_type != "ray":
             raise NotImplementedError("raymarch_type '%s'" % raymarch_type)
-        ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack = ops.raymarch_ray(
-            rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, jitter, bits, self.blas_level)
-        ridx64 = ridx.long()
+        ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack, ridx64 = ops.raymarch_ray(
+            rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, jitter, bits, self.blas_level, want_ridx64=True)
         self._pack_cache = (ridx64, ridx, pack_start, ray_of_pack)
         if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
             samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack)   # pose gradient

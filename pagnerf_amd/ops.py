@@ -480,7 +480,7 @@ def fused_mlp(x1, weights, biases, x2=None, x2_index=None, in_dim=None, out_act=
 
 
 # ------------------------------------------------------------------------------------------ ray march
-def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, occupancy_bits=None, blas_level=7):
+def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, occupancy_bits=None, blas_level=7, want_ridx64=False):
     """'ray'-mode march + occupancy filter + pack.  Returns
     (ridx i32[M], pidx i32[M], samples f32[M,3], depths f32[M], deltas f32[M], boundary bool[M],
      pack_start i64[P+1], ray_of_pack i32[P])."""
@@ -514,15 +514,19 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     depths = torch.empty(cap, device=dev)
     deltas = torch.empty(cap, device=dev)
     boundary = torch.empty(cap, device=dev, dtype=torch.uint8)
+    ridx64 = torch.empty(cap, device=dev, dtype=torch.int64) if want_ridx64 else None     # wisp hands out int64 ray ids
     if cap:
         _call("pag_raymarch_pack", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
                                       float(dist_max), occ, blas_level, L.ptr(pack_start), L.ptr(ridx), L.ptr(pidx),
-                                      L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), st)
+                                      L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), L.ptr(ridx64), st)
     # one pack per RAY (empty packs allowed): no nonzero() / second host sync.  A ray without samples composites to the
     # background with alpha = depth = 0 and hit = False, exactly what the pre-filled buffers hold (Appendix E.10).
     M = _poll_count(mailbox) if mailbox is not None else -1
     if M < 0:
         M = int(pack_start[N].item())
+    if want_ridx64:
+        return (ridx[:M], pidx[:M], samples[:M], depths[:M], deltas[:M], boundary[:M].view(torch.bool), pack_start, _ray_iota(N, dev),
+                ridx64[:M])
     return (ridx[:M], pidx[:M], samples[:M], depths[:M], deltas[:M], boundary[:M].view(torch.bool),   # kernel writes 0 / 1
             pack_start, _ray_iota(N, dev))
 
