@@ -140,3 +140,20 @@ def test_nef_and_tracer_api_surface():
     assert rb.rgb.shape == (6, 3) and rb.reshape(2, 3, -1).rgb.shape == (2, 3, 3)
     rays = pagnerf_amd.Rays(torch.zeros(10, 3), torch.ones(10, 3), 0.0, 2.0)
     assert [len(r) for r in rays.split(4)] == [4, 4, 2] and rays[2:5].origins.shape == (3, 3)
+
+
+def test_sample_count_mailbox_polling_host_logic():
+    """ops._poll_count: returns the value once it is non-negative, -1 after the timeout (the caller then falls back to the
+    synchronous read-back) - exercised on a plain numpy mailbox, no GPU."""
+    import threading
+    import time
+    import numpy as np
+    from pagnerf_amd import ops
+    box = (None, np.array([-1], dtype=np.int64))
+    t0 = time.perf_counter()
+    assert ops._poll_count(box, timeout_s=0.05) == -1
+    assert 0.04 < time.perf_counter() - t0 < 2.0
+    threading.Timer(0.02, lambda: box[1].__setitem__(0, 12345)).start()
+    assert ops._poll_count(box, timeout_s=5.0) == 12345
+    box[1][0] = 0
+    assert ops._poll_count(box) == 0                     # zero samples is a valid count
