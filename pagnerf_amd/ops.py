@@ -523,7 +523,11 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
     # background with alpha = depth = 0 and hit = False, exactly what the pre-filled buffers hold (Appendix E.10).
     M = _poll_count(mailbox) if mailbox is not None else -1
     if M < 0:
-        M = int(pack_start[N].item())
+        M = int(pack_start[N].item())          # stream-synchronising read-back
+        if mailbox is not None and int(mailbox[1][0]) < 0:
+            # the kernel has finished (the read-back above waited for it) and its store never reached the mailbox: device
+            # writes to this pinned allocation are not visible to the host on this system - stop polling for good
+            _disable_polling()
     if want_ridx64:
         return (ridx[:M], pidx[:M], samples[:M], depths[:M], deltas[:M], boundary[:M].view(torch.bool), pack_start, _ray_iota(N, dev),
                 ridx64[:M])
@@ -533,6 +537,11 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
 
 POLL_SAMPLE_COUNT = os.environ.get("PAG_NO_POLL") is None
 _MAILBOX = {}
+
+
+def _disable_polling():
+    global POLL_SAMPLE_COUNT
+    POLL_SAMPLE_COUNT = False
 
 
 def _count_mailbox(dev):
