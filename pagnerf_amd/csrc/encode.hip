@@ -150,6 +150,17 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
         int l = g + 8 * j;
         int le = l < p.L ? l : p.L - 1;
         uint32_t idx[4];
+#ifdef PAG_DBG_ONLY_J      // experiment: only the j-th level of every XCD group (what a level-phased launch would run per phase)
+        if (j != PAG_DBG_ONLY_J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bary[j][r] = 0.0f;
+#pragma unroll
+                for (int f = 0; f < F; ++f) e[j][r][f] = 0.0f;
+            }
+            continue;
+        }
+#endif
         permuto_simplex(x, p.shift[le], p.sf[le], p.capacity, p.pow2mask, idx, bary[j]);
         const TableT *tab = tables + (int64_t)le * p.capacity * F;
 #ifdef PAG_DBG_HOTIDX      // experiment: all gathers hit 256 hot rows (isolates the arithmetic + store cost)
