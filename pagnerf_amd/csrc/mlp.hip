@@ -412,7 +412,13 @@ __device__ __forceinline__ void hidden_layer(const bf16_t *Ws, const float *bs, 
 
 // ------------------------------------------------------------------------------------------ forward
 template <typename X1T, typename OutT, int NL, int OBMAX>
-__global__ __launch_bounds__(256, (OBMAX > 2 ? 3 : 1)) void mlp_fwd_mfma(FwdParams p) {
+#ifndef PAG_FWD_WAVES_WIDE
+#define PAG_FWD_WAVES_WIDE 3
+#endif
+#ifndef PAG_FWD_WAVES_NARROW
+#define PAG_FWD_WAVES_NARROW 1
+#endif
+__global__ __launch_bounds__(256, (OBMAX > 2 ? PAG_FWD_WAVES_WIDE : PAG_FWD_WAVES_NARROW)) void mlp_fwd_mfma(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.out_dim + 31) / 32;
     bf16_t *W0s = reinterpret_cast<bf16_t *>(smem);                  // [64][RS] natural k
