@@ -624,7 +624,10 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? PAG_FWD_WAVES_WIDE : PAG_FWD_WAVE
 template <typename OutT, typename DxT, int NL, int OBMAX>
 // 2 waves per SIMD: without the bound the 3-layer narrow variants took 252 VGPRs + 36 AGPRs (1 wave per SIMD); asking for 2 makes them fit 254 with no
 // scratch.  The 33..64-output variants (OBMAX 2) would spill 150 - 350 B and stay at 1.
-__global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : 2)) void mlp_bwd_mfma(BwdParams p) {
+#ifndef PAG_BWD_WAVES
+#define PAG_BWD_WAVES 2
+#endif
+__global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd_mfma(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.out_dim + 31) / 32;
     const int RSL = OB * 32 + 8;
