@@ -102,6 +102,19 @@ int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, in
                            const float *shift_host, const float *feat_scale_host,
                            float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* As pag_hash_encode_bwd / pag_permuto_encode_bwd, but grad_tables is OVERWRITTEN: every row of every level is written
+ * (zeros where no gradient arrived), so the caller need not clear the table first and the reduce pass does not read it.
+ * Binned algorithm only (workspace required).  M == 0 leaves grad_tables untouched. */
+int pag_hash_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
+                            int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
+                            int log2_T, const float *resolutions_host, const float *feat_scale_host,
+                            float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
+int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
+                               int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
+                               uint32_t capacity, const float *scale_factor_host, const float *shift_host,
+                               const float *feat_scale_host, float *grad_tables, void *workspace,
+                               int64_t workspace_bytes, void *stream);
+
 /* d loss / d xyz of the two encoders (camera pose optimisation, pc_nerf/ba_pipeline.py:85-92: the
  * samples o + t*d depend on the learnable extrinsics).  The reference gets this from autograd through
  * grids/hash_grid_torch.py:69-108 (hash) and from permutohedral_encoding's position gradient

@@ -63,8 +63,10 @@ _SIGS = {
     "pag_last_error_string": (ctypes.c_char_p, []),
     "pag_hash_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "pag_hash_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
+    "pag_hash_encode_bwd_set": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
     "pag_permuto_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
     "pag_permuto_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
+    "pag_permuto_encode_bwd_set": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
     "pag_hash_encode_bwd_xyz": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
     "pag_permuto_encode_bwd_xyz": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
     "pag_hash_encode_fwd_add": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_vp]),

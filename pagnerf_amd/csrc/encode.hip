@@ -609,7 +609,7 @@ __device__ __forceinline__ long long to_fixed(float v, int S) {
 }
 
 template <int F, int NV, bool PACK>
-__global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab) {
+__global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab, int overwrite) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [2^shift][F] fixed point
     const int level = blockIdx.x / lay.NS, slice = blockIdx.x % lay.NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -626,7 +626,15 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
     }
     __syncthreads();
     const float maxabs = __uint_as_float(lvl_max);
-    if (maxabs == 0.0f) return;                       // no gradient reached this level
+    if (maxabs == 0.0f) {                             // no gradient reached this level
+        if (overwrite) {                              // the caller did not zero the table: this slice's rows are ours to clear
+            const int64_t row0z = (int64_t)slice * slice_rows;
+            float *dz = gtab + ((int64_t)level * rows_per_level + row0z) * F;
+            const int64_t nz = min((int64_t)slice_rows, rows_per_level - row0z) * F;
+            for (int64_t j = tid; j < nz; j += blockDim.x) dz[j] = 0.0f;
+        }
+        return;
+    }
     const bool poisoned = !(maxabs <= 3.4e38f);       // inf / NaN upstream: propagate NaN
     int ex;
     frexpf(poisoned ? 1.0f : maxabs, &ex);            // maxabs < 2^ex
@@ -684,7 +692,7 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
     const int64_t valid = min((int64_t)slice_rows, rows_per_level - row0) * F;
     for (int64_t j = tid; j < valid; j += blockDim.x) {
         const float v = poisoned ? __uint_as_float(0x7FC00000u) : (float)ldexp((double)(long long)acc[j], -S);
-        dst[j] += v;
+        dst[j] = overwrite ? v : dst[j] + v;
     }
 }
 
@@ -709,7 +717,7 @@ inline BinPlan bin_plan(int64_t M, int L, int F, int NV, int64_t rows) {
 template <int KIND>
 int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t sm, int64_t sc, int grouped, int L, int F,
                   int64_t rows, const HashParams &hp, const PermutoParams &pp, float *gtab, void *workspace,
-                  int64_t workspace_bytes, hipStream_t st, const char *name) {
+                  int64_t workspace_bytes, hipStream_t st, const char *name, bool overwrite = false) {
     constexpr int NV = KIND == 0 ? 8 : 4;
     const BinPlan b = bin_plan(M, L, F, NV, rows);
     PAG_CHECK_ARG(workspace_bytes >= b.total, "%s: workspace %lld B < required %lld B", name, (long long)workspace_bytes, (long long)b.total);
@@ -735,7 +743,7 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
         else if (lpx == 2) BIN_LAUNCH1(GT, F_, 2);                                                                      \
         else if (lpx == 3) BIN_LAUNCH1(GT, F_, 3);                                                                      \
         else BIN_LAUNCH1(GT, F_, 4);                                                                                    \
-        hipLaunchKernelGGL((reduce_kernel<F_, NV, (sizeof(GT) == 2 && F_ == 2)>), g2, dim3(1024), lds, st, lay, rows, gtab); \
+        hipLaunchKernelGGL((reduce_kernel<F_, NV, (sizeof(GT) == 2 && F_ == 2)>), g2, dim3(1024), lds, st, lay, rows, gtab, overwrite ? 1 : 0); \
     } while (0)
     if (grad_dtype == PAG_F32) {
         if (F == 2) BIN_LAUNCH(float, 2);
@@ -841,12 +849,13 @@ extern "C" int pag_hash_encode_fwd_add(const float *xyz, int64_t M, const void *
                                 0, PAG_LAYOUT_XCD8, addend, stream);
 }
 
-extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
-                                   int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
-                                   const float *feat_scale_host, float *grad_tables, void *workspace,
-                                   int64_t workspace_bytes, void *stream) {
+static int hash_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                                int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
+                                const float *feat_scale_host, float *grad_tables, void *workspace,
+                                int64_t workspace_bytes, void *stream) {
     int rc = check_common("pag_hash_encode_bwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
+    PAG_CHECK_ARG(!overwrite || workspace, "pag_hash_encode_bwd_set: the overwriting form needs the binned algorithm (a workspace)");
     PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_bwd: log2_T %d not in [1,30]", log2_T);
     PAG_CHECK_ARG(resolutions_host, "pag_hash_encode_bwd: resolutions_host is NULL");
     PAG_CHECK_ARG(grad_dtype == PAG_F32 || grad_dtype == PAG_BF16, "pag_hash_encode_bwd: grad dtype must be F32 or BF16");
@@ -866,7 +875,7 @@ extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad
     if (workspace) {
         PermutoParams unused{};
         int r2 = launch_binned<0>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, grouped, n_levels, n_feat, (int64_t)1 << log2_T, p,
-                                  unused, grad_tables, workspace, workspace_bytes, st, "pag_hash_encode_bwd");
+                                  unused, grad_tables, workspace, workspace_bytes, st, "pag_hash_encode_bwd", overwrite);
         if (r2) return r2;
         PAG_CHECK_LAUNCH("pag_hash_encode_bwd");
         return PAG_OK;
@@ -951,12 +960,13 @@ extern "C" int pag_permuto_encode_fwd_add(const float *xyz, int64_t M, const voi
                                    out, PAG_BF16, 0, 0, PAG_LAYOUT_XCD8, addend, stream);
 }
 
-extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
-                                      int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
-                                      const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                      float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+static int permuto_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                                   int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
+                                   const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
+                                   float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
     int rc = check_common("pag_permuto_encode_bwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
+    PAG_CHECK_ARG(!overwrite || workspace, "pag_permuto_encode_bwd_set: the overwriting form needs the binned algorithm (a workspace)");
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_bwd: capacity is 0");
     PAG_CHECK_ARG(scale_factor_host && shift_host, "pag_permuto_encode_bwd: NULL scale_factor/shift");
     PAG_CHECK_ARG(grad_dtype == PAG_F32 || grad_dtype == PAG_BF16, "pag_permuto_encode_bwd: grad dtype must be F32 or BF16");
@@ -972,7 +982,7 @@ extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *g
     if (workspace) {
         HashParams unused{};
         int r2 = launch_binned<1>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, grouped, n_levels, n_feat, (int64_t)capacity, unused,
-                                  p, grad_tables, workspace, workspace_bytes, st, "pag_permuto_encode_bwd");
+                                  p, grad_tables, workspace, workspace_bytes, st, "pag_permuto_encode_bwd", overwrite);
         if (r2) return r2;
         PAG_CHECK_LAUNCH("pag_permuto_encode_bwd");
         return PAG_OK;
@@ -1060,4 +1070,33 @@ extern "C" int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const voi
 extern "C" int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int n_vertices, int64_t rows_per_level) {
     if (M <= 0 || n_levels <= 0 || (n_vertices != 4 && n_vertices != 8) || rows_per_level <= 0) return 0;
     return bin_plan(M, n_levels, n_feat, n_vertices, rows_per_level).total;
+}
+
+// Exported forms: *_bwd ACCUMULATES into grad_tables (caller zeroes it); *_bwd_set OVERWRITES every row (binned algorithm only) -
+// no zero fill of the 50 MB table before the call and no read of it in the reduce pass.
+extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                                   int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
+                                   const float *feat_scale_host, float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+    return hash_encode_bwd_impl(false, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, log2_T, resolutions_host,
+                                feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
+}
+extern "C" int pag_hash_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                                       int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
+                                       const float *feat_scale_host, float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+    return hash_encode_bwd_impl(true, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, log2_T, resolutions_host,
+                                feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
+}
+extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                                      int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
+                                      const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
+                                      float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+    return permuto_encode_bwd_impl(false, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, capacity, scale_factor_host,
+                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
+}
+extern "C" int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
+                                          int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
+                                          const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
+                                          float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+    return permuto_encode_bwd_impl(true, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, capacity, scale_factor_host,
+                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
 }

@@ -120,7 +120,8 @@ _DTYPE_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF1
 BWD_ALGO = "binned"     # "binned": atomic-free two-pass scatter (default); "atomic": per-vertex fp32 global atomics
 
 
-def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
+def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False):
+    """overwrite: grad_tables is uninitialised memory that the binned reduce pass fills completely (pag_*_encode_bwd_set)."""
     lib = L.load()
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
@@ -130,11 +131,13 @@ def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables):
         ws_bytes = lib.pag_encode_bwd_workspace_bytes(M, spec.L, spec.F, 8 if spec.kind == "hash" else 4, spec.rows())
         ws = torch.empty(ws_bytes, device=xyz.device, dtype=torch.uint8)
         ws_ptr = ws.data_ptr()
+    assert not overwrite or ws_ptr is not None
+    suffix = "_set" if overwrite else ""
     if spec.kind == "hash":
-        _call("pag_hash_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
+        _call("pag_hash_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
               spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
     else:
-        _call("pag_permuto_encode_bwd", L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
+        _call("pag_permuto_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
               spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
 
 
@@ -190,9 +193,14 @@ class _Encode(torch.autograd.Function):
         if g.dim() == 3:
             g = g.contiguous()
         if need_t:
-            gt = torch.zeros(ctx.tshape, device=xyz.device, dtype=torch.float32)
-            if xyz.shape[0]:
-                _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt)
+            binned = BWD_ALGO == "binned" or g.dim() == 3
+            if xyz.shape[0] and binned:       # the reduce pass writes every row: no zero fill, no read-modify-write
+                gt = torch.empty(ctx.tshape, device=xyz.device, dtype=torch.float32)
+                _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt, overwrite=True)
+            else:
+                gt = torch.zeros(ctx.tshape, device=xyz.device, dtype=torch.float32)
+                if xyz.shape[0]:
+                    _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt)
             gt = gt.to(ctx.tdtype)
         if need_x:
             d_xyz = _encode_bwd_xyz(ctx.spec, xyz, ctx.saved_tensors[1], g, ctx.feat_scale) if xyz.shape[0] else torch.zeros_like(xyz)

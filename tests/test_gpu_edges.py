@@ -165,3 +165,38 @@ def test_pack_offsets_and_view_embed_kernels(gpu_device):
         assert got.shape == (R, width)
         assert torch.allclose(got[:, :ref.shape[1]], ref, rtol=0.0, atol=1e-6)
         assert bool((got[:, ref.shape[1]:] == 0).all())
+
+
+def test_table_gradient_overwrite_mode_writes_every_row(gpu_device):
+    """The binned encode backward fills an UNINITIALISED gradient table (pag_*_encode_bwd_set): rows no sample touches, and
+    whole levels that receive no gradient, must come back as exact zeros.  The caching allocator is poisoned with NaNs first so
+    that an unwritten row cannot look right by accident; the touched rows are checked against the accumulating entry point."""
+    from pagnerf_amd import ops, grids
+    dev = gpu_device
+    g = torch.Generator().manual_seed(2)
+    for kind in ("permuto", "hash"):
+        L_, F_, M = 16, 2, 300
+        if kind == "permuto":
+            cap = 1 << 14
+            spec = ops.permuto_spec(grids.PermutoGridHIP.scale_factors(np.geomspace(1.0, 1e-3, L_)), torch.randn(L_, 3, generator=g) * 10, cap, F_)
+        else:
+            cap = 1 << 14
+            spec = ops.hash_spec(grids.HashGridHIP.level_resolutions(16, 512, L_), 14, F_)
+        tab = (torch.randn(L_, cap, F_, generator=g) * 1e-2).to(dev).requires_grad_(True)
+        xyz = ((torch.rand(M, 3, generator=g) - 0.5) * 1.6).to(dev)
+        go = torch.randn(M, L_ * F_, generator=g)
+        go[:, 4 * F_:6 * F_] = 0                                     # two levels without any gradient
+        go = go.to(dev)
+        # reference: accumulating entry point into a zeroed table
+        ref = torch.zeros(L_, cap, F_, device=dev)
+        ops._encode_bwd(spec, xyz, go, None, ref)
+        for _ in range(3):
+            poison = torch.full((L_ * cap * F_ + 1024,), float("nan"), device=dev)
+            del poison
+            out = ops.encode(xyz, tab, spec, None, torch.float32)
+            (gt,) = torch.autograd.grad(out, tab, go)
+            assert torch.isfinite(gt).all()
+            assert torch.equal(gt, ref)
+            assert float(gt[4:6].abs().max()) == 0.0
+            touched = (gt != 0).any(-1).float().mean().item()
+            assert 0 < touched < 0.2
