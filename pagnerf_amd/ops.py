@@ -590,6 +590,12 @@ def _poll_count(mailbox, timeout_s=0.5):
 _IOTA = {}
 
 
+def _one_pack_per_ray(ray_of_pack, N):
+    """True when the pack table is the cached identity of raymarch_ray (pack i = ray i, empty packs included): the compositing
+    kernels then write every ray's outputs themselves (an empty pack yields the background / zeros) and need no pre-filled buffers."""
+    return ray_of_pack.shape[0] == N and _IOTA.get((N, str(ray_of_pack.device))) is ray_of_pack
+
+
 def _ray_iota(N, dev):
     """arange(N) i32, cached per (N, device): ray_of_pack of the one-pack-per-ray layout (read-only by contract)."""
     key = (N, str(dev))
@@ -710,10 +716,16 @@ class _Composite(torch.autograd.Function):
         rgbc = rgb.detach().contiguous().float() if rgb is not None else None
         depc = depths.detach().contiguous().float() if depths is not None else None
         w = torch.empty(M, device=dev)
-        alpha = torch.zeros(N, device=dev)
-        hit = torch.zeros(N, device=dev, dtype=torch.uint8)
-        out_rgb = (torch.ones if bg_white else torch.zeros)(N, 3, device=dev) if rgb is not None else None
-        out_depth = torch.zeros(N, device=dev) if depths is not None else None
+        if M and _one_pack_per_ray(ray_of_pack, N):      # the kernel writes every ray (background for empty packs): no fills
+            alpha = torch.empty(N, device=dev)
+            hit = torch.empty(N, device=dev, dtype=torch.uint8)
+            out_rgb = torch.empty(N, 3, device=dev) if rgb is not None else None
+            out_depth = torch.empty(N, device=dev) if depths is not None else None
+        else:
+            alpha = torch.zeros(N, device=dev)
+            hit = torch.zeros(N, device=dev, dtype=torch.uint8)
+            out_rgb = (torch.ones if bg_white else torch.zeros)(N, 3, device=dev) if rgb is not None else None
+            out_depth = torch.zeros(N, device=dev) if depths is not None else None
         if P and M:                     # M == 0: every pack is empty, the outputs already hold the background
             _call("pag_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
                                           L.ptr(rgbc), L.BG_WHITE if bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
@@ -863,7 +875,9 @@ class _HeadComposite(_FusedMLP):
         C = wb[len(wb) // 2 - 1].shape[0]
         P = ray_of_pack.shape[0]
         M = x1.shape[1] if grouped is not None else x1.shape[0]
-        out = torch.zeros(N, C, device=x1.device)
+        # both compositing kernels used below write a row for every pack (zeros for an empty one)
+        full = M and _one_pack_per_ray(ray_of_pack, N) and (probs is None or C <= 16)
+        out = (torch.empty if full else torch.zeros)(N, C, device=x1.device)
         weights_w = weights_w.detach().contiguous()
         alpha = alpha.detach().contiguous()
         if probs is None:

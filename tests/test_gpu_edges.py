@@ -200,3 +200,31 @@ def test_table_gradient_overwrite_mode_writes_every_row(gpu_device):
             assert float(gt[4:6].abs().max()) == 0.0
             touched = (gt != 0).any(-1).float().mean().item()
             assert 0 < touched < 0.2
+
+
+def test_rays_without_samples_keep_the_background_without_prefilled_buffers(gpu_device):
+    """'ray' mode hands the compositing kernels one pack per ray (empty packs included); they write every ray themselves, so
+    the output buffers are no longer pre-filled.  Rays that miss the volume must still come back as background / zeros
+     - checked with a NaN-poisoned allocator so that an unwritten element cannot pass by accident."""
+    import pagnerf_amd
+    from test_gpu_parity import _make_scene
+    dev = gpu_device
+    nef, tracer, rays, occ, jitter = _make_scene(dev, "bf16", N=256, S=48, cap_log2=12)
+    o, d = rays.origins.clone(), rays.dirs.clone()
+    o[::2] = torch.tensor([5.0, 5.0, 5.0], device=dev)               # every other ray starts far outside and points away
+    d[::2] = torch.nn.functional.normalize(torch.tensor([1.0, 0.5, 0.25], device=dev), dim=0)
+    rays2 = pagnerf_amd.Rays(o, d, dist_min=0.0, dist_max=2.0)
+    for bg in ("white", "black"):
+        tracer.bg_color = bg
+        for _ in range(2):
+            poison = torch.full((1 << 22,), float("nan"), device=dev)
+            del poison
+            with torch.no_grad():
+                rb = tracer(nef, channels={"rgb", "depth", "semantics", "inst_embedding"}, rays=rays2, jitter=jitter.to(dev), stage="val")
+            miss = ~rb.hit
+            assert bool(miss[::2].all()) and bool(rb.hit[1::2].any())
+            for ch in ("rgb", "depth", "alpha", "semantics", "inst_embedding"):
+                assert bool(torch.isfinite(getattr(rb, ch)).all()), ch
+            assert torch.equal(rb.rgb[miss], torch.full_like(rb.rgb[miss], 1.0 if bg == "white" else 0.0))
+            for ch in ("depth", "alpha", "semantics", "inst_embedding"):
+                assert float(getattr(rb, ch)[miss].abs().max()) == 0.0, ch
