@@ -166,7 +166,7 @@ class PanopticDDensityPackedRFTracer(PanopticPackedRFTracer):
         alpha, hit, out_rgb, out_depth, w = ops.composite(sigma, rgb, deltas.reshape(-1), dep, pack_start, ray_of_pack, N,
                                                           bg_white=(bg_color == "white"))       # :114-160
         outputs["alpha"] = alpha[:, None]
-        outputs["hit"] = hit.bool()
+        outputs["hit"] = hit.view(torch.bool)          # the kernel writes 0 / 1 bytes: reinterpret, no cast launch
         if rgb is not None:
             outputs["rgb"] = out_rgb
         if dep is not None:

@@ -123,7 +123,7 @@ class PanopticPackedRFTracer(nn.Module):
         alpha, hit, out_rgb, out_depth, w = ops.composite(sigma, rgb, deltas.reshape(-1), dep, pack_start, ray_of_pack, N,
                                                           bg_white=(bg_color == "white"))  # :134-176
         outputs["alpha"] = alpha[:, None]
-        outputs["hit"] = hit.bool()
+        outputs["hit"] = hit.view(torch.bool)          # the kernel writes 0 / 1 bytes: reinterpret, no cast launch
         if rgb is not None:
             outputs["rgb"] = out_rgb
         if dep is not None:
