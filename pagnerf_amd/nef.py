@@ -202,6 +202,15 @@ class PanopticDeltaNeF(nn.Module):
         return grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None,
                                        addend=addend)
 
+    def prefetch_features(self, coords):
+        """Queue the main grid's interpolation of `coords` NOW; rgb_semantics() called with the same tensor picks it up.
+        The tracer calls this as soon as the ray march has returned: the GPU sits idle from the moment the host learns the
+        sample count until the step's first encode launch, and everything the tracer and the nef dispatcher do in between
+        (~35 us of Python) would otherwise be spent with an empty queue.  Same kernel, same arguments, same autograd node."""
+        if self.multiscale_type != "cat" or self.grid is None:
+            return
+        self._prefetched = (coords, self._interp(self.grid, coords), torch.is_grad_enabled())
+
     def _panoptic_feats(self, feats_detached, coords):
         """:210-236 - `feats.detach() + delta` ('delta'), delta alone ('separate') or the main features ('appearance').
         On the grouped bf16 path the sum is formed inside the delta grid's encode launch (same rounding as the tensor add)."""
@@ -225,7 +234,12 @@ class PanopticDeltaNeF(nn.Module):
         if self.multiscale_type != "cat":
             raise NotImplementedError("multiscale_type 'sum' with fused decoders")
         mode = self.mlp_mode
-        feats = self._interp(self.grid, coords)                                       # :170-171
+        pre = getattr(self, "_prefetched", None)
+        self._prefetched = None
+        if pre is not None and pre[0] is coords and pre[2] == torch.is_grad_enabled():
+            feats = pre[1]                                    # launched by the tracer right after the ray march
+        else:
+            feats = self._interp(self.grid, coords)                                   # :170-171
         self._feat_cache = (coords, feats.detach())           # reused by panoptic_composited() for the same samples
         grp = self._grouped()
         density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184

@@ -80,6 +80,8 @@ class PanopticPackedRFTracer(nn.Module):
         kw = {"jitter": jitter} if jitter is not None else {}
         ridx, pidx, samples, depths, deltas, boundary = nef.grid.raymarch(                 # :85-86
             rays, level=nef.grid.active_lods[lod_idx], num_samples=num_steps, raymarch_type=raymarch_type, **kw)
+        if raymarch_type == "ray" and samples.shape[0] and hasattr(nef, "prefetch_features"):
+            nef.prefetch_features(samples)        # first encode launch queued before the bookkeeping below (GPU idle otherwise)
         if raymarch_type == "voxel" and depths.numel() != 0:                              # :88-108
             # drop nuggets further than ray_max_travel past the first hit of their ray (strict <)
             _, counts_per_ray = ridx.unique(return_counts=True)
