@@ -451,6 +451,12 @@ template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool P
 __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
                                                  int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
+#ifndef PAG_BIN_NO_STAGE
+    constexpr bool STAGE = PACK && TS * NV * 8 <= 32768;      // packed 8-byte entries, tile fits 32 KiB of LDS (permutohedral: 4 vertices)
+#else
+    constexpr bool STAGE = false;
+#endif
+    __shared__ uint64_t stage[STAGE ? TS * NV : 1];
     __shared__ uint32_t cnt[LPX][NS_MAX + 2];     // [.][NS_MAX + 1] = max |g| of this (tile, level)
     __shared__ uint32_t offs[LPX][NS_MAX + 1];
     const int L = KIND == 0 ? hp.L : pp.L;
@@ -558,9 +564,24 @@ __global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, 
         const int level = grouped ? (int)blockIdx.y + 8 * j : (int)blockIdx.y;
         if (level >= L) break;
         const int64_t region = ((int64_t)level * lay.ntiles + tile) * (TS * NV);
+        if constexpr (STAGE) {
+            // The sorted entries of this (tile, level) occupy one contiguous run of the region, but a lane's entry lands anywhere in
+            // it: written straight to memory that is one 8-byte partial-line request per entry (the L2 takes ~16 requests per clock
+            // and XCD - the write phase was about half of this kernel).  Staged through LDS the run leaves as full 512-byte wave stores.
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (emit[j][k])
+                    stage[offs[j][idx[j][k] >> lay.shift] + rank[j][k]] =
+                        pack_entry(idx[j][k] & ((1u << lay.shift) - 1u), ev[j][k][0], ev[j][k][F - 1]);
+            __syncthreads();
+            const uint32_t total = offs[j][lay.NS];
+            uint64_t *dst = reinterpret_cast<uint64_t *>(lay.vals) + region;
+            for (uint32_t q = tid; q < total; q += TS) dst[q] = stage[q];
+            __syncthreads();      // the next level reuses the staging tile
+        }
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            if (emit[j][k]) {
+            if (!STAGE && emit[j][k]) {
                 const uint32_t s = idx[j][k] >> lay.shift;
                 const int64_t pos = region + offs[j][s] + rank[j][k];
                 if constexpr (PACK) {
