@@ -448,7 +448,16 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[
 }
 
 template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool PACK>
-__global__ __launch_bounds__(TS) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
+// TWO 1024-thread workgroups per CU (8 waves per SIMD, <= 64 VGPRs): with one, every block barrier of the counting sort / staging
+// stalls the whole CU - nothing else is resident to run.  The permutohedral variant fits 64 VGPRs with 48 B of scratch and the encode
+// backward drops from 2.18 to 1.75 ms per step; the hash variant (8 vertices) would spill 140 - 300 B and is measured separately.
+#ifndef PAG_BIN_WAVES
+#define PAG_BIN_WAVES 8
+#endif
+#ifndef PAG_BIN_WAVES_HASH
+#define PAG_BIN_WAVES_HASH 4
+#endif
+__global__ __launch_bounds__(TS, (KIND == 1 ? PAG_BIN_WAVES : PAG_BIN_WAVES_HASH)) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
                                                  int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
 #ifndef PAG_BIN_NO_STAGE
