@@ -377,7 +377,10 @@ __global__ __launch_bounds__(256) void xyz_grad_sum_kernel(const float *__restri
 //       table in LDS, walks every tile's segment for its slice (coalesced reads, each entry read
 //       exactly once), accumulates in 64-bit fixed point with ds_add_u64 (order-independent, hence
 //       bitwise reproducible) and finally adds the slice to the table with plain coalesced stores.
-constexpr int TS = 1024;          // samples per pass-1 tile (= threads per workgroup)
+#ifndef PAG_TS
+#define PAG_TS 1024
+#endif
+constexpr int TS = PAG_TS;        // samples per pass-1 tile (= threads per workgroup)
 constexpr int SLICE_SHIFT = 13;   // upper bound; bin_plan() shrinks it so a slice's int64 accumulators fit 64 KiB
 constexpr int NS_MAX = 256;       // slices per level supported (T <= 2^21)
 
