@@ -380,7 +380,12 @@ __global__ __launch_bounds__(256) void xyz_grad_sum_kernel(const float *__restri
 #ifndef PAG_TS
 #define PAG_TS 1024
 #endif
-constexpr int TS = PAG_TS;        // samples per pass-1 tile (= threads per workgroup)
+#ifndef PAG_TS_HASH
+#define PAG_TS_HASH 512
+#endif
+// samples per pass-1 tile (= threads per workgroup): 1024 with 4 vertices per level (permutohedral), 512 with 8 (hash) - the hash
+// variant needs ~100 VGPRs, and two workgroups per CU (block barriers!) as well as a 32 KiB staging tile only fit with the smaller tile
+constexpr int tile_samples(int nv) { return nv == 8 ? PAG_TS_HASH : PAG_TS; }
 constexpr int SLICE_SHIFT = 13;   // upper bound; bin_plan() shrinks it so a slice's int64 accumulators fit 64 KiB
 constexpr int NS_MAX = 256;       // slices per level supported (T <= 2^21)
 
@@ -460,9 +465,10 @@ template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool P
 #ifndef PAG_BIN_WAVES_HASH
 #define PAG_BIN_WAVES_HASH 4
 #endif
-__global__ __launch_bounds__(TS, (KIND == 1 ? PAG_BIN_WAVES : PAG_BIN_WAVES_HASH)) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
+__global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_BIN_WAVES : PAG_BIN_WAVES_HASH)) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
                                                  int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
+    constexpr int TS = tile_samples(NV);
 #ifndef PAG_BIN_NO_STAGE
     constexpr bool STAGE = PACK && TS * NV * 8 <= 32768;      // packed 8-byte entries, tile fits 32 KiB of LDS (permutohedral: 4 vertices)
 #else
@@ -665,6 +671,7 @@ __device__ __forceinline__ long long to_fixed(float v, int S) {
 template <int F, int NV, bool PACK>
 __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab, int overwrite) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [2^shift][F] fixed point
+    constexpr int TS = tile_samples(NV);
     const int level = blockIdx.x / lay.NS, slice = blockIdx.x % lay.NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int slice_rows = 1 << lay.shift;
@@ -756,6 +763,7 @@ struct BinPlan {
 };
 inline BinPlan bin_plan(int64_t M, int L, int F, int NV, int64_t rows) {
     BinPlan b;
+    const int TS = tile_samples(NV);
     b.shift = SLICE_SHIFT;
     while (b.shift > 0 && ((int64_t)1 << b.shift) * F * 8 > 65536) --b.shift;      // int64 accumulators, 64 KiB of LDS
     b.NS = (int)((rows + ((int64_t)1 << b.shift) - 1) >> b.shift);
@@ -790,7 +798,7 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
     const size_t lds = ((size_t)1 << b.shift) * F * sizeof(unsigned long long);
     const int lpx = grouped ? (L + 7) / 8 : 1;
 #define BIN_LAUNCH1(GT, F_, LPX_)                                                                                       \
-    hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_, (sizeof(GT) == 2 && F_ == 2)>), g1, dim3(TS), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay)
+    hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_, (sizeof(GT) == 2 && F_ == 2)>), g1, dim3(tile_samples(NV)), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay)
 #define BIN_LAUNCH(GT, F_)                                                                                              \
     do {                                                                                                                \
         if (lpx == 1) BIN_LAUNCH1(GT, F_, 1);                                                                           \
