@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 1
+#define PAG_ABI_VERSION 2
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -39,6 +39,12 @@ enum { PAG_BG_BLACK = 0, PAG_BG_WHITE = 1 };
  *   PAG_LAYOUT_XCD8     bf16 [8][M][8]: group g = level % 8, element e = (level / 8)*F + f, zero padded
  *                       (requires ceil(L/8)*F <= 8).  Strides are ignored. */
 enum { PAG_LAYOUT_STRIDED = 0, PAG_LAYOUT_XCD8 = 1 };
+/* `flags` of the encode entry points:
+ *   PAG_ENC_HALF_COORDS  xyz is rounded to fp16 (round-to-nearest-even) and widened back to f32 before anything else uses it -
+ *                        what `@torch.cuda.amp.custom_fwd(cast_inputs=torch.half)` + `.type(torch.float)` do to the coordinates under
+ *                        the reference trainer's autocast (grids/permuto_grid.py:65,71; grids/hash_grid_tinycudann.py:36-41).
+ *                        Forward, table gradient and position gradient must be called with the same flags. */
+enum { PAG_ENC_HALF_COORDS = 1 };
 #define PAG_MAX_LEVELS 32
 #define PAG_MAX_FEATS 64
 
@@ -63,7 +69,7 @@ const char *pag_last_error_string(void);
 int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype,
                         int n_levels, int n_feat, int log2_T, const float *resolutions_host,
                         const float *feat_scale_host, void *out, int out_dtype,
-                        int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream);
+                        int64_t out_stride_m, int64_t out_stride_c, int layout, int flags, void *stream);
 
 /* d loss / d tables (what autograd through grids/hash_grid_torch.py:95-108 yields).
  *   grad_out  [M, L*F] via strides (PAG_F32 or PAG_BF16);  grad_tables f32 [L,T,F], ACCUMULATED
@@ -71,7 +77,7 @@ int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int tab
 int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
                         int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                         int log2_T, const float *resolutions_host, const float *feat_scale_host,
-                        float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
+                        float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream);
 
 /* Permutohedral-lattice hash encoding.  Replaces permutohedral_encoding.PermutoEncoding's
  * forward as called at grids/permuto_grid.py:57-62,71.
@@ -83,24 +89,24 @@ int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int 
                            int n_levels, int n_feat, uint32_t capacity,
                            const float *scale_factor_host, const float *shift_host,
                            const float *feat_scale_host, void *out, int out_dtype,
-                           int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream);
+                           int64_t out_stride_m, int64_t out_stride_c, int layout, int flags, void *stream);
 
 /* Same encoders writing  out = bf16(addend + bf16(features))  in the XCD8 layout (addend, out: bf16 [8][M][8]).
  * pc_nerf/panoptic_delta_nef.py:226 forms the panoptic features as `feats.detach() + delta`; with the main grid's
  * features as addend the delta grid's encoder emits that sum directly (bit-identical to the separate bf16 add). */
 int pag_hash_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype,
                             int n_levels, int n_feat, int log2_T, const float *resolutions_host,
-                            const float *feat_scale_host, const void *addend, void *out, void *stream);
+                            const float *feat_scale_host, const void *addend, void *out, int flags, void *stream);
 int pag_permuto_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype,
                                int n_levels, int n_feat, uint32_t capacity,
                                const float *scale_factor_host, const float *shift_host,
-                               const float *feat_scale_host, const void *addend, void *out, void *stream);
+                               const float *feat_scale_host, const void *addend, void *out, int flags, void *stream);
 
 int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
                            int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                            uint32_t capacity, const float *scale_factor_host,
                            const float *shift_host, const float *feat_scale_host,
-                           float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
+                           float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream);
 
 /* As pag_hash_encode_bwd / pag_permuto_encode_bwd, but grad_tables is OVERWRITTEN: every row of every level is written
  * (zeros where no gradient arrived), so the caller need not clear the table first and the reduce pass does not read it.
@@ -108,12 +114,12 @@ int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, in
 int pag_hash_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
                             int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                             int log2_T, const float *resolutions_host, const float *feat_scale_host,
-                            float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream);
+                            float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream);
 int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
                                int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                                uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                const float *feat_scale_host, float *grad_tables, void *workspace,
-                               int64_t workspace_bytes, void *stream);
+                               int64_t workspace_bytes, int flags, void *stream);
 
 /* d loss / d xyz of the two encoders (camera pose optimisation, pc_nerf/ba_pipeline.py:85-92: the
  * samples o + t*d depend on the learnable extrinsics).  The reference gets this from autograd through
@@ -126,13 +132,13 @@ int pag_hash_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, int
                             const void *grad_out, int grad_dtype, int64_t g_stride_m,
                             int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T,
                             const float *resolutions_host, const float *feat_scale_host,
-                            float *d_xyz, void *workspace, int64_t workspace_bytes, void *stream);
+                            float *d_xyz, void *workspace, int64_t workspace_bytes, int flags, void *stream);
 int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, int table_dtype,
                                const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                int64_t g_stride_c, int layout, int n_levels, int n_feat,
                                uint32_t capacity, const float *scale_factor_host,
                                const float *shift_host, const float *feat_scale_host, float *d_xyz,
-                               void *workspace, int64_t workspace_bytes, void *stream);
+                               void *workspace, int64_t workspace_bytes, int flags, void *stream);
 
 /* Scratch size for the atomic-free ("binned") backward of either encoder: n_vertices = 8 (hash) or
  * 4 (permuto), rows_per_level = 2^log2_T or capacity.  The caller allocates it (device memory) and

@@ -207,3 +207,9 @@ def permuto_encode_f64(xyz, tables, shifts, sf):
             acc += tables[l][idx[:, r]] * bary[:, r:r + 1]
         out[:, l * F:(l + 1) * F] = acc
     return out
+
+
+def half_round(xyz):
+    """float(half(xyz)): what the encoder receives under the reference trainer's autocast - grids/permuto_grid.py:65
+    `@torch.cuda.amp.custom_fwd(cast_inputs=torch.half)` then :71 `.type(torch.float)` (round-to-nearest-even, as torch)."""
+    return np.asarray(xyz, dtype=F32).astype(np.float16).astype(F32)

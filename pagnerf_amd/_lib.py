@@ -15,6 +15,8 @@ ACT_NONE, ACT_SIGMOID, ACT_SOFTMAX = 0, 1, 2
 MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
 LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
+ENC_HALF_COORDS = 1
+ABI_VERSION = 2
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -61,16 +63,16 @@ class MlpBwdArgs(ctypes.Structure):
 _SIGS = {
     "pag_abi_version": (c_i32, []),
     "pag_last_error_string": (ctypes.c_char_p, []),
-    "pag_hash_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
-    "pag_hash_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
-    "pag_hash_encode_bwd_set": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
-    "pag_permuto_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp]),
-    "pag_permuto_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
-    "pag_permuto_encode_bwd_set": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
-    "pag_hash_encode_bwd_xyz": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
-    "pag_permuto_encode_bwd_xyz": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_vp]),
-    "pag_hash_encode_fwd_add": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_vp]),
-    "pag_permuto_encode_fwd_add": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_vp]),
+    "pag_hash_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "pag_hash_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "pag_hash_encode_bwd_set": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "pag_permuto_encode_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "pag_permuto_encode_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "pag_permuto_encode_bwd_set": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "pag_hash_encode_bwd_xyz": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "pag_permuto_encode_bwd_xyz": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "pag_hash_encode_fwd_add": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_i32, c_vp]),
+    "pag_permuto_encode_fwd_add": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i32, c_vp]),
     "pag_encode_bwd_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32, c_i64]),
     "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
@@ -117,7 +119,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.pag_abi_version() != 1:
+        if lib.pag_abi_version() != ABI_VERSION:
             raise RuntimeError("libpagnerf_hip.so ABI version mismatch")
         _lib = lib
     return _lib

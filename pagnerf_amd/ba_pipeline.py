@@ -87,6 +87,18 @@ class BAPipeline(Pipeline):
         dirs = dirs / torch.linalg.norm(dirs, dim=-1, keepdim=True)
         return Rays(origins.float().reshape(-1, 3), dirs.float().reshape(-1, 3), dist_min=self.near, dist_max=self.far)
 
+    def transform_rays_indexed(self, origins_c, dirs_c, cam_idx):
+        """Per-ray form of transform_rays(): ray i belongs to camera `cam_idx[i]` (row of camera_extrinsics), so a ray shard of a
+        multi-GPU step may start and end in the middle of an image.  Same arithmetic as :85-92."""
+        R_all = rotation_6d_to_matrix(self.camera_extrinsics[:, :6])      # [C,3,3] world -> camera, once per camera
+        idx = cam_idx.to(self.camera_extrinsics.device).long()
+        R = R_all.index_select(0, idx)                                   # [n,3,3]
+        t = self.camera_extrinsics[:, 6:].index_select(0, idx)
+        origins = torch.matmul((origins_c - t)[:, None, :], R)[:, 0]     # row-vector form of R^T (o - t)
+        dirs = torch.matmul(dirs_c[:, None, :], R)[:, 0]
+        dirs = dirs / torch.linalg.norm(dirs, dim=-1, keepdim=True)
+        return Rays(origins.float(), dirs.float(), dist_min=self.near, dist_max=self.far)
+
     def forward(self, *args, cam_ids=None, **kwargs):
         if isinstance(cam_ids, (tuple, list, torch.Tensor)):                                              # :69-70
             kwargs["rays"] = self.transform_rays(kwargs["rays"], cam_ids)

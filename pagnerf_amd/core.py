@@ -49,34 +49,30 @@ class Rays:
 
 
 class RenderBuffer:
-    """Named per-ray channels; `a += b` concatenates along the ray axis (trainer.py:648)."""
+    """Named per-ray channels; `a += b` concatenates along the ray axis (trainer.py:648).
+    Channels are plain instance attributes, as in wisp's dataclass: the reference trainer finds them by introspection
+    (`'ray_sparcity_loss' in dir(rb)` trainer.py:438, `vars(rb)['inst_embedding']` trainer.py:488)."""
 
     def __init__(self, **channels):
-        self.__dict__["_ch"] = dict(channels)
-
-    def __getattr__(self, name):
-        ch = self.__dict__["_ch"]
-        if name in ch:
-            return ch[name]
-        raise AttributeError(name)
-
-    def __setattr__(self, name, value):
-        self.__dict__["_ch"][name] = value
+        self.__dict__.update(channels)
 
     @property
     def channels(self):
-        return set(self._ch)
+        return set(self.__dict__)
+
+    def _items(self):
+        return list(self.__dict__.items())
 
     def _map(self, fn):
-        return RenderBuffer(**{k: (fn(v) if isinstance(v, torch.Tensor) and v.dim() > 0 else v) for k, v in self._ch.items()})
+        return RenderBuffer(**{k: (fn(v) if isinstance(v, torch.Tensor) and v.dim() > 0 else v) for k, v in self._items()})
 
     def __iadd__(self, other):
-        for k, v in other._ch.items():
-            mine = self._ch.get(k)
+        for k, v in other._items():
+            mine = self.__dict__.get(k)
             if isinstance(v, torch.Tensor) and v.dim() > 0 and mine is not None:
-                self._ch[k] = torch.cat([mine, v], 0)
+                self.__dict__[k] = torch.cat([mine, v], 0)
             else:
-                self._ch[k] = v if mine is None else mine
+                self.__dict__[k] = v if mine is None else mine
         return self
 
     def reshape(self, *dims):

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
-    float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    float x[3];
+    load_xyz(xyz, i, p.half_coords, x);
     const bf16x8_t addv = load_addend(addend, M, g, i);
     const int64_t T = (int64_t)1 << p.log2T;
     float e[LPX][8][F];
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(const float *__restrict__
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
-    float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    float x[3];
+    load_xyz(xyz, i, p.half_coords, x);
     const int64_t T = (int64_t)1 << p.log2T;
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
-    float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    float x[3];
+    load_xyz(xyz, i, p.half_coords, x);
     const bf16x8_t addv = load_addend(addend, M, g, i);
     float e[LPX][4][F];
     float bary[LPX][4];
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(const float *__restric
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
-    float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    float x[3];
+    load_xyz(xyz, i, p.half_coords, x);
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
         int l = g + 8 * j;
@@ -264,7 +268,8 @@ __global__ __launch_bounds__(256) void xyz_grad_kernel(const float *__restrict__
     const float *scale = KIND == 0 ? hp.scale : pp.scale;
     const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
     const int64_t rows = KIND == 0 ? ((int64_t)1 << hp.log2T) : (int64_t)pp.capacity;
-    float x[3] = {xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    float x[3];
+    load_xyz(xyz, i, KIND == 0 ? hp.half_coords : pp.half_coords, x);
     float gpiece[8];
     if (grouped) {
         typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
@@ -483,7 +488,8 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
     const int64_t i = tile * TS + tid;
     const bool live = i < M;
     const int64_t ic = live ? i : M - 1;
-    float x[3] = {xyz[ic * 3 + 0], xyz[ic * 3 + 1], xyz[ic * 3 + 2]};
+    float x[3];
+    load_xyz(xyz, ic, KIND == 0 ? hp.half_coords : pp.half_coords, x);
     // grouped (LPX = ceil(L/8)): blockIdx.y = XCD group g, levels g, g+8, ... share ONE counting sort and the 16-byte
     // gradient piece is read once.  strided (LPX = 1): blockIdx.y = level.
     float gpiece[8];
@@ -859,7 +865,7 @@ int check_common(const char *name, const void *xyz, int64_t M, int n_levels, int
 static int hash_encode_fwd_impl(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                 int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
                                 void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, int layout,
-                                const void *addend_p, void *stream) {
+                                const void *addend_p, int flags, void *stream) {
     const bf16_t *addend = (const bf16_t *)addend_p;
     PAG_CHECK_ARG(!addend || layout == PAG_LAYOUT_XCD8, "pag_hash_encode_fwd_add: the addend needs the XCD8 layout");
     int rc = check_common("pag_hash_encode_fwd", xyz, M, n_levels, n_feat);
@@ -878,6 +884,7 @@ static int hash_encode_fwd_impl(const float *xyz, int64_t M, const void *tables,
     p.log2T = log2_T;
     p.has_scale = feat_scale_host != nullptr;
     p.pair_loads = (reinterpret_cast<uintptr_t>(tables) & 15) == 0 && log2_T >= 1;
+    p.half_coords = (flags & PAG_ENC_HALF_COORDS) ? 1 : 0;
     for (int l = 0; l < n_levels; ++l) p.res[l] = resolutions_host[l];
     for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
     const int lpx = (n_levels + 7) / 8;
@@ -900,22 +907,22 @@ static int hash_encode_fwd_impl(const float *xyz, int64_t M, const void *tables,
 
 extern "C" int pag_hash_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                    int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
-                                   void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, int layout, void *stream) {
+                                   void *out, int out_dtype, int64_t out_stride_m, int64_t out_stride_c, int layout, int flags, void *stream) {
     return hash_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, log2_T, resolutions_host, feat_scale_host, out, out_dtype,
-                                out_stride_m, out_stride_c, layout, nullptr, stream);
+                                out_stride_m, out_stride_c, layout, nullptr, flags, stream);
 }
 
 extern "C" int pag_hash_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                        int n_feat, int log2_T, const float *resolutions_host, const float *feat_scale_host,
-                                       const void *addend, void *out, void *stream) {
+                                       const void *addend, void *out, int flags, void *stream) {
     return hash_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, log2_T, resolutions_host, feat_scale_host, out, PAG_BF16, 0,
-                                0, PAG_LAYOUT_XCD8, addend, stream);
+                                0, PAG_LAYOUT_XCD8, addend, flags, stream);
 }
 
 static int hash_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                 int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
                                 const float *feat_scale_host, float *grad_tables, void *workspace,
-                                int64_t workspace_bytes, void *stream) {
+                                int64_t workspace_bytes, int flags, void *stream) {
     int rc = check_common("pag_hash_encode_bwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(!overwrite || workspace, "pag_hash_encode_bwd_set: the overwriting form needs the binned algorithm (a workspace)");
@@ -931,6 +938,7 @@ static int hash_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, con
     p.L = n_levels;
     p.log2T = log2_T;
     p.has_scale = feat_scale_host != nullptr;
+    p.half_coords = (flags & PAG_ENC_HALF_COORDS) ? 1 : 0;
     for (int l = 0; l < n_levels; ++l) p.res[l] = resolutions_host[l];
     for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
     const int lpx = (n_levels + 7) / 8;
@@ -956,8 +964,9 @@ static int hash_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, con
 }
 
 static int fill_permuto(PermutoParams &p, int n_levels, int n_feat, uint32_t capacity, const float *sf, const float *sh,
-                        const float *scale) {
+                        const float *scale, int flags) {
     p.L = n_levels;
+    p.half_coords = (flags & PAG_ENC_HALF_COORDS) ? 1 : 0;
     p.capacity = capacity;
     p.pow2mask = (capacity & (capacity - 1)) == 0 ? capacity - 1 : 0;
     if (capacity == 1) p.pow2mask = 0;
@@ -974,7 +983,7 @@ static int fill_permuto(PermutoParams &p, int n_levels, int n_feat, uint32_t cap
 static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                    int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                    const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
-                                   int64_t out_stride_c, int layout, const void *addend_p, void *stream) {
+                                   int64_t out_stride_c, int layout, const void *addend_p, int flags, void *stream) {
     const bf16_t *addend = (const bf16_t *)addend_p;
     PAG_CHECK_ARG(!addend || layout == PAG_LAYOUT_XCD8, "pag_permuto_encode_fwd_add: the addend needs the XCD8 layout");
     int rc = check_common("pag_permuto_encode_fwd", xyz, M, n_levels, n_feat);
@@ -989,7 +998,7 @@ static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tabl
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(tables && out, "pag_permuto_encode_fwd: NULL tables/out");
     PermutoParams p;
-    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host);
+    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host, flags);
     const int lpx = (n_levels + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(encode_grid(M)), block(256);
@@ -1011,22 +1020,22 @@ static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tabl
 extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                       int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                       const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
-                                      int64_t out_stride_c, int layout, void *stream) {
+                                      int64_t out_stride_c, int layout, int flags, void *stream) {
     return permuto_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host,
-                                   out, out_dtype, out_stride_m, out_stride_c, layout, nullptr, stream);
+                                   out, out_dtype, out_stride_m, out_stride_c, layout, nullptr, flags, stream);
 }
 
 extern "C" int pag_permuto_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                           int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
-                                          const float *feat_scale_host, const void *addend, void *out, void *stream) {
+                                          const float *feat_scale_host, const void *addend, void *out, int flags, void *stream) {
     return permuto_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host,
-                                   out, PAG_BF16, 0, 0, PAG_LAYOUT_XCD8, addend, stream);
+                                   out, PAG_BF16, 0, 0, PAG_LAYOUT_XCD8, addend, flags, stream);
 }
 
 static int permuto_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                    int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
                                    const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                   float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+                                   float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     int rc = check_common("pag_permuto_encode_bwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(!overwrite || workspace, "pag_permuto_encode_bwd_set: the overwriting form needs the binned algorithm (a workspace)");
@@ -1039,7 +1048,7 @@ static int permuto_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, 
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(grad_out && grad_tables, "pag_permuto_encode_bwd: NULL grad_out/grad_tables");
     PermutoParams p;
-    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host);
+    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host, flags);
     const int lpx = (n_levels + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     if (workspace) {
@@ -1098,7 +1107,7 @@ static int launch_xyz_grad(const char *name, const float *xyz, int64_t M, const 
 extern "C" int pag_hash_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out,
                                        int grad_dtype, int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                                        int log2_T, const float *resolutions_host, const float *feat_scale_host, float *d_xyz,
-                                       void *workspace, int64_t workspace_bytes, void *stream) {
+                                       void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     int rc = check_common("pag_hash_encode_bwd_xyz", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_bwd_xyz: log2_T %d not in [1,30]", log2_T);
@@ -1107,6 +1116,7 @@ extern "C" int pag_hash_encode_bwd_xyz(const float *xyz, int64_t M, const void *
     p.L = n_levels;
     p.log2T = log2_T;
     p.has_scale = feat_scale_host != nullptr;
+    p.half_coords = (flags & PAG_ENC_HALF_COORDS) ? 1 : 0;
     for (int l = 0; l < n_levels; ++l) p.res[l] = resolutions_host[l];
     for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
     PermutoParams unused{};
@@ -1118,13 +1128,13 @@ extern "C" int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const voi
                                           int grad_dtype, int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels,
                                           int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                           const float *feat_scale_host, float *d_xyz, void *workspace, int64_t workspace_bytes,
-                                          void *stream) {
+                                          int flags, void *stream) {
     int rc = check_common("pag_permuto_encode_bwd_xyz", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_bwd_xyz: capacity is 0");
     PAG_CHECK_ARG(scale_factor_host && shift_host, "pag_permuto_encode_bwd_xyz: NULL scale_factor/shift");
     PermutoParams p;
-    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host);
+    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host, flags);
     HashParams unused{};
     return launch_xyz_grad<1>("pag_permuto_encode_bwd_xyz", xyz, M, tables, table_dtype, grad_out, grad_dtype, g_stride_m, g_stride_c,
                               layout, n_levels, n_feat, unused, p, d_xyz, workspace, workspace_bytes, (hipStream_t)stream);
@@ -1139,27 +1149,27 @@ extern "C" int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n
 // no zero fill of the 50 MB table before the call and no read of it in the reduce pass.
 extern "C" int pag_hash_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                    int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
-                                   const float *feat_scale_host, float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+                                   const float *feat_scale_host, float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     return hash_encode_bwd_impl(false, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, log2_T, resolutions_host,
-                                feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
+                                feat_scale_host, grad_tables, workspace, workspace_bytes, flags, stream);
 }
 extern "C" int pag_hash_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                        int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T, const float *resolutions_host,
-                                       const float *feat_scale_host, float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+                                       const float *feat_scale_host, float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     return hash_encode_bwd_impl(true, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, log2_T, resolutions_host,
-                                feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
+                                feat_scale_host, grad_tables, workspace, workspace_bytes, flags, stream);
 }
 extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                       int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
                                       const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                      float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+                                      float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     return permuto_encode_bwd_impl(false, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, capacity, scale_factor_host,
-                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
+                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, flags, stream);
 }
 extern "C" int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                           int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
                                           const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                          float *grad_tables, void *workspace, int64_t workspace_bytes, void *stream) {
+                                          float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     return permuto_encode_bwd_impl(true, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, capacity, scale_factor_host,
-                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, stream);
+                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, flags, stream);
 }

@@ -12,6 +12,7 @@ struct HashParams {
     float scale[PAG_MAX_FEATS];
     int L, log2T, has_scale;
     int pair_loads = 0;      // forward only: tables are 16-byte aligned and have >= 2 rows - x-corner pairs may be fetched as one float4
+    int half_coords = 0;     // PAG_ENC_HALF_COORDS
 };
 
 struct PermutoParams {
@@ -20,7 +21,18 @@ struct PermutoParams {
     float scale[PAG_MAX_FEATS];
     int L, has_scale;
     uint32_t capacity, pow2mask;   // pow2mask = capacity-1 when capacity is a power of two, else 0
+    int half_coords = 0;           // PAG_ENC_HALF_COORDS
 };
+
+// One sample's coordinates; with PAG_ENC_HALF_COORDS rounded through fp16 first (round-to-nearest-even, as torch's .half()):
+// grids/permuto_grid.py:65,71 - the encoder sees float(half(coords)) under the trainer's autocast.
+__device__ __forceinline__ void load_xyz(const float *__restrict__ xyz, int64_t i, int half_coords, float (&x)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = xyz[i * 3 + a];
+        x[a] = half_coords ? __half2float(__float2half_rn(v)) : v;
+    }
+}
 
 template <typename T, int F> struct Vec;
 template <> struct Vec<float, 1> { typedef float type; };

@@ -53,6 +53,17 @@ class OccupancyBLAS(nn.Module):
         self._all_occupied = True
         self._pack_cache = None
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """A checkpoint replaces buffers the kernels do not read directly: the march takes `_all_occupied`, the encoders a host copy of
+        the per-level shifts (`_spec`).  Both are derived state - rebuild them from what was just loaded (resume pattern of the
+        reference: main_hp_tunning.py:197 `pipeline.load_state_dict`)."""
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._refresh_derived()
+
+    def _refresh_derived(self):
+        self._all_occupied = bool((self.blas_bits == -1).all()) if self.num_cells >= 32 else False
+        self._pack_cache = None
+
     @property
     def dense_points(self):
         """int [R^3,3] cell coordinates, x slowest (same linear order as the bitfield)."""
@@ -78,8 +89,7 @@ class OccupancyBLAS(nn.Module):
         """Adopt a packed bitfield produced on the device (ops.occupancy_update)."""
         assert bits.dtype == torch.int32 and bits.numel() == self.blas_bits.numel()
         self.blas_bits = bits.clone()
-        full = self.num_cells if self.num_cells < 32 else 32
-        self._all_occupied = bool((bits == -1).all()) if full == 32 else False
+        self._refresh_derived()
 
     def occupancy_mask(self):
         bits = self.blas_bits.long() & 0xFFFFFFFF
@@ -145,9 +155,11 @@ class _GridBase(OccupancyBLAS):
 class HashGridHIP(_GridBase):
     """Multiresolution hash grid (every level hashed, fp32-derived resolutions - Appendix E.7)."""
 
-    def __init__(self, feature_dim, codebook_bitwidth=19, **kwargs):
+    def __init__(self, feature_dim, codebook_bitwidth=19, half_coords=False, **kwargs):
         super().__init__(feature_dim, **kwargs)
         self.codebook_bitwidth = int(codebook_bitwidth)
+        # grids/hash_grid_tinycudann.py:36 rounds the coordinates to fp16 under autocast; grids/hash_grid_torch.py does not (Appendix E.6)
+        self.half_coords = bool(half_coords)
 
     @staticmethod
     def level_resolutions(base_resolution, finest_resolution, n_levels):
@@ -171,7 +183,7 @@ class HashGridHIP(_GridBase):
         dev = self.blas_bits.device
         t = torch.empty(self.num_lods, T, self.feature_dim, device=dev).uniform_(-1e-4, 1e-4)   # hash_grid_torch.py:65
         self.tables = nn.Parameter(t.to(self.table_dtype))
-        self._spec = ops.hash_spec(res, self.codebook_bitwidth, self.feature_dim)
+        self._spec = ops.hash_spec(res, self.codebook_bitwidth, self.feature_dim, half_coords=self.half_coords)
 
     def init_from_geometric(self, min_width, max_width, num_lods):
         """wisp HashGrid.init_from_geometric (config_parser.py:733): int(1 + floor(min * b**l))."""
@@ -189,13 +201,14 @@ class PermutoGridHIP(_GridBase):
     """Permutohedral-lattice hash grid (grids/permuto_grid.py)."""
 
     def __init__(self, feature_dim, coarsest_scale=1.0, finest_scale=0.001, capacity_log_2=18, num_lods=24,
-                 half_coords=False, **kwargs):
+                 half_coords=True, **kwargs):
         kwargs.pop("multiscale_type", None)
         super().__init__(feature_dim, num_lods=num_lods, multiscale_type="cat", **kwargs)   # permuto_grid.py:31
         self.coarsest_scale, self.finest_scale = coarsest_scale, finest_scale
         self.capacity = 2 ** int(capacity_log_2)
-        # permuto_grid.py:65,71 - under the trainer's autocast the coordinates are rounded to fp16
-        self.half_coords = half_coords
+        # permuto_grid.py:65,71 - under the trainer's autocast the coordinates are rounded to fp16 before the encoder sees them
+        # (PAG_ENC_HALF_COORDS: done inside the kernels).  On by default because that is how the reference trains.
+        self.half_coords = bool(half_coords)
 
     def set_capacity(self, capacity_log_2):
         self.capacity = 2 ** int(capacity_log_2)
@@ -217,14 +230,18 @@ class PermutoGridHIP(_GridBase):
         if tables is None:
             tables = torch.randn(self.num_lods, self.capacity, self.feature_dim, device=dev) * 1e-5
         self.tables = nn.Parameter(tables.to(device=dev, dtype=self.table_dtype))
+        self._build_spec()
+
+    def _build_spec(self):
         self._spec = ops.permuto_spec(self.scale_factors(self.resolutions), self.random_shift_per_level, self.capacity,
-                                      self.feature_dim)
+                                      self.feature_dim, half_coords=self.half_coords)
+
+    def _refresh_derived(self):
+        super()._refresh_derived()
+        if getattr(self, "_spec", None) is not None and "random_shift_per_level" in self._buffers:
+            self._build_spec()        # the kernels hash with the host copy of the (just loaded) per-level shifts
 
     def interpolate(self, coords, lod_idx=None, pidx=None):
         if coords.numel() == 0:
             return torch.empty([0, 1, self.num_lods * self.feature_dim], device=coords.device)   # permuto_grid.py:68-69
         return self.interpolate_scaled(coords)
-
-    def _coords(self, coords):
-        c = coords.reshape(-1, 3)
-        return c.half().float() if self.half_coords else c

@@ -105,6 +105,8 @@ class PanopticDeltaNeF(nn.Module):
         # ---- grids (panoptic_nef.py:184-196, panoptic_delta_nef.py:39-44)
         gkw = dict(kwargs)
         gkw.pop("num_lods", None)
+        if grid_type == "HashGridTinyCudaNN":
+            gkw.setdefault("half_coords", True)       # grids/hash_grid_tinycudann.py:36 (custom_fwd cast_inputs=torch.half)
         self.grid = _GRIDS[grid_type](feature_dim, base_lod=base_lod, num_lods=num_lods,
                                       interpolation_type=interpolation_type, multiscale_type="cat", **gkw)
         self.lod_weights = torch.ones(num_lods * feature_dim)

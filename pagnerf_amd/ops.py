@@ -5,6 +5,7 @@ is test infrastructure and is never imported from this package).
 """
 import ctypes
 import os
+import threading
 import time
 
 import torch
@@ -56,34 +57,62 @@ def _check_gpu(*ts):
 
 # ------------------------------------------------------------------------------------------- encode
 class _EncodeSpec:
-    """Static description of a grid encoder (host-side per-level parameters)."""
+    """Static description of a grid encoder (host-side per-level parameters).  Holds plain Python numbers (picklable:
+    `torch.save(pipeline)` is the reference's default checkpoint format, config_parser.py:753-756); the ctypes float arrays
+    the C ABI takes are built from them once per process."""
 
     def __init__(self, kind, n_levels, n_feat, **kw):
         self.kind = kind
         self.L = int(n_levels)
         self.F = int(n_feat)
-        self.kw = kw
         if kind == "hash":
-            self.log2_T = int(kw["log2_T"])
-            self.res = L.host_floats(kw["resolutions"])
+            self.kw = dict(log2_T=int(kw["log2_T"]), resolutions=_float_list(kw["resolutions"]), half_coords=bool(kw.get("half_coords", False)))
         elif kind == "permuto":
-            self.capacity = int(kw["capacity"])
-            self.sf = L.host_floats(kw["scale_factor"])
-            self.shift = L.host_floats(kw["shift"])
+            self.kw = dict(capacity=int(kw["capacity"]), scale_factor=_float_list(kw["scale_factor"]), shift=_float_list(kw["shift"]),
+                           half_coords=bool(kw.get("half_coords", False)))
         else:
             raise ValueError(kind)
+        self._bind()
+
+    def _bind(self):
+        kw = self.kw
+        if self.kind == "hash":
+            self.log2_T = kw["log2_T"]
+            self.res = L.host_floats(kw["resolutions"])
+            self.flags = L.ENC_HALF_COORDS if kw["half_coords"] else 0
+        else:
+            self.capacity = kw["capacity"]
+            self.sf = L.host_floats(kw["scale_factor"])
+            self.shift = L.host_floats(kw["shift"])
+            self.flags = L.ENC_HALF_COORDS if kw["half_coords"] else 0
+
+    def __getstate__(self):
+        return dict(kind=self.kind, L=self.L, F=self.F, kw=self.kw)
+
+    def __setstate__(self, state):
+        self.kind, self.L, self.F, self.kw = state["kind"], state["L"], state["F"], state["kw"]
+        self._bind()
 
     def rows(self):
         return (1 << self.log2_T) if self.kind == "hash" else self.capacity
 
 
-def hash_spec(resolutions, log2_T, n_feat):
-    return _EncodeSpec("hash", len(resolutions), n_feat, log2_T=log2_T, resolutions=resolutions)
+def _float_list(values):
+    if isinstance(values, torch.Tensor):
+        return values.detach().cpu().float().reshape(-1).tolist()
+    import numpy as np
+    return np.asarray(values, dtype=np.float32).reshape(-1).tolist()
 
 
-def permuto_spec(scale_factor, shift, capacity, n_feat):
-    """scale_factor, shift: [L,3] (torch CPU / numpy)."""
-    return _EncodeSpec("permuto", len(scale_factor), n_feat, capacity=capacity, scale_factor=scale_factor, shift=shift)
+def hash_spec(resolutions, log2_T, n_feat, half_coords=False):
+    return _EncodeSpec("hash", len(resolutions), n_feat, log2_T=log2_T, resolutions=resolutions, half_coords=half_coords)
+
+
+def permuto_spec(scale_factor, shift, capacity, n_feat, half_coords=False):
+    """scale_factor, shift: [L,3] (torch CPU / numpy).  half_coords: the kernels round xyz to fp16 first - what the reference's
+    `custom_fwd(cast_inputs=torch.half)` does to the coordinates under the trainer's autocast (grids/permuto_grid.py:65,71)."""
+    return _EncodeSpec("permuto", len(scale_factor), n_feat, capacity=capacity, scale_factor=scale_factor, shift=shift,
+                       half_coords=half_coords)
 
 
 def _layout_args(t):
@@ -102,17 +131,17 @@ def _encode_fwd(spec, xyz, tables, feat_scale, out, addend=None):
         assert lay == L.LAYOUT_XCD8 and addend.shape == out.shape and addend.dtype == torch.bfloat16 and addend.is_contiguous()
         if spec.kind == "hash":
             _call("pag_hash_encode_fwd_add", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T, spec.res, fs,
-                  L.ptr(addend), out.data_ptr(), L.stream())
+                  L.ptr(addend), out.data_ptr(), spec.flags, L.stream())
         else:
             _call("pag_permuto_encode_fwd_add", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity, spec.sf,
-                  spec.shift, fs, L.ptr(addend), out.data_ptr(), L.stream())
+                  spec.shift, fs, L.ptr(addend), out.data_ptr(), spec.flags, L.stream())
         return
     if spec.kind == "hash":
         _call("pag_hash_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
-              spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, L.stream())
+              spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, spec.flags, L.stream())
     else:
         _call("pag_permuto_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity,
-              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, L.stream())
+              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, spec.flags, L.stream())
 
 
 _DTYPE_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
@@ -135,10 +164,10 @@ def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False):
     suffix = "_set" if overwrite else ""
     if spec.kind == "hash":
         _call("pag_hash_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
-              spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
+              spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, spec.flags, L.stream())
     else:
         _call("pag_permuto_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
-              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.stream())
+              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, spec.flags, L.stream())
 
 
 def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale):
@@ -150,11 +179,11 @@ def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale):
     ws = torch.empty(8 * M * 3, device=xyz.device)
     if spec.kind == "hash":
         _call("pag_hash_encode_bwd_xyz", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), grad_out.data_ptr(), L.dtype_code(grad_out),
-              sm, sc, lay, spec.L, spec.F, spec.log2_T, spec.res, fs, L.ptr(d_xyz), L.ptr(ws), ws.numel() * 4, L.stream())
+              sm, sc, lay, spec.L, spec.F, spec.log2_T, spec.res, fs, L.ptr(d_xyz), L.ptr(ws), ws.numel() * 4, spec.flags, L.stream())
     else:
         _call("pag_permuto_encode_bwd_xyz", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), grad_out.data_ptr(),
               L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F, spec.capacity, spec.sf, spec.shift, fs, L.ptr(d_xyz), L.ptr(ws),
-              ws.numel() * 4, L.stream())
+              ws.numel() * 4, spec.flags, L.stream())
     return d_xyz
 
 
@@ -514,7 +543,7 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
         _call("pag_raymarch_count", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min),
                                        float(dist_max), occ, blas_level, L.ptr(counts), st)
     pack_start = torch.empty(N + 1, device=dev, dtype=torch.int64)      # [i] = first sample of ray i, [N] = M
-    mailbox = _count_mailbox(dev) if POLL_SAMPLE_COUNT else None
+    mailbox = _count_mailbox() if POLL_SAMPLE_COUNT else None
     if mailbox is not None:
         mailbox[1][0] = -1
     _call("pag_pack_offsets", L.ptr(counts), N, L.ptr(pack_start), mailbox[0].data_ptr() if mailbox is not None else None, st)
@@ -542,6 +571,10 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
             # the kernel has finished (the read-back above waited for it) and its store never reached the mailbox: device
             # writes to this pinned allocation are not visible to the host on this system - stop polling for good
             _disable_polling()
+    if mailbox is not None:
+        if int(mailbox[1][0]) >= 0:       # the kernel has written its word: nobody else will touch it, back to the pool
+            _release_mailbox(mailbox)
+        # else: a store may still arrive later (timed-out poll) - the word is dropped, never lent again
     if want_ridx64:
         return (ridx[:M], pidx[:M], samples[:M], depths[:M], deltas[:M], boundary[:M].view(torch.bool), pack_start, _ray_iota(N, dev),
                 ridx64[:M])
@@ -550,7 +583,8 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, num_samples, jitter=None, oc
 
 
 POLL_SAMPLE_COUNT = os.environ.get("PAG_NO_POLL") is None
-_MAILBOX = {}
+_MAILBOX_LOCK = threading.Lock()
+_MAILBOX_FREE = []          # pinned int64[1] words not lent to a march in flight
 
 
 def _disable_polling():
@@ -558,33 +592,43 @@ def _disable_polling():
     POLL_SAMPLE_COUNT = False
 
 
-def _count_mailbox(dev):
-    """(pinned i64[1] tensor, its numpy view) per device: the pack-offset kernel stores the sample count there (system-scope
-    release) and the host polls it - it continues as soon as that tiny kernel has run instead of after a stream-synchronising
-    copy behind the pack kernel (~50 us of the GPU-idle window at the head of every step)."""
-    key = str(dev)
-    if key not in _MAILBOX:
-        t = torch.empty(1, dtype=torch.int64).pin_memory()
-        _MAILBOX[key] = (t, t.numpy())
-    return _MAILBOX[key]
+def _count_mailbox(dev=None):
+    """(pinned i64[1] tensor, its numpy view) lent to ONE raymarch_ray call: the pack-offset kernel stores the sample count there
+    (system-scope release) and the host polls it - it continues as soon as that tiny kernel has run instead of after a
+    stream-synchronising copy behind the pack kernel (~50 us of the GPU-idle window at the head of every step).  Words come from a
+    small pool under a lock and go back with _release_mailbox(), so two marches in flight (another stream or thread, e.g. an
+    interactive render next to training) never preset and poll the same word."""
+    with _MAILBOX_LOCK:
+        if _MAILBOX_FREE:
+            return _MAILBOX_FREE.pop()
+    t = torch.empty(1, dtype=torch.int64).pin_memory()
+    return (t, t.numpy())
+
+
+def _release_mailbox(mailbox):
+    with _MAILBOX_LOCK:
+        if len(_MAILBOX_FREE) < 16:
+            _MAILBOX_FREE.append(mailbox)
 
 
 def _poll_count(mailbox, timeout_s=0.5):
-    """Spin on the mailbox; -1 if nothing arrived in time (the caller then falls back to the synchronous read-back)."""
+    """Wait for the mailbox; -1 if nothing arrived in time (the caller then falls back to the synchronous read-back).  The first
+    ~50 us are a tight spin (the usual case: the count arrives within 10-20 us); after that the loop yields the GIL with short
+    sleeps so a delayed kernel (earlier work queued on the stream) does not starve other Python threads."""
     arr = mailbox[1]
-    t_end = None
+    t0 = time.perf_counter()
     spins = 0
     while True:
         v = int(arr[0])
         if v >= 0:
             return v
         spins += 1
-        if spins % 4096 == 0:
-            now = time.perf_counter()
-            if t_end is None:
-                t_end = now + timeout_s
-            elif now > t_end:
+        if spins % 256 == 0:
+            el = time.perf_counter() - t0
+            if el > timeout_s:
                 return -1
+            if el > 50e-6:
+                time.sleep(20e-6)
 
 
 _IOTA = {}

@@ -27,21 +27,21 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == 1
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_argument_validation_without_gpu(lib):
     from pagnerf_amd import _lib as L
     f = (ctypes.c_float * 4)(16, 32, 64, 128)
     # M == 0 is a no-op for every entry point (empty packs / empty batches, permuto_grid.py:68-69)
-    assert lib.pag_hash_encode_fwd(None, 0, None, L.F32, 4, 2, 10, f, None, None, L.F32, 8, 1, 0, None) == 0
+    assert lib.pag_hash_encode_fwd(None, 0, None, L.F32, 4, 2, 10, f, None, None, L.F32, 8, 1, 0, 0, None) == 0
     assert lib.pag_composite_fwd(None, None, 0, None, None, None, None, 1, None, None, None, None, None, None) == 0
     assert lib.pag_raymarch_count(None, None, 0, 8, None, None, 0.0, 2.0, None, 7, None, None) == 0
     # bad arguments are rejected before any launch
-    assert lib.pag_hash_encode_fwd(None, 5, None, L.F32, 4, 2, 10, f, None, None, L.F32, 8, 1, 0, None) == -1
+    assert lib.pag_hash_encode_fwd(None, 5, None, L.F32, 4, 2, 10, f, None, None, L.F32, 8, 1, 0, 0, None) == -1
     assert b"xyz" in lib.pag_last_error_string()
-    assert lib.pag_hash_encode_fwd(None, 0, None, L.F32, 99, 2, 10, f, None, None, L.F32, 8, 1, 0, None) == -1
-    assert lib.pag_hash_encode_fwd(None, 0, None, L.F32, 4, 3, 10, f, None, None, L.F32, 8, 1, 0, None) == -1
+    assert lib.pag_hash_encode_fwd(None, 0, None, L.F32, 99, 2, 10, f, None, None, L.F32, 8, 1, 0, 0, None) == -1
+    assert lib.pag_hash_encode_fwd(None, 0, None, L.F32, 4, 3, 10, f, None, None, L.F32, 8, 1, 0, 0, None) == -1
     a = L.MlpFwdArgs()
     a.n_layers, a.k1, a.in_dim, a.out_dim = 5, 48, 48, 16
     assert lib.pag_mlp_fwd(ctypes.byref(a), 0, None) == -1 and b"n_layers" in lib.pag_last_error_string()
@@ -157,3 +157,133 @@ def test_sample_count_mailbox_polling_host_logic():
     assert ops._poll_count(box, timeout_s=5.0) == 12345
     box[1][0] = 0
     assert ops._poll_count(box) == 0                     # zero samples is a valid count
+
+
+def test_state_dict_reload_rebuilds_host_side_derived_state():
+    """after load_state_dict the kernels must hash with the LOADED per-level shifts and march with the LOADED
+    occupancy - both live in host-side copies (`_spec`, `_all_occupied`) derived from the buffers."""
+    from pagnerf_amd.grids import PermutoGridHIP
+    torch.manual_seed(1)
+    g = PermutoGridHIP(2, capacity_log_2=8, num_lods=4, finest_scale=0.01, blas_level=3)
+    g.init_from_scales()
+    g.blas_init(torch.rand(512) > 0.5)
+    assert not g._all_occupied
+    torch.manual_seed(2)
+    h = PermutoGridHIP(2, capacity_log_2=8, num_lods=4, finest_scale=0.01, blas_level=3)
+    h.init_from_scales()
+    assert h._all_occupied and list(h._spec.shift) != list(g._spec.shift)
+    res = h.load_state_dict(g.state_dict())
+    assert not res.missing_keys and not res.unexpected_keys
+    assert list(h._spec.shift) == list(g._spec.shift) == g.random_shift_per_level.reshape(-1).tolist()
+    assert h._all_occupied is False and torch.equal(h.occupancy_mask(), g.occupancy_mask())
+    assert h._spec.flags == g._spec.flags == 1          # half_coords is the default (grids/permuto_grid.py:65)
+    # through a parent module too (pipeline.load_state_dict)
+    import pagnerf_amd
+    mk = lambda seed: (torch.manual_seed(seed), pagnerf_amd.PanopticDeltaNeF(
+        grid_type="PermutoGrid", num_lods=4, feature_dim=2, num_classes=6, num_instances=8, inst_num_layers=2, sem_num_layers=1,
+        capacity_log_2=6, delta_capacity_log_2=6, blas_level=3, panoptic_features_type="delta"))[1]
+    a, b = mk(3), mk(4)
+    for n in (a, b):
+        n.grid.init_from_scales()
+        n.delta_grid.init_from_scales()
+    a.grid.blas_init(torch.rand(512) > 0.3)
+    b.load_state_dict(a.state_dict())
+    assert list(b.grid._spec.shift) == list(a.grid._spec.shift) and list(b.delta_grid._spec.shift) == list(a.delta_grid._spec.shift)
+    assert b.grid._all_occupied is False and b.delta_grid._all_occupied is True
+
+
+def test_pipeline_pickles_and_torch_saves(tmp_path):
+    """`torch.save(pipeline)` is the reference's default checkpoint format (config_parser.py:753-756)."""
+    import copy
+    import io
+    import pickle
+    import pagnerf_amd
+    nef = pagnerf_amd.PanopticDeltaNeF(grid_type="PermutoGrid", num_lods=4, feature_dim=2, num_classes=6, num_instances=8,
+                                       inst_num_layers=2, sem_num_layers=1, capacity_log_2=6, delta_capacity_log_2=5, blas_level=3,
+                                       panoptic_features_type="delta")
+    nef.grid.init_from_scales()
+    nef.delta_grid.init_from_scales()
+    pipe = pagnerf_amd.Pipeline(nef, pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=16))
+    blob = pickle.dumps(pipe)
+    back = pickle.loads(blob)
+    assert list(back.nef.grid._spec.shift) == list(nef.grid._spec.shift) and back.nef.grid._spec.capacity == 64
+    assert back.nef.delta_grid._spec.capacity == 32 and back.nef.grid._spec.flags == nef.grid._spec.flags
+    path = tmp_path / "model.pth"
+    torch.save(pipe, path)
+    again = torch.load(path, weights_only=False)
+    assert torch.equal(again.nef.grid.tables, nef.grid.tables) and again.tracer.num_steps == 16
+    hs = pagnerf_amd.HashGridHIP(2, codebook_bitwidth=6, blas_level=3)
+    hs.init_from_resolutions([16, 32, 64])
+    hs2 = copy.deepcopy(hs)
+    assert list(hs2._spec.res) == list(hs._spec.res) and pickle.loads(pickle.dumps(hs))._spec.log2_T == 6
+
+
+def test_render_buffer_channels_are_real_attributes():
+    """the reference trainer finds channels with dir() / vars() (trainer.py:438, :488)."""
+    import pagnerf_amd
+    rb = pagnerf_amd.RenderBuffer(rgb=torch.zeros(4, 3), inst_embedding=torch.ones(4, 5), ray_sparcity_loss=torch.tensor(0.5))
+    assert "ray_sparcity_loss" in dir(rb) and vars(rb)["inst_embedding"].shape == (4, 5)
+    assert rb.channels == {"rgb", "inst_embedding", "ray_sparcity_loss"}
+    rb.depth = torch.zeros(4, 1)
+    assert "depth" in vars(rb) and rb.cpu().depth.shape == (4, 1)
+    rb += pagnerf_amd.RenderBuffer(rgb=torch.ones(2, 3), inst_embedding=torch.ones(2, 5), depth=torch.ones(2, 1))
+    assert rb.rgb.shape == (6, 3) and float(rb.ray_sparcity_loss) == 0.5
+    with pytest.raises(AttributeError):
+        rb.nonexistent
+
+
+def test_mailbox_pool_never_lends_one_word_twice():
+    """concurrent marches (threads / streams) each get their own pinned word."""
+    import threading
+    from pagnerf_amd import ops
+    if not torch.cuda.is_available():
+        # pin_memory needs the HIP runtime: exercise the pool logic with plain words
+        real = torch.Tensor.pin_memory
+        torch.Tensor.pin_memory = lambda self, *a, **k: self
+    try:
+        held, lock = [], threading.Lock()
+
+        def worker():
+            for _ in range(50):
+                m = ops._count_mailbox()
+                with lock:
+                    assert all(m[0] is not h[0] for h in held)
+                    held.append(m)
+                m[1][0] = 7
+                with lock:
+                    held.remove(m)
+                ops._release_mailbox(m)
+        ts = [threading.Thread(target=worker) for _ in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert len(ops._MAILBOX_FREE) <= 16
+    finally:
+        if not torch.cuda.is_available():
+            torch.Tensor.pin_memory = real
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` (no WORLD_SIZE) must start two ranks itself, prove the process group saw
+    both, run the shard collectives over it and relay rank 0's line; a size mismatch must fail instead of reporting."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["warmup"] == 1
+    # N = 1 dry run: no spawn, same schema
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
+                        capture_output=True, text=True, env=env, timeout=600)
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # a rank count that does not match --gpus refuses to report
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                        env=env2, timeout=600)
+    assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]

@@ -199,3 +199,107 @@ def test_g8_delta_density_variant():
         for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding", "ray_sparcity_loss"):
             np.testing.assert_allclose(comp[ch].numpy(), g[f"t_{bg}_{ch}"], rtol=1e-5, atol=1e-6, err_msg=f"{bg} {ch}")
         assert np.array_equal(comp["hit"].numpy(), g[f"t_{bg}_hit"])
+
+
+# ------------------------------------------------------------------------------- permutohedral encoder: independent checks
+# The third-party package behind grids/permuto_grid.py:57-71 is absent, so oracle/permuto_encode.py is "parity unpinned".
+# These tests narrow what that leaves open: the oracle is compared with a second implementation written from the definitions
+# of Adams et al. 2010 that shares no code or formula with it (oracle/permuto_adams.py), and the hash with hand-derived values.
+
+# k = 0; for i in 0..2: k = (k + key_i) * 2531011 mod 2^32 - worked by hand (m = 2531011, m^2 mod 2^32 = 2220443785,
+# m^3 mod 2^32 = 2937900635, -m mod 2^32 = 4292436285):
+#   (0,0,1): ((0*m + 0)*m + 1)*m = m                      (0,1,0): (1*m)*m = m^2            (1,0,0): ((1*m)*m)*m = m^3
+#   (-1,0,0): -(m^3) mod 2^32 = 4294967296 - 2937900635   (1,1,1): m^3 + m^2 + m mod 2^32
+HAND_HASH = {(0, 0, 0): 0, (0, 0, 1): 2531011, (0, 1, 0): 2220443785, (1, 0, 0): 2937900635, (-1, 0, 0): 1357066661,
+             (1, 1, 1): 865908135, (2, 2, -2): 1721692226, (3, -1, -1): 2295759813, (4, -8, 12): 2608358984, (-3, 1, 1): 1999207483}
+
+
+def test_permuto_hash_hand_derived_vectors():
+    from oracle import permuto_encode as op, permuto_adams as pa
+    assert (2531011 ** 2) % 2 ** 32 == 2220443785 and (2531011 ** 3) % 2 ** 32 == 2937900635
+    assert HAND_HASH[(1, 1, 1)] == (2937900635 + 2220443785 + 2531011) % 2 ** 32
+    assert HAND_HASH[(-1, 0, 0)] == 2 ** 32 - 2937900635
+    for cap in (2 ** 18, 2 ** 32, 1000003, 1):
+        for key, k in HAND_HASH.items():
+            assert pa.lattice_hash_scalar(key, cap) == k % cap
+            assert int(pa.lattice_hash(np.array([key], dtype=np.int64), cap)[0]) == k % cap
+    # the oracle hashes vertex r of (rem0, rank) with key_i = rem0_i + r - 4*[rank_i > 3 - r]; rank = (0,1,2,3), rem0 = 0 is the
+    # canonical simplex whose vertices are (0,0,0,0), (1,1,1,-3), (2,2,-2,-2), (3,-1,-1,-1)
+    rem0, rank = np.zeros((1, 4), np.int32), np.array([[0, 1, 2, 3]], np.int32)
+    for cap in (2 ** 18, 1000003):
+        got = op.vertex_indices(rem0, rank, cap)[0]
+        want = [HAND_HASH[k] % cap for k in ((0, 0, 0), (1, 1, 1), (2, 2, -2), (3, -1, -1))]
+        assert got.tolist() == want
+    # centroid of that simplex: x = (0.5, 0.5, 0.5) with unit scale factors and no shift -> E = (1.5, 0.5, -0.5, -1.5), weights 1/4
+    tab = np.zeros((1, 2 ** 18, 1), np.float32)
+    for v, key in zip((1.0, 2.0, 4.0, 8.0), ((0, 0, 0), (1, 1, 1), (2, 2, -2), (3, -1, -1))):
+        tab[0, HAND_HASH[key] % 2 ** 18, 0] = v
+    x = np.full((1, 3), 0.5, np.float32)
+    f, idx, b = op.permuto_encode(x, tab, np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32))
+    assert f[0, 0] == 3.75 and np.array_equal(b[0, 0], np.full(4, 0.25, np.float32))
+
+
+def _permuto_setup(L=24, cap=1 << 18, F=2, seed=0):
+    from oracle import permuto_encode as op
+    rs = np.random.RandomState(seed)
+    sf = op.scale_factors(np.geomspace(1.0, 1e-4, L))                      # grids/permuto_grid.py:53 at best.yaml sizes
+    shifts = (rs.standard_normal((L, 3)) * 10).astype(np.float32)
+    tab = rs.standard_normal((L, cap, F)).astype(np.float32)
+    return rs, sf, shifts, tab
+
+
+def _check_levels(x, levels, sf, shifts, tab, min_same):
+    from oracle import permuto_encode as op, permuto_adams as pa
+    F = tab.shape[2]
+    sub = lambda a: np.ascontiguousarray(a[levels])
+    f32, i32, b32 = op.permuto_encode(x, sub(tab), sub(shifts), sub(sf))
+    f64, i64, b64 = pa.encode(x, sub(tab), sub(shifts), sub(sf))
+    for j, l in enumerate(levels):
+        _, _, E = pa.enclosing_simplex(x[:1000], shifts[l], sf[l])
+        ulp = float(np.spacing(np.float32(np.abs(E).max())))             # fp32 resolution of the elevated coordinates at this level
+        same = (i32[j] == i64[j]).all(1)
+        assert same.mean() >= min_same(l), (l, same.mean())
+        # where both pick the same simplex the weights agree to the fp32 rounding of E; everywhere the FEATURES agree to it,
+        # because the interpolant is continuous across faces (a different simplex near a face carries a ~0 weight there)
+        assert np.abs(b32[j][same] - b64[j][same]).max() <= 4 * ulp + 2e-6, (l, ulp)
+        err = np.abs(f32[:, j * F:(j + 1) * F] - f64[:, j * F:(j + 1) * F]).max()
+        assert err <= (8 * ulp + 1e-5) * np.abs(tab[l]).max(), (l, err, ulp)
+        assert (b64[j] >= -1e-9).all() and np.abs(b64[j].sum(1) - 1).max() < 1e-9
+
+
+def test_permuto_oracle_matches_independent_adams_statement():
+    rs, sf, shifts, tab = _permuto_setup()
+    min_same = lambda l: 0.9999 if l <= 8 else (0.998 if l <= 18 else 0.98)
+    x = rs.uniform(-1, 1, size=(1_000_000, 3)).astype(np.float32)
+    _check_levels(x, [0, 9, 17], sf, shifts, tab, min_same)                 # 1e6 points on a coarse, a middle and a fine level
+    _check_levels(x[:40000], list(range(24)), sf, shifts, tab, min_same)    # every level
+    from oracle import permuto_encode as op
+    _check_levels(op.half_round(x[:200000]), [3, 12, 23], sf, shifts, tab, min_same)   # fp16-rounded coordinates (the training default)
+
+
+def test_permuto_points_on_simplex_faces_edges_and_vertices():
+    """Points constructed ON faces / edges / vertices of lattice simplices (one, two or three barycentric weights zero), where
+    the choice of simplex is ambiguous: both implementations must still produce the same (continuous) features."""
+    from oracle import permuto_encode as op, permuto_adams as pa
+    rs, sf, shifts, tab = _permuto_setup(L=12, cap=1 << 16)
+    sf = op.scale_factors(np.geomspace(1.0, 1e-2, 12))
+    shifts = (rs.standard_normal((12, 3)) * 2).astype(np.float32)
+    for l in (0, 5, 11):
+        seed_pts = rs.uniform(-1, 1, size=(30000, 3))
+        verts, _, _ = pa.enclosing_simplex(seed_pts, shifts[l], sf[l])
+        w = rs.dirichlet(np.ones(4), size=len(seed_pts))
+        n_zero = rs.randint(1, 4, size=len(seed_pts))                       # 1: face, 2: edge, 3: vertex
+        order = np.argsort(rs.rand(len(seed_pts), 4), axis=1)
+        for i in range(len(seed_pts)):
+            w[i, order[i, :n_zero[i]]] = 0.0
+        w /= w.sum(1, keepdims=True)
+        E = (w[:, :, None] * verts).sum(1)
+        x = pa.unelevate(E, shifts[l], sf[l]).astype(np.float32)
+        keep = (np.abs(x) <= 1.5).all(1)
+        x = x[keep]
+        f32, _, b32 = op.permuto_encode(x, tab[l:l + 1], shifts[l:l + 1], sf[l:l + 1])
+        f64, _, b64 = pa.encode(x, tab[l:l + 1], shifts[l:l + 1], sf[l:l + 1])
+        _, _, Ef = pa.enclosing_simplex(x[:100], shifts[l], sf[l])
+        ulp = float(np.spacing(np.float32(np.abs(Ef).max())))
+        assert np.abs(f32 - f64).max() <= (8 * ulp + 1e-5) * np.abs(tab[l]).max(), l
+        assert (b32 >= -4 * ulp - 1e-6).all() and np.abs(b32.sum(-1) - 1).max() < 1e-5
