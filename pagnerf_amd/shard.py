@@ -22,6 +22,16 @@ def world_info():
     return 0, 1
 
 
+def _reduce_op(average):
+    """(op, divide afterwards?) - RCCL averages inside the collective (ReduceOp.AVG: no separate pass over a 50 MB table
+    gradient); gloo (the CPU tests) has no AVG, so there the sum is divided by the world size afterwards."""
+    if not average:
+        return dist.ReduceOp.SUM, False
+    if dist.get_backend() == "nccl":
+        return dist.ReduceOp.AVG, False
+    return dist.ReduceOp.SUM, True
+
+
 def shard_bounds(n, rank, world):
     """Contiguous block partition of n rays: the first n % world ranks get one extra ray."""
     base, rem = divmod(n, world)
@@ -76,11 +86,12 @@ def allreduce_grads(params, average=True, big=1 << 20):
         return
     large = [g for g in grads if g.numel() >= big and g.is_contiguous()]
     small = [g for g in grads if not (g.numel() >= big and g.is_contiguous())]
-    handles = [dist.all_reduce(g, async_op=True) for g in large]
+    op, divide = _reduce_op(average)
+    handles = [dist.all_reduce(g, op=op, async_op=True) for g in large]
     if small:
         flat = torch.cat([g.reshape(-1).float() for g in small])
-        dist.all_reduce(flat)
-        if average:
+        dist.all_reduce(flat, op=op)
+        if divide:
             flat /= world
         off = 0
         for g in small:
@@ -88,7 +99,7 @@ def allreduce_grads(params, average=True, big=1 << 20):
             off += g.numel()
     for g, h in zip(large, handles):
         h.wait()
-        if average:
+        if divide:
             g /= world
 
 
@@ -100,8 +111,9 @@ class GradSync:
     finish() waits for them, exchanges everything else as one flat all-reduce and averages.  On the xGMI mesh the 50 MB
     early message therefore travels while the GPU still computes; only the main table (produced last) is exposed."""
 
-    def __init__(self, params, early=()):
+    def __init__(self, params, early=(), average=True):
         self.params = list(params)
+        self.average = average
         self.early = [p for p in early]
         self._early_ids = {id(p) for p in self.early}
         self._handles = []
@@ -113,17 +125,18 @@ class GradSync:
 
     def _launch(self, p):
         if p.grad is not None:
-            self._handles.append((p, dist.all_reduce(p.grad, async_op=True)))
+            op, divide = _reduce_op(self.average)
+            self._handles.append((p, dist.all_reduce(p.grad, op=op, async_op=True), divide))
 
-    def finish(self, average=True):
+    def finish(self):
         _, world = world_info()
         if world == 1:
             return
-        rest = [p for p in self.params if id(p) not in self._early_ids or not any(q is p for q, _ in self._handles)]
-        allreduce_grads(rest, average=average)
-        for p, h in self._handles:
+        rest = [p for p in self.params if id(p) not in self._early_ids or not any(q is p for q, _, _ in self._handles)]
+        allreduce_grads(rest, average=self.average)
+        for p, h, divide in self._handles:
             h.wait()
-            if average:
+            if divide:
                 p.grad /= world
         self._handles = []
 

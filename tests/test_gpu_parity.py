@@ -442,6 +442,7 @@ def test_voxel_mode_end_to_end_after_prune(gpu_device):
     deltas = deltas.reshape(-1, 2)[keep].reshape(-1, 1)
     boundary = boundary.reshape(-1, 2)[keep].reshape(-1)
     xyz = samples.reshape(-1, 3).numpy()
+    xyz = op.half_round(xyz) if nef.grid.half_coords else xyz         # grids/permuto_grid.py:65,71 (autocast cast to half)
 
     def enc(grid):
         f, _, _ = op.permuto_encode(xyz, grid.tables.detach().cpu().numpy(), grid.random_shift_per_level.cpu().numpy(),
@@ -558,6 +559,7 @@ def _oracle_render(nef, rays, occ, jitter, S, channels):
     o, d = rays.origins.cpu(), rays.dirs.cpu()
     ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_ray(o, d, rays.dist_min, rays.dist_max, S, jitter, occ, nef.grid.blas_level)
     xyz = samples[:, 0].numpy()
+    xyz = op.half_round(xyz) if nef.grid.half_coords else xyz         # grids/permuto_grid.py:65,71 (autocast cast to half)
 
     def enc(grid):
         sf = grid.scale_factors(grid.resolutions).numpy()
@@ -603,7 +605,8 @@ def test_end_to_end_train_step_gradients_fp32(gpu_device):
     g = nef.grid
     sf = g.scale_factors(g.resolutions).numpy()
     tab = g.tables.detach().cpu().clone().requires_grad_(True)
-    _, idx, bary = op.permuto_encode(samples[:, 0].numpy(), tab.detach().numpy(), g.random_shift_per_level.cpu().numpy(), sf)
+    xyz = op.half_round(samples[:, 0].numpy()) if g.half_coords else samples[:, 0].numpy()
+    _, idx, bary = op.permuto_encode(xyz, tab.detach().numpy(), g.random_shift_per_level.cpu().numpy(), sf)
     idx_t, bary_t = torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(bary)
     feats = torch.cat([(tab[l][idx_t[l]] * bary_t[l][..., None]).sum(1) for l in range(tab.shape[0])], -1)
     params = {}
@@ -776,6 +779,8 @@ def test_pose_gradients_vs_oracle(gpu_device, mode):
         @staticmethod
         def forward(ctx, xyz, grid):
             ctx.grid, ctx.xyz = grid, xyz.detach().numpy()
+            if grid.half_coords:       # grids/permuto_grid.py:65,71; autograd passes the gradient straight through the casts
+                ctx.xyz = op.half_round(ctx.xyz)
             f, _, _ = op.permuto_encode(ctx.xyz, grid.tables.detach().cpu().numpy(), grid.random_shift_per_level.cpu().numpy(), sf[id(grid)])
             return torch.from_numpy(f)
 
