@@ -312,14 +312,31 @@ int pag_raymarch_pack(const float *origins, const float *dirs, int64_t N, int S,
  *   ridx i32 [M'], pidx i32 [M'] per nugget; samples f32 [M',k,3], depths f32 [M',k], deltas f32 [M'*k],
  *   boundary u8 [M'*k] (1 at the first sample of a ray's first nugget) - the shapes
  *   tracers/panoptic_packed_rf_tracer.py:88-108 indexes. */
-int pag_raymarch_voxel_count(const float *origins, const float *dirs, int64_t N, float dist_min,
-                             float dist_max, const uint32_t *occupancy_bits, int blas_level,
+/* counts (out, i32 [N]) are in SAMPLES (nuggets * samples_per_voxel): pag_pack_offsets() of them is at once the pack
+ * pass's offset table and the compositing kernels' pack_start (one pack per ray, empty packs allowed).
+ *   max_travel        the travel filter of tracers/panoptic_packed_rf_tracer.py:88-108 applied inside the walk: a nugget is kept
+ *                     iff (depth of its first sample) - (depth of the ray's first sample) < max_travel (strict; fp32 subtraction
+ *                     as in the tensor expression :91-92).  INFINITY disables it (plain OctreeAS.raymarch 'voxel' output).
+ *   occupancy_coarse  optional u32 bitfield of the (2^blas_level / 4)^3 grid from pag_occupancy_coarse(): the walk consults it
+ *                     from LDS and reads the fine word only inside non-empty coarse cells.  Same result with or without.
+ *   ridx_sample       optional i32 [M'*k]: the ray of every SAMPLE (the decoders' per-sample ray index); ridx64 optional
+ *                     i64 [M'] copy of ridx (wisp hands out int64 ray ids). */
+int pag_raymarch_voxel_count(const float *origins, const float *dirs, int64_t N, int samples_per_voxel,
+                             float dist_min, float dist_max, const uint32_t *occupancy_bits,
+                             const uint32_t *occupancy_coarse, int blas_level, float max_travel,
                              int32_t *counts, void *stream);
 int pag_raymarch_voxel_pack(const float *origins, const float *dirs, int64_t N, int samples_per_voxel,
                             float dist_min, float dist_max, const uint32_t *occupancy_bits,
-                            int blas_level, const int64_t *offsets, int32_t *ridx, int32_t *pidx,
-                            float *samples, float *depths, float *deltas, uint8_t *boundary,
-                            void *stream);
+                            const uint32_t *occupancy_coarse, int blas_level, float max_travel,
+                            const int64_t *offsets, int32_t *ridx, int32_t *pidx, float *samples,
+                            float *depths, float *deltas, uint8_t *boundary, int32_t *ridx_sample,
+                            int64_t *ridx64, void *stream);
+
+/* Coarse occupancy for the voxel march: bit ((x/4)*RC + y/4)*RC + z/4 (RC = 2^blas_level / 4) is set iff any of the 64 fine
+ * cells under it is.  pag_occupancy_coarse_bytes() = size of `coarse` in bytes, 0 when blas_level is outside [5,8]
+ * (the march then runs without it).  Rebuild after every prune (pc_nerf/panoptic_delta_nef.py:98-104). */
+int64_t pag_occupancy_coarse_bytes(int blas_level);
+int pag_occupancy_coarse(const uint32_t *occupancy_bits, int blas_level, uint32_t *coarse, void *stream);
 
 /* Occupancy update of pc_nerf/panoptic_delta_nef.py:63-104 (prune), one launch:
  *   occupancy[i] <- max(density[i * density_stride], occupancy[i] * decay)     (:74, :90)

@@ -85,8 +85,11 @@ _SIGS = {
     "pag_pack_offsets": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "pag_view_embed": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "pag_raymarch_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "pag_raymarch_voxel_count": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),
-    "pag_raymarch_voxel_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_raymarch_voxel_count": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp]),
+    "pag_raymarch_voxel_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_vp, c_vp]),
+    "pag_occupancy_coarse_bytes": (c_i64, [c_i32]),
+    "pag_occupancy_coarse": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "pag_occupancy_update": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
     "pag_label_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "pag_render_loss_workspace_bytes": (c_i64, []),

@@ -110,14 +110,28 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a, int32_t *counts
 // ------------------------------------------------------------------------------ voxel-mode ray march
 // 3-D DDA through the 2^level occupancy grid (oracle/render.py raymarch_voxel(), same fp32 op order): every occupied
 // cell a ray crosses is a nugget [t_in, t_out] that receives k samples at t_in + (t_out - t_in) (i + 0.5) / k.
-// One lane per ray (rays are few - 4k..25k - and each walks <= 3R cells); PACK = false counts nuggets only.
+// One lane per ray (rays are few - 4k..25k - and each walks <= 3R cells); PACK = false counts only.
+//   max_travel (finite): the tracer's travel filter (tracers/panoptic_packed_rf_tracer.py:88-108) applied inside the walk - a nugget
+//     is kept iff  depth of its first sample - depth of the ray's first sample < max_travel  (strict, fp32 subtraction as the
+//     tensor expression).  Depths grow along the ray, so the first nugget that fails ends the walk.  INFINITY: no filter.
+//   counts are in SAMPLES (nuggets * k): their exclusive scan (pag_pack_offsets) is the compositing kernels' pack table.
+// The walk reads one occupancy word per step (a dependent L2 access, ~250 ns): a workgroup first ORs the bitfield down to a
+// (R/4)^3 coarse grid in LDS (R >= 32) and only touches the fine word where the coarse cell has anything in it.
 template <bool PACK>
-__global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, int32_t *counts, const int64_t *offsets,
-                                                          int32_t *ridx, int32_t *pidx, float *samples, float *depths,
-                                                          float *deltas, uint8_t *boundary) {
+__global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, float max_travel, const uint32_t *coarse, int32_t *counts,
+                                                          const int64_t *offsets, int32_t *ridx, int32_t *pidx, float *samples,
+                                                          float *depths, float *deltas, uint8_t *boundary, int32_t *ridx_sample) {
+    extern __shared__ uint32_t coarse_lds[];
+    const int R = 1 << a.level;
+    const int RC = R >> 2;                                  // coarse cells per axis
+    const bool use_coarse = coarse != nullptr;
+    if (use_coarse) {
+        const int words = (RC * RC * RC + 31) >> 5;
+        for (int w = threadIdx.x; w < words; w += blockDim.x) coarse_lds[w] = coarse[w];
+        __syncthreads();
+    }
     const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ray >= a.N) return;
-    const int R = 1 << a.level;
     const float cs = __fdiv_rn(2.0f, (float)R);
     const float o[3] = {a.origins[ray * 3], a.origins[ray * 3 + 1], a.origins[ray * 3 + 2]};
     const float d[3] = {a.dirs[ray * 3], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2]};
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, in
         }
     }
     int n = 0;
-    int64_t base = PACK ? offsets[ray] : 0;
+    const int64_t base = PACK ? offsets[ray] / k : 0;       // first nugget of this ray
     if (t0 < t1) {
         const float tm = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), 1e-6f));
         int c0, c1, c2, s0 = 0, s1 = 0, s2 = 0;
@@ -157,18 +171,29 @@ __global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, in
         setup(1, c1, s1, n1, e1);
         setup(2, c2, s2, n2, e2);
         float t = t0;
+        float first = 0.0f;                                  // depth of the ray's first sample (first kept nugget)
+        const float fr0 = __fdiv_rn(0.5f, (float)k);
         for (int it = 0; it < 3 * R + 3; ++it) {
             const int ax = (n0 <= n1 && n0 <= n2) ? 0 : (n1 <= n2 ? 1 : 2);
             const float tn = ax == 0 ? n0 : (ax == 1 ? n1 : n2);
             const float tout = tn <= t1 ? tn : t1;
             const int lin = (c0 * R + c1) * R + c2;
-            const bool occ = a.occ == nullptr || ((a.occ[lin >> 5] >> (lin & 31)) & 1u);
-            if (tout > t && occ) {
+            bool occ = tout > t;
+            if (occ && use_coarse) {
+                const int cl = ((c0 >> 2) * RC + (c1 >> 2)) * RC + (c2 >> 2);
+                occ = (coarse_lds[cl >> 5] >> (cl & 31)) & 1u;
+            }
+            if (occ && a.occ) occ = (a.occ[lin >> 5] >> (lin & 31)) & 1u;
+            if (occ) {
+                const float span = __fsub_rn(tout, t);
+                const float dep0 = __fadd_rn(t, __fmul_rn(span, fr0));
+                if (n == 0) first = dep0;
+                if (!(__fsub_rn(dep0, first) < max_travel)) break;          // travel filter: later nuggets are farther still
                 if (PACK) {
                     const int64_t g = base + n;
                     ridx[g] = (int32_t)ray;
+                    if (a.ridx64) a.ridx64[g] = ray;
                     pidx[g] = lin;
-                    const float span = __fsub_rn(tout, t);
                     const float dl = __fdiv_rn(span, (float)k);
                     for (int i = 0; i < k; ++i) {
                         const float fr = __fdiv_rn((float)i + 0.5f, (float)k);
@@ -177,6 +202,7 @@ __global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, in
                         depths[q] = dep;
                         deltas[q] = dl;
                         boundary[q] = (n == 0 && i == 0) ? 1 : 0;
+                        if (ridx_sample) ridx_sample[q] = (int32_t)ray;
 #pragma unroll
                         for (int x = 0; x < 3; ++x) samples[q * 3 + x] = __fmaf_rn(d[x], dep, o[x]);
                     }
@@ -190,7 +216,32 @@ __global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, in
             else { c2 += s2; n2 = __fadd_rn(n2, e2); if (c2 < 0 || c2 >= R) break; }
         }
     }
-    if (!PACK) counts[ray] = n;
+    if (!PACK) counts[ray] = n * k;
+}
+
+// OR the 2^level occupancy bitfield down by 4 per axis: coarse bit ((x/4)*RC + y/4)*RC + z/4 is set iff any of its 64 fine cells
+// is.  One lane per coarse cell (RC^3 <= 32768 at level 7): 16 fine words of 32 z-bits each hold its 4x4 columns' nibbles.
+__global__ __launch_bounds__(256) void occupancy_coarse_kernel(const uint32_t *__restrict__ bits, int level, uint32_t *__restrict__ coarse) {
+    const int R = 1 << level, RC = R >> 2;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    const int total = RC * RC * RC;
+    bool any = false;
+    if (cell < total) {
+        const int C2 = cell % RC, C1 = (cell / RC) % RC, C0 = cell / (RC * RC);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lin = ((C0 * 4 + i) * R + (C1 * 4 + j)) * R + C2 * 4;       // 4 consecutive z cells: one nibble of one word
+                any = any || ((bits[lin >> 5] >> (lin & 31)) & 0xFu);
+            }
+    }
+    const unsigned long long m = __ballot(any);
+    const int lane = threadIdx.x & 63;
+    const int word = (cell - lane) >> 5;
+    const int words = (total + 31) >> 5;
+    if (lane == 0 && word < words) coarse[word] = (uint32_t)m;
+    if (lane == 32 && word + 1 < words) coarse[word + 1] = (uint32_t)(m >> 32);
 }
 
 // ------------------------------------------------------------------------------------- compositing
@@ -651,31 +702,62 @@ extern "C" int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t 
     return PAG_OK;
 }
 
-extern "C" int pag_raymarch_voxel_count(const float *origins, const float *dirs, int64_t N, float dist_min, float dist_max,
-                                        const uint32_t *occupancy_bits, int blas_level, int32_t *counts, void *stream) {
+static size_t voxel_coarse_lds(int level) {
+    const int RC = (1 << level) >> 2;
+    return (size_t)((RC * RC * RC + 31) / 32) * sizeof(uint32_t);
+}
+
+extern "C" int64_t pag_occupancy_coarse_bytes(int blas_level) {
+    if (blas_level < 5 || blas_level > 8) return 0;       // below 32^3 the walk is short; above 256^3 the coarse grid outgrows LDS
+    return (int64_t)voxel_coarse_lds(blas_level);
+}
+
+extern "C" int pag_occupancy_coarse(const uint32_t *occupancy_bits, int blas_level, uint32_t *coarse, void *stream) {
+    PAG_CHECK_ARG(pag_occupancy_coarse_bytes(blas_level) > 0, "pag_occupancy_coarse: blas_level %d not in [5,8]", blas_level);
+    PAG_CHECK_ARG(occupancy_bits && coarse, "pag_occupancy_coarse: NULL input/output");
+    const int RC = (1 << blas_level) >> 2;
+    hipLaunchKernelGGL(occupancy_coarse_kernel, dim3((unsigned)((RC * RC * RC + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occupancy_bits,
+                       blas_level, coarse);
+    PAG_CHECK_LAUNCH("pag_occupancy_coarse");
+    return PAG_OK;
+}
+
+extern "C" int pag_raymarch_voxel_count(const float *origins, const float *dirs, int64_t N, int samples_per_voxel, float dist_min,
+                                        float dist_max, const uint32_t *occupancy_bits, const uint32_t *occupancy_coarse, int blas_level,
+                                        float max_travel, int32_t *counts, void *stream) {
     PAG_CHECK_ARG(N >= 0, "pag_raymarch_voxel_count: N < 0");
+    PAG_CHECK_ARG(samples_per_voxel >= 1 && samples_per_voxel <= 64, "pag_raymarch_voxel_count: samples_per_voxel %d not in [1,64]", samples_per_voxel);
     PAG_CHECK_ARG(blas_level >= 0 && blas_level <= 10, "pag_raymarch_voxel_count: blas_level %d not in [0,10]", blas_level);
+    PAG_CHECK_ARG(!occupancy_coarse || (occupancy_bits && pag_occupancy_coarse_bytes(blas_level) > 0),
+                  "pag_raymarch_voxel_count: a coarse grid needs the occupancy bits and blas_level in [5,8]");
+    PAG_CHECK_ARG(!(max_travel != max_travel), "pag_raymarch_voxel_count: max_travel is NaN");
     if (N == 0) return PAG_OK;
     PAG_CHECK_ARG(origins && dirs && counts, "pag_raymarch_voxel_count: NULL input");
     MarchArgs a{origins, dirs, nullptr, nullptr, occupancy_bits, N, 0, blas_level, dist_min, dist_max};
-    hipLaunchKernelGGL((voxel_march_kernel<false>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, 1, counts,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const size_t lds = occupancy_coarse ? voxel_coarse_lds(blas_level) : 0;
+    hipLaunchKernelGGL((voxel_march_kernel<false>), dim3((unsigned)((N + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a, samples_per_voxel,
+                       max_travel, occupancy_coarse, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     PAG_CHECK_LAUNCH("pag_raymarch_voxel_count");
     return PAG_OK;
 }
 
 extern "C" int pag_raymarch_voxel_pack(const float *origins, const float *dirs, int64_t N, int samples_per_voxel, float dist_min,
-                                       float dist_max, const uint32_t *occupancy_bits, int blas_level, const int64_t *offsets,
-                                       int32_t *ridx, int32_t *pidx, float *samples, float *depths, float *deltas,
-                                       uint8_t *boundary, void *stream) {
+                                       float dist_max, const uint32_t *occupancy_bits, const uint32_t *occupancy_coarse, int blas_level,
+                                       float max_travel, const int64_t *offsets, int32_t *ridx, int32_t *pidx, float *samples,
+                                       float *depths, float *deltas, uint8_t *boundary, int32_t *ridx_sample, int64_t *ridx64,
+                                       void *stream) {
     PAG_CHECK_ARG(N >= 0, "pag_raymarch_voxel_pack: N < 0");
     PAG_CHECK_ARG(samples_per_voxel >= 1 && samples_per_voxel <= 64, "pag_raymarch_voxel_pack: samples_per_voxel %d not in [1,64]", samples_per_voxel);
     PAG_CHECK_ARG(blas_level >= 0 && blas_level <= 10, "pag_raymarch_voxel_pack: blas_level %d not in [0,10]", blas_level);
+    PAG_CHECK_ARG(!occupancy_coarse || (occupancy_bits && pag_occupancy_coarse_bytes(blas_level) > 0),
+                  "pag_raymarch_voxel_pack: a coarse grid needs the occupancy bits and blas_level in [5,8]");
+    PAG_CHECK_ARG(!(max_travel != max_travel), "pag_raymarch_voxel_pack: max_travel is NaN");
     if (N == 0) return PAG_OK;
     PAG_CHECK_ARG(origins && dirs && offsets && ridx && pidx && samples && depths && deltas && boundary, "pag_raymarch_voxel_pack: NULL input/output");
-    MarchArgs a{origins, dirs, nullptr, nullptr, occupancy_bits, N, 0, blas_level, dist_min, dist_max};
-    hipLaunchKernelGGL((voxel_march_kernel<true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       samples_per_voxel, nullptr, offsets, ridx, pidx, samples, depths, deltas, boundary);
+    MarchArgs a{origins, dirs, nullptr, nullptr, occupancy_bits, N, 0, blas_level, dist_min, dist_max, ridx64};
+    const size_t lds = occupancy_coarse ? voxel_coarse_lds(blas_level) : 0;
+    hipLaunchKernelGGL((voxel_march_kernel<true>), dim3((unsigned)((N + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a, samples_per_voxel,
+                       max_travel, occupancy_coarse, nullptr, offsets, ridx, pidx, samples, depths, deltas, boundary, ridx_sample);
     PAG_CHECK_LAUNCH("pag_raymarch_voxel_pack");
     return PAG_OK;
 }

@@ -52,6 +52,7 @@ class OccupancyBLAS(nn.Module):
         self._dense_points = None
         self._all_occupied = True
         self._pack_cache = None
+        self._coarse = None          # (blas_bits identity, version) -> coarse bitfield of the voxel march (ops.occupancy_coarse)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         """A checkpoint replaces buffers the kernels do not read directly: the march takes `_all_occupied`, the encoders a host copy of
@@ -63,6 +64,14 @@ class OccupancyBLAS(nn.Module):
     def _refresh_derived(self):
         self._all_occupied = bool((self.blas_bits == -1).all()) if self.num_cells >= 32 else False
         self._pack_cache = None
+        self._coarse = None
+
+    def _coarse_bits(self, bits):
+        """Coarse occupancy for the voxel march, rebuilt when the bitfield object or its contents (version counter) change."""
+        key = (id(bits), bits._version, str(bits.device))
+        if self._coarse is None or self._coarse[0] != key:
+            self._coarse = (key, ops.occupancy_coarse(bits, self.blas_level))
+        return self._coarse[1]
 
     @property
     def dense_points(self):
@@ -96,20 +105,25 @@ class OccupancyBLAS(nn.Module):
         m = ((bits[:, None] >> torch.arange(32, device=bits.device)) & 1).bool().reshape(-1)
         return m[:self.num_cells]
 
-    def raymarch(self, rays, level=None, num_samples=64, raymarch_type="ray", jitter=None):
+    accepts_max_travel = True      # raymarch(..., max_travel=) applies the tracer's travel filter inside the voxel walk
+
+    def raymarch(self, rays, level=None, num_samples=64, raymarch_type="ray", jitter=None, max_travel=None):
         """'ray'  : (ridx i64[M], pidx i32[M], samples [M,1,3], depths [M,1], deltas [M,1], boundary bool[M])
         'voxel': per nugget ridx i64[M'], pidx i32[M']; samples [M',k,3], depths [M',k,1], deltas [M'*k,1], boundary bool[M'*k]
-        (the shapes tracers/panoptic_packed_rf_tracer.py:88-108 indexes; k = num_samples)."""
+        (the shapes tracers/panoptic_packed_rf_tracer.py:88-108 indexes; k = num_samples).  max_travel ('voxel' only): the
+        travel filter of tracer :88-108 already applied - the tracer then skips its own."""
         bits = None if self._all_occupied else self.blas_bits
         if bits is not None and bits.device != rays.origins.device:
             self.blas_bits = bits = bits.to(rays.origins.device)
         if raymarch_type == "voxel":
-            ridx, pidx, samples, depths, deltas, boundary = ops.raymarch_voxel(
-                rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, bits, self.blas_level)
-            self._pack_cache = None
+            coarse = self._coarse_bits(bits) if bits is not None else None
+            ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack, ridx_sample, ridx64 = ops.raymarch_voxel(
+                rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, bits, self.blas_level, max_travel=max_travel,
+                occupancy_coarse_bits=coarse, want_packs=True)
+            self._pack_cache = (ridx64, ridx_sample, pack_start, ray_of_pack)
             if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
                 samples = _VoxelSamples.apply(rays.origins, rays.dirs, samples, depths, ridx)   # pose gradient
-            return ridx.long(), pidx, samples, depths[..., None], deltas[:, None], boundary
+            return ridx64, pidx, samples, depths[..., None], deltas[:, None], boundary
         if raymarch_type != "ray":
             raise NotImplementedError("raymarch_type '%s'" % raymarch_type)
         ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack, ridx64 = ops.raymarch_ray(

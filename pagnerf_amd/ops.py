@@ -699,9 +699,24 @@ def _tvals(S, dev):
     return _TVALS[key]
 
 
-def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupancy_bits=None, blas_level=7):
+def occupancy_coarse(occupancy_bits, blas_level):
+    """u32 bitfield of the (2^level / 4)^3 coarse occupancy the voxel march keeps in LDS, or None when the level has none."""
+    nbytes = L.load().pag_occupancy_coarse_bytes(int(blas_level))
+    if occupancy_bits is None or nbytes == 0:
+        return None
+    coarse = torch.empty(nbytes // 4, device=occupancy_bits.device, dtype=torch.int32)
+    _call("pag_occupancy_coarse", L.ptr(occupancy_bits), int(blas_level), L.ptr(coarse), L.stream())
+    return coarse
+
+
+def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupancy_bits=None, blas_level=7, max_travel=None,
+                   occupancy_coarse_bits=None, want_packs=False):
     """'voxel'-mode march (3-D DDA over the occupancy grid).  Returns per NUGGET ridx i32[M'], pidx i32[M'] and per sample
-    samples f32[M',k,3], depths f32[M',k], deltas f32[M'*k], boundary bool[M'*k]."""
+    samples f32[M',k,3], depths f32[M',k], deltas f32[M'*k], boundary bool[M'*k].
+    max_travel: the tracer's travel filter (tracers/panoptic_packed_rf_tracer.py:88-108) applied inside the walk (None = off).
+    want_packs: also (pack_start i64[N+1] in samples, ray_of_pack i32[N] = arange, ridx_sample i32[M'*k], ridx64 i64[M']) - one
+    (possibly empty) pack per ray, straight from the kernels: no unique / nonzero / repeat_interleave passes, and the sample
+    count reaches the host through the polled mailbox of raymarch_ray()."""
     _check_gpu(origins, dirs)
     dev = origins.device
     N, k = origins.shape[0], int(samples_per_voxel)
@@ -709,22 +724,40 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     dirs = dirs.detach().contiguous().float()
     counts = torch.empty(N, device=dev, dtype=torch.int32)
     occ = L.ptr(occupancy_bits) if occupancy_bits is not None else None
+    coarse = L.ptr(occupancy_coarse_bits) if (occupancy_coarse_bits is not None and occupancy_bits is not None) else None
+    travel = float("inf") if max_travel is None else float(max_travel)
+    st = L.stream()
     if N:
-        _call("pag_raymarch_voxel_count", L.ptr(origins), L.ptr(dirs), N, float(dist_min), float(dist_max), occ, blas_level,
-              L.ptr(counts), L.stream())
-    csum = torch.cumsum(counts.long(), 0)
-    offsets = csum - counts
-    Mn = int(csum[-1].item()) if N else 0
+        _call("pag_raymarch_voxel_count", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse, blas_level,
+              travel, L.ptr(counts), st)
+    pack_start = torch.empty(N + 1, device=dev, dtype=torch.int64)      # [i] = first SAMPLE of ray i, [N] = M' * k
+    mailbox = _count_mailbox() if POLL_SAMPLE_COUNT else None
+    if mailbox is not None:
+        mailbox[1][0] = -1
+    _call("pag_pack_offsets", L.ptr(counts), N, L.ptr(pack_start), mailbox[0].data_ptr() if mailbox is not None else None, st)
+    total = _poll_count(mailbox) if mailbox is not None else -1
+    if total < 0:
+        total = int(pack_start[N].item())          # stream-synchronising read-back
+        if mailbox is not None and int(mailbox[1][0]) < 0:
+            _disable_polling()
+    if mailbox is not None and int(mailbox[1][0]) >= 0:
+        _release_mailbox(mailbox)
+    Mn = total // k
     ridx = torch.empty(Mn, device=dev, dtype=torch.int32)
     pidx = torch.empty(Mn, device=dev, dtype=torch.int32)
     samples = torch.empty(Mn, k, 3, device=dev)
     depths = torch.empty(Mn, k, device=dev)
     deltas = torch.empty(Mn * k, device=dev)
     boundary = torch.empty(Mn * k, device=dev, dtype=torch.uint8)
+    ridx_sample = torch.empty(Mn * k, device=dev, dtype=torch.int32) if want_packs else None
+    ridx64 = torch.empty(Mn, device=dev, dtype=torch.int64) if want_packs else None
     if Mn:
-        _call("pag_raymarch_voxel_pack", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, blas_level,
-              L.ptr(offsets), L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), L.stream())
-    return ridx, pidx, samples, depths, deltas, boundary.bool()
+        _call("pag_raymarch_voxel_pack", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse, blas_level,
+              travel, L.ptr(pack_start), L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary),
+              L.ptr(ridx_sample), L.ptr(ridx64), st)
+    if want_packs:
+        return (ridx, pidx, samples, depths, deltas, boundary.view(torch.bool), pack_start, _ray_iota(N, dev), ridx_sample, ridx64)
+    return ridx, pidx, samples, depths, deltas, boundary.view(torch.bool)
 
 
 def packs_from_boundary(ridx, boundary):

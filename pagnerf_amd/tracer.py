@@ -78,11 +78,16 @@ class PanopticPackedRFTracer(nn.Module):
         if lod_idx is None:
             lod_idx = nef.grid.num_lods - 1
         kw = {"jitter": jitter} if jitter is not None else {}
+        # voxel mode: grids of this package apply the travel filter of :88-108 inside the walk (pag_raymarch_voxel_*: same
+        # strict `<` on the same fp32 difference) and hand back one pack per ray - no unique / repeat_interleave / mask passes
+        filtered = raymarch_type == "voxel" and getattr(nef.grid, "accepts_max_travel", False)
+        if filtered:
+            kw["max_travel"] = self.ray_max_travel
         ridx, pidx, samples, depths, deltas, boundary = nef.grid.raymarch(                 # :85-86
             rays, level=nef.grid.active_lods[lod_idx], num_samples=num_steps, raymarch_type=raymarch_type, **kw)
-        if raymarch_type == "ray" and samples.shape[0] and hasattr(nef, "prefetch_features"):
+        if samples.shape[0] and hasattr(nef, "prefetch_features") and (raymarch_type == "ray" or filtered):
             nef.prefetch_features(samples)        # first encode launch queued before the bookkeeping below (GPU idle otherwise)
-        if raymarch_type == "voxel" and depths.numel() != 0:                              # :88-108
+        if raymarch_type == "voxel" and depths.numel() != 0 and not filtered:             # :88-108
             # drop nuggets further than ray_max_travel past the first hit of their ray (strict <)
             _, counts_per_ray = ridx.unique(return_counts=True)
             ray_start_idx = torch.cumsum(counts_per_ray, dim=0)

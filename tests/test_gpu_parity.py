@@ -379,6 +379,57 @@ def test_voxel_raymarch_matches_oracle(gpu_device):
         assert got[2].shape == (ref[0].shape[0], k, 3)
 
 
+def test_voxel_raymarch_with_travel_filter_and_coarse_grid(gpu_device):
+    """pag_raymarch_voxel_* with max_travel == oracle march followed by the tracer's travel filter (:88-108), bit for bit; the
+    LDS coarse occupancy changes nothing; the pack table / per-sample ray ids the kernels emit equal what
+    mark_pack_boundaries + repeat_interleave would give."""
+    ops, L = _ops()
+    from oracle import render as orr
+    from pagnerf_amd.grids import OccupancyBLAS
+    rs = np.random.RandomState(12)
+    for (N, k, level, keep_frac, far, travel) in ((300, 2, 5, 0.3, 3.0, 0.5), (257, 2, 7, 0.1, 3.0, 0.25), (64, 3, 6, 0.5, 2.0, 1e9),
+                                                  (50, 2, 5, 0.4, 3.0, 0.0), (40, 1, 4, 0.5, 3.0, 0.3)):
+        o = torch.from_numpy(rs.uniform(-1.3, 1.3, size=(N, 3)).astype(np.float32))
+        d = rs.standard_normal(size=(N, 3)).astype(np.float32)
+        d = torch.from_numpy(d / np.linalg.norm(d, axis=1, keepdims=True))
+        d[0] = torch.tensor([0.0, 0.0, 1.0])
+        R = 2 ** level
+        # blobs, so that coarse cells are a mix of empty / partly / fully occupied
+        f = rs.uniform(size=(R // 4, R // 4, R // 4)).repeat(4, 0).repeat(4, 1).repeat(4, 2) * 0.7 + rs.uniform(size=(R, R, R)) * 0.3
+        occ = torch.from_numpy(f > np.quantile(f, 1 - keep_frac))
+        ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_voxel(o, d, 0.0, far, k, occ, level)
+        keep = orr.voxel_travel_filter(ridx, depths, travel) if ridx.numel() else torch.zeros(0, dtype=torch.bool)
+        ref = (ridx[keep], pidx[keep], samples[keep], depths[keep][..., 0], deltas.reshape(-1, k)[keep].reshape(-1),
+               boundary.reshape(-1, k)[keep].reshape(-1))
+        blas = OccupancyBLAS(level)
+        blas.blas_init(occ.reshape(-1))
+        bits = blas.blas_bits.to(gpu_device)
+        coarse = ops.occupancy_coarse(bits, level)
+        assert (coarse is not None) == (5 <= level <= 8)
+        if coarse is not None:      # the coarse grid is the 4x4x4 OR of the fine one
+            want = occ.reshape(R // 4, 4, R // 4, 4, R // 4, 4).any(5).any(3).any(1).reshape(-1)
+            cb = ((coarse.long()[:, None] & 0xFFFFFFFF) >> torch.arange(32, device=gpu_device)) & 1
+            assert torch.equal(cb.reshape(-1)[:want.numel()].bool().cpu(), want)
+        outs = []
+        for cg in (None, coarse):
+            got = ops.raymarch_voxel(o.to(gpu_device), d.to(gpu_device), 0.0, far, k, bits, level, max_travel=travel,
+                                     occupancy_coarse_bits=cg, want_packs=True)
+            outs.append([t.cpu() for t in got])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        got = outs[1]
+        assert torch.equal(got[0].long(), ref[0]) and torch.equal(got[1].long(), ref[1]), (N, k, level)
+        assert torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4]) and torch.equal(got[5], ref[5])
+        np.testing.assert_allclose(got[2].numpy(), ref[2].numpy(), rtol=0, atol=2e-7)
+        pack_start, ray_of_pack, ridx_sample, ridx64 = got[6:]
+        per_ray = torch.bincount(ref[0], minlength=N) * k
+        assert torch.equal(pack_start, torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(per_ray, 0)]))
+        assert torch.equal(ray_of_pack.long(), torch.arange(N)) and torch.equal(ridx64, ref[0])
+        assert torch.equal(ridx_sample.long(), ref[0].repeat_interleave(k))
+        if travel == 0.0:
+            assert got[0].numel() == 0          # `0 < 0` is false: the reference's strict filter drops even the first nugget
+
+
 def test_g4_voxel_mode_trace_against_reference_golden(gpu_device):
     """The reference tracer's voxel-mode path (travel filter :88-108 + compositing) on its own golden inputs,
     through this build's tracer and HIP compositing."""
