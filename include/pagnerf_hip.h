@@ -220,8 +220,23 @@ typedef struct {
                                     that column: pass the forward's x1_col0_relu) */
     const float *g_ray_scale;    /* optional f32 [N] with the rank-1 gradient: grad_out[m][c] = g_scale[m] * g_ray_scale[g_index[m]] *
                                     g_ray[g_index[m]][c] (g_scale = the compositing weights w_m, g_ray_scale = the rays' alpha) */
+    /* Fused weight gradients (optional; pag_mlp_bwd_fused_supported() == 1).  With wgrad_workspace != NULL the launch also forms
+     * dW[i] = dz_i^T . input_i (f32 [out_i, in_i], nn.Linear layout) and db[i] = column sums of dz_i for every layer, from the
+     * tiles it holds anyway: no dz tensor is written (dz[] may be NULL) and no second pass re-reads [M,64] activations
+     * (536 MB per 64 x 64 layer at M = 2.1 M - the separate pag_mlp_wgrad_batch ran at the HBM rate on exactly those bytes).
+     * Needs the forward's layer-0 input: x1 (bf16; layout / levels / feats as above) and, if the forward had it, x2 / x2_index.
+     * wgrad_workspace: device scratch of pag_mlp_bwd_fused_workspace_bytes(n_layers, M) bytes (per-wave partial sums, reduced in a
+     * fixed order by a second tiny launch: deterministic). */
+    const void *x1; int x1_dtype; const float *x2; int k2p; const int32_t *x2_index;
+    float *wgrad_workspace; int64_t wgrad_workspace_bytes;
+    float *dW[3]; float *db[3];
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
+/* 1 when pag_mlp_bwd can fuse the weight gradients for this decoder shape: MFMA mode, out_dim <= 32, and input column 63 free
+ * (XCD8: staged position 63 is padding; strided: in_dim <= 63 and k1 + k2p <= 64) - it carries the constant 1 whose weight
+ * gradient is the layer-0 bias gradient. */
+int pag_mlp_bwd_fused_supported(int mode, int out_dim, int k1, int x1_layout, int x1_levels, int x1_feats, int in_dim, int k2p);
+int64_t pag_mlp_bwd_fused_workspace_bytes(int n_layers, int64_t M);
 
 /* Wide softmax head fused with the per-ray weighted sum of tracers/panoptic_packed_rf_tracer.py:197-205:
  *   out[ray][c] = alpha[ray] * sum_{i in pack} weights[i] * softmax(W_last . hidden[i] + b_last)[c]

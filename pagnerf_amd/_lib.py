@@ -57,7 +57,10 @@ class MlpBwdArgs(ctypes.Structure):
                 ("mode", c_i32),
                 ("g_ray", c_vp), ("g_scale", c_vp), ("g_index", c_vp),
                 ("softmax_stats", c_vp), ("b_last", c_vp), ("dx1_accumulate", c_i32), ("dx1_col0_add", c_vp),
-                ("dx1_col0_gate", c_vp), ("g_ray_scale", c_vp)]
+                ("dx1_col0_gate", c_vp), ("g_ray_scale", c_vp),
+                ("x1", c_vp), ("x1_dtype", c_i32), ("x2", c_vp), ("k2p", c_i32), ("x2_index", c_vp),
+                ("wgrad_workspace", c_vp), ("wgrad_workspace_bytes", c_i64),
+                ("dW", c_vp * 3), ("db", c_vp * 3)]
 
 
 _SIGS = {
@@ -76,6 +79,8 @@ _SIGS = {
     "pag_encode_bwd_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32, c_i64]),
     "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
+    "pag_mlp_bwd_fused_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "pag_mlp_bwd_fused_workspace_bytes": (c_i64, [c_i32, c_i64]),
     "pag_head_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_mlp_wgrad_blocks": (c_i32, [c_i64]),
     "pag_mlp_wgrad_batch": (c_i32, [ctypes.POINTER(WgradLayer), c_i32, c_i64, c_vp]),

@@ -83,6 +83,12 @@ struct BwdParams {
     int dx1_acc;           // XCD8 dx1: add to the existing contents instead of overwriting
     const float *dx_col0;  // strided dx1: f32 [M] added to column 0
     const float *dx_col0_gate;   // optional f32 [M]: the addend counts only where gate[m] > 0 (relu of that column)
+    // fused weight gradients (mlp_bwd_mfma<.., FUSE = true>): the forward's layer-0 input and one slab set per layer
+    const void *x1;            // bf16: [8][M][8] (grp_L > 0) or [M, k1]
+    const float *x2;           // optional f32 [R, k2p] gathered through x2_index (view embedding)
+    const int32_t *x2_index;
+    int k2p;
+    float *slabs[3];           // per layer: f32 [4 * gridDim.x][rows_pad][WG_SLAB_COLS]  (cols 0..63 dW, col 64 db)
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
@@ -410,6 +416,65 @@ __device__ __forceinline__ void hidden_layer(const bf16_t *Ws, const float *bs, 
     }
 }
 
+// ---------------------------------------------------------------------- swizzled tiles for the fused weight gradients
+// dW = dz^T . a sums over the SAMPLES, which sit on the lanes in every register layout of the backward kernel - both MFMA
+// operands need one transpose.  A wave keeps its 32-sample tiles ([32 samples][64 channels] bf16, 128-byte rows, 4 KiB) in LDS
+// and reads operand fragments with ds_read_b64_tr_b16 (a 4-row x 16-column block per 16 lanes, delivered column-major).
+// 8-byte chunk `c` of row `s` lives at chunk position c ^ tw_f(s): the accumulator-layout stores (lane = sample, 16 lanes =
+// 16 rows, one chunk column) land in 16 different bank pairs, and the 4 rows of a transposed block use 4 different chunk
+// groups, so neither access pattern has bank conflicts (the 32-lane ds_read_b64 of a whole column is 2-way).
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+constexpr int TW_ELEMS = 32 * 64;
+__device__ __forceinline__ int tw_f(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int tw_off(int row, int chunk) { return row * 64 + ((chunk ^ tw_f(row)) << 2); }
+// row-major global pieces (tile64_fetch: piece `it` of a lane = row it*8 + lane/8, channels 8*(lane%8)..+7)
+__device__ __forceinline__ void tw_put_rows(bf16_t *T, const bf16x8 (&v)[4], int lane) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = (lane & 7) * 2;
+        bf16x4 lo = {v[it][0], v[it][1], v[it][2], v[it][3]}, hi = {v[it][4], v[it][5], v[it][6], v[it][7]};
+        *reinterpret_cast<bf16x4 *>(T + tw_off(row, ch)) = lo;
+        *reinterpret_cast<bf16x4 *>(T + tw_off(row, ch + 1)) = hi;
+    }
+}
+// forward-style B fragments of this lane's sample: xf[s] = channels 16s + 8h .. +7
+__device__ __forceinline__ void tw_put_frags(bf16_t *T, const bf16x8 (&xf)[4], int r, int h) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int ch = 4 * s + 2 * h;
+        bf16x4 lo = {xf[s][0], xf[s][1], xf[s][2], xf[s][3]}, hi = {xf[s][4], xf[s][5], xf[s][6], xf[s][7]};
+        *reinterpret_cast<bf16x4 *>(T + tw_off(r, ch)) = lo;
+        *reinterpret_cast<bf16x4 *>(T + tw_off(r, ch + 1)) = hi;
+    }
+}
+// accumulator block mb (rows rho(q,h) + 32 mb of sample r)
+__device__ __forceinline__ void tw_put_block(bf16_t *T, int mb, int r, int h, const f32x16 &acc) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 v = {(bf16_t)acc[4 * g], (bf16_t)acc[4 * g + 1], (bf16_t)acc[4 * g + 2], (bf16_t)acc[4 * g + 3]};
+        *reinterpret_cast<bf16x4 *>(T + tw_off(r, 8 * mb + 2 * g + h)) = v;
+    }
+}
+__device__ __forceinline__ void tw_get_raw(const bf16_t *T, int r, int h, bf16x4 (&raw)[2][4]) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) raw[mb][g] = *reinterpret_cast<const bf16x4 *>(T + tw_off(r, 8 * mb + 2 * g + h));
+}
+// MFMA 32x32x16 operand fragment with k = sample: lane (c = lane & 31, h) gets samples 16ks + 8h .. +7 of channel 32 blk + c
+__device__ __forceinline__ bf16x8 tw_frag(const bf16_t *T, int blk, int ks, int lane) {
+    typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+    const int li = lane & 15, q = li >> 2, pp = li & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
+    const int chunk = 8 * blk + 4 * g1 + pp, row0 = 16 * ks + 8 * h + q;
+    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(T + tw_off(row0, chunk)));
+    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(T + tw_off(row0 + 4, chunk)));
+    union { i16x4 v[2]; bf16x8 f; } u;
+    u.v[0] = lo;
+    u.v[1] = hi;
+    return u.f;
+}
+constexpr int WG_SLAB_COLS_F = 96;      // = WG_SLAB_COLS (declared with the weight-gradient kernels below)
+
 // ------------------------------------------------------------------------------------------ forward
 template <typename X1T, typename OutT, int NL, int OBMAX>
 #ifndef PAG_FWD_WAVES_WIDE
@@ -621,13 +686,25 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? PAG_FWD_WAVES_WIDE : PAG_FWD_WAVE
 }
 
 // ----------------------------------------------------------------------------------------- backward
-template <typename OutT, typename DxT, int NL, int OBMAX>
+template <typename OutT, typename DxT, int NL, int OBMAX, bool FUSE = false>
 // 2 waves per SIMD: without the bound the 3-layer narrow variants took 252 VGPRs + 36 AGPRs (1 wave per SIMD); asking for 2 makes them fit 254 with no
 // scratch.  The 33..64-output variants (OBMAX 2) would spill 150 - 350 B and stay at 1.
+//
+// FUSE (out_dim <= 32, bf16 layer-0 input): the weight gradients are formed HERE, per wave, instead of by a second kernel that
+// re-reads every dz and every layer input ([M,64] each: 536 MB per 64x64 layer at M = 2.1 M, 4.7 TB/s - at the practical
+// HBM rate, so only removing the bytes helps).  Each wave keeps dW of all layers as MFMA accumulators (6 - 10 blocks of 16
+// registers + one block for the biases) for the whole launch - one wave per SIMD, 512 registers - and feeds them from its
+// own tiles: dz (just computed) and the layer inputs (the saved activations it loads anyway for the ReLU masks + the layer-0
+// input) are kept as swizzled LDS images and read back TRANSPOSED (ds_read_b64_tr_b16: the sum runs over the samples).  No
+// shared tiles, no block barriers, no dz tensors in memory; per-wave slabs at the end, summed by wgrad_finish_kernel.
 #ifndef PAG_BWD_WAVES
 #define PAG_BWD_WAVES 2
 #endif
-__global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd_mfma(BwdParams p) {
+#ifndef PAG_BWD_FUSE_WAVES
+#define PAG_BWD_FUSE_WAVES 1
+#endif
+__global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 : PAG_BWD_WAVES))) void mlp_bwd_mfma(BwdParams p) {
+    static_assert(!FUSE || OBMAX == 1, "fused weight gradients: out_dim <= 32");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.out_dim + 31) / 32;
     const int RSL = OB * 32 + 8;
@@ -637,7 +714,10 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
     stage_weight_t(WLt, RSL, 64, OB * 32, p.W[NL - 1], p.out_dim, HID);
     if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
     if (p.dx1) stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
-    bf16_t *stg = W0t + 64 * RS + (threadIdx.x >> 6) * (ST_BYTES / 2);      // wave-private staging tile
+    bf16_t *stg = W0t + 64 * RS + (threadIdx.x >> 6) * (ST_BYTES / 2);      // wave-private staging tile (unused with FUSE)
+    // FUSE: wave-private swizzled tiles - layer-0 input, saved activations of every hidden layer, the current dz
+    bf16_t *Tx = W0t + 64 * RS + (threadIdx.x >> 6) * ((NL + 1) * TW_ELEMS);
+    bf16_t *Th0 = Tx + TW_ELEMS, *Th1 = Th0 + (NL == 3 ? TW_ELEMS : 0), *Tz = Th1 + TW_ELEMS;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -676,17 +756,99 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
         }
     };
     if constexpr (PREFETCH) fetch_h((int64_t)blockIdx.x * 4 + wave, hnext);
+    // ---- FUSE: layer-0 input fragments of the next tile (the forward's load_x) and the weight-gradient accumulators
+    const bf16_t *x1b = reinterpret_cast<const bf16_t *>(p.x1);
+    auto load_x = [&](int64_t tile, bf16x8 (&xf)[4]) __attribute__((always_inline)) {
+        const int64_t m = tile * 32 + r;
+        const bool lv = tile < ntiles && m < p.M;
+        const int64_t mx = lv ? m : 0;
+        const int32_t ray = (p.x2 && lv) ? p.x2_index[mx] : 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int f0 = 16 * s + 8 * h;
+            if (p.grp_L && lv)
+                xf[s] = load8(x1b + ((int64_t)(2 * s + h) * p.M + mx) * 8);
+            else if (!p.grp_L && lv && f0 < p.k1)
+                xf[s] = load8(x1b + mx * p.k1 + f0);
+            else if (!p.grp_L && lv && p.x2 && f0 < p.k1 + p.k2p)
+                xf[s] = load8(p.x2 + (int64_t)ray * p.k2p + (f0 - p.k1));
+            else
+                xf[s] = zero8();
+        }
+    };
+    bf16x8 xnext[FUSE ? 4 : 1];
+    f32x16 awL[1][2], awM[FUSE && NL == 3 ? 2 : 1][2], aw0[FUSE ? 2 : 1][2], dbacc;      // dW of the last / middle / first layer, db
+    if constexpr (FUSE) {
+        load_x((int64_t)blockIdx.x * 4 + wave, xnext);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            dbacc[q] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                awL[0][i][q] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    aw0[i][j][q] = 0.0f;
+                    if constexpr (NL == 3) awM[i][j][q] = 0.0f;
+                }
+            }
+        }
+    }
+    // B fragment "1 in column j": dbacc[:, j] += row sums of the A operand (bias gradients of the layers fed by hidden activations)
+    auto ones_col = [&](int j) __attribute__((always_inline)) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(r == j ? 1.0f : 0.0f);
+        return o;
+    };
+    // dW[ob][ib] += dz(Tz block ob)^T . input(Tin block ib) over this tile's 32 samples; dbcol >= 0: bias gradients into dbacc
+    int lane_w = lane;
+    auto wgrad_tile = [&](const bf16_t *Tin, auto &aw, int dbcol) __attribute__((always_inline)) {      // aw: f32x16 [out blocks][2]
+        constexpr int NOB = (int)(sizeof(aw) / sizeof(aw[0]));
+        asm volatile("" : "+v"(lane_w));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[2];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) bfr[ib] = tw_frag(Tin, ib, ks, lane_w);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const bf16x8 afr = tw_frag(Tz, ob, ks, lane_w);
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) aw[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[ib], aw[ob][ib], 0, 0, 0);
+                if (dbcol >= 0) dbacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones_col(dbcol + ob), dbacc, 0, 0, 0);
+            }
+        }
+    };
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
-        if constexpr (OBMAX > 2) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
+        if constexpr (OBMAX > 2 || FUSE) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
             asm volatile("" : "+v"(r), "+v"(h));
         }
+        int lane_t = lane;                      // FUSE: the many swizzled LDS addresses are recomputed per tile, not kept live
+        if constexpr (FUSE) asm volatile("" : "+v"(lane_t));
         const int64_t m = tile * 32 + r;
         const bool live = m < p.M;
         const int64_t mc = live ? m : p.M - 1;
         // ReLU masks of the hidden layers: requested first, consumed after the first MFMA chain
         const int rows_valid = (int)min((int64_t)32, p.M - tile * 32);
         bf16x4 hraw[NL - 1][2][4];
-        if constexpr (PREFETCH) {
+        if constexpr (FUSE) {
+            // this tile's saved activations and layer-0 input become LDS images (kept for the whole tile: the transposed
+            // operand reads of the weight gradients come back to them); the next tile's requests go out right away
+            wave_lds_sync();
+            tw_put_rows(Th0, hnext[0], lane_t);
+            if constexpr (NL == 3) tw_put_rows(Th1, hnext[1], lane_t);
+            {
+                bf16x8 xb[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xb[s] = xnext[s];
+                if (h == 1) xb[3][7] = (bf16_t)(live ? 1.0f : 0.0f);      // column 63 := 1: its dW column is the layer-0 bias gradient
+                tw_put_frags(Tx, xb, r, h);
+            }
+            wave_lds_sync();
+            fetch_h(tile + tile_step, hnext);
+            load_x(tile + tile_step, xnext);
+        } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int l = 0; l < NL - 1; ++l) tile64_unstage(stg, hnext[l], lane, r, h, hraw[l]);
             fetch_h(tile + tile_step, hnext);
@@ -720,7 +882,12 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
             }
             const int zi = OBMAX > 2 ? 0 : 2 * ob;
             pack_block(zz, zb[zi], zb[zi + 1]);
-            if (OBMAX > 2 && (p.out_dim & 7) == 0)
+            if constexpr (FUSE) {      // dz_L stays in LDS: A operand of the last layer's weight gradient
+                tw_put_block(Tz, 0, r, h, zz);
+                wave_lds_sync();
+                wgrad_tile(NL == 3 ? Th1 : Th0, awL, 0);
+                wave_lds_sync();
+            } else if (OBMAX > 2 && (p.out_dim & 7) == 0)
                 block32_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + tile * 32 * p.out_dim, p.out_dim, 32 * ob, rows_valid, lane, r, h, zz);
             else if (live)
                 store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, zz, p.out_dim, vec_out);
@@ -914,12 +1081,26 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
                 }
             }
             f32x16 hv;
+            if constexpr (FUSE) {      // the activations are still in their LDS image: read the ReLU mask where it is used
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hraw[NL - 2][mb][g] = *reinterpret_cast<const bf16x4 *>((NL == 3 ? Th1 : Th0) + tw_off(r, 8 * mb + 2 * g + h));
+            }
             raw_to_block(hraw[NL - 2][mb], hv);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
             pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
         }
-        tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
+        if constexpr (FUSE) {      // dz of the last hidden layer -> its weight gradient (input: previous activations, or x for NL == 2)
+            tw_put_block(Tz, 0, r, h, acc[0]);
+            tw_put_block(Tz, 1, r, h, acc[1]);
+            wave_lds_sync();
+            if constexpr (NL == 3) wgrad_tile(Th0, awM, 1);
+            else wgrad_tile(Tx, aw0, -1);
+            wave_lds_sync();
+        } else {
+            tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
+        }
         if (NL == 3) {
             bf16x8 hb2[4];
 #pragma unroll
@@ -932,12 +1113,24 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
                     acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
                 }
                 f32x16 hv;
+                if constexpr (FUSE) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) hraw[0][mb][g] = *reinterpret_cast<const bf16x4 *>(Th0 + tw_off(r, 8 * mb + 2 * g + h));
+                }
                 raw_to_block(hraw[0][mb], hv);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
                 pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
             }
-            tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[0]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
+            if constexpr (FUSE) {
+                tw_put_block(Tz, 0, r, h, acc[0]);
+                tw_put_block(Tz, 1, r, h, acc[1]);
+                wave_lds_sync();
+                wgrad_tile(Tx, aw0, -1);
+                wave_lds_sync();
+            } else {
+                tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[0]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
         }
@@ -975,6 +1168,35 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
                     }
                 }
             }
+        }
+    }
+    if constexpr (FUSE) {
+        // per-wave slabs [rows_pad][96] per layer (cols 0..63 dW - staged positions for XCD8 inputs -, col 64 db), summed by wgrad_finish_kernel
+        const int64_t slab_id = (int64_t)blockIdx.x * 4 + wave;
+        auto put = [&](float *base, int rows_pad, int ob, int ib, const f32x16 &a) __attribute__((always_inline)) {
+            float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = a[q];
+        };
+        auto put_db = [&](float *base, int rows_pad, int ob, bool mine, const f32x16 &a) __attribute__((always_inline)) {
+            float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = a[q];
+            }
+        };
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) put(p.slabs[NL - 1], 32, 0, ib, awL[0][ib]);
+        put_db(p.slabs[NL - 1], 32, 0, r == 0, dbacc);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                put(p.slabs[0], 64, ob, ib, aw0[ob][ib]);
+                if constexpr (NL == 3) put(p.slabs[1], 64, ob, ib, awM[ob][ib]);
+            }
+            put_db(p.slabs[0], 64, ob, r == 31, aw0[ob][1]);             // input column 63 (the ones column)
+            if constexpr (NL == 3) put_db(p.slabs[1], 64, ob, r == 1 + ob, dbacc);
         }
     }
 }
@@ -1810,6 +2032,73 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
         else MLP_BWD_OB(OutT, DxT, 3);                               \
     } while (0)
 
+// Sum the per-workgroup slabs of pag_mlp_wgrad into the final dW [n_out][n_in] / db [n_out] (fixed order: deterministic).
+// One workgroup per output row, 4 slab quarters x 96 columns; XCD8 inputs: slab column p is a staged position and lands in
+// feature column grp_col(p).
+constexpr int WF_SPLITS = 10;      // slab range split over 10 x 96 threads of the row's workgroup
+struct FinishParams {
+    const float *slabs;
+    int n_blocks, n_out, rows_pad, n_in, grp_L, grp_F;
+    float *dW, *db;
+};
+struct FinishBatch {
+    FinishParams p[WG_MAX_BATCH];
+};
+__global__ __launch_bounds__(WF_SPLITS * WG_SLAB_COLS) void wgrad_finish_kernel(FinishBatch batch) {
+    __shared__ float part[WF_SPLITS][WG_SLAB_COLS];
+    const FinishParams &fp = batch.p[blockIdx.y];     // blockIdx.y = layer
+    if ((int)blockIdx.x >= fp.n_out) return;
+    const float *__restrict__ slabs = fp.slabs;
+    float *__restrict__ dW = fp.dW, *__restrict__ db = fp.db;
+    const int n_blocks = fp.n_blocks, rows_pad = fp.rows_pad, n_in = fp.n_in, grp_L = fp.grp_L, grp_F = fp.grp_F;
+    const int o = blockIdx.x, c = threadIdx.x % WG_SLAB_COLS, q = threadIdx.x / WG_SLAB_COLS;
+    const int64_t stride = (int64_t)rows_pad * WG_SLAB_COLS;
+    const float *src = slabs + (int64_t)o * WG_SLAB_COLS + c;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int b = q;
+    for (; b + 3 * WF_SPLITS < n_blocks; b += 4 * WF_SPLITS) {
+        a0 += src[(int64_t)b * stride];
+        a1 += src[(int64_t)(b + WF_SPLITS) * stride];
+        a2 += src[(int64_t)(b + 2 * WF_SPLITS) * stride];
+        a3 += src[(int64_t)(b + 3 * WF_SPLITS) * stride];
+    }
+    for (; b < n_blocks; b += WF_SPLITS) a0 += src[(int64_t)b * stride];
+    part[q][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WF_SPLITS; ++k) v += part[k][c];
+        if (c == 64) {
+            db[o] = v;
+        } else if (c < 64) {
+            const int col = grp_L ? grp_col(c, grp_L, grp_F) : c;
+            if (col >= 0 && col < n_in) dW[(int64_t)o * n_in + col] = v;
+        }
+    }
+}
+
+static unsigned fused_grid(int64_t M) {
+    const int64_t tiles = (M + 31) / 32;
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, 256));      // one 4-wave workgroup per CU, tiles grid-strided
+}
+
+extern "C" int pag_mlp_bwd_fused_supported(int mode, int out_dim, int k1, int x1_layout, int x1_levels, int x1_feats, int in_dim, int k2p) {
+    if (mode != PAG_MLP_MFMA_BF16 || out_dim < 1 || out_dim > 32) return 0;
+    if (x1_layout == PAG_LAYOUT_XCD8) {
+        if (k1 != 64 || x1_levels < 1 || x1_feats < 1 || ((x1_levels + 7) / 8) * x1_feats > 8) return 0;
+        const int e = 7, j = e / x1_feats;                       // staged position 63 = group 7, element 7
+        return (j < (x1_levels + 7) / 8 && 7 + 8 * j < x1_levels) ? 0 : 1;      // must be padding
+    }
+    return (in_dim <= 63 && k1 + k2p <= 64 && k1 % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int64_t pag_mlp_bwd_fused_workspace_bytes(int n_layers, int64_t M) {
+    if (n_layers < 2 || n_layers > 3 || M < 1) return 0;
+    const int64_t slabs = (int64_t)fused_grid(M) * 4;
+    return slabs * ((int64_t)(n_layers - 1) * 64 + 32) * WG_SLAB_COLS * (int64_t)sizeof(float);
+}
+
 extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a, "pag_mlp_bwd: args is NULL");
     PAG_CHECK_ARG(M >= 0, "pag_mlp_bwd: M < 0");
@@ -1827,7 +2116,16 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a->grad_out || (a->g_ray && a->g_scale && a->g_index), "pag_mlp_bwd: NULL grad_out (and no rank-1 gradient)");
     PAG_CHECK_ARG(!a->g_ray || (a->mode == PAG_MLP_MFMA_BF16 && (a->out || a->softmax_stats)),
                   "pag_mlp_bwd: rank-1 gradients need MFMA mode and the saved output");
-    for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && a->dz[l], "pag_mlp_bwd: NULL weight/dz of layer %d", l);
+    const bool fuse = a->wgrad_workspace != nullptr;
+    if (fuse) {
+        PAG_CHECK_ARG(pag_mlp_bwd_fused_supported(a->mode, a->out_dim, a->k1, a->x1_layout, a->x1_levels, a->x1_feats, a->in_dim, a->x2 ? a->k2p : 0) == 1,
+                      "pag_mlp_bwd: fused weight gradients need MFMA mode, out_dim <= 32 and a free input column 63");
+        PAG_CHECK_ARG(a->x1 && a->x1_dtype == PAG_BF16, "pag_mlp_bwd: fused weight gradients need the bf16 layer-0 input x1");
+        PAG_CHECK_ARG(a->x2 == nullptr || (a->k2p > 0 && a->k2p % 8 == 0 && a->x2_index), "pag_mlp_bwd: x2 needs k2p %% 8 == 0 and x2_index");
+        PAG_CHECK_ARG(a->wgrad_workspace_bytes >= pag_mlp_bwd_fused_workspace_bytes(a->n_layers, M), "pag_mlp_bwd: wgrad_workspace too small");
+        for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->dW[l] && a->db[l], "pag_mlp_bwd: NULL dW/db of layer %d", l);
+    }
+    for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && (fuse || a->dz[l]), "pag_mlp_bwd: NULL weight/dz of layer %d", l);
     for (int l = 0; l + 1 < a->n_layers; ++l) PAG_CHECK_ARG(a->hidden_save[l], "pag_mlp_bwd: NULL hidden_save[%d]", l);
     BwdParams p;
     p.g_ray = a->g_ray;
@@ -1867,6 +2165,49 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(!a->dx1_col0_add || (a->dx1 && !p.grp_L && a->mode == PAG_MLP_MFMA_BF16 && a->out_dim <= 64),
                   "pag_mlp_bwd: dx1_col0_add needs a strided dx1, MFMA mode and out_dim <= 64");
     PAG_CHECK_ARG(!a->dx1_accumulate || (p.grp_L && a->dx1), "pag_mlp_bwd: dx1_accumulate needs an XCD8 dx1");
+    p.x1 = a->x1;
+    p.x2 = a->x2;
+    p.x2_index = a->x2_index;
+    p.k2p = a->x2 ? a->k2p : 0;
+    for (int l = 0; l < 3; ++l) p.slabs[l] = nullptr;
+    if (fuse) {
+        // one workgroup per CU, four per-wave slabs each: [n_slabs][rows_pad][96] f32 per layer, hidden layers first
+        const unsigned grid = fused_grid(M);
+        float *ws = a->wgrad_workspace;
+        for (int l = 0; l < a->n_layers; ++l) {
+            p.slabs[l] = ws;
+            ws += (int64_t)grid * 4 * (l + 1 < a->n_layers ? 64 : 32) * WG_SLAB_COLS;
+        }
+        const size_t lds = (size_t)(64 * (32 + 8) + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t) +
+                           (size_t)4 * (a->n_layers + 1) * TW_ELEMS * sizeof(bf16_t);
+#define MLP_BWD_FUSED(OutT, NL_)                                                                                                      \
+    do {                                                                                                                              \
+        static bool attr_done = false;                                                                                                \
+        if (!attr_done) {                                                                                                             \
+            hipFuncSetAttribute((const void *)mlp_bwd_mfma<OutT, bf16_t, NL_, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                                         \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((mlp_bwd_mfma<OutT, bf16_t, NL_, 1, true>), dim3(grid), dim3(256), lds, st, p);                          \
+    } while (0)
+        PAG_CHECK_ARG(a->dx1 == nullptr || a->dx1_dtype == PAG_BF16, "pag_mlp_bwd: fused weight gradients write a bf16 dx1");
+        if (out_f32 && a->n_layers == 2) MLP_BWD_FUSED(float, 2);
+        else if (out_f32) MLP_BWD_FUSED(float, 3);
+        else if (a->n_layers == 2) MLP_BWD_FUSED(bf16_t, 2);
+        else MLP_BWD_FUSED(bf16_t, 3);
+#undef MLP_BWD_FUSED
+        PAG_CHECK_LAUNCH("pag_mlp_bwd (fused)");
+        FinishBatch fb{};
+        int max_out = 0;
+        for (int l = 0; l < a->n_layers; ++l) {
+            const int n_out = l + 1 < a->n_layers ? HID : a->out_dim;
+            const int n_in = l == 0 ? a->in_dim : HID;
+            fb.p[l] = FinishParams{p.slabs[l], (int)grid * 4, n_out, (n_out + 31) / 32 * 32, n_in, l == 0 ? p.grp_L : 0, p.grp_F, a->dW[l], a->db[l]};
+            max_out = std::max(max_out, n_out);
+        }
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(max_out, a->n_layers), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
+        PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, finish)");
+        return PAG_OK;
+    }
     const bool wide_rebuild = a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64 && a->out_act == PAG_ACT_SOFTMAX && a->softmax_stats &&
                               a->b_last && !out_f32 && (a->g_ray || (a->grad_out && a->out_dim % 8 == 0));
     if (wide_rebuild) {
@@ -1956,52 +2297,6 @@ extern "C" int pag_mlp_wgrad(const void *dz, int dz_cols, int n_out, const void 
     wgrad_launch(b, 1, a1_dtype == PAG_F32, small, n_blocks, lds, (hipStream_t)stream);
     PAG_CHECK_LAUNCH("pag_mlp_wgrad");
     return PAG_OK;
-}
-
-// Sum the per-workgroup slabs of pag_mlp_wgrad into the final dW [n_out][n_in] / db [n_out] (fixed order: deterministic).
-// One workgroup per output row, 4 slab quarters x 96 columns; XCD8 inputs: slab column p is a staged position and lands in
-// feature column grp_col(p).
-constexpr int WF_SPLITS = 10;      // slab range split over 10 x 96 threads of the row's workgroup
-struct FinishParams {
-    const float *slabs;
-    int n_blocks, n_out, rows_pad, n_in, grp_L, grp_F;
-    float *dW, *db;
-};
-struct FinishBatch {
-    FinishParams p[WG_MAX_BATCH];
-};
-__global__ __launch_bounds__(WF_SPLITS * WG_SLAB_COLS) void wgrad_finish_kernel(FinishBatch batch) {
-    __shared__ float part[WF_SPLITS][WG_SLAB_COLS];
-    const FinishParams &fp = batch.p[blockIdx.y];     // blockIdx.y = layer
-    if ((int)blockIdx.x >= fp.n_out) return;
-    const float *__restrict__ slabs = fp.slabs;
-    float *__restrict__ dW = fp.dW, *__restrict__ db = fp.db;
-    const int n_blocks = fp.n_blocks, rows_pad = fp.rows_pad, n_in = fp.n_in, grp_L = fp.grp_L, grp_F = fp.grp_F;
-    const int o = blockIdx.x, c = threadIdx.x % WG_SLAB_COLS, q = threadIdx.x / WG_SLAB_COLS;
-    const int64_t stride = (int64_t)rows_pad * WG_SLAB_COLS;
-    const float *src = slabs + (int64_t)o * WG_SLAB_COLS + c;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int b = q;
-    for (; b + 3 * WF_SPLITS < n_blocks; b += 4 * WF_SPLITS) {
-        a0 += src[(int64_t)b * stride];
-        a1 += src[(int64_t)(b + WF_SPLITS) * stride];
-        a2 += src[(int64_t)(b + 2 * WF_SPLITS) * stride];
-        a3 += src[(int64_t)(b + 3 * WF_SPLITS) * stride];
-    }
-    for (; b < n_blocks; b += WF_SPLITS) a0 += src[(int64_t)b * stride];
-    part[q][c] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (q == 0) {
-        float v = 0.0f;
-#pragma unroll
-        for (int k = 0; k < WF_SPLITS; ++k) v += part[k][c];
-        if (c == 64) {
-            db[o] = v;
-        } else if (c < 64) {
-            const int col = grp_L ? grp_col(c, grp_L, grp_F) : c;
-            if (col >= 0 && col < n_in) dW[(int64_t)o * n_in + col] = v;
-        }
-    }
 }
 
 extern "C" int pag_mlp_wgrad_finish(const float *slabs, int n_blocks, int n_out, int n_in, int a1_layout, int a1_levels, int a1_feats,

@@ -352,10 +352,21 @@ class _FusedMLP(torch.autograd.Function):
         out_dim = Wc[-1].shape[0]
         dev = x1.device
         zdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
-        dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
         out_dtype = ctx.out_dtype
         need_dx = ctx.needs_input_grad[0]
+        need_dx2 = ctx.needs_input_grad[1] and x2 is not None
         dx1 = (dx1_into if dx1_into is not None else torch.empty(x1.shape, device=dev, dtype=x1.dtype)) if need_dx else None
+        # weight gradients inside the backward-data launch (pag_mlp_bwd_args.wgrad_workspace): narrow decoders on the bf16 path;
+        # d x2 (pose optimisation) is formed from dz_0, so that case keeps the dz tensors and the separate weight-gradient launches
+        k2p = x2.shape[1] if x2 is not None else 0
+        fused = bool(WGRAD_FUSED and M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 and not need_dx2 and
+                     (dx1 is None or dx1.dtype == torch.bfloat16) and
+                     lib.pag_mlp_bwd_fused_supported(mode, out_dim, k1, L.LAYOUT_XCD8 if grouped is not None else L.LAYOUT_STRIDED,
+                                                     grouped[0] if grouped is not None else 0, grouped[1] if grouped is not None else 0,
+                                                     in_dim, k2p) == 1)
+        dz = None
+        if not fused:
+            dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
         a = L.MlpBwdArgs()
         if rank1 is None:
             g = g.contiguous().to(out_dtype)       # grad_out travels in the output's dtype
@@ -371,7 +382,9 @@ class _FusedMLP(torch.autograd.Function):
         if grouped is not None:
             a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
         for i in range(n_layers):
-            a.W[i], a.dz[i] = L.ptr(Wc[i]), L.ptr(dz[i])
+            a.W[i] = L.ptr(Wc[i])
+            if dz is not None:
+                a.dz[i] = L.ptr(dz[i])
         for i, h in enumerate(hidden):
             a.hidden_save[i] = L.ptr(h)
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
@@ -384,12 +397,25 @@ class _FusedMLP(torch.autograd.Function):
             a.dx1_col0_add = L.ptr(col0_add)
             if col0_gate is not None:
                 a.dx1_col0_gate = L.ptr(col0_gate)
+        gW, gb = [], []
+        if fused:
+            ws_bytes = lib.pag_mlp_bwd_fused_workspace_bytes(n_layers, M)
+            ws = torch.empty(ws_bytes // 4, device=dev)
+            a.x1, a.x1_dtype = L.ptr(x1), L.BF16
+            if x2 is not None:
+                a.x2, a.k2p, a.x2_index = L.ptr(x2), k2p, L.ptr(x2_index)
+            a.wgrad_workspace, a.wgrad_workspace_bytes = L.ptr(ws), ws_bytes
+            for l in range(n_layers):
+                gW.append(torch.empty(Wc[l].shape[0], in_dim if l == 0 else 64, device=dev))
+                gb.append(torch.empty(Wc[l].shape[0], device=dev))
+                a.dW[l], a.db[l] = L.ptr(gW[l]), L.ptr(gb[l])
         if M:
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
         if col0_add is not None and need_dx and not fuse_col0:
             dx1[:, 0] += col0_add.to(dx1.dtype)          # parity path: same sum with torch ops
-        gW, gb = [], []
-        if mode == L.MLP_MFMA_BF16 and M:
+        if fused:
+            pass
+        elif mode == L.MLP_MFMA_BF16 and M:
             # weight gradients on the matrix cores: per-workgroup fp32 slabs, summed here (deterministic)
             specs = []
             for l in range(n_layers):
@@ -427,7 +453,7 @@ class _FusedMLP(torch.autograd.Function):
                 gW.append(w)
                 gb.append(z.sum(0, dtype=torch.float32))
         dx2 = None
-        if ctx.needs_input_grad[1] and x2 is not None:
+        if need_dx2:
             # d x2[r] = (sum of dz_0 over the samples that gathered row r) @ W_0[:, k1:]  - the per-ray view embedding's
             # gradient (pose optimisation: the view direction depends on the camera rotation, ba_pipeline.py:89-90)
             R = x2.shape[0]
@@ -445,6 +471,7 @@ class _FusedMLP(torch.autograd.Function):
 
 
 WGRAD_MAX_BATCH = 6      # WG_MAX_BATCH of csrc/mlp.hip
+WGRAD_FUSED = os.environ.get("PAG_NO_FUSED_WGRAD") is None      # narrow decoders: weight gradients inside pag_mlp_bwd (no dz tensors)
 
 
 def _launch_wgrad(specs, M):

@@ -957,3 +957,105 @@ def test_short_training_run_converges_and_bf16_tracks_fp32(gpu_device):
         assert hist[-1] < 0.8 * hist[0], (precision, hist[0], hist[-1])
     assert abs(losses["bf16"][0] - losses["fp32"][0]) < 0.02 * losses["fp32"][0]
     assert abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.1 * losses["fp32"][-1], (losses["bf16"][-1], losses["fp32"][-1])
+
+
+def test_fused_weight_gradients_match_separate_kernels(gpu_device):
+    """pag_mlp_bwd with wgrad_workspace (dW / db formed per wave from transposed LDS tiles inside the backward-data kernel) against
+    the separate path (dz tensors + pag_mlp_wgrad_batch) on the three narrow production decoders - XCD8 density, strided colour
+    with the per-ray view embedding (+ the density column), rank-1 semantic head alone and next to the wide instance head - and
+    against an fp32 torch reference.  Same bf16 operands on both GPU paths: only the fp32 summation order differs."""
+    ops, L = _ops()
+    dev = gpu_device
+    rs = np.random.RandomState(31)
+
+    def run(fn, params, fused):
+        ops.WGRAD_FUSED = fused
+        try:
+            for prm in params:
+                prm.grad = None
+            fn()
+            torch.cuda.synchronize()
+            return [prm.grad.clone() for prm in params]
+        finally:
+            ops.WGRAD_FUSED = True
+
+    for M, N in ((32 * 37 + 5, 9), (5, 2), (4096 * 3, 16)):
+        ridx = torch.from_numpy(np.sort(rs.randint(0, N, size=M)).astype(np.int32)).to(dev)
+        counts = torch.bincount(ridx.long(), minlength=N)
+        pack_start = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(counts, 0)])
+        ray_of_pack = torch.arange(N, dtype=torch.int32, device=dev)
+        x8 = torch.from_numpy(rs.standard_normal(size=(8, M, 8)).astype(np.float32)).to(dev)
+        x8[:, :, 6:] = 0.0                                   # L = 24, F = 2: elements 6, 7 of every group are padding
+        x8 = x8.bfloat16().requires_grad_(True)
+        cols = ops.xcd8_columns(24, 2)
+        xs = torch.zeros(M, 48, device=dev)
+        flat = x8.detach().float().permute(1, 0, 2).reshape(M, 64)
+        for pos, c in enumerate(cols):
+            if c >= 0:
+                xs[:, c] = flat[:, pos]
+        # ---- density: 48 -> 64 -> 16, XCD8 input, bf16 output
+        W, b = _rand_mlp(rs, (48, 64, 16))
+        Wg = [w.to(dev).requires_grad_(True) for w in W]
+        bg = [v.to(dev).requires_grad_(True) for v in b]
+        g = torch.from_numpy(rs.standard_normal(size=(M, 16)).astype(np.float32)).to(dev).bfloat16()
+
+        def density():
+            ops.fused_mlp(x8, Wg, bg, in_dim=48, out_act=L.ACT_NONE, out_dtype=torch.bfloat16, x1_grouped=(24, 2)).backward(g)
+        a = run(density, Wg + bg + [x8], True)
+        bsep = run(density, Wg + bg + [x8], False)
+        for u, v in zip(a, bsep):
+            assert _rel_l2(u.float(), v.float()) < 1e-4
+        Wt = [w.bfloat16().float().to(dev).requires_grad_(True) for w in W]
+        bt = [v.to(dev).clone().requires_grad_(True) for v in b]
+        _torch_mlp(xs, Wt, bt, 0, round_hidden=True).backward(g.float())
+        for u, v in zip(a[:4], [t.grad for t in Wt + bt]):
+            assert _rel_l2(u, v) < 2e-2
+        # ---- colour: (16 + 27) -> 64 -> 64 -> 3 sigmoid, strided bf16 x1 + per-ray x2, f32 output, density column
+        W, b = _rand_mlp(rs, (43, 64, 64, 3))
+        Wg = [w.to(dev).requires_grad_(True) for w in W]
+        bg = [v.to(dev).requires_grad_(True) for v in b]
+        x1 = torch.from_numpy(rs.standard_normal(size=(M, 16)).astype(np.float32)).to(dev).bfloat16().requires_grad_(True)
+        x2 = torch.zeros(N, 32, device=dev)
+        x2[:, :27] = torch.from_numpy(rs.standard_normal(size=(N, 27)).astype(np.float32)).to(dev)
+        g_rgb = torch.from_numpy(rs.standard_normal(size=(M, 3)).astype(np.float32)).to(dev)
+        g_sig = torch.from_numpy(rs.standard_normal(size=(M,)).astype(np.float32)).to(dev)
+
+        def colour():
+            rgb, sigma = ops.colour_and_density(x1, Wg, bg, x2, ridx, 43, out_act=L.ACT_SIGMOID, out_dtype=torch.float32)
+            ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+        a = run(colour, Wg + bg + [x1], True)
+        bsep = run(colour, Wg + bg + [x1], False)
+        for u, v in zip(a, bsep):
+            assert _rel_l2(u.float(), v.float()) < 1e-4
+        Wt = [w.bfloat16().float().to(dev).requires_grad_(True) for w in W]
+        bt = [v.to(dev).clone().requires_grad_(True) for v in b]
+        xfull = torch.cat([x1.detach().float(), x2.bfloat16().float()[ridx.long(), :27]], -1)
+        (_torch_mlp(xfull, Wt, bt, 1, round_hidden=True) * g_rgb).sum().backward()
+        for u, v in zip(a[:6], [t.grad for t in Wt + bt]):
+            assert _rel_l2(u, v) < 2e-2
+        # ---- semantic head (48 -> 64 -> 6 softmax) composited with rank-1 gradients, alone and next to the instance head
+        Ws, bs_ = _rand_mlp(rs, (48, 64, 6))
+        Wi, bi = _rand_mlp(rs, (48, 64, 64, 200))
+        Wsg = [w.to(dev).requires_grad_(True) for w in Ws]
+        bsg = [v.to(dev).requires_grad_(True) for v in bs_]
+        Wig = [w.to(dev).requires_grad_(True) for w in Wi]
+        big = [v.to(dev).requires_grad_(True) for v in bi]
+        wts = torch.rand(M, device=dev)
+        alpha = torch.rand(N, device=dev)
+        gs = torch.from_numpy(rs.standard_normal(size=(N, 6)).astype(np.float32)).to(dev)
+        gi = torch.from_numpy(rs.standard_normal(size=(N, 200)).astype(np.float32)).to(dev)
+
+        def sem():
+            o = ops.head_composite(x8, Wsg, bsg, wts, alpha, ridx, pack_start, ray_of_pack, N, in_dim=48, out_act=L.ACT_SOFTMAX,
+                                   out_dtype=torch.bfloat16, x1_grouped=(24, 2))
+            (o * gs).sum().backward()
+
+        def pair():
+            oi, os_ = ops.head_composite_pair(x8, ((Wig, big, 48), (Wsg, bsg, 48)), wts, alpha, ridx, pack_start, ray_of_pack, N,
+                                              out_dtype=torch.bfloat16, x1_grouped=(24, 2))
+            ((oi * gi).sum() + (os_ * gs).sum()).backward()
+        for fn, prms in ((sem, Wsg + bsg + [x8]), (pair, Wsg + bsg + Wig + big + [x8])):
+            a = run(fn, prms, True)
+            bsep = run(fn, prms, False)
+            for u, v in zip(a, bsep):
+                assert _rel_l2(u.float(), v.float()) < 1e-4
