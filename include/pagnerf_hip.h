@@ -232,10 +232,16 @@ typedef struct {
     float *dW[3]; float *db[3];
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
-/* 1 when pag_mlp_bwd can fuse the weight gradients for this decoder shape: MFMA mode, out_dim <= 32, and input column 63 free
- * (XCD8: staged position 63 is padding; strided: in_dim <= 63 and k1 + k2p <= 64) - it carries the constant 1 whose weight
- * gradient is the layer-0 bias gradient. */
-int pag_mlp_bwd_fused_supported(int mode, int out_dim, int k1, int x1_layout, int x1_levels, int x1_feats, int in_dim, int k2p);
+/* 1 when pag_mlp_bwd has a fused weight-gradient kernel for these (fully filled in, wgrad_workspace aside) arguments.  Three
+ * decoder shapes are covered - the narrow decoders of pc_nerf/panoptic_nef.py:114-164 on the bf16 path:
+ *   density-like   XCD8 bf16 x1, dense bf16 grad_out, no output activation, out_dim % 4 == 0, XCD8 bf16 dx1
+ *   colour-like    bf16 x1 [M,16] + f32 x2 [R,32] through x2_index, dense f32 grad_out, sigmoid, out_dim <= 4, bf16 dx1 [M,16] with
+ *                  dx1_col0_add + dx1_col0_gate
+ *   semantic-like  XCD8 bf16 x1, rank-1 gradient (g_ray, g_scale, g_index, g_ray_scale), softmax with the saved bf16 `out`,
+ *                  out_dim <= 8, XCD8 bf16 dx1 (dx1_accumulate allowed)
+ * each with 2 or 3 layers, out_dim <= 32, and input column 63 free (XCD8: staged position 63 is padding; it carries the
+ * constant 1 whose weight gradient is the layer-0 bias gradient).  Anything else: dz[] + pag_mlp_wgrad_batch. */
+int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *args);
 int64_t pag_mlp_bwd_fused_workspace_bytes(int n_layers, int64_t M);
 
 /* Wide softmax head fused with the per-ray weighted sum of tracers/panoptic_packed_rf_tracer.py:197-205:

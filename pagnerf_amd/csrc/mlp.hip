@@ -23,6 +23,7 @@
 // broadcast from LDS - the parity path (tolerance 1e-5 against the fp32 oracle).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -686,25 +687,13 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? PAG_FWD_WAVES_WIDE : PAG_FWD_WAVE
 }
 
 // ----------------------------------------------------------------------------------------- backward
-template <typename OutT, typename DxT, int NL, int OBMAX, bool FUSE = false>
+template <typename OutT, typename DxT, int NL, int OBMAX>
 // 2 waves per SIMD: without the bound the 3-layer narrow variants took 252 VGPRs + 36 AGPRs (1 wave per SIMD); asking for 2 makes them fit 254 with no
 // scratch.  The 33..64-output variants (OBMAX 2) would spill 150 - 350 B and stay at 1.
-//
-// FUSE (out_dim <= 32, bf16 layer-0 input): the weight gradients are formed HERE, per wave, instead of by a second kernel that
-// re-reads every dz and every layer input ([M,64] each: 536 MB per 64x64 layer at M = 2.1 M, 4.7 TB/s - at the practical
-// HBM rate, so only removing the bytes helps).  Each wave keeps dW of all layers as MFMA accumulators (6 - 10 blocks of 16
-// registers + one block for the biases) for the whole launch - one wave per SIMD, 512 registers - and feeds them from its
-// own tiles: dz (just computed) and the layer inputs (the saved activations it loads anyway for the ReLU masks + the layer-0
-// input) are kept as swizzled LDS images and read back TRANSPOSED (ds_read_b64_tr_b16: the sum runs over the samples).  No
-// shared tiles, no block barriers, no dz tensors in memory; per-wave slabs at the end, summed by wgrad_finish_kernel.
 #ifndef PAG_BWD_WAVES
 #define PAG_BWD_WAVES 2
 #endif
-#ifndef PAG_BWD_FUSE_WAVES
-#define PAG_BWD_FUSE_WAVES 1
-#endif
-__global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 : PAG_BWD_WAVES))) void mlp_bwd_mfma(BwdParams p) {
-    static_assert(!FUSE || OBMAX == 1, "fused weight gradients: out_dim <= 32");
+__global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd_mfma(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.out_dim + 31) / 32;
     const int RSL = OB * 32 + 8;
@@ -714,10 +703,7 @@ __global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 :
     stage_weight_t(WLt, RSL, 64, OB * 32, p.W[NL - 1], p.out_dim, HID);
     if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
     if (p.dx1) stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
-    bf16_t *stg = W0t + 64 * RS + (threadIdx.x >> 6) * (ST_BYTES / 2);      // wave-private staging tile (unused with FUSE)
-    // FUSE: wave-private swizzled tiles - layer-0 input, saved activations of every hidden layer, the current dz
-    bf16_t *Tx = W0t + 64 * RS + (threadIdx.x >> 6) * ((NL + 1) * TW_ELEMS);
-    bf16_t *Th0 = Tx + TW_ELEMS, *Th1 = Th0 + (NL == 3 ? TW_ELEMS : 0), *Tz = Th1 + TW_ELEMS;
+    bf16_t *stg = W0t + 64 * RS + (threadIdx.x >> 6) * (ST_BYTES / 2);      // wave-private staging tile
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -756,99 +742,17 @@ __global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 :
         }
     };
     if constexpr (PREFETCH) fetch_h((int64_t)blockIdx.x * 4 + wave, hnext);
-    // ---- FUSE: layer-0 input fragments of the next tile (the forward's load_x) and the weight-gradient accumulators
-    const bf16_t *x1b = reinterpret_cast<const bf16_t *>(p.x1);
-    auto load_x = [&](int64_t tile, bf16x8 (&xf)[4]) __attribute__((always_inline)) {
-        const int64_t m = tile * 32 + r;
-        const bool lv = tile < ntiles && m < p.M;
-        const int64_t mx = lv ? m : 0;
-        const int32_t ray = (p.x2 && lv) ? p.x2_index[mx] : 0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int f0 = 16 * s + 8 * h;
-            if (p.grp_L && lv)
-                xf[s] = load8(x1b + ((int64_t)(2 * s + h) * p.M + mx) * 8);
-            else if (!p.grp_L && lv && f0 < p.k1)
-                xf[s] = load8(x1b + mx * p.k1 + f0);
-            else if (!p.grp_L && lv && p.x2 && f0 < p.k1 + p.k2p)
-                xf[s] = load8(p.x2 + (int64_t)ray * p.k2p + (f0 - p.k1));
-            else
-                xf[s] = zero8();
-        }
-    };
-    bf16x8 xnext[FUSE ? 4 : 1];
-    f32x16 awL[1][2], awM[FUSE && NL == 3 ? 2 : 1][2], aw0[FUSE ? 2 : 1][2], dbacc;      // dW of the last / middle / first layer, db
-    if constexpr (FUSE) {
-        load_x((int64_t)blockIdx.x * 4 + wave, xnext);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            dbacc[q] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                awL[0][i][q] = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    aw0[i][j][q] = 0.0f;
-                    if constexpr (NL == 3) awM[i][j][q] = 0.0f;
-                }
-            }
-        }
-    }
-    // B fragment "1 in column j": dbacc[:, j] += row sums of the A operand (bias gradients of the layers fed by hidden activations)
-    auto ones_col = [&](int j) __attribute__((always_inline)) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(r == j ? 1.0f : 0.0f);
-        return o;
-    };
-    // dW[ob][ib] += dz(Tz block ob)^T . input(Tin block ib) over this tile's 32 samples; dbcol >= 0: bias gradients into dbacc
-    int lane_w = lane;
-    auto wgrad_tile = [&](const bf16_t *Tin, auto &aw, int dbcol) __attribute__((always_inline)) {      // aw: f32x16 [out blocks][2]
-        constexpr int NOB = (int)(sizeof(aw) / sizeof(aw[0]));
-        asm volatile("" : "+v"(lane_w));
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bfr[2];
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) bfr[ib] = tw_frag(Tin, ib, ks, lane_w);
-#pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                const bf16x8 afr = tw_frag(Tz, ob, ks, lane_w);
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib) aw[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[ib], aw[ob][ib], 0, 0, 0);
-                if (dbcol >= 0) dbacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones_col(dbcol + ob), dbacc, 0, 0, 0);
-            }
-        }
-    };
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tile_step) {
-        if constexpr (OBMAX > 2 || FUSE) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
+        if constexpr (OBMAX > 2) {      // keep lane-constant addresses from being hoisted out of the tile loop and spilled
             asm volatile("" : "+v"(r), "+v"(h));
         }
-        int lane_t = lane;                      // FUSE: the many swizzled LDS addresses are recomputed per tile, not kept live
-        if constexpr (FUSE) asm volatile("" : "+v"(lane_t));
         const int64_t m = tile * 32 + r;
         const bool live = m < p.M;
         const int64_t mc = live ? m : p.M - 1;
         // ReLU masks of the hidden layers: requested first, consumed after the first MFMA chain
         const int rows_valid = (int)min((int64_t)32, p.M - tile * 32);
         bf16x4 hraw[NL - 1][2][4];
-        if constexpr (FUSE) {
-            // this tile's saved activations and layer-0 input become LDS images (kept for the whole tile: the transposed
-            // operand reads of the weight gradients come back to them); the next tile's requests go out right away
-            wave_lds_sync();
-            tw_put_rows(Th0, hnext[0], lane_t);
-            if constexpr (NL == 3) tw_put_rows(Th1, hnext[1], lane_t);
-            {
-                bf16x8 xb[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) xb[s] = xnext[s];
-                if (h == 1) xb[3][7] = (bf16_t)(live ? 1.0f : 0.0f);      // column 63 := 1: its dW column is the layer-0 bias gradient
-                tw_put_frags(Tx, xb, r, h);
-            }
-            wave_lds_sync();
-            fetch_h(tile + tile_step, hnext);
-            load_x(tile + tile_step, xnext);
-        } else if constexpr (PREFETCH) {
+        if constexpr (PREFETCH) {
 #pragma unroll
             for (int l = 0; l < NL - 1; ++l) tile64_unstage(stg, hnext[l], lane, r, h, hraw[l]);
             fetch_h(tile + tile_step, hnext);
@@ -882,12 +786,7 @@ __global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 :
             }
             const int zi = OBMAX > 2 ? 0 : 2 * ob;
             pack_block(zz, zb[zi], zb[zi + 1]);
-            if constexpr (FUSE) {      // dz_L stays in LDS: A operand of the last layer's weight gradient
-                tw_put_block(Tz, 0, r, h, zz);
-                wave_lds_sync();
-                wgrad_tile(NL == 3 ? Th1 : Th0, awL, 0);
-                wave_lds_sync();
-            } else if (OBMAX > 2 && (p.out_dim & 7) == 0)
+            if (OBMAX > 2 && (p.out_dim & 7) == 0)
                 block32_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + tile * 32 * p.out_dim, p.out_dim, 32 * ob, rows_valid, lane, r, h, zz);
             else if (live)
                 store_block(reinterpret_cast<bf16_t *>(p.dz[NL - 1]) + m * p.out_dim, 32 * ob, h, zz, p.out_dim, vec_out);
@@ -1081,26 +980,12 @@ __global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 :
                 }
             }
             f32x16 hv;
-            if constexpr (FUSE) {      // the activations are still in their LDS image: read the ReLU mask where it is used
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    hraw[NL - 2][mb][g] = *reinterpret_cast<const bf16x4 *>((NL == 3 ? Th1 : Th0) + tw_off(r, 8 * mb + 2 * g + h));
-            }
             raw_to_block(hraw[NL - 2][mb], hv);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
             pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
         }
-        if constexpr (FUSE) {      // dz of the last hidden layer -> its weight gradient (input: previous activations, or x for NL == 2)
-            tw_put_block(Tz, 0, r, h, acc[0]);
-            tw_put_block(Tz, 1, r, h, acc[1]);
-            wave_lds_sync();
-            if constexpr (NL == 3) wgrad_tile(Th0, awM, 1);
-            else wgrad_tile(Tx, aw0, -1);
-            wave_lds_sync();
-        } else {
-            tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
-        }
+        tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[NL - 2]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
         if (NL == 3) {
             bf16x8 hb2[4];
 #pragma unroll
@@ -1113,24 +998,12 @@ __global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 :
                     acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
                 }
                 f32x16 hv;
-                if constexpr (FUSE) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) hraw[0][mb][g] = *reinterpret_cast<const bf16x4 *>(Th0 + tw_off(r, 8 * mb + 2 * g + h));
-                }
                 raw_to_block(hraw[0][mb], hv);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mb][q] = (hv[q] > 0.0f && live) ? acc[mb][q] : 0.0f;
                 pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
             }
-            if constexpr (FUSE) {
-                tw_put_block(Tz, 0, r, h, acc[0]);
-                tw_put_block(Tz, 1, r, h, acc[1]);
-                wave_lds_sync();
-                wgrad_tile(Tx, aw0, -1);
-                wave_lds_sync();
-            } else {
-                tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[0]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
-            }
+            tile64_store(stg, reinterpret_cast<bf16_t *>(p.dz[0]) + tile * 32 * HID, rows_valid, lane, r, h, acc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
         }
@@ -1170,34 +1043,365 @@ __global__ __launch_bounds__(256, (FUSE ? PAG_BWD_FUSE_WAVES : (OBMAX == 2 ? 1 :
             }
         }
     }
-    if constexpr (FUSE) {
-        // per-wave slabs [rows_pad][96] per layer (cols 0..63 dW - staged positions for XCD8 inputs -, col 64 db), summed by wgrad_finish_kernel
-        const int64_t slab_id = (int64_t)blockIdx.x * 4 + wave;
-        auto put = [&](float *base, int rows_pad, int ob, int ib, const f32x16 &a) __attribute__((always_inline)) {
-            float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
+}
+
+// ------------------------------------------------------ backward-data + weight gradients, narrow decoders (one launch)
+// The separate weight-gradient kernel re-read every dz and every layer input ([M,64] bf16 each: 536 MB per 64 x 64 layer at
+// M = 2.1 M) at 4.7 TB/s - the practical HBM rate, so only removing the bytes helps.  Here every wave keeps dW of ALL layers
+// as MFMA accumulators for the whole launch (6 - 10 blocks of 16 registers + one block for the biases; one wave per SIMD,
+// 512 registers) and feeds them from its own 32-sample tiles: dz (just computed) and the layer inputs (the saved activations it
+// needs anyway for the ReLU masks + the layer-0 input) live as swizzled LDS images and are read back TRANSPOSED
+// (ds_read_b64_tr_b16: the sum runs over the samples).  No shared tiles, no block barriers, no dz tensors in memory.
+// The three decoder shapes of the model are separate instantiations so that the tile loop is straight-line code: every
+// global load of tile t+1 is issued unconditionally (clamped addresses) at the top of tile t - with one wave per SIMD an
+// exposed round trip costs a whole tile, and branches make the compiler drain vmcnt to 0 at each join.
+//   KIND 0  density-like : XCD8 bf16 input, dense bf16 gradient (out_dim % 4 == 0, <= 32), no activation, XCD8 bf16 dx
+//   KIND 1  colour-like  : bf16 x1 [M,16] + per-ray f32 x2 [R,32], dense f32 gradient, sigmoid (out_dim <= 4), bf16 dx [M,16] with
+//                          the gated column-0 addend (the density read off x1[:,0])
+//   KIND 2  semantic-like: XCD8 bf16 input, rank-1 gradient, softmax with saved bf16 probabilities (out_dim <= 8), XCD8 bf16 dx
+//                          (DXACC: added to the other head's gradient in place)
+// Full 32-sample tiles run in the main loop; a ragged last tile runs once after it with predicated stores.
+template <int NL, int KIND, bool DXACC>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
+    constexpr bool GRP = KIND != 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RSL = 32 + 8;
+    bf16_t *WLt = reinterpret_cast<bf16_t *>(smem);              // [64 in][RSL]  k = output channel (permuted)
+    bf16_t *W1t = WLt + 64 * RSL;                                // [64][RS]      (NL == 3)
+    bf16_t *W0t = W1t + (NL == 3 ? 64 * RS : 0);                 // [64 in-feature rows][RS]
+    stage_weight_t(WLt, RSL, 64, 32, p.W[NL - 1], p.out_dim, HID);
+    if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
+    stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
+    bf16_t *Tx = W0t + 64 * RS + (threadIdx.x >> 6) * ((NL + 1) * TW_ELEMS);      // wave-private swizzled tiles
+    bf16_t *Th0 = Tx + TW_ELEMS, *Th1 = Th0 + (NL == 3 ? TW_ELEMS : 0), *Tz = Th1 + TW_ELEMS;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t M = p.M, ntiles = (M + 31) / 32, nfull = M / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const bf16_t *x1b = reinterpret_cast<const bf16_t *>(p.x1);
+    const int32_t *ridx = KIND == 1 ? p.x2_index : p.g_index;      // per-sample row of the per-ray tables
+
+    // ---- registers of the NEXT tile (requested one tile ahead; the per-ray row index two tiles ahead)
+    bf16x8 hn[NL - 1][4], xn[4];
+    bf16x4 gz[KIND == 0 ? 4 : 1], oldx[DXACC ? 2 : 1][4];
+    float gs[4], gy[4], gsc = 0.0f, c0a = 0.0f, c0g = 0.0f;      // KIND 1: gradient / output; KIND 2: g_ray row / probabilities
+    int ray1 = 0, ray2 = 0;                                        // row index of the tile after next (and the one after that)
+    auto row_of = [&](int64_t tile) __attribute__((always_inline)) { return min(min(tile, ntiles - 1) * 32 + r, M - 1); };
+    auto prefetch = [&](int64_t tile_raw, int ray) __attribute__((always_inline)) {
+        const int64_t tile = min(tile_raw, ntiles - 1);
+        const int64_t m = min(tile * 32 + r, M - 1);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = a[q];
-        };
-        auto put_db = [&](float *base, int rows_pad, int ob, bool mine, const f32x16 &a) __attribute__((always_inline)) {
-            float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
-            if (mine) {
+        for (int l = 0; l < NL - 1; ++l)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = a[q];
+            for (int it = 0; it < 4; ++it) {
+                const int64_t row = min(tile * 32 + it * 8 + (lane >> 3), M - 1);
+                hn[l][it] = load8(reinterpret_cast<const bf16_t *>(p.hsave[l]) + row * HID + (lane & 7) * 8);
             }
-        };
+        if constexpr (GRP) {
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib) put(p.slabs[NL - 1], 32, 0, ib, awL[0][ib]);
-        put_db(p.slabs[NL - 1], 32, 0, r == 0, dbacc);
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                put(p.slabs[0], 64, ob, ib, aw0[ob][ib]);
-                if constexpr (NL == 3) put(p.slabs[1], 64, ob, ib, awM[ob][ib]);
-            }
-            put_db(p.slabs[0], 64, ob, r == 31, aw0[ob][1]);             // input column 63 (the ones column)
-            if constexpr (NL == 3) put_db(p.slabs[1], 64, ob, r == 1 + ob, dbacc);
+            for (int s = 0; s < 4; ++s) xn[s] = load8(x1b + ((int64_t)(2 * s + h) * M + m) * 8);
+        } else {      // k1 = 16, k2p = 32: x1 | x2[ray][0:16] | x2[ray][16:32] | 0
+            xn[0] = load8(x1b + m * 16 + 8 * h);
+            xn[1] = load8(p.x2 + (int64_t)ray * 32 + 8 * h);
+            xn[2] = load8(p.x2 + (int64_t)ray * 32 + 16 + 8 * h);
+            xn[3] = zero8();
         }
+        if constexpr (KIND == 0) {
+            const bf16_t *gop = reinterpret_cast<const bf16_t *>(p.grad_out) + m * p.out_dim;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 8 * g + 4 * h;
+                gz[g] = *reinterpret_cast<const bf16x4 *>(gop + (c0 < p.out_dim ? c0 : 0));
+            }
+        } else if constexpr (KIND == 1) {
+            const float *gop = reinterpret_cast<const float *>(p.grad_out) + m * p.out_dim;
+            const float *yop = reinterpret_cast<const float *>(p.out) + m * p.out_dim;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = j < p.out_dim ? j : 0;
+                gs[j] = gop[c];
+                gy[j] = yop[c];
+            }
+            c0a = p.dx_col0[m];
+            c0g = p.dx_col0_gate[m];
+        } else {
+            gsc = __fmul_rn(p.g_scale[m], p.g_ray_scale[ray]);
+            const float *grow = p.g_ray + (int64_t)ray * p.out_dim;
+            const bf16_t *yop = reinterpret_cast<const bf16_t *>(p.out) + m * p.out_dim;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (4 * h + j) < p.out_dim ? (4 * h + j) : 0;
+                gs[j] = grow[c];
+                gy[j] = (float)yop[c];
+            }
+        }
+        if constexpr (DXACC) {
+            const bf16_t *dg = reinterpret_cast<const bf16_t *>(p.dx1);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    oldx[mb][g] = *reinterpret_cast<const bf16x4 *>(dg + ((int64_t)(4 * mb + g) * M + m) * 8 + 4 * h);
+        }
+    };
+
+    // ---- weight-gradient accumulators (the whole launch) and their feeding
+    f32x16 awL[1][2], awM[NL == 3 ? 2 : 1][2], aw0[2][2], dbacc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        dbacc[q] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            awL[0][i][q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                aw0[i][j][q] = 0.0f;
+                if constexpr (NL == 3) awM[i][j][q] = 0.0f;
+            }
+        }
+    }
+    // B fragment "1 in column j": dbacc[:, j] += row sums of the A operand (bias gradients of the layers fed by hidden activations)
+    auto ones_col = [&](int j) __attribute__((always_inline)) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(r == j ? 1.0f : 0.0f);
+        return o;
+    };
+    // dW[ob][ib] += dz(Tz block ob)^T . input(Tin block ib) over this tile's 32 samples; dbcol >= 0: bias gradients into dbacc
+    auto wgrad_tile = [&](const bf16_t *Tin, auto &aw, int dbcol) __attribute__((always_inline)) {      // aw: f32x16 [out blocks][2]
+        constexpr int NOB = (int)(sizeof(aw) / sizeof(aw[0]));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[2], afr[NOB];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) bfr[ib] = tw_frag(Tin, ib, ks, lane);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) afr[ob] = tw_frag(Tz, ob, ks, lane);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) aw[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ob], bfr[ib], aw[ob][ib], 0, 0, 0);
+                if (dbcol >= 0) dbacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ob], ones_col(dbcol + ob), dbacc, 0, 0, 0);
+            }
+        }
+    };
+
+    // dx of tile t is STORED at the top of tile t+1 (after that tile's prefetched registers have been consumed, before the next
+    // prefetch is issued): vmcnt counts loads and stores in issue order, so stores issued at the end of a tile would have to drain
+    // before the next tile could touch its prefetched data - a full write round trip per tile with one wave per SIMD.  The very
+    // first flush writes zeros to the wave's first tile; the real values follow from the same wave (stores of one wave stay ordered).
+    constexpr int NPB = GRP ? 2 : 1, NPG = GRP ? 4 : 2;
+    bf16x4 pend[NPB][NPG];
+#pragma unroll
+    for (int mb = 0; mb < NPB; ++mb)
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) pend[mb][g] = bf16x4{(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
+    int64_t pend_m = min((int64_t)blockIdx.x * 4 * 32 + (int64_t)wave * 32 + r, M - 1);
+    auto flush = [&](bool pred) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < NPB; ++mb)
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) {
+                bf16_t *dst = GRP ? reinterpret_cast<bf16_t *>(p.dx1) + ((int64_t)(4 * mb + g) * M + pend_m) * 8 + 4 * h
+                                  : reinterpret_cast<bf16_t *>(p.dx1) + pend_m * 16 + 8 * g + 4 * h;
+                if (pred) *reinterpret_cast<bf16x4 *>(dst) = pend[mb][g];
+            }
+    };
+    auto body = [&](int64_t tile, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int64_t m = tile * 32 + r;
+        const bool live = FULL || m < M;
+        // ---- this tile's saved activations and layer-0 input become LDS images (kept for the whole tile)
+        wave_lds_sync();
+        tw_put_rows(Th0, hn[0], lane);
+        if constexpr (NL == 3) tw_put_rows(Th1, hn[1], lane);
+        {
+            bf16x8 xb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xb[s] = xn[s];
+            if (h == 1) xb[3][7] = (bf16_t)1.0f;      // column 63 := 1: its dW column is the layer-0 bias gradient
+            tw_put_frags(Tx, xb, r, h);
+        }
+        // ---- upstream gradient of this tile -> dz of the output layer (one 32-row block)
+        f32x16 z;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) z[q] = 0.0f;
+        if constexpr (KIND == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bool ok = 8 * g + 4 * h < p.out_dim;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[4 * g + j] = ok ? (float)gz[g][j] : 0.0f;
+            }
+        } else if constexpr (KIND == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = gy[j];
+                z[j] = (h == 0 && j < p.out_dim) ? gs[j] * y * (1.0f - y) : 0.0f;
+            }
+        } else {
+            float zr[4], yv[4], dot = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = 4 * h + j < p.out_dim;
+                zr[j] = ok ? gsc * gs[j] : 0.0f;
+                yv[j] = ok ? gy[j] : 0.0f;
+                dot += zr[j] * yv[j];
+            }
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = yv[j] * (zr[j] - dot);
+        }
+        const float col0 = (KIND == 1 && h == 0 && c0g > 0.0f) ? c0a : 0.0f;
+        bf16x4 ox[DXACC ? 2 : 1][4];
+        if constexpr (DXACC) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ox[mb][g] = oldx[mb][g];
+        }
+        // ---- the previous tile's dx goes out, then everything of the next tile is requested (its row index was loaded one tile earlier)
+        flush(true);
+        prefetch(tile + tile_step, ray1);
+        ray1 = ray2;
+        if constexpr (KIND != 0) ray2 = ridx[row_of(tile + 3 * tile_step)];
+        if constexpr (!FULL) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) z[q] = live ? z[q] : 0.0f;
+        }
+        bf16x8 zb[2];
+        pack_block(z, zb[0], zb[1]);
+        tw_put_block(Tz, 0, r, h, z);
+        wave_lds_sync();
+        wgrad_tile(NL == 3 ? Th1 : Th0, awL, 0);
+        wave_lds_sync();
+        // ---- back through the output layer, masked by the saved ReLU output (read from its LDS image)
+        f32x16 acc[2];
+        bf16x8 hb[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * s + 8 * h);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[s], acc[mb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4 *>((NL == 3 ? Th1 : Th0) + tw_off(r, 8 * mb + 2 * g + h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] = ((float)hv[j] > 0.0f && live) ? acc[mb][4 * g + j] : 0.0f;
+            }
+            pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
+        }
+        tw_put_block(Tz, 0, r, h, acc[0]);
+        tw_put_block(Tz, 1, r, h, acc[1]);
+        wave_lds_sync();
+        if constexpr (NL == 3) wgrad_tile(Th0, awM, 1);
+        else wgrad_tile(Tx, aw0, -1);
+        wave_lds_sync();
+        if constexpr (NL == 3) {
+            bf16x8 hb2[4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(W1t + (32 * mb + r) * RS + 16 * s + 8 * h);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(Th0 + tw_off(r, 8 * mb + 2 * g + h));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] = ((float)hv[j] > 0.0f && live) ? acc[mb][4 * g + j] : 0.0f;
+                }
+                pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
+            }
+            tw_put_block(Tz, 0, r, h, acc[0]);
+            tw_put_block(Tz, 1, r, h, acc[1]);
+            wave_lds_sync();
+            wgrad_tile(Tx, aw0, -1);
+            wave_lds_sync();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
+        }
+        // ---- dx1 = (W_0^T . dz_0)[0:k1]
+#pragma unroll
+        for (int mb = 0; mb < (GRP ? 2 : 1); ++mb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a = *reinterpret_cast<const bf16x8 *>(W0t + (32 * mb + r) * RS + 16 * s + 8 * h);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
+            }
+            if constexpr (GRP) {      // XCD8: row 32mb + 8g + 4h + j of dx^T -> piece [4mb + g][m][4h + j]
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (DXACC) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] += (float)ox[mb][g][j];
+                    }
+                    pend[mb][g] = bf16x4{(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
+                }
+            } else {                  // [M,16] bf16: columns 8g + 4h + j, g < 2; the density gradient joins column 0
+                acc[0][0] += col0;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    pend[0][g] = bf16x4{(bf16_t)acc[0][4 * g], (bf16_t)acc[0][4 * g + 1], (bf16_t)acc[0][4 * g + 2], (bf16_t)acc[0][4 * g + 3]};
+            }
+        }
+        pend_m = min(m, M - 1);
+    };
+
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    int ray0 = 0;
+    if constexpr (KIND != 0) {
+        ray0 = ridx[row_of(tile)];
+        ray1 = ridx[row_of(tile + tile_step)];
+        ray2 = ridx[row_of(tile + 2 * tile_step)];
+    }
+    prefetch(tile, ray0);
+    const bool any_tile = tile < ntiles;
+    bool last_ragged = false;
+    for (; tile < nfull; tile += tile_step) body(tile, std::true_type{});
+    if (tile < ntiles) {      // the ragged last tile (one wave of the launch)
+        body(tile, std::false_type{});
+        last_ragged = true;
+    }
+    if (any_tile) flush(!last_ragged || (nfull * 32 + r) < M);
+
+    // ---- per-wave slabs [rows_pad][96] per layer (cols 0..63 dW - staged positions for XCD8 inputs -, col 64 db), summed by wgrad_finish_kernel
+    const int64_t slab_id = (int64_t)blockIdx.x * 4 + wave;
+    auto put = [&](float *base, int rows_pad, int ob, int ib, const f32x16 &a) __attribute__((always_inline)) {
+        float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = a[q];
+    };
+    auto put_db = [&](float *base, int rows_pad, int ob, bool mine, const f32x16 &a) __attribute__((always_inline)) {
+        float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = a[q];
+        }
+    };
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) put(p.slabs[NL - 1], 32, 0, ib, awL[0][ib]);
+    put_db(p.slabs[NL - 1], 32, 0, r == 0, dbacc);
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            put(p.slabs[0], 64, ob, ib, aw0[ob][ib]);
+            if constexpr (NL == 3) put(p.slabs[1], 64, ob, ib, awM[ob][ib]);
+        }
+        put_db(p.slabs[0], 64, ob, r == 31, aw0[ob][1]);             // input column 63 (the ones column)
+        if constexpr (NL == 3) put_db(p.slabs[1], 64, ob, r == 1 + ob, dbacc);
     }
 }
 
@@ -2083,15 +2287,30 @@ static unsigned fused_grid(int64_t M) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, 256));      // one 4-wave workgroup per CU, tiles grid-strided
 }
 
-extern "C" int pag_mlp_bwd_fused_supported(int mode, int out_dim, int k1, int x1_layout, int x1_levels, int x1_feats, int in_dim, int k2p) {
-    if (mode != PAG_MLP_MFMA_BF16 || out_dim < 1 || out_dim > 32) return 0;
-    if (x1_layout == PAG_LAYOUT_XCD8) {
-        if (k1 != 64 || x1_levels < 1 || x1_feats < 1 || ((x1_levels + 7) / 8) * x1_feats > 8) return 0;
-        const int e = 7, j = e / x1_feats;                       // staged position 63 = group 7, element 7
-        return (j < (x1_levels + 7) / 8 && 7 + 8 * j < x1_levels) ? 0 : 1;      // must be padding
+// which mlp_bwd_fused instantiation serves these arguments: 0 density-like, 1 colour-like, 2 semantic-like, -1 none
+static int fused_kind(const pag_mlp_bwd_args *a) {
+    if (!a || a->mode != PAG_MLP_MFMA_BF16 || a->out_dim < 1 || a->out_dim > 32 || !a->dx1 || a->dx1_dtype != PAG_BF16) return -1;
+    if (a->n_layers != 2 && a->n_layers != 3) return -1;
+    if (!a->x1 || a->x1_dtype != PAG_BF16) return -1;
+    const bool rank1 = a->g_ray != nullptr;
+    if (a->x1_layout == PAG_LAYOUT_XCD8) {
+        if (a->k1 != 64 || a->x1_levels < 1 || a->x1_feats < 1 || ((a->x1_levels + 7) / 8) * a->x1_feats > 8) return -1;
+        const int j = 7 / a->x1_feats;                            // staged position 63 = group 7, element 7: must be padding
+        if (j < (a->x1_levels + 7) / 8 && 7 + 8 * j < a->x1_levels) return -1;
+        if (a->x2 || a->dx1_col0_add) return -1;
+        if (!rank1 && a->grad_out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_NONE && a->out_dim % 4 == 0 && !a->dx1_accumulate) return 0;
+        if (rank1 && a->g_scale && a->g_index && a->g_ray_scale && a->out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_SOFTMAX &&
+            a->out_dim <= 8)
+            return 2;
+        return -1;
     }
-    return (in_dim <= 63 && k1 + k2p <= 64 && k1 % 8 == 0) ? 1 : 0;
+    if (a->k1 == 16 && a->x2 && a->k2p == 32 && a->x2_index && a->in_dim <= 48 && !rank1 && a->grad_out && a->out && a->out_dtype == PAG_F32 &&
+        a->out_act == PAG_ACT_SIGMOID && a->out_dim <= 4 && a->dx1_col0_add && a->dx1_col0_gate && !a->dx1_accumulate)
+        return 1;
+    return -1;
 }
+
+extern "C" int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *a) { return fused_kind(a) >= 0 ? 1 : 0; }
 
 extern "C" int64_t pag_mlp_bwd_fused_workspace_bytes(int n_layers, int64_t M) {
     if (n_layers < 2 || n_layers > 3 || M < 1) return 0;
@@ -2117,11 +2336,9 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(!a->g_ray || (a->mode == PAG_MLP_MFMA_BF16 && (a->out || a->softmax_stats)),
                   "pag_mlp_bwd: rank-1 gradients need MFMA mode and the saved output");
     const bool fuse = a->wgrad_workspace != nullptr;
+    const int kind = fuse ? fused_kind(a) : -1;
     if (fuse) {
-        PAG_CHECK_ARG(pag_mlp_bwd_fused_supported(a->mode, a->out_dim, a->k1, a->x1_layout, a->x1_levels, a->x1_feats, a->in_dim, a->x2 ? a->k2p : 0) == 1,
-                      "pag_mlp_bwd: fused weight gradients need MFMA mode, out_dim <= 32 and a free input column 63");
-        PAG_CHECK_ARG(a->x1 && a->x1_dtype == PAG_BF16, "pag_mlp_bwd: fused weight gradients need the bf16 layer-0 input x1");
-        PAG_CHECK_ARG(a->x2 == nullptr || (a->k2p > 0 && a->k2p % 8 == 0 && a->x2_index), "pag_mlp_bwd: x2 needs k2p %% 8 == 0 and x2_index");
+        PAG_CHECK_ARG(kind >= 0, "pag_mlp_bwd: this decoder shape has no fused weight-gradient kernel (pag_mlp_bwd_fused_supported)");
         PAG_CHECK_ARG(a->wgrad_workspace_bytes >= pag_mlp_bwd_fused_workspace_bytes(a->n_layers, M), "pag_mlp_bwd: wgrad_workspace too small");
         for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->dW[l] && a->db[l], "pag_mlp_bwd: NULL dW/db of layer %d", l);
     }
@@ -2180,20 +2397,27 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         }
         const size_t lds = (size_t)(64 * (32 + 8) + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t) +
                            (size_t)4 * (a->n_layers + 1) * TW_ELEMS * sizeof(bf16_t);
-#define MLP_BWD_FUSED(OutT, NL_)                                                                                                      \
+#define MLP_BWD_FUSED(NL_, KIND_, ACC_)                                                                                              \
     do {                                                                                                                              \
         static bool attr_done = false;                                                                                                \
         if (!attr_done) {                                                                                                             \
-            hipFuncSetAttribute((const void *)mlp_bwd_mfma<OutT, bf16_t, NL_, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipFuncSetAttribute((const void *)mlp_bwd_fused<NL_, KIND_, ACC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_done = true;                                                                                                         \
         }                                                                                                                             \
-        hipLaunchKernelGGL((mlp_bwd_mfma<OutT, bf16_t, NL_, 1, true>), dim3(grid), dim3(256), lds, st, p);                          \
+        hipLaunchKernelGGL((mlp_bwd_fused<NL_, KIND_, ACC_>), dim3(grid), dim3(256), lds, st, p);                                     \
     } while (0)
-        PAG_CHECK_ARG(a->dx1 == nullptr || a->dx1_dtype == PAG_BF16, "pag_mlp_bwd: fused weight gradients write a bf16 dx1");
-        if (out_f32 && a->n_layers == 2) MLP_BWD_FUSED(float, 2);
-        else if (out_f32) MLP_BWD_FUSED(float, 3);
-        else if (a->n_layers == 2) MLP_BWD_FUSED(bf16_t, 2);
-        else MLP_BWD_FUSED(bf16_t, 3);
+        const bool acc = a->dx1_accumulate != 0;
+        if (a->n_layers == 2) {
+            if (kind == 0) MLP_BWD_FUSED(2, 0, false);
+            else if (kind == 1) MLP_BWD_FUSED(2, 1, false);
+            else if (acc) MLP_BWD_FUSED(2, 2, true);
+            else MLP_BWD_FUSED(2, 2, false);
+        } else {
+            if (kind == 0) MLP_BWD_FUSED(3, 0, false);
+            else if (kind == 1) MLP_BWD_FUSED(3, 1, false);
+            else if (acc) MLP_BWD_FUSED(3, 2, true);
+            else MLP_BWD_FUSED(3, 2, false);
+        }
 #undef MLP_BWD_FUSED
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused)");
         FinishBatch fb{};

@@ -356,17 +356,7 @@ class _FusedMLP(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         need_dx2 = ctx.needs_input_grad[1] and x2 is not None
         dx1 = (dx1_into if dx1_into is not None else torch.empty(x1.shape, device=dev, dtype=x1.dtype)) if need_dx else None
-        # weight gradients inside the backward-data launch (pag_mlp_bwd_args.wgrad_workspace): narrow decoders on the bf16 path;
-        # d x2 (pose optimisation) is formed from dz_0, so that case keeps the dz tensors and the separate weight-gradient launches
         k2p = x2.shape[1] if x2 is not None else 0
-        fused = bool(WGRAD_FUSED and M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 and not need_dx2 and
-                     (dx1 is None or dx1.dtype == torch.bfloat16) and
-                     lib.pag_mlp_bwd_fused_supported(mode, out_dim, k1, L.LAYOUT_XCD8 if grouped is not None else L.LAYOUT_STRIDED,
-                                                     grouped[0] if grouped is not None else 0, grouped[1] if grouped is not None else 0,
-                                                     in_dim, k2p) == 1)
-        dz = None
-        if not fused:
-            dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
         a = L.MlpBwdArgs()
         if rank1 is None:
             g = g.contiguous().to(out_dtype)       # grad_out travels in the output's dtype
@@ -383,8 +373,6 @@ class _FusedMLP(torch.autograd.Function):
             a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
         for i in range(n_layers):
             a.W[i] = L.ptr(Wc[i])
-            if dz is not None:
-                a.dz[i] = L.ptr(dz[i])
         for i, h in enumerate(hidden):
             a.hidden_save[i] = L.ptr(h)
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
@@ -397,18 +385,29 @@ class _FusedMLP(torch.autograd.Function):
             a.dx1_col0_add = L.ptr(col0_add)
             if col0_gate is not None:
                 a.dx1_col0_gate = L.ptr(col0_gate)
+        # Weight gradients inside the backward-data launch (pag_mlp_bwd_args.wgrad_workspace) where the library has a fused
+        # kernel for this decoder shape: no dz tensors, no second pass over the activations.  d x2 (pose optimisation) is formed
+        # from dz_0, so that case keeps the dz tensors and the separate weight-gradient launches.
+        fused = False
+        if WGRAD_FUSED and M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 and not need_dx2:
+            a.x1, a.x1_dtype = L.ptr(x1), L.BF16
+            if x2 is not None:
+                a.x2, a.k2p, a.x2_index = L.ptr(x2), k2p, L.ptr(x2_index)
+            fused = lib.pag_mlp_bwd_fused_supported(ctypes.byref(a)) == 1
+        dz = None
         gW, gb = [], []
         if fused:
             ws_bytes = lib.pag_mlp_bwd_fused_workspace_bytes(n_layers, M)
             ws = torch.empty(ws_bytes // 4, device=dev)
-            a.x1, a.x1_dtype = L.ptr(x1), L.BF16
-            if x2 is not None:
-                a.x2, a.k2p, a.x2_index = L.ptr(x2), k2p, L.ptr(x2_index)
             a.wgrad_workspace, a.wgrad_workspace_bytes = L.ptr(ws), ws_bytes
             for l in range(n_layers):
                 gW.append(torch.empty(Wc[l].shape[0], in_dim if l == 0 else 64, device=dev))
                 gb.append(torch.empty(Wc[l].shape[0], device=dev))
                 a.dW[l], a.db[l] = L.ptr(gW[l]), L.ptr(gb[l])
+        else:
+            dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
+            for i in range(n_layers):
+                a.dz[i] = L.ptr(dz[i])
         if M:
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
         if col0_add is not None and need_dx and not fuse_col0:
