@@ -225,7 +225,7 @@ typedef struct {
      * tiles it holds anyway: no dz tensor is written (dz[] may be NULL) and no second pass re-reads [M,64] activations
      * (536 MB per 64 x 64 layer at M = 2.1 M - the separate pag_mlp_wgrad_batch ran at the HBM rate on exactly those bytes).
      * Needs the forward's layer-0 input: x1 (bf16; layout / levels / feats as above) and, if the forward had it, x2 / x2_index.
-     * wgrad_workspace: device scratch of pag_mlp_bwd_fused_workspace_bytes(n_layers, M) bytes (per-wave partial sums, reduced in a
+     * wgrad_workspace: device scratch of pag_mlp_bwd_fused_workspace_bytes(args, M) bytes (per-wave partial sums, reduced in a
      * fixed order by a second tiny launch: deterministic). */
     const void *x1; int x1_dtype; const float *x2; int k2p; const int32_t *x2_index;
     float *wgrad_workspace; int64_t wgrad_workspace_bytes;
@@ -239,10 +239,13 @@ int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
  *                  dx1_col0_add + dx1_col0_gate
  *   semantic-like  XCD8 bf16 x1, rank-1 gradient (g_ray, g_scale, g_index, g_ray_scale), softmax with the saved bf16 `out`,
  *                  out_dim <= 8, XCD8 bf16 dx1 (dx1_accumulate allowed)
- * each with 2 or 3 layers, out_dim <= 32, and input column 63 free (XCD8: staged position 63 is padding; it carries the
+ *   wide softmax   XCD8 bf16 x1, rank-1 gradient, softmax_stats + b_last (the instance head: 3 layers, 192 < out_dim <= 224), XCD8
+ *                  bf16 dx1: two launches - the output layer with its weight gradient (the [M, out_dim] softmax gradient is never
+ *                  written), then the two layers below it on the hidden gradient
+ * the first three with 2 or 3 layers, out_dim <= 32, and input column 63 free (XCD8: staged position 63 is padding; it carries the
  * constant 1 whose weight gradient is the layer-0 bias gradient).  Anything else: dz[] + pag_mlp_wgrad_batch. */
 int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *args);
-int64_t pag_mlp_bwd_fused_workspace_bytes(int n_layers, int64_t M);
+int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *args, int64_t M);
 
 /* Wide softmax head fused with the per-ray weighted sum of tracers/panoptic_packed_rf_tracer.py:197-205:
  *   out[ray][c] = alpha[ray] * sum_{i in pack} weights[i] * softmax(W_last . hidden[i] + b_last)[c]

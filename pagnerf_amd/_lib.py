@@ -80,7 +80,7 @@ _SIGS = {
     "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd_fused_supported": (c_i32, [ctypes.POINTER(MlpBwdArgs)]),
-    "pag_mlp_bwd_fused_workspace_bytes": (c_i64, [c_i32, c_i64]),
+    "pag_mlp_bwd_fused_workspace_bytes": (c_i64, [ctypes.POINTER(MlpBwdArgs), c_i64]),
     "pag_head_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_mlp_wgrad_blocks": (c_i32, [c_i64]),
     "pag_mlp_wgrad_batch": (c_i32, [ctypes.POINTER(WgradLayer), c_i32, c_i64, c_vp]),

@@ -1061,15 +1061,16 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
 //   KIND 2  semantic-like: XCD8 bf16 input, rank-1 gradient, softmax with saved bf16 probabilities (out_dim <= 8), XCD8 bf16 dx
 //                          (DXACC: added to the other head's gradient in place)
 // Full 32-sample tiles run in the main loop; a ragged last tile runs once after it with predicated stores.
-template <int NL, int KIND, bool DXACC>
+template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
+    static_assert(OBL == 1 || KIND == 0, "a 64-wide output layer exists for the dense-gradient form only");
     constexpr bool GRP = KIND != 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RSL = 32 + 8;
+    constexpr int RSL = OBL * 32 + 8;
     bf16_t *WLt = reinterpret_cast<bf16_t *>(smem);              // [64 in][RSL]  k = output channel (permuted)
     bf16_t *W1t = WLt + 64 * RSL;                                // [64][RS]      (NL == 3)
     bf16_t *W0t = W1t + (NL == 3 ? 64 * RS : 0);                 // [64 in-feature rows][RS]
-    stage_weight_t(WLt, RSL, 64, 32, p.W[NL - 1], p.out_dim, HID);
+    stage_weight_t(WLt, RSL, 64, OBL * 32, p.W[NL - 1], p.out_dim, HID);
     if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
     stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
     bf16_t *Tx = W0t + 64 * RS + (threadIdx.x >> 6) * ((NL + 1) * TW_ELEMS);      // wave-private swizzled tiles
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
 
     // ---- registers of the NEXT tile (requested one tile ahead; the per-ray row index two tiles ahead)
     bf16x8 hn[NL - 1][4], xn[4];
-    bf16x4 gz[KIND == 0 ? 4 : 1], oldx[DXACC ? 2 : 1][4];
+    bf16x4 gz[OBL][KIND == 0 ? 4 : 1], oldx[DXACC ? 2 : 1][4];
     float gs[4], gy[4], gsc = 0.0f, c0a = 0.0f, c0g = 0.0f;      // KIND 1: gradient / output; KIND 2: g_ray row / probabilities
     int ray1 = 0, ray2 = 0;                                        // row index of the tile after next (and the one after that)
     auto row_of = [&](int64_t tile) __attribute__((always_inline)) { return min(min(tile, ntiles - 1) * 32 + r, M - 1); };
@@ -1111,10 +1112,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         if constexpr (KIND == 0) {
             const bf16_t *gop = reinterpret_cast<const bf16_t *>(p.grad_out) + m * p.out_dim;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 8 * g + 4 * h;
-                gz[g] = *reinterpret_cast<const bf16x4 *>(gop + (c0 < p.out_dim ? c0 : 0));
-            }
+            for (int ob = 0; ob < OBL; ++ob)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 32 * ob + 8 * g + 4 * h;
+                    gz[ob][g] = *reinterpret_cast<const bf16x4 *>(gop + (c0 < p.out_dim ? c0 : 0));
+                }
         } else if constexpr (KIND == 1) {
             const float *gop = reinterpret_cast<const float *>(p.grad_out) + m * p.out_dim;
             const float *yop = reinterpret_cast<const float *>(p.out) + m * p.out_dim;
@@ -1148,13 +1151,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     };
 
     // ---- weight-gradient accumulators (the whole launch) and their feeding
-    f32x16 awL[1][2], awM[NL == 3 ? 2 : 1][2], aw0[2][2], dbacc;
+    f32x16 awL[OBL][2], awM[NL == 3 ? 2 : 1][2], aw0[2][2], dbacc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         dbacc[q] = 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            awL[0][i][q] = 0.0f;
+#pragma unroll
+            for (int ob = 0; ob < OBL; ++ob) awL[ob][i][q] = 0.0f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 aw0[i][j][q] = 0.0f;
@@ -1224,17 +1228,22 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
             if (h == 1) xb[3][7] = (bf16_t)1.0f;      // column 63 := 1: its dW column is the layer-0 bias gradient
             tw_put_frags(Tx, xb, r, h);
         }
-        // ---- upstream gradient of this tile -> dz of the output layer (one 32-row block)
-        f32x16 z;
+        // ---- upstream gradient of this tile -> dz of the output layer (OBL 32-row blocks)
+        f32x16 zv[OBL];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) z[q] = 0.0f;
+        for (int ob = 0; ob < OBL; ++ob)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) zv[ob][q] = 0.0f;
+        f32x16 &z = zv[0];
         if constexpr (KIND == 0) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bool ok = 8 * g + 4 * h < p.out_dim;
+            for (int ob = 0; ob < OBL; ++ob)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) z[4 * g + j] = ok ? (float)gz[g][j] : 0.0f;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const bool ok = 32 * ob + 8 * g + 4 * h < p.out_dim;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zv[ob][4 * g + j] = ok ? (float)gz[ob][g][j] : 0.0f;
+                }
         } else if constexpr (KIND == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1267,13 +1276,16 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         prefetch(tile + tile_step, ray1);
         ray1 = ray2;
         if constexpr (KIND != 0) ray2 = ridx[row_of(tile + 3 * tile_step)];
-        if constexpr (!FULL) {
+        bf16x8 zb[2 * OBL];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) z[q] = live ? z[q] : 0.0f;
+        for (int ob = 0; ob < OBL; ++ob) {
+            if constexpr (!FULL) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) zv[ob][q] = live ? zv[ob][q] : 0.0f;
+            }
+            pack_block(zv[ob], zb[2 * ob], zb[2 * ob + 1]);
+            tw_put_block(Tz, ob, r, h, zv[ob]);
         }
-        bf16x8 zb[2];
-        pack_block(z, zb[0], zb[1]);
-        tw_put_block(Tz, 0, r, h, z);
         wave_lds_sync();
         wgrad_tile(NL == 3 ? Th1 : Th0, awL, 0);
         wave_lds_sync();
@@ -1285,7 +1297,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 2 * OBL; ++s) {
                 bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * s + 8 * h);
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[s], acc[mb], 0, 0, 0);
             }
@@ -1300,7 +1312,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         tw_put_block(Tz, 0, r, h, acc[0]);
         tw_put_block(Tz, 1, r, h, acc[1]);
         wave_lds_sync();
-        if constexpr (NL == 3) wgrad_tile(Th0, awM, 1);
+        if constexpr (NL == 3) wgrad_tile(Th0, awM, OBL);
         else wgrad_tile(Tx, aw0, -1);
         wave_lds_sync();
         if constexpr (NL == 3) {
@@ -1391,8 +1403,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         }
     };
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib) put(p.slabs[NL - 1], 32, 0, ib, awL[0][ib]);
-    put_db(p.slabs[NL - 1], 32, 0, r == 0, dbacc);
+    for (int ob = 0; ob < OBL; ++ob) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) put(p.slabs[NL - 1], OBL * 32, ob, ib, awL[ob][ib]);
+        put_db(p.slabs[NL - 1], OBL * 32, ob, r == ob, dbacc);
+    }
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
 #pragma unroll
@@ -1401,7 +1416,276 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
             if constexpr (NL == 3) put(p.slabs[1], 64, ob, ib, awM[ob][ib]);
         }
         put_db(p.slabs[0], 64, ob, r == 31, aw0[ob][1]);             // input column 63 (the ones column)
-        if constexpr (NL == 3) put_db(p.slabs[1], 64, ob, r == 1 + ob, dbacc);
+        if constexpr (NL == 3) put_db(p.slabs[1], 64, ob, r == OBL + ob, dbacc);
+    }
+}
+
+// -------------------------------------------- wide softmax head: output layer backward + its weight gradient (one launch)
+// Stage A of the fused backward of a decoder whose last layer is wide (the 200-way instance head): per 32-sample tile the
+// probabilities are rebuilt from the saved last hidden layer and the forward's softmax statistics (as mlp_bwd_wide_mfma does),
+// dz_L is formed block by block from the rank-1 upstream gradient and consumed at once - by the W_L^T chain (-> the hidden
+// layer's gradient, written as a [M,64] bf16 tensor for stage B: mlp_bwd_fused<.., KIND 0, OBL 2> on the remaining layers) and by
+// this wave's dW_L accumulators (OB x 2 blocks of 16 registers, for the whole launch; transposed LDS reads as in
+// mlp_bwd_fused).  The [M, out_dim] softmax gradient (839 MB at M = 2.1 M, written once and read once before) never exists.
+// One wave per SIMD; straight-line tile loop: next tile's hidden rows, statistics and the gradient rows of its (up to 4) rays
+// are requested one tile ahead, the hidden-gradient stores of a tile go out at the top of the next one.
+constexpr int WR_MAX = 2;          // rays whose gradient rows are staged per tile (a tile spanning more takes per-lane global loads)
+constexpr int WR_RS = 256;         // floats per staged row
+template <int OB>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_wide_fused(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RSL = OB * 32 + 8;
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16_t *WLt = reinterpret_cast<bf16_t *>(smem);              // [64 hidden][RSL]   k = output channel (permuted)
+    bf16_t *WLs = WLt + 64 * RSL;                                // [OB*32 channels][RS] permuted k (forward layout)
+    float *bLs = reinterpret_cast<float *>(WLs + OB * 32 * RS);  // [OB*32]
+    bf16_t *Th = reinterpret_cast<bf16_t *>(bLs + OB * 32) + (threadIdx.x >> 6) * (3 * TW_ELEMS);      // wave-private: activations, dz, hidden gradient
+    bf16_t *Tz = Th + TW_ELEMS, *Tp = Tz + TW_ELEMS;
+    float *grow = reinterpret_cast<float *>(reinterpret_cast<bf16_t *>(bLs + OB * 32) + 4 * 3 * TW_ELEMS) + (threadIdx.x >> 6) * (WR_MAX * WR_RS);
+    stage_weight_t(WLt, RSL, 64, OB * 32, p.W[0], p.out_dim, HID);
+    stage_weight(WLs, RS, OB * 32, 64, p.W[0], p.out_dim, HID, true);
+    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b_last[e] : 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t M = p.M, ntiles = (M + 31) / 32, nfull = M / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const bf16_t *hsrc = reinterpret_cast<const bf16_t *>(p.hsave[0]);
+    bf16_t *dzh = reinterpret_cast<bf16_t *>(p.dz[0]);
+
+    // ---- registers of the next tile
+    bf16x8 hn[4];
+    float2 st_n = {0.0f, 1.0f};
+    float gs_n = 0.0f, grow_n[4 * WR_MAX];
+    int ray1 = 0, ray2 = 0;          // this lane's ray in the next tile / the one after
+    auto row_of = [&](int64_t tile) __attribute__((always_inline)) { return min(min(tile, ntiles - 1) * 32 + r, M - 1); };
+    auto prefetch = [&](int64_t tile_raw, int ray) __attribute__((always_inline)) {
+        const int64_t tile = min(tile_raw, ntiles - 1);
+        const int64_t m = min(tile * 32 + r, M - 1);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int64_t row = min(tile * 32 + it * 8 + (lane >> 3), M - 1);
+            hn[it] = load8(hsrc + row * HID + (lane & 7) * 8);
+        }
+        st_n = *reinterpret_cast<const float2 *>(p.stats + 2 * m);
+        gs_n = __fmul_rn(p.g_scale[m], p.g_ray_scale[ray]);
+        const int ray_first = __builtin_amdgcn_readfirstlane(ray), ray_last = __builtin_amdgcn_readlane(ray, 31);
+#pragma unroll
+        for (int k = 0; k < 4 * WR_MAX; ++k) {      // staged row k / 4 (ray_first + k / 4, clamped to the tile's last ray), column 64 (k % 4) + lane
+            const int rr = min(ray_first + (k >> 2), ray_last);
+            const int col = min(64 * (k & 3) + lane, p.out_dim - 1);
+            grow_n[k] = p.g_ray[(int64_t)rr * p.out_dim + col];
+        }
+    };
+
+    f32x16 awL[OB][2], dbacc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        dbacc[q] = 0.0f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+            awL[ob][0][q] = 0.0f;
+            awL[ob][1][q] = 0.0f;
+        }
+    }
+    auto ones_col = [&](int j) __attribute__((always_inline)) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(r == j ? 1.0f : 0.0f);
+        return o;
+    };
+    // The hidden-layer gradient of a tile stays in its LDS image (Tp) and is stored at the top of the NEXT tile, after that tile's
+    // prefetched registers have been consumed and before the next prefetch is issued (see mlp_bwd_fused: stores issued at the end
+    // of a tile would have to drain before the next tile could touch its prefetched data).  First flush: zeros.
+    for (int e = lane; e < TW_ELEMS / 4; e += 64) reinterpret_cast<bf16x4 *>(Tp)[e] = bf16x4{(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
+    int64_t pend_tile = min((int64_t)blockIdx.x * 4 + wave, ntiles - 1);
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rowl = it * 8 + (lane >> 3), ch = (lane & 7) * 2;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(Tp + tw_off(rowl, ch));
+            const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(Tp + tw_off(rowl, ch + 1));
+            const int64_t row = pend_tile * 32 + rowl;
+            if (row < M) *reinterpret_cast<bf16x8 *>(dzh + row * HID + (lane & 7) * 8) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+
+    int ray_cur = 0;
+    auto body = [&](int64_t tile) __attribute__((always_inline)) {
+        const int64_t m = tile * 32 + r;
+        const bool live = m < M;
+        // ---- this tile's activations -> LDS image; the gradient rows of its first WR_MAX rays -> LDS
+        wave_lds_sync();
+        tw_put_rows(Th, hn, lane);
+#pragma unroll
+        for (int k = 0; k < 4 * WR_MAX; ++k) grow[(k >> 2) * WR_RS + 64 * (k & 3) + lane] = grow_n[k];
+        const float Ms = st_n.x, inv = st_n.y, g_sc = gs_n;
+        const int ray_first = __builtin_amdgcn_readfirstlane(ray_cur), ray_last = __builtin_amdgcn_readlane(ray_cur, 31);
+        const int roff = ray_cur - ray_first;
+        flush();
+        prefetch(tile + tile_step, ray1);
+        ray_cur = ray1;
+        ray1 = ray2;
+        ray2 = p.g_index[row_of(tile + 3 * tile_step)];
+        wave_lds_sync();
+        // the forward's B operand of the output layer (exact: the saved bf16 activations) and the transposed fragments for dW_L
+        bf16x8 hbL[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(Th + tw_off(r, 8 * mb + 4 * half + h));
+                const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(Th + tw_off(r, 8 * mb + 4 * half + 2 + h));
+                hbL[2 * mb + half] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        auto prob_block = [&](int ob, f32x16 &o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bLs + 32 * ob + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[4 * g + j] = b4[j];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hbL[s], o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[q] = __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -Ms)) * inv;
+            if (ob == OB - 1) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) o[q] = (32 * ob + rho(q, h) < p.out_dim) ? o[q] : 0.0f;
+            }
+        };
+        f32x16 acc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+        // A tile normally lies inside one ray (or a few): its samples' gradient rows are the <= WR_MAX staged ones.  A tile that
+        // spans more rays (short packs after pruning) is processed in windows of WR_MAX rays: the lanes of the other windows
+        // count as dead (dz = 0), every accumulator simply adds up, and the later windows' rows are loaded in place (rare path).
+        int w0 = 0;
+        bool more;
+        do {
+            const bool mine = live && roff >= w0 && roff < w0 + WR_MAX;
+            const float *grow_l = grow + min(max(roff - w0, 0), WR_MAX - 1) * WR_RS;
+            auto grad_block = [&](int ob, f32x16 &z) __attribute__((always_inline)) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(grow_l + 32 * ob + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[4 * g + j] = g_sc * v[j];
+                }
+            };
+            // pass 1: <p, g> per sample.  The dW_L accumulators leave no registers to keep the probability blocks between the
+            // passes (as mlp_bwd_wide_mfma does): pass 2 rebuilds each block once more (4 MFMAs on idle matrix cores + 16 exp2) -
+            // bitwise the same values, rounded to bf16 like the stored tensor was.
+            float dot = 0.0f;
+#pragma unroll 1
+            for (int ob = 0; ob < OB; ++ob) {
+                f32x16 z, pf;
+                prob_block(ob, pf);
+                grad_block(ob, z);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dot += (float)(bf16_t)pf[q] * z[q];
+            }
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+                f32x16 zz, z, pf;
+                prob_block(ob, pf);
+                grad_block(ob, z);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) zz[q] = mine ? (float)(bf16_t)pf[q] * (z[q] - dot) : 0.0f;
+                bf16x8 zb[2];
+                pack_block(zz, zb[0], zb[1]);
+                tw_put_block(Tz, 0, r, h, zz);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * (2 * ob + half) + 8 * h);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[half], acc[mb], 0, 0, 0);
+                    }
+                wave_lds_sync();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 afr = tw_frag(Tz, 0, ks, lane);
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)      // the activations' transposed fragments are re-read per block: no registers to keep them
+                        awL[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, tw_frag(Th, ib, ks, lane), awL[ob][ib], 0, 0, 0);
+                    dbacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones_col(ob), dbacc, 0, 0, 0);
+                }
+                wave_lds_sync();
+            }
+            w0 += WR_MAX;
+            more = ray_last - ray_first >= w0;
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < 4 * WR_MAX; ++k) {
+                    const int rr = min(ray_first + w0 + (k >> 2), ray_last);
+                    const int col = min(64 * (k & 3) + lane, p.out_dim - 1);
+                    grow[(k >> 2) * WR_RS + 64 * (k & 3) + lane] = p.g_ray[(int64_t)rr * p.out_dim + col];
+                }
+                wave_lds_sync();
+            }
+        } while (more);
+        // ---- dA = W_L^T . dz_L masked by the saved ReLU output -> its LDS image for the deferred store
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(Th + tw_off(r, 8 * mb + 2 * g + h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] = ((float)hv[j] > 0.0f && live) ? acc[mb][4 * g + j] : 0.0f;
+            }
+            tw_put_block(Tp, mb, r, h, acc[mb]);
+        }
+        pend_tile = tile;
+    };
+
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    ray_cur = p.g_index[row_of(tile)];
+    ray1 = p.g_index[row_of(tile + tile_step)];
+    ray2 = p.g_index[row_of(tile + 2 * tile_step)];
+    prefetch(tile, ray_cur);
+    const bool any_tile = tile < ntiles;
+    for (; tile < ntiles; tile += tile_step) body(tile);
+    if (any_tile) {
+        wave_lds_sync();
+        flush();
+    }
+
+    // ---- the four waves' accumulators are summed through LDS (the tiles and weights are dead): one slab per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);                      // [(2 OB + 1) blocks][16 q][64 lanes]
+    constexpr int NB = 2 * OB + 1;
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f32x16 &a = b < 2 * OB ? awL[b >> 1][b & 1] : dbacc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float *dst = red + (b * 16 + q) * 64 + lane;
+                    *dst = w == 0 ? a[q] : *dst + a[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *sl = p.slabs[0] + (int64_t)blockIdx.x * (OB * 32) * WG_SLAB_COLS_F;
+    for (int b = wave; b < NB; b += 4) {
+        const int ob = b >> 1, ib = b & 1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float v = red[(b * 16 + q) * 64 + lane];
+            if (b < 2 * OB) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = v;
+            else if (r < OB) sl[(32 * r + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;      // dbacc column r = bias gradients of block r
+        }
     }
 }
 
@@ -2289,10 +2573,19 @@ static unsigned fused_grid(int64_t M) {
 
 // which mlp_bwd_fused instantiation serves these arguments: 0 density-like, 1 colour-like, 2 semantic-like, -1 none
 static int fused_kind(const pag_mlp_bwd_args *a) {
-    if (!a || a->mode != PAG_MLP_MFMA_BF16 || a->out_dim < 1 || a->out_dim > 32 || !a->dx1 || a->dx1_dtype != PAG_BF16) return -1;
+    if (!a || a->mode != PAG_MLP_MFMA_BF16 || a->out_dim < 1 || a->out_dim > 224 || !a->dx1 || a->dx1_dtype != PAG_BF16) return -1;
     if (a->n_layers != 2 && a->n_layers != 3) return -1;
     if (!a->x1 || a->x1_dtype != PAG_BF16) return -1;
     const bool rank1 = a->g_ray != nullptr;
+    if (a->out_dim > 32) {      // wide softmax head: stage A (output layer, mlp_bwd_wide_fused) + stage B (the two layers below it)
+        if (a->out_dim <= 192 || a->out_dim > 224 || a->n_layers != 3 || !a->g_ray || !a->g_scale || !a->g_index || !a->g_ray_scale) return -1;
+        if (a->out_act != PAG_ACT_SOFTMAX || !a->softmax_stats || !a->b_last || a->out_dtype != PAG_BF16 || !a->dx1 || a->dx1_dtype != PAG_BF16) return -1;
+        if (!a->x1 || a->x1_dtype != PAG_BF16 || a->x1_layout != PAG_LAYOUT_XCD8 || a->k1 != 64 || a->x2 || a->dx1_col0_add || a->dx1_accumulate) return -1;
+        if (a->x1_levels < 1 || a->x1_feats < 1 || ((a->x1_levels + 7) / 8) * a->x1_feats > 8) return -1;
+        const int j = 7 / a->x1_feats;
+        if (j < (a->x1_levels + 7) / 8 && 7 + 8 * j < a->x1_levels) return -1;
+        return 3;
+    }
     if (a->x1_layout == PAG_LAYOUT_XCD8) {
         if (a->k1 != 64 || a->x1_levels < 1 || a->x1_feats < 1 || ((a->x1_levels + 7) / 8) * a->x1_feats > 8) return -1;
         const int j = 7 / a->x1_feats;                            // staged position 63 = group 7, element 7: must be padding
@@ -2312,10 +2605,13 @@ static int fused_kind(const pag_mlp_bwd_args *a) {
 
 extern "C" int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *a) { return fused_kind(a) >= 0 ? 1 : 0; }
 
-extern "C" int64_t pag_mlp_bwd_fused_workspace_bytes(int n_layers, int64_t M) {
-    if (n_layers < 2 || n_layers > 3 || M < 1) return 0;
-    const int64_t slabs = (int64_t)fused_grid(M) * 4;
-    return slabs * ((int64_t)(n_layers - 1) * 64 + 32) * WG_SLAB_COLS * (int64_t)sizeof(float);
+extern "C" int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *a, int64_t M) {
+    const int kind = fused_kind(a);
+    if (kind < 0 || M < 1) return 0;
+    const int64_t grid = fused_grid(M);
+    if (kind == 3)      // stage A: one [224][96] slab per workgroup; stage B: per-wave slabs of two 64-row layers; + the [M,64] bf16 hidden gradient
+        return (grid * 224 + grid * 4 * 128) * WG_SLAB_COLS * (int64_t)sizeof(float) + ((M * HID * 2 + 255) / 256) * 256;
+    return grid * 4 * ((int64_t)(a->n_layers - 1) * 64 + 32) * WG_SLAB_COLS * (int64_t)sizeof(float);
 }
 
 extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
@@ -2339,7 +2635,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     const int kind = fuse ? fused_kind(a) : -1;
     if (fuse) {
         PAG_CHECK_ARG(kind >= 0, "pag_mlp_bwd: this decoder shape has no fused weight-gradient kernel (pag_mlp_bwd_fused_supported)");
-        PAG_CHECK_ARG(a->wgrad_workspace_bytes >= pag_mlp_bwd_fused_workspace_bytes(a->n_layers, M), "pag_mlp_bwd: wgrad_workspace too small");
+        PAG_CHECK_ARG(a->wgrad_workspace_bytes >= pag_mlp_bwd_fused_workspace_bytes(a, M), "pag_mlp_bwd: wgrad_workspace too small");
         for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->dW[l] && a->db[l], "pag_mlp_bwd: NULL dW/db of layer %d", l);
     }
     for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && (fuse || a->dz[l]), "pag_mlp_bwd: NULL weight/dz of layer %d", l);
@@ -2387,6 +2683,58 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     p.x2_index = a->x2_index;
     p.k2p = a->x2 ? a->k2p : 0;
     for (int l = 0; l < 3; ++l) p.slabs[l] = nullptr;
+    if (fuse && kind == 3) {
+        // ---- wide softmax head: stage A (output layer + dW_L) then stage B (layers 0, 1 as a 2-layer decoder whose upstream gradient is
+        //      the hidden gradient stage A wrote)
+        const unsigned grid = fused_grid(M);
+        float *ws = a->wgrad_workspace;
+        float *slabA = ws;
+        ws += (int64_t)grid * 224 * WG_SLAB_COLS;
+        float *slabB0 = ws;
+        ws += (int64_t)grid * 4 * 64 * WG_SLAB_COLS;
+        float *slabB1 = ws;
+        ws += (int64_t)grid * 4 * 64 * WG_SLAB_COLS;
+        bf16_t *dzh = reinterpret_cast<bf16_t *>(ws);
+        BwdParams pa = p;
+        pa.W[0] = a->W[2];
+        pa.hsave[0] = a->hidden_save[1];
+        pa.dz[0] = dzh;
+        pa.slabs[0] = slabA;
+        constexpr int OBW = 7;
+        const size_t ldsA = (size_t)(64 * (OBW * 32 + 8) + OBW * 32 * RS) * sizeof(bf16_t) + (size_t)OBW * 32 * sizeof(float) +
+                            (size_t)4 * 3 * TW_ELEMS * sizeof(bf16_t) + (size_t)4 * WR_MAX * WR_RS * sizeof(float);
+        static bool attrA = false;
+        if (!attrA) {
+            hipFuncSetAttribute((const void *)mlp_bwd_wide_fused<OBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void *)mlp_bwd_fused<2, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attrA = true;
+        }
+        hipLaunchKernelGGL((mlp_bwd_wide_fused<OBW>), dim3(grid), dim3(256), ldsA, st, pa);
+        PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, wide head)");
+        BwdParams pb = p;
+        pb.grad_out = dzh;
+        pb.out = dzh;
+        pb.g_ray = nullptr;
+        pb.out_dim = HID;
+        pb.act = PAG_ACT_NONE;
+        pb.W[0] = a->W[0];
+        pb.W[1] = a->W[1];
+        pb.W[2] = nullptr;
+        pb.hsave[0] = a->hidden_save[0];
+        pb.hsave[1] = nullptr;
+        pb.slabs[0] = slabB0;
+        pb.slabs[1] = slabB1;
+        const size_t ldsB = (size_t)(64 * (64 + 8) + 64 * RS) * sizeof(bf16_t) + (size_t)4 * 3 * TW_ELEMS * sizeof(bf16_t);
+        hipLaunchKernelGGL((mlp_bwd_fused<2, 0, false, 2>), dim3(grid), dim3(256), ldsB, st, pb);
+        PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, layers below the wide head)");
+        FinishBatch fb{};
+        fb.p[0] = FinishParams{slabB0, (int)grid * 4, HID, 64, a->in_dim, p.grp_L, p.grp_F, a->dW[0], a->db[0]};
+        fb.p[1] = FinishParams{slabB1, (int)grid * 4, HID, 64, HID, 0, 0, a->dW[1], a->db[1]};
+        fb.p[2] = FinishParams{slabA, (int)grid, a->out_dim, 224, HID, 0, 0, a->dW[2], a->db[2]};
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(a->out_dim, 3), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
+        PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, finish)");
+        return PAG_OK;
+    }
     if (fuse) {
         // one workgroup per CU, four per-wave slabs each: [n_slabs][rows_pad][96] f32 per layer, hidden layers first
         const unsigned grid = fused_grid(M);

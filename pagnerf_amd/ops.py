@@ -397,7 +397,7 @@ class _FusedMLP(torch.autograd.Function):
         dz = None
         gW, gb = [], []
         if fused:
-            ws_bytes = lib.pag_mlp_bwd_fused_workspace_bytes(n_layers, M)
+            ws_bytes = lib.pag_mlp_bwd_fused_workspace_bytes(ctypes.byref(a), M)
             ws = torch.empty(ws_bytes // 4, device=dev)
             a.wgrad_workspace, a.wgrad_workspace_bytes = L.ptr(ws), ws_bytes
             for l in range(n_layers):

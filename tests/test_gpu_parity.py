@@ -979,7 +979,7 @@ def test_fused_weight_gradients_match_separate_kernels(gpu_device):
         finally:
             ops.WGRAD_FUSED = True
 
-    for M, N in ((32 * 37 + 5, 9), (5, 2), (4096 * 3, 16)):
+    for M, N in ((32 * 37 + 5, 9), (5, 2), (4096 * 3, 16), (1000, 300)):      # the last: ~3 samples per ray, tiles span ~10 rays
         ridx = torch.from_numpy(np.sort(rs.randint(0, N, size=M)).astype(np.int32)).to(dev)
         counts = torch.bincount(ridx.long(), minlength=N)
         pack_start = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(counts, 0)])
