@@ -1581,7 +1581,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wide_fused(BwdParams p) {
             };
             // pass 1: <p, g> per sample.  The dW_L accumulators leave no registers to keep the probability blocks between the
             // passes (as mlp_bwd_wide_mfma does): pass 2 rebuilds each block once more (4 MFMAs on idle matrix cores + 16 exp2) -
-            // bitwise the same values, rounded to bf16 like the stored tensor was.
+            // bitwise the same values; the dot product uses them in fp32, dz their bf16 rounding (the precision the stored
+            // tensor had) - exactly the arithmetic of mlp_bwd_wide_mfma.
             float dot = 0.0f;
 #pragma unroll 1
             for (int ob = 0; ob < OB; ++ob) {
@@ -1589,7 +1590,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wide_fused(BwdParams p) {
                 prob_block(ob, pf);
                 grad_block(ob, z);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) dot += (float)(bf16_t)pf[q] * z[q];
+                for (int q = 0; q < 16; ++q) dot += pf[q] * z[q];
             }
             dot += __shfl_xor(dot, 32);
 #pragma unroll

@@ -1054,8 +1054,10 @@ def test_fused_weight_gradients_match_separate_kernels(gpu_device):
             oi, os_ = ops.head_composite_pair(x8, ((Wig, big, 48), (Wsg, bsg, 48)), wts, alpha, ridx, pack_start, ray_of_pack, N,
                                               out_dtype=torch.bfloat16, x1_grouped=(24, 2))
             ((oi * gi).sum() + (os_ * gs).sum()).backward()
-        for fn, prms in ((sem, Wsg + bsg + [x8]), (pair, Wsg + bsg + Wig + big + [x8])):
+        # the instance head runs as two launches with its hidden gradient as a bf16 tensor in between (the rounding the register
+        # path applies too) and sums a tile that spans several rays in windows: a few bf16 ulps move
+        for fn, prms, lim in ((sem, Wsg + bsg + [x8], 1e-4), (pair, Wsg + bsg + Wig + big + [x8], 5e-4)):
             a = run(fn, prms, True)
             bsep = run(fn, prms, False)
             for u, v in zip(a, bsep):
-                assert _rel_l2(u.float(), v.float()) < 1e-4
+                assert _rel_l2(u.float(), v.float()) < lim
