@@ -89,7 +89,7 @@ int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int 
                            int n_levels, int n_feat, uint32_t capacity,
                            const float *scale_factor_host, const float *shift_host,
                            const float *feat_scale_host, void *out, int out_dtype,
-                           int64_t out_stride_m, int64_t out_stride_c, int layout, void *records, int flags, void *stream);
+                           int64_t out_stride_m, int64_t out_stride_c, int layout, int flags, void *stream);
 
 /* Same encoders writing  out = bf16(addend + bf16(features))  in the XCD8 layout (addend, out: bf16 [8][M][8]).
  * pc_nerf/panoptic_delta_nef.py:226 forms the panoptic features as `feats.detach() + delta`; with the main grid's
@@ -100,13 +100,13 @@ int pag_hash_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int
 int pag_permuto_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype,
                                int n_levels, int n_feat, uint32_t capacity,
                                const float *scale_factor_host, const float *shift_host,
-                               const float *feat_scale_host, const void *addend, void *out, void *records, int flags, void *stream);
+                               const float *feat_scale_host, const void *addend, void *out, int flags, void *stream);
 
 int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype,
                            int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                            uint32_t capacity, const float *scale_factor_host,
                            const float *shift_host, const float *feat_scale_host,
-                           float *grad_tables, void *workspace, int64_t workspace_bytes, const void *records, int flags, void *stream);
+                           float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream);
 
 /* As pag_hash_encode_bwd / pag_permuto_encode_bwd, but grad_tables is OVERWRITTEN: every row of every level is written
  * (zeros where no gradient arrived), so the caller need not clear the table first and the reduce pass does not read it.
@@ -119,7 +119,7 @@ int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out
                                int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat,
                                uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                const float *feat_scale_host, float *grad_tables, void *workspace,
-                               int64_t workspace_bytes, const void *records, int flags, void *stream);
+                               int64_t workspace_bytes, int flags, void *stream);
 
 /* d loss / d xyz of the two encoders (camera pose optimisation, pc_nerf/ba_pipeline.py:85-92: the
  * samples o + t*d depend on the learnable extrinsics).  The reference gets this from autograd through
@@ -139,14 +139,6 @@ int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const void *tables, 
                                uint32_t capacity, const float *scale_factor_host,
                                const float *shift_host, const float *feat_scale_host, float *d_xyz,
                                void *workspace, int64_t workspace_bytes, int flags, void *stream);
-
-/* Simplex records (permutohedral encoder, optional): with `records` != NULL (u64 [n_levels][M], pag_permuto_records_bytes()) the forward
- * also stores 8 bytes per (sample, level) - row of vertex 0, the rank permutation, the barycentric weights of vertices 1..3 as
- * fixed point (13 bits at capacity 2^18) - and pag_permuto_encode_bwd(_set) given the same buffer skips re-deriving the lattice
- * (about 200 of the bin pass's ~470 instructions per 64 samples and level).  F = 2, f32 tables, bf16 output / gradients and a
- * power-of-two capacity only; the quantised weights change a gradient contribution by <= 6e-5 relative to the weight sum, a
- * twentieth of the bf16 rounding of the upstream gradient.  xyz is then not read by the table-gradient call. */
-int64_t pag_permuto_records_bytes(int64_t M, int n_levels);
 
 /* Scratch size for the atomic-free ("binned") backward of either encoder: n_vertices = 8 (hash) or
  * 4 (permuto), rows_per_level = 2^log2_T or capacity.  The caller allocates it (device memory) and

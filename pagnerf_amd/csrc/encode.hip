@@ -153,12 +153,11 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(const float *__restrict__
     }
 }
 
-template <typename TableT, typename OutT, int F, int LPX, bool ADD = false, bool REC = false>
+template <typename TableT, typename OutT, int F, int LPX>
 __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                           const TableT *__restrict__ tables, PermutoParams p,
                                                           OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped,
-                                                          const bf16_t *__restrict__ addend_in, uint64_t *__restrict__ records) {
-    const bf16_t *addend = ADD ? addend_in : nullptr;      // ADD is a separate symbol so that kernel statistics tell the two launches apart
+                                                          const bf16_t *__restrict__ addend) {
     const int g = blockIdx.x & 7;
     const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
     if (i >= M) return;
@@ -186,13 +185,7 @@ __global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restric
             continue;
         }
 #endif
-        if constexpr (REC) {
-            int slot[4];
-            permuto_simplex(x, p.shift[le], p.sf[le], p.capacity, p.pow2mask, idx, bary[j], slot);
-            if (l < p.L) __builtin_nontemporal_store(record_pack(record_format(p.capacity), idx[0], slot, bary[j]), records + (int64_t)l * M + i);
-        } else {
-            permuto_simplex(x, p.shift[le], p.sf[le], p.capacity, p.pow2mask, idx, bary[j]);
-        }
+        permuto_simplex(x, p.shift[le], p.sf[le], p.capacity, p.pow2mask, idx, bary[j]);
         const TableT *tab = tables + (int64_t)le * p.capacity * F;
 #ifdef PAG_DBG_HOTIDX      // experiment: all gathers hit 256 hot rows (isolates the arithmetic + store cost)
 #pragma unroll
@@ -467,7 +460,7 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[
     emit = live && (lane == 63 || !next_same);
 }
 
-template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool PACK, bool REC = false>
+template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool PACK>
 // TWO 1024-thread workgroups per CU (8 waves per SIMD, <= 64 VGPRs): with one, every block barrier of the counting sort / staging
 // stalls the whole CU - nothing else is resident to run.  The permutohedral variant fits 64 VGPRs with 48 B of scratch and the encode
 // backward drops from 2.18 to 1.75 ms per step; the hash variant (8 vertices) would spill 140 - 300 B and is measured separately.
@@ -478,8 +471,7 @@ template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool P
 #define PAG_BIN_WAVES_HASH 4
 #endif
 __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_BIN_WAVES : PAG_BIN_WAVES_HASH)) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
-                                                 int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay,
-                                                 const uint64_t *__restrict__ records) {
+                                                 int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
     constexpr int NV = KIND == 0 ? 8 : 4;
     constexpr int TS = tile_samples(NV);
 #ifndef PAG_BIN_NO_STAGE
@@ -496,8 +488,8 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
     const int64_t i = tile * TS + tid;
     const bool live = i < M;
     const int64_t ic = live ? i : M - 1;
-    float x[3] = {0.0f, 0.0f, 0.0f};
-    if constexpr (!REC) load_xyz(xyz, ic, KIND == 0 ? hp.half_coords : pp.half_coords, x);
+    float x[3];
+    load_xyz(xyz, ic, KIND == 0 ? hp.half_coords : pp.half_coords, x);
     // grouped (LPX = ceil(L/8)): blockIdx.y = XCD group g, levels g, g+8, ... share ONE counting sort and the 16-byte
     // gradient piece is read once.  strided (LPX = 1): blockIdx.y = level.
     float gpiece[8];
@@ -534,23 +526,7 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
         } else {
             uint32_t id4[4];
             float b4[4];
-            if constexpr (REC) record_unpack(record_format(pp.capacity), __builtin_nontemporal_load(records + (int64_t)lc * M + ic), pp.pow2mask, id4, b4);
-            else permuto_simplex(x, pp.shift[lc], pp.sf[lc], pp.capacity, pp.pow2mask, id4, b4);
-#ifdef PAG_DBG_BIN_TWICE      // experiment: what ONE lattice evaluation costs inside this kernel (the second result is kept alive, not used)
-            {
-                int zero = 0;
-                asm volatile("" : "+v"(zero));
-                float x2[3] = {x[0] + (float)zero, x[1] + (float)zero, x[2] + (float)zero};
-                uint32_t id4b[4];
-                float b4b[4];
-                permuto_simplex(x2, pp.shift[lc], pp.sf[lc], pp.capacity, pp.pow2mask, id4b, b4b);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    id4[k] += id4b[k] & (uint32_t)zero;
-                    b4[k] += b4b[k] * (float)zero;
-                }
-            }
-#endif
+            permuto_simplex(x, pp.shift[lc], pp.sf[lc], pp.capacity, pp.pow2mask, id4, b4);
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 idx[j][k] = id4[k & 3];
@@ -809,7 +785,7 @@ inline BinPlan bin_plan(int64_t M, int L, int F, int NV, int64_t rows) {
 template <int KIND>
 int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t sm, int64_t sc, int grouped, int L, int F,
                   int64_t rows, const HashParams &hp, const PermutoParams &pp, float *gtab, void *workspace,
-                  int64_t workspace_bytes, hipStream_t st, const char *name, bool overwrite = false, const void *records = nullptr) {
+                  int64_t workspace_bytes, hipStream_t st, const char *name, bool overwrite = false) {
     constexpr int NV = KIND == 0 ? 8 : 4;
     const BinPlan b = bin_plan(M, L, F, NV, rows);
     PAG_CHECK_ARG(workspace_bytes >= b.total, "%s: workspace %lld B < required %lld B", name, (long long)workspace_bytes, (long long)b.total);
@@ -827,17 +803,8 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
     dim3 g1((unsigned)b.ntiles, (unsigned)(grouped ? (L < 8 ? L : 8) : L)), g2((unsigned)(L * b.NS));
     const size_t lds = ((size_t)1 << b.shift) * F * sizeof(unsigned long long);
     const int lpx = grouped ? (L + 7) / 8 : 1;
-    const uint64_t *recs = (const uint64_t *)records;
 #define BIN_LAUNCH1(GT, F_, LPX_)                                                                                       \
-    do {                                                                                                                \
-        if constexpr (KIND == 1 && sizeof(GT) == 2 && F_ == 2) {                                                        \
-            if (recs) {                                                                                                 \
-                hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_, true, true>), g1, dim3(tile_samples(NV)), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay, recs); \
-                break;                                                                                                  \
-            }                                                                                                           \
-        }                                                                                                               \
-        hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_, (sizeof(GT) == 2 && F_ == 2)>), g1, dim3(tile_samples(NV)), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay, (const uint64_t *)nullptr); \
-    } while (0)
+    hipLaunchKernelGGL((bin_kernel<KIND, GT, F_, LPX_, (sizeof(GT) == 2 && F_ == 2)>), g1, dim3(tile_samples(NV)), 0, st, xyz, M, (const GT *)grad_out, sm, sc, grouped, hp, pp, lay)
 #define BIN_LAUNCH(GT, F_)                                                                                              \
     do {                                                                                                                \
         if (lpx == 1) BIN_LAUNCH1(GT, F_, 1);                                                                           \
@@ -1016,12 +983,9 @@ static int fill_permuto(PermutoParams &p, int n_levels, int n_feat, uint32_t cap
 static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                    int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                    const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
-                                   int64_t out_stride_c, int layout, const void *addend_p, void *records, int flags, void *stream) {
+                                   int64_t out_stride_c, int layout, const void *addend_p, int flags, void *stream) {
     const bf16_t *addend = (const bf16_t *)addend_p;
     PAG_CHECK_ARG(!addend || layout == PAG_LAYOUT_XCD8, "pag_permuto_encode_fwd_add: the addend needs the XCD8 layout");
-    PAG_CHECK_ARG(!records || (n_feat == 2 && table_dtype == PAG_F32 && out_dtype == PAG_BF16 && capacity >= 2 && (capacity & (capacity - 1)) == 0 &&
-                               capacity <= (1u << 24)),
-                  "pag_permuto_encode_fwd: simplex records need F = 2, f32 tables, bf16 output and a power-of-two capacity <= 2^24");
     int rc = check_common("pag_permuto_encode_fwd", xyz, M, n_levels, n_feat);
     if (rc) return rc;
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_fwd: capacity is 0");
@@ -1039,33 +1003,15 @@ static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tabl
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(encode_grid(M)), block(256);
     bool launched = false;
-    uint64_t *recs = (uint64_t *)records;
-#define PFWD(TT, OT, ADD_, REC_)                                                                                                     \
-    PAG_DISPATCH_ALL((permuto_fwd_kernel<TT, OT, F, LPX, ADD_, REC_><<<grid, block, 0, st>>>(xyz, M, (const TT *)tables, p, (OT *)out, out_stride_m, \
-                                                                                               out_stride_c, grouped, addend, recs)))
-#define PFWD_REC(ADD_)                                                                                                               \
-    do {                                                                                                                             \
-        constexpr int F = 2;                                                                                                         \
-        if (lpx == 1) permuto_fwd_kernel<float, bf16_t, F, 1, ADD_, true><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend, recs); \
-        else if (lpx == 2) permuto_fwd_kernel<float, bf16_t, F, 2, ADD_, true><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend, recs); \
-        else if (lpx == 3) permuto_fwd_kernel<float, bf16_t, F, 3, ADD_, true><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend, recs); \
-        else permuto_fwd_kernel<float, bf16_t, F, 4, ADD_, true><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend, recs); \
-        launched = true;                                                                                                             \
-    } while (0)
-    if (recs) {
-        if (addend) PFWD_REC(true);
-        else PFWD_REC(false);
-    } else if (table_dtype == PAG_F32 && out_dtype == PAG_F32) {
-        PFWD(float, float, false, false)
+    if (table_dtype == PAG_F32 && out_dtype == PAG_F32) {
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else if (table_dtype == PAG_F32 && out_dtype == PAG_BF16) {
-        if (addend) { PFWD(float, bf16_t, true, false) } else { PFWD(float, bf16_t, false, false) }
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<float, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else if (table_dtype == PAG_F16 && out_dtype == PAG_F32) {
-        PFWD(__half, float, false, false)
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped, addend)))
     } else {
-        if (addend) { PFWD(__half, bf16_t, true, false) } else { PFWD(__half, bf16_t, false, false) }
+        PAG_DISPATCH_ALL((permuto_fwd_kernel<__half, bf16_t, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const __half *)tables, p, (bf16_t *)out, out_stride_m, out_stride_c, grouped, addend)))
     }
-#undef PFWD
-#undef PFWD_REC
     PAG_CHECK_ARG(launched, "pag_permuto_encode_fwd: unsupported (n_feat=%d, n_levels=%d)", n_feat, n_levels);
     PAG_CHECK_LAUNCH("pag_permuto_encode_fwd");
     return PAG_OK;
@@ -1074,25 +1020,23 @@ static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tabl
 extern "C" int pag_permuto_encode_fwd(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                       int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
                                       const float *feat_scale_host, void *out, int out_dtype, int64_t out_stride_m,
-                                      int64_t out_stride_c, int layout, void *records, int flags, void *stream) {
+                                      int64_t out_stride_c, int layout, int flags, void *stream) {
     return permuto_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host,
-                                   out, out_dtype, out_stride_m, out_stride_c, layout, nullptr, records, flags, stream);
+                                   out, out_dtype, out_stride_m, out_stride_c, layout, nullptr, flags, stream);
 }
 
 extern "C" int pag_permuto_encode_fwd_add(const float *xyz, int64_t M, const void *tables, int table_dtype, int n_levels,
                                           int n_feat, uint32_t capacity, const float *scale_factor_host, const float *shift_host,
-                                          const float *feat_scale_host, const void *addend, void *out, void *records, int flags, void *stream) {
+                                          const float *feat_scale_host, const void *addend, void *out, int flags, void *stream) {
     return permuto_encode_fwd_impl(xyz, M, tables, table_dtype, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host,
-                                   out, PAG_BF16, 0, 0, PAG_LAYOUT_XCD8, addend, records, flags, stream);
+                                   out, PAG_BF16, 0, 0, PAG_LAYOUT_XCD8, addend, flags, stream);
 }
 
 static int permuto_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                    int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
                                    const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                   float *grad_tables, void *workspace, int64_t workspace_bytes, const void *records, int flags, void *stream) {
+                                   float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     int rc = check_common("pag_permuto_encode_bwd", xyz, M, n_levels, n_feat);
-    PAG_CHECK_ARG(!records || (workspace && n_feat == 2 && grad_dtype == PAG_BF16 && capacity >= 2 && (capacity & (capacity - 1)) == 0 && capacity <= (1u << 24)),
-                  "pag_permuto_encode_bwd: simplex records need the binned algorithm, F = 2, bf16 gradients and a power-of-two capacity");
     if (rc) return rc;
     PAG_CHECK_ARG(!overwrite || workspace, "pag_permuto_encode_bwd_set: the overwriting form needs the binned algorithm (a workspace)");
     PAG_CHECK_ARG(capacity >= 1, "pag_permuto_encode_bwd: capacity is 0");
@@ -1110,7 +1054,7 @@ static int permuto_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, 
     if (workspace) {
         HashParams unused{};
         int r2 = launch_binned<1>(xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, grouped, n_levels, n_feat, (int64_t)capacity, unused,
-                                  p, grad_tables, workspace, workspace_bytes, st, "pag_permuto_encode_bwd", overwrite, records);
+                                  p, grad_tables, workspace, workspace_bytes, st, "pag_permuto_encode_bwd", overwrite);
         if (r2) return r2;
         PAG_CHECK_LAUNCH("pag_permuto_encode_bwd");
         return PAG_OK;
@@ -1196,8 +1140,6 @@ extern "C" int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const voi
                               layout, n_levels, n_feat, unused, p, d_xyz, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-extern "C" int64_t pag_permuto_records_bytes(int64_t M, int n_levels) { return (M > 0 && n_levels > 0) ? M * n_levels * (int64_t)sizeof(uint64_t) : 0; }
-
 extern "C" int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int n_vertices, int64_t rows_per_level) {
     if (M <= 0 || n_levels <= 0 || (n_vertices != 4 && n_vertices != 8) || rows_per_level <= 0) return 0;
     return bin_plan(M, n_levels, n_feat, n_vertices, rows_per_level).total;
@@ -1220,14 +1162,14 @@ extern "C" int pag_hash_encode_bwd_set(const float *xyz, int64_t M, const void *
 extern "C" int pag_permuto_encode_bwd(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                       int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
                                       const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                      float *grad_tables, void *workspace, int64_t workspace_bytes, const void *records, int flags, void *stream) {
+                                      float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     return permuto_encode_bwd_impl(false, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, capacity, scale_factor_host,
-                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, records, flags, stream);
+                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, flags, stream);
 }
 extern "C" int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const void *grad_out, int grad_dtype, int64_t g_stride_m,
                                           int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
                                           const float *scale_factor_host, const float *shift_host, const float *feat_scale_host,
-                                          float *grad_tables, void *workspace, int64_t workspace_bytes, const void *records, int flags, void *stream) {
+                                          float *grad_tables, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
     return permuto_encode_bwd_impl(true, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, capacity, scale_factor_host,
-                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, records, flags, stream);
+                                   shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, flags, stream);
 }

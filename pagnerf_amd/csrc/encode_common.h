@@ -186,64 +186,4 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
     permuto_simplex(x, sh, sf, capacity, pow2mask, idx, bary, unused);
 }
 
-// ---------------------------------------------------------------------- simplex records (forward -> table-gradient pass)
-// The bin pass of the table gradient re-derived every simplex the forward had just computed: ~200 of its ~470 VALU instructions per
-// 64 samples and level (measured: one extra lattice evaluation in that kernel = +0.285 ms per 2.1 M-sample launch).  On request the
-// forward stores 8 bytes per (sample, level): the row of vertex 0, which coordinate holds rank 1 / 2 / 3 (the other rows follow from
-// the hash's linearity, see permuto_simplex) and the barycentric weights of vertices 1..3 as WB-bit fixed point (weight 0 =
-// 1 - the others).  Power-of-two capacities only.  WB = 13 at capacity 2^18: a weight is off by <= 6e-5 - a twentieth of the
-// rounding the bf16 upstream gradient already carries - which is why this form is used for bf16 gradients only.
-struct RecordFormat {
-    int idx_bits, wbits;      // idx_bits + 6 + 3 * wbits <= 64
-};
-__host__ __device__ inline RecordFormat record_format(uint32_t capacity) {
-    RecordFormat f;
-    f.idx_bits = 0;
-    while ((1u << f.idx_bits) < capacity) ++f.idx_bits;
-    f.wbits = (64 - 6 - f.idx_bits) / 3;
-    if (f.wbits > 16) f.wbits = 16;
-    return f;
-}
-__device__ __forceinline__ uint64_t record_pack(const RecordFormat f, uint32_t idx0, const int (&slot)[4], const float (&bary)[4]) {
-    // coordinate with rank q (slot = 3 - rank): c_q = sum_a a * [rank_a == q]
-    uint32_t code = 0;
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-        const uint32_t c = slot[0] == 3 - q ? 0u : (slot[1] == 3 - q ? 1u : (slot[2] == 3 - q ? 2u : 3u));
-        code |= c << (2 * (q - 1));
-    }
-    const float scale = (float)((1u << f.wbits) - 1u);
-    uint64_t rec = (uint64_t)idx0 | ((uint64_t)code << f.idx_bits);
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-        const float b = fminf(fmaxf(bary[r], 0.0f), 1.0f);
-        const uint32_t qv = (uint32_t)__float2int_rn(b * scale);
-        rec |= (uint64_t)qv << (f.idx_bits + 6 + (r - 1) * f.wbits);
-    }
-    return rec;
-}
-__device__ __forceinline__ void record_unpack(const RecordFormat f, uint64_t rec, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4]) {
-    constexpr uint32_t m1 = 2531011u, m2 = m1 * m1, m3 = m2 * m1;
-    constexpr uint32_t step = m3 + m2 + m1;
-    const uint32_t lo = (uint32_t)rec, code = (uint32_t)(rec >> f.idx_bits) & 63u;
-    idx[0] = lo & pow2mask;
-    uint32_t B[4];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-        const uint32_t c = (code >> (2 * (q - 1))) & 3u;
-        B[q] = c == 0 ? 4u * m3 : (c == 1 ? 4u * m2 : (c == 2 ? 4u * m1 : 0u));
-    }
-#pragma unroll
-    for (int r = 1; r < 4; ++r) idx[r] = (idx[r - 1] + (step - B[4 - r])) & pow2mask;
-    const float inv = 1.0f / (float)((1u << f.wbits) - 1u);
-    const uint32_t wmask = (1u << f.wbits) - 1u;
-    float rest = 0.0f;
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-        bary[r] = (float)((uint32_t)(rec >> (f.idx_bits + 6 + (r - 1) * f.wbits)) & wmask) * inv;
-        rest += bary[r];
-    }
-    bary[0] = 1.0f - rest;
-}
-
 }  // namespace pag_enc

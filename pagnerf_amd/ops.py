@@ -123,16 +123,7 @@ def _layout_args(t):
     return t.stride(0), t.stride(1), L.LAYOUT_STRIDED
 
 
-ENCODE_RECORDS = os.environ.get("PAG_NO_ENCODE_RECORDS") is None      # permutohedral forward -> table-gradient simplex records (bf16 path)
-
-
-def _records_ok(spec, tables, out):
-    """The record path of pag_permuto_encode_*: F = 2, f32 tables, bf16 XCD8 output, power-of-two capacity."""
-    return (ENCODE_RECORDS and spec.kind == "permuto" and spec.F == 2 and tables.dtype == torch.float32 and out.dim() == 3
-            and spec.capacity >= 2 and (spec.capacity & (spec.capacity - 1)) == 0 and spec.capacity <= (1 << 24))
-
-
-def _encode_fwd(spec, xyz, tables, feat_scale, out, addend=None, records=None):
+def _encode_fwd(spec, xyz, tables, feat_scale, out, addend=None):
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
     sm, sc, lay = _layout_args(out)
@@ -143,14 +134,14 @@ def _encode_fwd(spec, xyz, tables, feat_scale, out, addend=None, records=None):
                   L.ptr(addend), out.data_ptr(), spec.flags, L.stream())
         else:
             _call("pag_permuto_encode_fwd_add", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity, spec.sf,
-                  spec.shift, fs, L.ptr(addend), out.data_ptr(), L.ptr(records), spec.flags, L.stream())
+                  spec.shift, fs, L.ptr(addend), out.data_ptr(), spec.flags, L.stream())
         return
     if spec.kind == "hash":
         _call("pag_hash_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
               spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, spec.flags, L.stream())
     else:
         _call("pag_permuto_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity,
-              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, L.ptr(records), spec.flags, L.stream())
+              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, spec.flags, L.stream())
 
 
 _DTYPE_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
@@ -158,9 +149,8 @@ _DTYPE_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF1
 BWD_ALGO = "binned"     # "binned": atomic-free two-pass scatter (default); "atomic": per-vertex fp32 global atomics
 
 
-def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False, records=None):
-    """overwrite: grad_tables is uninitialised memory that the binned reduce pass fills completely (pag_*_encode_bwd_set).
-    records: the forward's simplex records (permutohedral, bf16 XCD8 gradients) - the bin pass then skips the lattice."""
+def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False):
+    """overwrite: grad_tables is uninitialised memory that the binned reduce pass fills completely (pag_*_encode_bwd_set)."""
     lib = L.load()
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
@@ -176,10 +166,8 @@ def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False, r
         _call("pag_hash_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
               spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, spec.flags, L.stream())
     else:
-        use_rec = records is not None and ws_ptr is not None and grad_out.dtype == torch.bfloat16 and lay == L.LAYOUT_XCD8
         _call("pag_permuto_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
-              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, L.ptr(records) if use_rec else None, spec.flags,
-              L.stream())
+              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, spec.flags, L.stream())
 
 
 def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale):
@@ -214,14 +202,8 @@ class _Encode(torch.autograd.Function):
         else:
             out = torch.empty(M, C, device=xyz.device, dtype=out_dtype)
         tc = tables.detach().contiguous()
-        # simplex records for the table-gradient pass (8 bytes per sample and level, written by the forward): only when a table
-        # gradient will be asked for, on the production bf16 XCD8 path
-        records = None
-        if M and ctx.needs_input_grad[1] and _records_ok(spec, tc, out):
-            records = torch.empty(spec.L, M, device=xyz.device, dtype=torch.int64)
         if M:
-            _encode_fwd(spec, xyz, tc, feat_scale, out, addend.detach() if addend is not None else None, records)
-        ctx.records = records
+            _encode_fwd(spec, xyz, tc, feat_scale, out, addend.detach() if addend is not None else None)
         ctx.spec, ctx.feat_scale = spec, feat_scale
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(xyz, tc)           # d/d xyz needs the table rows again
@@ -243,8 +225,7 @@ class _Encode(torch.autograd.Function):
             binned = BWD_ALGO == "binned" or g.dim() == 3
             if xyz.shape[0] and binned:       # the reduce pass writes every row: no zero fill, no read-modify-write
                 gt = torch.empty(ctx.tshape, device=xyz.device, dtype=torch.float32)
-                _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt, overwrite=True, records=getattr(ctx, "records", None))
-                ctx.records = None
+                _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt, overwrite=True)
             else:
                 gt = torch.zeros(ctx.tshape, device=xyz.device, dtype=torch.float32)
                 if xyz.shape[0]:

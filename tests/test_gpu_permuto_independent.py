@@ -336,49 +336,3 @@ def test_checkpoint_round_trip_renders_identically(gpu_device):
         third = pipe(channels=chans, rays=rays, jitter=jitter.to(dev))
     for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding", "hit"):
         assert torch.equal(getattr(third, ch), getattr(rb, ch)), ch
-
-
-def test_simplex_records_reproduce_the_recomputed_table_gradient(gpu_device):
-    """pag_permuto_encode_fwd(records) + pag_permuto_encode_bwd_set(records): the bin pass decodes the forward's 8-byte simplex
-    records instead of re-deriving the lattice.  Rows are exact; the weights are 13-bit fixed point at capacity 2^18 (<= 6e-5 off),
-    so the table gradient equals the recomputing path to ~1e-4 relative - a twentieth of the bf16 rounding of its input - and the
-    forward output is bit-identical with or without records."""
-    ops, L = _ops()
-    from pagnerf_amd import grids
-    dev = gpu_device
-    gen = torch.Generator().manual_seed(23)
-    for M, cap_log2 in ((200000, 18), (1000 + 37, 12), (5, 22)):
-        Lv, F, cap = 24, 2, 1 << cap_log2
-        x = (torch.rand(M, 3, generator=gen) * 2 - 1).to(dev)
-        shifts = torch.randn(Lv, 3, generator=gen) * 10
-        sfac = grids.PermutoGridHIP.scale_factors(np.geomspace(1.0, 1e-4, Lv))
-        spec = ops.permuto_spec(sfac, shifts, cap, F, half_coords=True)
-        tab = (torch.randn(Lv, cap, F, generator=gen) * 0.1).to(dev)
-        out_a = torch.empty(8, M, 8, device=dev, dtype=torch.bfloat16)
-        out_b = torch.empty_like(out_a)
-        rec = torch.empty(Lv, M, device=dev, dtype=torch.int64)
-        ops._encode_fwd(spec, x, tab, None, out_a)
-        ops._encode_fwd(spec, x, tab, None, out_b, records=rec)
-        assert torch.equal(out_a, out_b)
-        g8 = torch.randn(8, M, 8, generator=gen).to(dev).bfloat16()
-        gt_rec = torch.empty(Lv, cap, F, device=dev)
-        gt_ref = torch.empty(Lv, cap, F, device=dev)
-        ops._encode_bwd(spec, x, g8, None, gt_rec, overwrite=True, records=rec)
-        ops._encode_bwd(spec, x, g8, None, gt_ref, overwrite=True)
-        for l in range(Lv):
-            a, b = gt_rec[l].double(), gt_ref[l].double()
-            assert torch.equal(a != 0, b != 0) or float(((a != 0) != (b != 0)).float().mean()) < 1e-3      # same rows touched (a weight may round to 0)
-            assert float((a - b).norm() / (b.norm() + 1e-30)) < 3e-4, (M, l)
-        # through autograd on the production path: records are made and consumed automatically
-        t = tab.clone().requires_grad_(True)
-        o = ops.encode(x, t, spec, None, torch.bfloat16, layout="xcd8")
-        assert o.grad_fn.records is not None
-        o.backward(g8)
-        assert torch.equal(t.grad, gt_rec)
-        ops.ENCODE_RECORDS = False
-        try:
-            t2 = tab.clone().requires_grad_(True)
-            ops.encode(x, t2, spec, None, torch.bfloat16, layout="xcd8").backward(g8)
-            assert torch.equal(t2.grad, gt_ref)
-        finally:
-            ops.ENCODE_RECORDS = True
