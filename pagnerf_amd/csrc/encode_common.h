@@ -110,27 +110,35 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
     s = __fadd_rn(s, cf[0]);
     E[0] = s;
 
-    int rem0[4], rank[4] = {0, 0, 0, 0};
+    // Nearest remainder-0 point, per coordinate "up if strictly closer to up, else down" (oracle: up = ceil(v)*4, dn = floor(v)*4).
+    // up is written dn + 4: when v is an integer the oracle's up equals dn and both differences are 0 (-> dn); with dn + 4 the
+    // test reads 4 < 0 (-> dn) - the same choice, one instruction less, and dn + 4 is exact.  The residual E - r is exact
+    // (|E - r| <= 2 and r is E's nearest multiple of 4: Sterbenz), so it is -(up - E) or (E - dn): a select instead of a subtraction.
+    int rem0[4], rank[4];
     float resid[4];
     int sum = 0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        float v = E[a] * 0.25f;
-        float up = ceilf(v) * 4.0f, dn = floorf(v) * 4.0f;
-        float r = (__fsub_rn(up, E[a]) < __fsub_rn(E[a], dn)) ? up : dn;
-        rem0[a] = (int)r;
+        const float dn = floorf(E[a] * 0.25f) * 4.0f, up = dn + 4.0f;
+        const float d_up = __fsub_rn(up, E[a]), d_dn = __fsub_rn(E[a], dn);
+        const bool take_up = d_up < d_dn;
+        rem0[a] = (int)dn + (take_up ? 4 : 0);
         sum += rem0[a];
-        resid[a] = __fsub_rn(E[a], r);
+        resid[a] = take_up ? -d_up : d_dn;
     }
     sum >>= 2;   // exact: every rem0 is a multiple of 4
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = a + 1; b < 4; ++b) {
-            int lt = resid[a] < resid[b];
-            rank[a] += lt;
-            rank[b] += 1 - lt;
-        }
+    // rank_a = #{b : resid_b > resid_a} + #{b < a : resid_b == resid_a} (the oracle's pairwise rule: for a < b, `lt = resid_a <
+    // resid_b` adds to rank_a, its negation to rank_b).  lt is the sign bit of resid_a - resid_b: the difference of two floats is
+    // exactly 0 only when they are equal (gradual underflow), so n_ab = (resid_a - resid_b) >> 31 is -1 or 0 = -lt.
+    {
+        const int n01 = __float_as_int(__fsub_rn(resid[0], resid[1])) >> 31, n02 = __float_as_int(__fsub_rn(resid[0], resid[2])) >> 31;
+        const int n03 = __float_as_int(__fsub_rn(resid[0], resid[3])) >> 31, n12 = __float_as_int(__fsub_rn(resid[1], resid[2])) >> 31;
+        const int n13 = __float_as_int(__fsub_rn(resid[1], resid[3])) >> 31, n23 = __float_as_int(__fsub_rn(resid[2], resid[3])) >> 31;
+        rank[0] = -(n01 + n02 + n03);
+        rank[1] = 1 + n01 - (n12 + n13);
+        rank[2] = 2 + n02 + n12 - n23;
+        rank[3] = 3 + n03 + n13 + n23;
+    }
     // rank += sum, wrapped into 0..3 with rem0 moved by the same amount.  |sum| <= 2 (four roundings of < 2 each on
     // coordinates that add up to 0), so rank + sum lies in [-2, 5] and one +-4 step is the whole wrap: t & 3.
 #pragma unroll
