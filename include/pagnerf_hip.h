@@ -230,6 +230,11 @@ typedef struct {
     const void *x1; int x1_dtype; const float *x2; int k2p; const int32_t *x2_index;
     float *wgrad_workspace; int64_t wgrad_workspace_bytes;
     float *dW[3]; float *db[3];
+    /* Fused mode RECOMPUTES the hidden activations from x1 (same MFMA sequence as pag_mlp_fwd: bit-identical) instead of reading
+     * hidden_save - the forward then need not write them (pag_mlp_fwd_args.hidden_save = NULL): 268 MB less each way per hidden
+     * layer at M = 2.1 M.  Needs the hidden layers' biases b[0 .. n_layers-2]; hidden_save[] may be NULL except, for the wide
+     * softmax head, the LAST hidden layer's (the probabilities are rebuilt from it). */
+    const float *b[3];
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 /* 1 when pag_mlp_bwd has a fused weight-gradient kernel for these (fully filled in, wgrad_workspace aside) arguments.  Three

@@ -60,7 +60,7 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dx1_col0_gate", c_vp), ("g_ray_scale", c_vp),
                 ("x1", c_vp), ("x1_dtype", c_i32), ("x2", c_vp), ("k2p", c_i32), ("x2_index", c_vp),
                 ("wgrad_workspace", c_vp), ("wgrad_workspace_bytes", c_i64),
-                ("dW", c_vp * 3), ("db", c_vp * 3)]
+                ("dW", c_vp * 3), ("db", c_vp * 3), ("b", c_vp * 3)]
 
 
 _SIGS = {

@@ -90,6 +90,7 @@ struct BwdParams {
     const int32_t *x2_index;
     int k2p;
     float *slabs[3];           // per layer: f32 [4 * gridDim.x][rows_pad][WG_SLAB_COLS]  (cols 0..63 dW, col 64 db)
+    const float *b[3];         // biases of the hidden layers: mlp_bwd_fused recomputes the hidden activations instead of reading saved ones
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
@@ -1073,7 +1074,20 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     stage_weight_t(WLt, RSL, 64, OBL * 32, p.W[NL - 1], p.out_dim, HID);
     if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
     stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
-    bf16_t *Tx = W0t + 64 * RS + (threadIdx.x >> 6) * ((NL + 1) * TW_ELEMS);      // wave-private swizzled tiles
+    // the forward's own images of the hidden layers: their activations are RECOMPUTED here (8 - 16 MFMAs per tile on idle matrix
+    // cores, same fragments and instruction sequence as mlp_fwd_mfma: bit-identical) instead of being written by the forward and
+    // read back - 268 MB each way per hidden layer at M = 2.1 M, in kernels that run at the HBM rate
+    bf16_t *W0s = W0t + 64 * RS;                                 // [64][RS] natural k
+    bf16_t *W1s = W0s + 64 * RS;                                 // [64][RS] permuted k (NL == 3)
+    float *b0s = reinterpret_cast<float *>(W1s + (NL == 3 ? 64 * RS : 0));
+    float *b1s = b0s + 64;
+    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
+    if (NL == 3) stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        b0s[e] = p.b[0][e];
+        b1s[e] = NL == 3 ? p.b[1][e] : 0.0f;
+    }
+    bf16_t *Tx = reinterpret_cast<bf16_t *>(b1s + 64) + (threadIdx.x >> 6) * ((NL + 1) * TW_ELEMS);      // wave-private swizzled tiles
     bf16_t *Th0 = Tx + TW_ELEMS, *Th1 = Th0 + (NL == 3 ? TW_ELEMS : 0), *Tz = Th1 + TW_ELEMS;
     __syncthreads();
 
@@ -1085,7 +1099,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     const int32_t *ridx = KIND == 1 ? p.x2_index : p.g_index;      // per-sample row of the per-ray tables
 
     // ---- registers of the NEXT tile (requested one tile ahead; the per-ray row index two tiles ahead)
-    bf16x8 hn[NL - 1][4], xn[4];
+    bf16x8 xn[4];
     bf16x4 gz[OBL][KIND == 0 ? 4 : 1], oldx[DXACC ? 2 : 1][4];
     float gs[4], gy[4], gsc = 0.0f, c0a = 0.0f, c0g = 0.0f;      // KIND 1: gradient / output; KIND 2: g_ray row / probabilities
     int ray1 = 0, ray2 = 0;                                        // row index of the tile after next (and the one after that)
@@ -1093,13 +1107,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     auto prefetch = [&](int64_t tile_raw, int ray) __attribute__((always_inline)) {
         const int64_t tile = min(tile_raw, ntiles - 1);
         const int64_t m = min(tile * 32 + r, M - 1);
-#pragma unroll
-        for (int l = 0; l < NL - 1; ++l)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int64_t row = min(tile * 32 + it * 8 + (lane >> 3), M - 1);
-                hn[l][it] = load8(reinterpret_cast<const bf16_t *>(p.hsave[l]) + row * HID + (lane & 7) * 8);
-            }
         if constexpr (GRP) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) xn[s] = load8(x1b + ((int64_t)(2 * s + h) * M + m) * 8);
@@ -1217,16 +1224,33 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int64_t m = tile * 32 + r;
         const bool live = FULL || m < M;
-        // ---- this tile's saved activations and layer-0 input become LDS images (kept for the whole tile)
+        // ---- this tile's layer-0 input and the hidden activations recomputed from it become LDS images (kept for the whole tile)
         wave_lds_sync();
-        tw_put_rows(Th0, hn[0], lane);
-        if constexpr (NL == 3) tw_put_rows(Th1, hn[1], lane);
         {
             bf16x8 xb[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) xb[s] = xn[s];
-            if (h == 1) xb[3][7] = (bf16_t)1.0f;      // column 63 := 1: its dW column is the layer-0 bias gradient
+            if (h == 1) xb[3][7] = (bf16_t)1.0f;      // column 63 := 1 (its weight is 0 in the forward): its dW column is the layer-0 bias gradient
             tw_put_frags(Tx, xb, r, h);
+            f32x16 ha[2];
+            bf16x8 hf[4];
+            hidden_layer<4>(W0s, b0s, xb, 4, r, h, ha);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ha[mb][q] = fmaxf(ha[mb][q], 0.0f);
+                tw_put_block(Th0, mb, r, h, ha[mb]);
+                if constexpr (NL == 3) pack_block(ha[mb], hf[2 * mb], hf[2 * mb + 1]);
+            }
+            if constexpr (NL == 3) {
+                hidden_layer<4>(W1s, b1s, hf, 4, r, h, ha);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) ha[mb][q] = fmaxf(ha[mb][q], 0.0f);
+                    tw_put_block(Th1, mb, r, h, ha[mb]);
+                }
+            }
         }
         // ---- upstream gradient of this tile -> dz of the output layer (OBL 32-row blocks)
         f32x16 zv[OBL];
@@ -2453,6 +2477,7 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a->out || (a->softmax_stats && a->mode == PAG_MLP_MFMA_BF16 && a->out_dim > 64 && a->out_act == PAG_ACT_SOFTMAX),
                   "pag_mlp_fwd: NULL out (allowed only for wide softmax heads that write softmax_stats)");
     FwdParams p;
+    for (int l = 0; l < 3; ++l) p.b[l] = a->b[l];
     p.x1 = a->x1;
     p.x2 = a->x2;
     p.x2_index = a->x2_index;
@@ -2638,9 +2663,11 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         PAG_CHECK_ARG(kind >= 0, "pag_mlp_bwd: this decoder shape has no fused weight-gradient kernel (pag_mlp_bwd_fused_supported)");
         PAG_CHECK_ARG(a->wgrad_workspace_bytes >= pag_mlp_bwd_fused_workspace_bytes(a, M), "pag_mlp_bwd: wgrad_workspace too small");
         for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->dW[l] && a->db[l], "pag_mlp_bwd: NULL dW/db of layer %d", l);
+        for (int l = 0; l + 1 < a->n_layers; ++l) PAG_CHECK_ARG(a->b[l], "pag_mlp_bwd: fused mode recomputes the hidden activations: NULL bias b[%d]", l);
     }
     for (int l = 0; l < a->n_layers; ++l) PAG_CHECK_ARG(a->W[l] && (fuse || a->dz[l]), "pag_mlp_bwd: NULL weight/dz of layer %d", l);
-    for (int l = 0; l + 1 < a->n_layers; ++l) PAG_CHECK_ARG(a->hidden_save[l], "pag_mlp_bwd: NULL hidden_save[%d]", l);
+    for (int l = 0; l + 1 < a->n_layers; ++l)
+        PAG_CHECK_ARG(a->hidden_save[l] || (a->wgrad_workspace && (a->out_dim <= 32 || l + 2 < a->n_layers)), "pag_mlp_bwd: NULL hidden_save[%d]", l);
     BwdParams p;
     p.g_ray = a->g_ray;
     p.g_scale = a->g_scale;
@@ -2679,6 +2706,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(!a->dx1_col0_add || (a->dx1 && !p.grp_L && a->mode == PAG_MLP_MFMA_BF16 && a->out_dim <= 64),
                   "pag_mlp_bwd: dx1_col0_add needs a strided dx1, MFMA mode and out_dim <= 64");
     PAG_CHECK_ARG(!a->dx1_accumulate || (p.grp_L && a->dx1), "pag_mlp_bwd: dx1_accumulate needs an XCD8 dx1");
+    for (int l = 0; l < 3; ++l) p.b[l] = a->b[l];
     p.x1 = a->x1;
     p.x2 = a->x2;
     p.x2_index = a->x2_index;
@@ -2721,11 +2749,13 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         pb.W[0] = a->W[0];
         pb.W[1] = a->W[1];
         pb.W[2] = nullptr;
+        pb.b[0] = a->b[0];
+        pb.b[1] = nullptr;
         pb.hsave[0] = a->hidden_save[0];
         pb.hsave[1] = nullptr;
         pb.slabs[0] = slabB0;
         pb.slabs[1] = slabB1;
-        const size_t ldsB = (size_t)(64 * (64 + 8) + 64 * RS) * sizeof(bf16_t) + (size_t)4 * 3 * TW_ELEMS * sizeof(bf16_t);
+        const size_t ldsB = (size_t)(64 * (64 + 8) + 2 * 64 * RS) * sizeof(bf16_t) + 128 * sizeof(float) + (size_t)4 * 3 * TW_ELEMS * sizeof(bf16_t);
         hipLaunchKernelGGL((mlp_bwd_fused<2, 0, false, 2>), dim3(grid), dim3(256), ldsB, st, pb);
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, layers below the wide head)");
         FinishBatch fb{};
@@ -2744,7 +2774,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
             p.slabs[l] = ws;
             ws += (int64_t)grid * 4 * (l + 1 < a->n_layers ? 64 : 32) * WG_SLAB_COLS;
         }
-        const size_t lds = (size_t)(64 * (32 + 8) + (a->n_layers == 3 ? 64 * RS : 0) + 64 * RS) * sizeof(bf16_t) +
+        const size_t lds = (size_t)(64 * (32 + 8) + 2 * (a->n_layers == 3 ? 64 * RS : 0) + 2 * 64 * RS) * sizeof(bf16_t) + 128 * sizeof(float) +
                            (size_t)4 * (a->n_layers + 1) * TW_ELEMS * sizeof(bf16_t);
 #define MLP_BWD_FUSED(NL_, KIND_, ACC_)                                                                                              \
     do {                                                                                                                              \

@@ -269,6 +269,46 @@ def _mm_f32(a, b):
         return (a @ b).float()
 
 
+def _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, stats_only):
+    """Forward-time guess of pag_mlp_bwd_fused_supported(): shapes whose backward recomputes the hidden activations."""
+    if not WGRAD_FUSED or mode != L.MLP_MFMA_BF16 or x1.dtype != torch.bfloat16 or not ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        return False
+    if grouped is not None:
+        levels, feats = grouped
+        j = 7 // feats
+        if j < (levels + 7) // 8 and 7 + 8 * j < levels:      # staged position 63 is a real feature: no room for the bias column
+            return False
+        if x2 is not None:
+            return False
+        return out_dim <= 32 or (stats_only and n_layers == 3 and 192 < out_dim <= 224)
+    return x2 is not None and k1 == 16 and x2.shape[1] == 32 and in_dim <= 48 and out_dim <= 4
+
+
+def _recompute_hidden(x1, x2, x2_index, Wc, bc, in_dim, k1, grouped, mode, hidden):
+    """Fill the missing entries of `hidden` by re-running the forward (pag_mlp_fwd with hidden_save) - the fallback for a backward
+    that the fused kernels cannot serve although the forward did not save the activations."""
+    M = x1.shape[1] if grouped is not None else x1.shape[0]
+    n_layers = len(Wc)
+    dev = x1.device
+    full = [h if h is not None else torch.empty(M, 64, device=dev, dtype=torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32) for h in hidden]
+    out_dim = Wc[-1].shape[0]
+    a = L.MlpFwdArgs()
+    a.x1, a.x1_dtype, a.k1 = L.ptr(x1), L.dtype_code(x1), k1
+    if grouped is not None:
+        a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
+    if x2 is not None:
+        a.x2, a.k2p, a.x2_index = L.ptr(x2), x2.shape[1], L.ptr(x2_index)
+    a.in_dim, a.n_layers, a.out_dim = in_dim, n_layers, out_dim
+    for i in range(n_layers):
+        a.W[i], a.b[i] = L.ptr(Wc[i]), L.ptr(bc[i])
+    scratch = torch.empty(M, out_dim, device=dev, dtype=torch.bfloat16)
+    a.out_act, a.out, a.out_dtype, a.mode = L.ACT_NONE, L.ptr(scratch), L.BF16, mode
+    for i, h in enumerate(full):
+        a.hidden_save[i] = L.ptr(h)
+    _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
+    return full
+
+
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb):
@@ -290,7 +330,16 @@ class _FusedMLP(torch.autograd.Function):
         stats_only = bool(getattr(ctx, "stats_only", False)) and wide_softmax       # _HeadComposite: no [M,out] tensor at all
         out = None if stats_only else torch.empty(M, out_dim, device=x1.device, dtype=out_dtype)
         hdt = torch.bfloat16 if mode == L.MLP_MFMA_BF16 else torch.float32
-        hidden = [torch.empty(M, 64, device=x1.device, dtype=hdt) for _ in range(n_layers - 1)] if (need_grad or stats_only) else []
+        # The fused backward kernels RECOMPUTE the hidden activations from x1 (bit-identical MFMA sequence), so the forward of a
+        # decoder they will serve does not write them: 268 MB per hidden layer at M = 2.1 M, in launches that run at the HBM rate.
+        # Wide head: the LAST hidden layer is kept (the probabilities are rebuilt from it).  A backward that turns out not to be
+        # fusable (no column-0 gradient, d x2 requested, ...) re-runs the forward for them (_recompute_hidden: rare, slow, correct).
+        recompute = need_grad and M > 0 and _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, stats_only)
+        hidden = []
+        if need_grad or stats_only:
+            for i in range(n_layers - 1):
+                keep = not recompute or (stats_only and i == n_layers - 2)
+                hidden.append(torch.empty(M, 64, device=x1.device, dtype=hdt) if keep else None)
         a = L.MlpFwdArgs()
         a.x1, a.x1_dtype, a.k1 = L.ptr(x1), L.dtype_code(x1), k1
         if grouped is not None:
@@ -329,6 +378,7 @@ class _FusedMLP(torch.autograd.Function):
         extra = (stats, bc[-1]) if stats is not None else ()
         ctx.save_for_backward(x1, x2, x2_index, out, *hidden, *Wc, *extra)
         ctx.n_hidden = len(hidden)
+        ctx.bc = bc
         if stats_only:
             ctx.fwd_state = (hidden[-1], Wc[-1], bc[-1], stats)
         return out
@@ -373,8 +423,10 @@ class _FusedMLP(torch.autograd.Function):
             a.x1_layout, a.x1_levels, a.x1_feats = L.LAYOUT_XCD8, grouped[0], grouped[1]
         for i in range(n_layers):
             a.W[i] = L.ptr(Wc[i])
-        for i, h in enumerate(hidden):
-            a.hidden_save[i] = L.ptr(h)
+        bc = getattr(ctx, "bc", None)
+        if bc is not None:
+            for i in range(n_layers):
+                a.b[i] = L.ptr(bc[i])
         a.dx1, a.dx1_dtype, a.mode = L.ptr(dx1), (L.dtype_code(dx1) if need_dx else 0), mode
         a.softmax_stats, a.b_last = L.ptr(stats), L.ptr(b_last)
         a.dx1_accumulate = 1 if (need_dx and dx1_into is not None) else 0
@@ -394,6 +446,10 @@ class _FusedMLP(torch.autograd.Function):
             if x2 is not None:
                 a.x2, a.k2p, a.x2_index = L.ptr(x2), k2p, L.ptr(x2_index)
             fused = lib.pag_mlp_bwd_fused_supported(ctypes.byref(a)) == 1
+        if not fused and any(h is None for h in hidden):      # the forward counted on the fused kernels: rebuild what it skipped
+            hidden = _recompute_hidden(x1, x2, x2_index, Wc, bc, in_dim, k1, grouped, mode, hidden)
+        for i, h in enumerate(hidden):
+            a.hidden_save[i] = L.ptr(h)
         dz = None
         gW, gb = [], []
         if fused:
