@@ -476,6 +476,13 @@ __device__ __forceinline__ bf16x8 tw_frag(const bf16_t *T, int blk, int ks, int 
     return u.f;
 }
 constexpr int WG_SLAB_COLS_F = 96;      // = WG_SLAB_COLS (declared with the weight-gradient kernels below)
+template <int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 // ------------------------------------------------------------------------------------------ forward
 template <typename X1T, typename OutT, int NL, int OBMAX>
@@ -1412,36 +1419,63 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     }
     if (any_tile) flush(!last_ragged || (nfull * 32 + r) < M);
 
-    // ---- per-wave slabs [rows_pad][96] per layer (cols 0..63 dW - staged positions for XCD8 inputs -, col 64 db), summed by wgrad_finish_kernel
-    const int64_t slab_id = (int64_t)blockIdx.x * 4 + wave;
-    auto put = [&](float *base, int rows_pad, int ob, int ib, const f32x16 &a) __attribute__((always_inline)) {
-        float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = a[q];
+    // ---- the four waves' accumulators are summed through LDS (tiles and weights are dead), then ONE slab per workgroup and layer:
+    //      [rows_pad][96] (cols 0..63 dW - staged positions for XCD8 inputs -, col 64 db), summed over workgroups by wgrad_finish_kernel
+    constexpr int BM = 2 * OBL, B0 = BM + (NL == 3 ? 4 : 0), NBLK = B0 + 4 + 1;      // blocks: last layer | middle layer | layer 0 | db
+    auto blk = [&](auto bi) -> const f32x16 & {
+        constexpr int bb = decltype(bi)::value;
+        if constexpr (bb < BM) return awL[bb >> 1][bb & 1];
+        else if constexpr (bb < B0) return awM[(bb - BM) >> 1][(bb - BM) & 1];
+        else if constexpr (bb < NBLK - 1) return aw0[(bb - B0) >> 1][(bb - B0) & 1];
+        else return dbacc;
     };
-    auto put_db = [&](float *base, int rows_pad, int ob, bool mine, const f32x16 &a) __attribute__((always_inline)) {
-        float *sl = base + slab_id * rows_pad * WG_SLAB_COLS_F;
-        if (mine) {
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);                      // [NBLK][16 q][64 lanes]
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            static_for<NBLK>([&](auto bi) {
+                constexpr int bb = decltype(bi)::value;
+                const f32x16 &a = blk(bi);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = a[q];
+                for (int q = 0; q < 16; ++q) {
+                    float *dst = red + (bb * 16 + q) * 64 + lane;
+                    *dst = w == 0 ? a[q] : *dst + a[q];
+                }
+            });
         }
-    };
-#pragma unroll
-    for (int ob = 0; ob < OBL; ++ob) {
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) put(p.slabs[NL - 1], OBL * 32, ob, ib, awL[ob][ib]);
-        put_db(p.slabs[NL - 1], OBL * 32, ob, r == ob, dbacc);
+        __syncthreads();
     }
+    static_for<NBLK>([&](auto bi) {
+        constexpr int bb = decltype(bi)::value;
+        if ((bb & 3) != wave) return;
+        const float *src = red + bb * 16 * 64 + lane;
+        if constexpr (bb < BM) {
+            float *sl = p.slabs[NL - 1] + (int64_t)blockIdx.x * (OBL * 32) * WG_SLAB_COLS_F;
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
+            for (int q = 0; q < 16; ++q) sl[(32 * (bb >> 1) + rho(q, h)) * WG_SLAB_COLS_F + 32 * (bb & 1) + r] = src[q * 64];
+        } else if constexpr (bb < B0) {
+            float *sl = p.slabs[1] + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F;
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-            put(p.slabs[0], 64, ob, ib, aw0[ob][ib]);
-            if constexpr (NL == 3) put(p.slabs[1], 64, ob, ib, awM[ob][ib]);
+            for (int q = 0; q < 16; ++q) sl[(32 * ((bb - BM) >> 1) + rho(q, h)) * WG_SLAB_COLS_F + 32 * ((bb - BM) & 1) + r] = src[q * 64];
+        } else if constexpr (bb < NBLK - 1) {
+            constexpr int ob = (bb - B0) >> 1, ib = (bb - B0) & 1;
+            float *sl = p.slabs[0] + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float v = src[q * 64];
+                sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = v;
+                if (ib == 1 && r == 31) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;      // input column 63 (the ones column) = db of layer 0
+            }
+        } else {      // dbacc: column ob -> last layer's block ob; column OBL + ob -> middle layer's block ob
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float v = src[q * 64];
+                if (r < OBL) p.slabs[NL - 1][((int64_t)blockIdx.x * (OBL * 32) + 32 * r + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
+                if (NL == 3 && r >= OBL && r < OBL + 2) p.slabs[1][((int64_t)blockIdx.x * 64 + 32 * (r - OBL) + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
+            }
         }
-        put_db(p.slabs[0], 64, ob, r == 31, aw0[ob][1]);             // input column 63 (the ones column)
-        if constexpr (NL == 3) put_db(p.slabs[1], 64, ob, r == OBL + ob, dbacc);
-    }
+    });
 }
 
 // -------------------------------------------- wide softmax head: output layer backward + its weight gradient (one launch)
@@ -2636,8 +2670,8 @@ extern "C" int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *a, 
     if (kind < 0 || M < 1) return 0;
     const int64_t grid = fused_grid(M);
     if (kind == 3)      // stage A: one [224][96] slab per workgroup; stage B: per-wave slabs of two 64-row layers; + the [M,64] bf16 hidden gradient
-        return (grid * 224 + grid * 4 * 128) * WG_SLAB_COLS * (int64_t)sizeof(float) + ((M * HID * 2 + 255) / 256) * 256;
-    return grid * 4 * ((int64_t)(a->n_layers - 1) * 64 + 32) * WG_SLAB_COLS * (int64_t)sizeof(float);
+        return (grid * 224 + grid * 128) * WG_SLAB_COLS * (int64_t)sizeof(float) + ((M * HID * 2 + 255) / 256) * 256;
+    return grid * ((int64_t)(a->n_layers - 1) * 64 + 32) * WG_SLAB_COLS * (int64_t)sizeof(float);
 }
 
 extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
@@ -2720,9 +2754,9 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         float *slabA = ws;
         ws += (int64_t)grid * 224 * WG_SLAB_COLS;
         float *slabB0 = ws;
-        ws += (int64_t)grid * 4 * 64 * WG_SLAB_COLS;
+        ws += (int64_t)grid * 64 * WG_SLAB_COLS;
         float *slabB1 = ws;
-        ws += (int64_t)grid * 4 * 64 * WG_SLAB_COLS;
+        ws += (int64_t)grid * 64 * WG_SLAB_COLS;
         bf16_t *dzh = reinterpret_cast<bf16_t *>(ws);
         BwdParams pa = p;
         pa.W[0] = a->W[2];
@@ -2759,20 +2793,20 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         hipLaunchKernelGGL((mlp_bwd_fused<2, 0, false, 2>), dim3(grid), dim3(256), ldsB, st, pb);
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, layers below the wide head)");
         FinishBatch fb{};
-        fb.p[0] = FinishParams{slabB0, (int)grid * 4, HID, 64, a->in_dim, p.grp_L, p.grp_F, a->dW[0], a->db[0]};
-        fb.p[1] = FinishParams{slabB1, (int)grid * 4, HID, 64, HID, 0, 0, a->dW[1], a->db[1]};
+        fb.p[0] = FinishParams{slabB0, (int)grid, HID, 64, a->in_dim, p.grp_L, p.grp_F, a->dW[0], a->db[0]};
+        fb.p[1] = FinishParams{slabB1, (int)grid, HID, 64, HID, 0, 0, a->dW[1], a->db[1]};
         fb.p[2] = FinishParams{slabA, (int)grid, a->out_dim, 224, HID, 0, 0, a->dW[2], a->db[2]};
         hipLaunchKernelGGL(wgrad_finish_kernel, dim3(a->out_dim, 3), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, finish)");
         return PAG_OK;
     }
     if (fuse) {
-        // one workgroup per CU, four per-wave slabs each: [n_slabs][rows_pad][96] f32 per layer, hidden layers first
+        // one workgroup per CU, one slab each (its four waves are summed in LDS): [grid][rows_pad][96] f32 per layer, hidden layers first
         const unsigned grid = fused_grid(M);
         float *ws = a->wgrad_workspace;
         for (int l = 0; l < a->n_layers; ++l) {
             p.slabs[l] = ws;
-            ws += (int64_t)grid * 4 * (l + 1 < a->n_layers ? 64 : 32) * WG_SLAB_COLS;
+            ws += (int64_t)grid * (l + 1 < a->n_layers ? 64 : 32) * WG_SLAB_COLS;
         }
         const size_t lds = (size_t)(64 * (32 + 8) + 2 * (a->n_layers == 3 ? 64 * RS : 0) + 2 * 64 * RS) * sizeof(bf16_t) + 128 * sizeof(float) +
                            (size_t)4 * (a->n_layers + 1) * TW_ELEMS * sizeof(bf16_t);
@@ -2804,7 +2838,7 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         for (int l = 0; l < a->n_layers; ++l) {
             const int n_out = l + 1 < a->n_layers ? HID : a->out_dim;
             const int n_in = l == 0 ? a->in_dim : HID;
-            fb.p[l] = FinishParams{p.slabs[l], (int)grid * 4, n_out, (n_out + 31) / 32 * 32, n_in, l == 0 ? p.grp_L : 0, p.grp_F, a->dW[l], a->db[l]};
+            fb.p[l] = FinishParams{p.slabs[l], (int)grid, n_out, (n_out + 31) / 32 * 32, n_in, l == 0 ? p.grp_L : 0, p.grp_F, a->dW[l], a->db[l]};
             max_out = std::max(max_out, n_out);
         }
         hipLaunchKernelGGL(wgrad_finish_kernel, dim3(max_out, a->n_layers), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
