@@ -511,7 +511,7 @@ def run_rank(args):
     if cands and (args.grid, args.rays, args.samples, args.precision, args.raymarch) == ("permuto", 4096, 512, "bf16", "ray"):
         blob = json.load(open(os.path.join(pdir, cands[-1])))      # newest committed PMC pass (profiles/README.md)
         for k, v in blob.items():
-            if isinstance(v, dict) and "permuto_fwd_kernel" in k and "hbm_bytes_per_launch_corrected" in v:
+            if isinstance(v, dict) and "permuto_fwd_kernel" in k and "permuto_fwd_add_kernel" not in k and "hbm_bytes_per_launch_corrected" in v:
                 traffic = v["hbm_bytes_per_launch_corrected"]
         traffic_src = dict(file="profiles/" + cands[-1], commit=blob.get("_commit"), note="offline rocprofv3 --pmc passes, not this run")
     enc_ms = (prof or {}).get(enc_name, [])

@@ -23,6 +23,8 @@ def main():
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         out[k] = {"FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1),
                   "hbm_bytes_per_launch_raw": int((f + w) * 1024), "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+    import os
+    out["_commit"] = os.environ.get("PAG_COMMIT")      # the commit the passes were taken at (the GPU box has no .git: passed in by the caller)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print("wrote", sys.argv[3], len(out), "kernels")
 
