@@ -218,13 +218,16 @@ __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, 
 
 // Two kernel symbols for the same body: the plain launch (the roofline kernel of bench.py) and the `_add` launch of the delta grid, so that
 // rocprofv3's per-kernel statistics and PMC counters keep them apart.
+#ifndef PAG_ENC_FWD_WAVES
+#define PAG_ENC_FWD_WAVES 1      // minimum waves per SIMD asked of the compiler for the permutohedral forward (experiments: 8 = 64 VGPRs)
+#endif
 template <typename TableT, typename OutT, int F, int LPX>
-__global__ __launch_bounds__(256) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
+__global__ __launch_bounds__(256, PAG_ENC_FWD_WAVES) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
                                                           OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped) {
     permuto_fwd_body<TableT, OutT, F, LPX>(xyz, M, tables, p, out, sm, sc, grouped, nullptr);
 }
 template <typename TableT, typename OutT, int F, int LPX>
-__global__ __launch_bounds__(256) void permuto_fwd_add_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
+__global__ __launch_bounds__(256, PAG_ENC_FWD_WAVES) void permuto_fwd_add_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
                                                               OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped,
                                                               const bf16_t *__restrict__ addend) {
     permuto_fwd_body<TableT, OutT, F, LPX>(xyz, M, tables, p, out, sm, sc, grouped, addend);
