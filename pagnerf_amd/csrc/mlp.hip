@@ -1748,6 +1748,385 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wide_fused(BwdParams p) {
     }
 }
 
+// ------------------------------------------------ wide softmax head, stage A, block-parallel form (the one that is launched)
+// mlp_bwd_wide_fused above gives every wave whole tiles and ALL dW_L blocks: 240 accumulator registers = one wave per SIMD, where a
+// lone wave issues a VALU instruction every 4 cycles (2 with a second wave) and nothing hides its waits - 0.70 ms, VALU 41 % /
+// waiting 38 %, with both passes rebuilding the probabilities for lack of registers.  Here the OUTPUT BLOCKS are spread over the
+// waves of a workgroup instead: wave ob (< OB) owns the 32 channels of block ob for EVERY tile of the workgroup - it rebuilds that
+// block once per tile (kept in registers between the passes), and accumulates dW_L[32 ob .. +31][:] (2 blocks + the bias block:
+// 48 accumulator registers) for the whole launch; one helper wave runs the W_L^T chain on the dz fragments the block waves leave
+// in LDS, applies the ReLU mask, writes the hidden gradient and stages the coming tiles.  What crosses waves per tile: the partial
+// <p, g> of each block (256 B per wave) and the dz B-fragments (2 KiB per wave).
+//
+// The three steps of a tile are SKEWED over three iterations so that ONE workgroup barrier per iteration orders everything and
+// every wave has two independent instruction streams between barriers:
+//     iteration it:   block waves   finish(it-1): <p,g> from the partials, dz -> LDS fragments, dW_L MFMAs
+//                                   rebuild(it) : probabilities of tile it, z = scaled gradient rows, partial <p,g> -> LDS
+//                     helper wave   tiles it+1 (registers -> LDS) and it+2 (global -> registers) staged,
+//                                   chain(it-2) : W_L^T . dz, ReLU mask, hidden gradient of tile it-2 -> global
+// LDS rings: activations 4 deep (tiles it-2 .. it+1), dz fragments / partial dots / gradient rows 2 deep.  Tiles that do not exist
+// (the two drain iterations, tiles past the end) run with live = false: their dz is zero and their stores are predicated off.
+// OB + 1 = 8 waves per workgroup, one workgroup per CU: two waves per SIMD.
+#ifdef PAG_WB_PROF
+__device__ unsigned long long g_wb_prof[2][8];      // [0] cycles at the barrier, [1] loop cycles; per wave role, summed over workgroups
+#endif
+constexpr int WB_RMAX = 4;         // rays whose gradient rows are staged per tile; tiles spanning more read their rows from global
+template <int OB>
+__global__ __launch_bounds__((OB + 1) * 64) void mlp_bwd_wide_blocks(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RSL = OB * 32 + 8;
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16_t *WLt = reinterpret_cast<bf16_t *>(smem);              // [64 hidden][RSL]   k = output channel (permuted)
+    bf16_t *WLs = WLt + 64 * RSL;                                // [OB*32 channels][RS] permuted k (forward layout)
+    float *bLs = reinterpret_cast<float *>(WLs + OB * 32 * RS);  // [OB*32]
+    bf16_t *Th = reinterpret_cast<bf16_t *>(bLs + OB * 32);      // [4][tile]  activations, ring over tiles
+    bf16_t *Tp = Th + 4 * TW_ELEMS;                              // helper's transpose buffer for the hidden-gradient store
+    bf16_t *TzAll = Tp + TW_ELEMS;                               // [OB][tile] dz block of each block wave (block 0 of its tile)
+    float *grow = reinterpret_cast<float *>(TzAll + OB * TW_ELEMS);      // [2][WB_RMAX][WR_RS]
+    float *dotbuf = grow + 2 * WB_RMAX * WR_RS;                  // [2][OB][64]
+    bf16x8 *zbuf = reinterpret_cast<bf16x8 *>(dotbuf + 2 * OB * 64);     // [2][OB][2][64]
+    stage_weight_t(WLt, RSL, 64, OB * 32, p.W[0], p.out_dim, HID);
+    stage_weight(WLs, RS, OB * 32, 64, p.W[0], p.out_dim, HID, true);
+    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b_last[e] : -1e30f;      // padding channels: p = exp2(-huge) = 0
+    for (int e = threadIdx.x; e < 2 * OB * 64; e += blockDim.x) dotbuf[e] = 0.0f;
+    for (int e = threadIdx.x; e < 2 * OB * 2 * 64 * 4; e += blockDim.x) reinterpret_cast<float *>(zbuf)[e] = 0.0f;
+    for (int e = threadIdx.x; e < 4 * TW_ELEMS / 2; e += blockDim.x) reinterpret_cast<float *>(Th)[e] = 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t M = p.M, ntiles = (M + 31) / 32;
+    const int64_t tile_step = gridDim.x;
+    const bf16_t *hsrc = reinterpret_cast<const bf16_t *>(p.hsave[0]);
+    bf16_t *dzh = reinterpret_cast<bf16_t *>(p.dz[0]);
+    const bool is_block = wave < OB;
+    const int ob = is_block ? wave : 0;
+    bf16_t *Tz = TzAll + ob * TW_ELEMS;
+    auto row_of = [&](int64_t tile) __attribute__((always_inline)) { return min(min(tile, ntiles - 1) * 32 + r, M - 1); };
+    // The helper wave stages through registers: loads are issued a whole iteration before the LDS writes that consume them.  Its wave
+    // shares a SIMD with a block wave, so every VALU instruction it saves is issue time for both: all its global traffic goes through
+    // buffer descriptors (scalar base + loop-invariant lane offset, out-of-range lanes read 0 / are not written) instead of per-lane
+    // 64-bit address arithmetic with clamps.
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(hsrc), 0, (int)min(M * HID * 2, (int64_t)0x7fffffff), 0x00020000);
+    const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.g_index), 0, (int)min(M * 4, (int64_t)0x7fffffff), 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(dzh, 0, (int)min((ntiles + 1) * 32 * HID * 2, (int64_t)0x7fffffff), 0x00020000);
+    const int voff_tile = (lane >> 3) * (HID * 2) + (lane & 7) * 16;          // + 8 rows per load
+    auto load_rows = [&](float (&v)[4 * WB_RMAX], int ray_first, int ray_last) __attribute__((always_inline)) {      // WB_RMAX gradient rows
+#pragma unroll
+        for (int k = 0; k < WB_RMAX; ++k) {
+            const int rr = min(ray_first + k, ray_last);
+            const auto rs_row = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.g_ray) + (int64_t)rr * p.out_dim, 0, p.out_dim * 4, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * k + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_row, lane * 4, 256 * j, 0));
+        }
+    };
+    auto put_rows = [&](float *dst, const float (&v)[4 * WB_RMAX]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4 * WB_RMAX; ++k) dst[(k >> 2) * WR_RS + 64 * (k & 3) + lane] = v[k];
+    };
+    auto load_tile = [&](bf16x8 (&v)[4], int64_t tile_raw) __attribute__((always_inline)) {                          // activations of a tile
+        const int voff = voff_tile + (int)min(tile_raw, ntiles) * (32 * HID * 2);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) v[it] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff + it * (8 * HID * 2), 0, 0));
+    };
+    auto load_ray = [&](int64_t tile_raw) __attribute__((always_inline)) {                                           // ray of this lane's sample (clamped row)
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_i, (int)row_of(tile_raw) * 4, 0, 0);
+    };
+    const int64_t tile0 = blockIdx.x;
+    const int n_own = tile0 < ntiles ? (int)((ntiles - 1 - tile0) / tile_step) + 1 : 0;      // tiles of this workgroup
+    // The two roles run their own loops (same number of barriers) so that neither carries the other's registers.  The barrier is
+    // the bare instruction behind an LDS-only wait: __syncthreads() would also drain the global loads that are meant to stay in flight.
+#ifdef PAG_WB_PROF
+    unsigned long long prof_wait = 0, prof_t0 = __builtin_amdgcn_s_memtime(), prof_seg[4] = {0, 0, 0, 0};
+    auto wg_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_barrier" ::: "memory");
+        prof_wait += __builtin_amdgcn_s_memtime() - t0;
+    };
+#else
+    auto wg_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+#endif
+    if (!is_block) {
+        // =========================================================================================== helper wave
+        bf16x8 vt[4];
+        float vr[4 * WB_RMAX];
+        load_tile(vt, tile0);
+        int ray = load_ray(tile0);
+        load_rows(vr, __builtin_amdgcn_readfirstlane(ray), __builtin_amdgcn_readlane(ray, 31));
+        tw_put_rows(Th, vt, lane);
+        put_rows(grow, vr);
+        load_tile(vt, tile0 + tile_step);                                   // tile 1 waits in registers
+        ray = load_ray(tile0 + tile_step);
+        load_rows(vr, __builtin_amdgcn_readfirstlane(ray), __builtin_amdgcn_readlane(ray, 31));
+        int ray_nn = load_ray(tile0 + 2 * tile_step);                       // ray of this lane's sample two tiles ahead
+        f32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][q] = acc[1][q] = 0.0f;
+        // W_L^T as MFMA A fragments, resident for the whole launch: rows = hidden units 32 mb + r, k = channels 16 s2 + 8 h ..
+        bf16x8 wt[2][2 * OB];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * OB; ++s2)
+                wt[mb][s2] = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * s2 + 8 * h);
+        wg_barrier();
+        for (int it = 0; it < n_own + 2; ++it) {
+            const int64_t tile = tile0 + (int64_t)it * tile_step;
+            // ---------------- tile it+1 registers -> LDS, tile it+2 global -> registers (in flight for a whole iteration).  The ring slot
+            // written here was last read by this wave's own ReLU mask one iteration ago.
+#ifdef PAG_WB_PROF
+            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+            tw_put_rows(Th + ((it + 1) & 3) * TW_ELEMS, vt, lane);
+            put_rows(grow + ((it + 1) & 1) * (WB_RMAX * WR_RS), vr);
+            asm volatile("" ::: "memory");
+#ifdef PAG_WB_PROF
+            const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+            prof_seg[0] += ts1 - ts0;
+#endif
+            load_tile(vt, tile + 2 * tile_step);
+            load_rows(vr, __builtin_amdgcn_readfirstlane(ray_nn), __builtin_amdgcn_readlane(ray_nn, 31));
+            ray_nn = load_ray(tile + 3 * tile_step);
+            asm volatile("" ::: "memory");
+#ifdef PAG_WB_PROF
+            const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+            prof_seg[1] += ts2 - ts1;
+#endif
+            // ---------------- chain(it-2): dA = W_L^T . dz_L masked by the saved ReLU output -> global.  The stores are unconditional (the
+            // buffer has a padding tile and a dump tile): a predicated store is a branch, and past a branch the compiler no longer counts
+            // the operations in flight - it would wait for ALL of them, stores included, before the next iteration's LDS writes.
+            const bf16x8 *zbp = zbuf + (it & 1) * (OB * 2 * 64);
+            const bf16_t *Thq = Th + ((it + 2) & 3) * TW_ELEMS;
+            // every dz fragment is requested before the first MFMA (W_L^T stays in registers): one LDS latency per tile, not one per MFMA
+            bf16x8 zf[OB];          // rolling window: fragment s2 + OB is requested when fragment s2 has been consumed
+#pragma unroll
+            for (int s2 = 0; s2 < OB; ++s2) zf[s2] = zbp[s2 * 64 + lane];
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * OB; ++s2) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[mb][s2], zf[s2 % OB], acc[mb], 0, 0, 0);
+                if (s2 < OB) zf[s2] = zbp[(s2 + OB) * 64 + lane];
+            }
+            // the order above is the order wanted: OB reads, then (2 MFMAs, 1 read) x OB, then the remaining MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, OB, 0);
+#pragma unroll
+            for (int s2 = 0; s2 < OB; ++s2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * OB, 0);
+            asm volatile("" ::: "memory");
+#ifdef PAG_WB_PROF
+            asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[1]));
+            const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+            prof_seg[2] += ts3 - ts2;
+#endif
+            // ReLU mask and bf16 rounding on PAIRS: the saved activation is 0 or positive, so min(max(h as i16, 0), 1) is the 0 / 1
+            // mask of a half-word and a 16-bit multiply applies it - 4 instructions per pair instead of 7
+            typedef short i16x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x2 hv = *reinterpret_cast<const u32x2 *>(Thq + tw_off(r, 8 * mb + 2 * g + h));
+                    u32x2 o;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+                        const bf16x2 a2 = {(bf16_t)acc[mb][4 * g + 2 * d], (bf16_t)acc[mb][4 * g + 2 * d + 1]};
+                        unsigned int m;
+                        asm("v_pk_max_i16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(m) : "v"(hv[d]), "s"(0u), "s"(0x00010001u));
+                        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o[d]) : "v"(__builtin_bit_cast(unsigned int, a2)), "v"(m));
+                    }
+                    *reinterpret_cast<u32x2 *>(Tp + tw_off(r, 8 * mb + 2 * g + h)) = o;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+            }
+            wave_lds_sync();
+            {
+                const int voff = voff_tile + (int)(it >= 2 ? tile - 2 * tile_step : ntiles) * (32 * HID * 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rowl = k * 8 + (lane >> 3), ch = (lane & 7) * 2;
+                    const u32x2 lo = *reinterpret_cast<const u32x2 *>(Tp + tw_off(rowl, ch));
+                    const u32x2 hi = *reinterpret_cast<const u32x2 *>(Tp + tw_off(rowl, ch + 1));
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, rs_d, voff + k * (8 * HID * 2), 0, 0);
+                }
+            }
+#ifdef PAG_WB_PROF
+            prof_seg[3] += __builtin_amdgcn_s_memtime() - ts3;
+#endif
+            wg_barrier();
+        }
+#ifdef PAG_WB_PROF
+        if (lane == 0)
+            for (int k = 0; k < 4; ++k) atomicAdd(&g_wb_prof[1][k], prof_seg[k]);
+        if (lane == 0) {
+            atomicAdd(&g_wb_prof[0][wave], prof_wait);
+            atomicAdd(&g_wb_prof[1][wave], __builtin_amdgcn_s_memtime() - prof_t0);
+        }
+#endif
+        return;
+    }
+    // =============================================================================================== block waves
+    f32x16 aw[2], dbacc;        // dW_L of the own block (2 in-blocks) + bias block
+#pragma unroll
+    for (int q = 0; q < 16; ++q) aw[0][q] = aw[1][q] = dbacc[q] = 0.0f;
+    bf16x8 ones0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones0[e] = (bf16_t)(r == 0 ? 1.0f : 0.0f);
+    // per-lane scalars of the tile the NEXT iteration rebuilds; the ray index runs one tile further ahead so that the load of the
+    // per-ray scale it addresses never waits for it inside an iteration
+    int ray_c = p.g_index[row_of(tile0)], ray_n1 = p.g_index[row_of(tile0 + tile_step)];
+    float2 st_n = *reinterpret_cast<const float2 *>(p.stats + 2 * row_of(tile0));
+    float gsa_n = p.g_scale[row_of(tile0)], grs_n = p.g_ray_scale[ray_c];
+    // carried from rebuild(it) to finish(it) one iteration later: probabilities, the ray's raw gradient slice, its scale (0 = dead row).
+    // The element-wise arithmetic is written on pairs: packed fp32 instructions do two elements per issue slot.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 pf_c[8], v_c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pf_c[q] = v_c[q] = f32x2{0.0f, 0.0f};
+    float gsc_c = 0.0f;
+    wg_barrier();
+
+    // One iteration = finish(it-1) and rebuild(it), two independent instruction streams.  They are INTERLEAVED in program order (the
+    // LDS queue is in order, so program order decides what a wait waits for): every LDS round trip of one stream runs under arithmetic
+    // of the other.
+    for (int it = 0; it < n_own + 2; ++it) {
+        const int64_t tile = tile0 + (int64_t)it * tile_step;
+        asm volatile("" ::: "memory");          // keep the loop-invariant weight fragments in LDS, not hoisted into registers
+        const bf16_t *Thc = Th + (it & 3) * TW_ELEMS, *Thp = Th + ((it + 3) & 3) * TW_ELEMS;
+        const bool live = tile * 32 + r < M && it < n_own;
+        const float Ms = st_n.x, inv = st_n.y, g_sc = live ? __fmul_rn(gsa_n, grs_n) : 0.0f;
+        const int ray = ray_c;
+        const int ray_first = __builtin_amdgcn_readfirstlane(ray), ray_last = __builtin_amdgcn_readlane(ray, 31);
+        // ---- rebuild(it), reads: this lane's slice of its ray's gradient row - from the staged rows, or from global when the tile spans
+        //      too many rays (the only branch of the loop, kept first: a join drains every load still in flight)
+        f32x16 z;
+        if (ray_last - ray_first < WB_RMAX) {
+            const float *grow_l = grow + (it & 1) * (WB_RMAX * WR_RS) + (ray - ray_first) * WR_RS;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(grow_l + 32 * ob + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[4 * g + j] = v[j];
+            }
+        } else {
+            const float *gr = p.g_ray + (int64_t)ray * p.out_dim;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) z[q] = gr[min(32 * ob + rho(q, h), p.out_dim - 1)];
+        }
+        //      ... the forward's B operand of the output layer (exact: the saved bf16 activations), bias, weight fragments
+        bf16x8 hbL[4], wa[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(Thc + tw_off(r, 8 * mb + 4 * half + h));
+                const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(Thc + tw_off(r, 8 * mb + 4 * half + 2 + h));
+                hbL[2 * mb + half] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        f32x16 pf;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bLs + 32 * ob + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf[4 * g + j] = b4[j];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) wa[s2] = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s2 + 8 * h);
+        // ---- finish(it-1): <p, g> from the partials, dz = p (g - <p, g>) with g = scale * row:  p_bf16 * fma(row, scale, -scale <p, row>)
+        {
+            const float *dotp = dotbuf + ((it + 1) & 1) * (OB * 64);
+            bf16x8 *zbp = zbuf + ((it + 1) & 1) * (OB * 2 * 64);
+            float dot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < OB; ++w) dot += dotp[w * 64 + lane];
+            dot += __shfl_xor(dot, 32);
+            const f32x2 sc2 = {gsc_c, gsc_c}, nd2 = {-gsc_c * dot, -gsc_c * dot};
+            f32x16 zz;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x2 pb = {(float)(bf16_t)pf_c[q][0], (float)(bf16_t)pf_c[q][1]};
+                const f32x2 t = pb * (v_c[q] * sc2 + nd2);
+                zz[2 * q] = t[0];
+                zz[2 * q + 1] = t[1];
+            }
+            bf16x8 zb[2];
+            pack_block(zz, zb[0], zb[1]);
+            zbp[(ob * 2 + 0) * 64 + lane] = zb[0];
+            zbp[(ob * 2 + 1) * 64 + lane] = zb[1];
+            tw_put_block(Tz, 0, r, h, zz);
+        }
+        // ---- rebuild(it): logits
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) pf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s2], hbL[s2], pf, 0, 0, 0);
+        // ---- finish(it-1): operand fragments of dW_L (k = sample) come back transposed from LDS
+        wave_lds_sync();
+        bf16x8 fz[2], fh[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fz[ks] = tw_frag(Tz, 0, ks, lane);
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) fh[ks][ib] = tw_frag(Thp, ib, ks, lane);
+        }
+        // ---- rebuild(it): next tile's scalars (consumed next iteration), probabilities, partial <p, row>
+        {
+            const int64_t m1 = row_of(tile + tile_step);
+            st_n = *reinterpret_cast<const float2 *>(p.stats + 2 * m1);
+            gsa_n = p.g_scale[m1];
+            grs_n = p.g_ray_scale[ray_n1];
+            ray_c = ray_n1;
+            ray_n1 = p.g_index[row_of(tile + 2 * tile_step)];
+            const f32x2 l2 = {LOG2E, LOG2E}, nm2 = {-Ms, -Ms}, inv2 = {inv, inv};
+            f32x2 dp2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x2 t = f32x2{pf[2 * q], pf[2 * q + 1]} * l2 + nm2;
+                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} * inv2;
+                const f32x2 v = {z[2 * q], z[2 * q + 1]};
+                dp2 = e * v + dp2;
+                pf_c[q] = e;
+                v_c[q] = v;
+            }
+            dotbuf[(it & 1) * (OB * 64) + ob * 64 + lane] = dp2[0] + dp2[1];
+            gsc_c = g_sc;
+        }
+        // ---- finish(it-1): dW_L and its bias column
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) aw[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz[ks], fh[ks][ib], aw[ib], 0, 0, 0);
+            dbacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz[ks], ones0, dbacc, 0, 0, 0);
+        }
+        wg_barrier();
+    }
+#ifdef PAG_WB_PROF
+    if (lane == 0) {
+        atomicAdd(&g_wb_prof[0][wave], prof_wait);
+        atomicAdd(&g_wb_prof[1][wave], __builtin_amdgcn_s_memtime() - prof_t0);
+    }
+#endif
+    // ---- every block wave owns its 32 rows of the workgroup's slab [OB*32][96]: cols 0..63 dW_L, col 64 db
+    {
+        float *sl = p.slabs[0] + (int64_t)blockIdx.x * (OB * 32) * WG_SLAB_COLS_F;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * ob + rho(q, h);
+            sl[row * WG_SLAB_COLS_F + r] = aw[0][q];
+            sl[row * WG_SLAB_COLS_F + 32 + r] = aw[1][q];
+            if (r == 0) sl[row * WG_SLAB_COLS_F + 64] = dbacc[q];
+        }
+    }
+}
+
 // ------------------------------------------------------------------- backward of wide softmax heads
 // The 200-way instance head dominated the decoder backward: its [M,200] probabilities were streamed through twice
 // (dot product of the softmax backward, then dz) - 1.7 GB per launch.  With the forward's per-sample softmax statistics
@@ -2670,7 +3049,7 @@ extern "C" int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *a, 
     if (kind < 0 || M < 1) return 0;
     const int64_t grid = fused_grid(M);
     if (kind == 3)      // stage A: one [224][96] slab per workgroup; stage B: per-wave slabs of two 64-row layers; + the [M,64] bf16 hidden gradient
-        return (grid * 224 + grid * 128) * WG_SLAB_COLS * (int64_t)sizeof(float) + ((M * HID * 2 + 255) / 256) * 256;
+        return (grid * 224 + grid * 128) * WG_SLAB_COLS * (int64_t)sizeof(float) + ((M + 31) / 32 + 1) * 32 * HID * 2;      // + a dump tile
     return grid * ((int64_t)(a->n_layers - 1) * 64 + 32) * WG_SLAB_COLS * (int64_t)sizeof(float);
 }
 
@@ -2765,15 +3144,28 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         pa.slabs[0] = slabA;
         constexpr int OBW = 7;
         const size_t ldsA = (size_t)(64 * (OBW * 32 + 8) + OBW * 32 * RS) * sizeof(bf16_t) + (size_t)OBW * 32 * sizeof(float) +
-                            (size_t)4 * 3 * TW_ELEMS * sizeof(bf16_t) + (size_t)4 * WR_MAX * WR_RS * sizeof(float);
+                            (size_t)(5 + OBW) * TW_ELEMS * sizeof(bf16_t) + (size_t)2 * WB_RMAX * WR_RS * sizeof(float) +
+                            (size_t)2 * OBW * 64 * sizeof(float) + (size_t)2 * OBW * 2 * 64 * 16;
         static bool attrA = false;
         if (!attrA) {
-            hipFuncSetAttribute((const void *)mlp_bwd_wide_fused<OBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void *)mlp_bwd_wide_blocks<OBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void *)mlp_bwd_fused<2, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attrA = true;
         }
-        hipLaunchKernelGGL((mlp_bwd_wide_fused<OBW>), dim3(grid), dim3(256), ldsA, st, pa);
+        hipLaunchKernelGGL((mlp_bwd_wide_blocks<OBW>), dim3(grid), dim3((OBW + 1) * 64), ldsA, st, pa);
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, wide head)");
+#ifdef PAG_WB_PROF
+        {
+            unsigned long long hp[2][8];
+            hipStreamSynchronize(st);
+            hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_wb_prof), sizeof(hp));
+            fprintf(stderr, "[wb_prof] grid %u:", grid);
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " w%d %.0f/%.0f", w, (double)hp[0][w] / grid, (double)hp[1][w] / grid);
+            fprintf(stderr, "\n");
+            for (auto &row : hp) for (auto &v : row) v = 0;
+            hipMemcpyToSymbol(HIP_SYMBOL(g_wb_prof), hp, sizeof(hp));
+        }
+#endif
         BwdParams pb = p;
         pb.grad_out = dzh;
         pb.out = dzh;
