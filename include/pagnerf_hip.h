@@ -250,6 +250,9 @@ int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
  * the first three with 2 or 3 layers, out_dim <= 32, and input column 63 free (XCD8: staged position 63 is padding; it carries the
  * constant 1 whose weight gradient is the layer-0 bias gradient).  Anything else: dz[] + pag_mlp_wgrad_batch. */
 int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *args);
+/* The wide softmax kernels address the [M,64] bf16 tensors with 32-bit byte offsets: pag_mlp_bwd refuses M above this on that path
+ * (PAG_ERR_ARG; callers split the batch or leave wgrad_workspace NULL). */
+#define PAG_MLP_FUSED_WIDE_MAX_M ((int64_t)1 << 24)
 int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *args, int64_t M);
 
 /* Wide softmax head fused with the per-ray weighted sum of tracers/panoptic_packed_rf_tracer.py:197-205:

@@ -1483,292 +1483,31 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
 // probabilities are rebuilt from the saved last hidden layer and the forward's softmax statistics (as mlp_bwd_wide_mfma does),
 // dz_L is formed block by block from the rank-1 upstream gradient and consumed at once - by the W_L^T chain (-> the hidden
 // layer's gradient, written as a [M,64] bf16 tensor for stage B: mlp_bwd_fused<.., KIND 0, OBL 2> on the remaining layers) and by
-// this wave's dW_L accumulators (OB x 2 blocks of 16 registers, for the whole launch; transposed LDS reads as in
-// mlp_bwd_fused).  The [M, out_dim] softmax gradient (839 MB at M = 2.1 M, written once and read once before) never exists.
-// One wave per SIMD; straight-line tile loop: next tile's hidden rows, statistics and the gradient rows of its (up to 4) rays
-// are requested one tile ahead, the hidden-gradient stores of a tile go out at the top of the next one.
-constexpr int WR_MAX = 2;          // rays whose gradient rows are staged per tile (a tile spanning more takes per-lane global loads)
-constexpr int WR_RS = 256;         // floats per staged row
-template <int OB>
-__global__ __launch_bounds__(256, 1) void mlp_bwd_wide_fused(BwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RSL = OB * 32 + 8;
-    constexpr float LOG2E = 1.4426950408889634f;
-    bf16_t *WLt = reinterpret_cast<bf16_t *>(smem);              // [64 hidden][RSL]   k = output channel (permuted)
-    bf16_t *WLs = WLt + 64 * RSL;                                // [OB*32 channels][RS] permuted k (forward layout)
-    float *bLs = reinterpret_cast<float *>(WLs + OB * 32 * RS);  // [OB*32]
-    bf16_t *Th = reinterpret_cast<bf16_t *>(bLs + OB * 32) + (threadIdx.x >> 6) * (3 * TW_ELEMS);      // wave-private: activations, dz, hidden gradient
-    bf16_t *Tz = Th + TW_ELEMS, *Tp = Tz + TW_ELEMS;
-    float *grow = reinterpret_cast<float *>(reinterpret_cast<bf16_t *>(bLs + OB * 32) + 4 * 3 * TW_ELEMS) + (threadIdx.x >> 6) * (WR_MAX * WR_RS);
-    stage_weight_t(WLt, RSL, 64, OB * 32, p.W[0], p.out_dim, HID);
-    stage_weight(WLs, RS, OB * 32, 64, p.W[0], p.out_dim, HID, true);
-    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b_last[e] : 0.0f;
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t M = p.M, ntiles = (M + 31) / 32, nfull = M / 32;
-    const int64_t tile_step = (int64_t)gridDim.x * 4;
-    const bf16_t *hsrc = reinterpret_cast<const bf16_t *>(p.hsave[0]);
-    bf16_t *dzh = reinterpret_cast<bf16_t *>(p.dz[0]);
-
-    // ---- registers of the next tile
-    bf16x8 hn[4];
-    float2 st_n = {0.0f, 1.0f};
-    float gs_n = 0.0f, grow_n[4 * WR_MAX];
-    int ray1 = 0, ray2 = 0;          // this lane's ray in the next tile / the one after
-    auto row_of = [&](int64_t tile) __attribute__((always_inline)) { return min(min(tile, ntiles - 1) * 32 + r, M - 1); };
-    auto prefetch = [&](int64_t tile_raw, int ray) __attribute__((always_inline)) {
-        const int64_t tile = min(tile_raw, ntiles - 1);
-        const int64_t m = min(tile * 32 + r, M - 1);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int64_t row = min(tile * 32 + it * 8 + (lane >> 3), M - 1);
-            hn[it] = load8(hsrc + row * HID + (lane & 7) * 8);
-        }
-        st_n = *reinterpret_cast<const float2 *>(p.stats + 2 * m);
-        gs_n = __fmul_rn(p.g_scale[m], p.g_ray_scale[ray]);
-        const int ray_first = __builtin_amdgcn_readfirstlane(ray), ray_last = __builtin_amdgcn_readlane(ray, 31);
-#pragma unroll
-        for (int k = 0; k < 4 * WR_MAX; ++k) {      // staged row k / 4 (ray_first + k / 4, clamped to the tile's last ray), column 64 (k % 4) + lane
-            const int rr = min(ray_first + (k >> 2), ray_last);
-            const int col = min(64 * (k & 3) + lane, p.out_dim - 1);
-            grow_n[k] = p.g_ray[(int64_t)rr * p.out_dim + col];
-        }
-    };
-
-    f32x16 awL[OB][2], dbacc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        dbacc[q] = 0.0f;
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) {
-            awL[ob][0][q] = 0.0f;
-            awL[ob][1][q] = 0.0f;
-        }
-    }
-    auto ones_col = [&](int j) __attribute__((always_inline)) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(r == j ? 1.0f : 0.0f);
-        return o;
-    };
-    // The hidden-layer gradient of a tile stays in its LDS image (Tp) and is stored at the top of the NEXT tile, after that tile's
-    // prefetched registers have been consumed and before the next prefetch is issued (see mlp_bwd_fused: stores issued at the end
-    // of a tile would have to drain before the next tile could touch its prefetched data).  First flush: zeros.
-    for (int e = lane; e < TW_ELEMS / 4; e += 64) reinterpret_cast<bf16x4 *>(Tp)[e] = bf16x4{(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
-    int64_t pend_tile = min((int64_t)blockIdx.x * 4 + wave, ntiles - 1);
-    auto flush = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rowl = it * 8 + (lane >> 3), ch = (lane & 7) * 2;
-            const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(Tp + tw_off(rowl, ch));
-            const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(Tp + tw_off(rowl, ch + 1));
-            const int64_t row = pend_tile * 32 + rowl;
-            if (row < M) *reinterpret_cast<bf16x8 *>(dzh + row * HID + (lane & 7) * 8) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-    };
-
-    int ray_cur = 0;
-    auto body = [&](int64_t tile) __attribute__((always_inline)) {
-        const int64_t m = tile * 32 + r;
-        const bool live = m < M;
-        // ---- this tile's activations -> LDS image; the gradient rows of its first WR_MAX rays -> LDS
-        wave_lds_sync();
-        tw_put_rows(Th, hn, lane);
-#pragma unroll
-        for (int k = 0; k < 4 * WR_MAX; ++k) grow[(k >> 2) * WR_RS + 64 * (k & 3) + lane] = grow_n[k];
-        const float Ms = st_n.x, inv = st_n.y, g_sc = gs_n;
-        const int ray_first = __builtin_amdgcn_readfirstlane(ray_cur), ray_last = __builtin_amdgcn_readlane(ray_cur, 31);
-        const int roff = ray_cur - ray_first;
-        flush();
-        prefetch(tile + tile_step, ray1);
-        ray_cur = ray1;
-        ray1 = ray2;
-        ray2 = p.g_index[row_of(tile + 3 * tile_step)];
-        wave_lds_sync();
-        // the forward's B operand of the output layer (exact: the saved bf16 activations) and the transposed fragments for dW_L
-        bf16x8 hbL[4];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(Th + tw_off(r, 8 * mb + 4 * half + h));
-                const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(Th + tw_off(r, 8 * mb + 4 * half + 2 + h));
-                hbL[2 * mb + half] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-        auto prob_block = [&](int ob, f32x16 &o) __attribute__((always_inline)) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bLs + 32 * ob + 8 * g + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[4 * g + j] = b4[j];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hbL[s], o, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) o[q] = __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -Ms)) * inv;
-            if (ob == OB - 1) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) o[q] = (32 * ob + rho(q, h) < p.out_dim) ? o[q] : 0.0f;
-            }
-        };
-        f32x16 acc[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
-        // A tile normally lies inside one ray (or a few): its samples' gradient rows are the <= WR_MAX staged ones.  A tile that
-        // spans more rays (short packs after pruning) is processed in windows of WR_MAX rays: the lanes of the other windows
-        // count as dead (dz = 0), every accumulator simply adds up, and the later windows' rows are loaded in place (rare path).
-        int w0 = 0;
-        bool more;
-        do {
-            const bool mine = live && roff >= w0 && roff < w0 + WR_MAX;
-            const float *grow_l = grow + min(max(roff - w0, 0), WR_MAX - 1) * WR_RS;
-            auto grad_block = [&](int ob, f32x16 &z) __attribute__((always_inline)) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(grow_l + 32 * ob + 8 * g + 4 * h);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) z[4 * g + j] = g_sc * v[j];
-                }
-            };
-            // pass 1: <p, g> per sample.  The dW_L accumulators leave no registers to keep the probability blocks between the
-            // passes (as mlp_bwd_wide_mfma does): pass 2 rebuilds each block once more (4 MFMAs on idle matrix cores + 16 exp2) -
-            // bitwise the same values; the dot product uses them in fp32, dz their bf16 rounding (the precision the stored
-            // tensor had) - exactly the arithmetic of mlp_bwd_wide_mfma.
-            float dot = 0.0f;
-#pragma unroll 1
-            for (int ob = 0; ob < OB; ++ob) {
-                f32x16 z, pf;
-                prob_block(ob, pf);
-                grad_block(ob, z);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) dot += pf[q] * z[q];
-            }
-            dot += __shfl_xor(dot, 32);
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob) {
-                f32x16 zz, z, pf;
-                prob_block(ob, pf);
-                grad_block(ob, z);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) zz[q] = mine ? (float)(bf16_t)pf[q] * (z[q] - dot) : 0.0f;
-                bf16x8 zb[2];
-                pack_block(zz, zb[0], zb[1]);
-                tw_put_block(Tz, 0, r, h, zz);
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * (2 * ob + half) + 8 * h);
-                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[half], acc[mb], 0, 0, 0);
-                    }
-                wave_lds_sync();
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 afr = tw_frag(Tz, 0, ks, lane);
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib)      // the activations' transposed fragments are re-read per block: no registers to keep them
-                        awL[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, tw_frag(Th, ib, ks, lane), awL[ob][ib], 0, 0, 0);
-                    dbacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones_col(ob), dbacc, 0, 0, 0);
-                }
-                wave_lds_sync();
-            }
-            w0 += WR_MAX;
-            more = ray_last - ray_first >= w0;
-            if (more) {
-#pragma unroll
-                for (int k = 0; k < 4 * WR_MAX; ++k) {
-                    const int rr = min(ray_first + w0 + (k >> 2), ray_last);
-                    const int col = min(64 * (k & 3) + lane, p.out_dim - 1);
-                    grow[(k >> 2) * WR_RS + 64 * (k & 3) + lane] = p.g_ray[(int64_t)rr * p.out_dim + col];
-                }
-                wave_lds_sync();
-            }
-        } while (more);
-        // ---- dA = W_L^T . dz_L masked by the saved ReLU output -> its LDS image for the deferred store
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(Th + tw_off(r, 8 * mb + 2 * g + h));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] = ((float)hv[j] > 0.0f && live) ? acc[mb][4 * g + j] : 0.0f;
-            }
-            tw_put_block(Tp, mb, r, h, acc[mb]);
-        }
-        pend_tile = tile;
-    };
-
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    ray_cur = p.g_index[row_of(tile)];
-    ray1 = p.g_index[row_of(tile + tile_step)];
-    ray2 = p.g_index[row_of(tile + 2 * tile_step)];
-    prefetch(tile, ray_cur);
-    const bool any_tile = tile < ntiles;
-    for (; tile < ntiles; tile += tile_step) body(tile);
-    if (any_tile) {
-        wave_lds_sync();
-        flush();
-    }
-
-    // ---- the four waves' accumulators are summed through LDS (the tiles and weights are dead): one slab per workgroup
-    __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);                      // [(2 OB + 1) blocks][16 q][64 lanes]
-    constexpr int NB = 2 * OB + 1;
-#pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const f32x16 &a = b < 2 * OB ? awL[b >> 1][b & 1] : dbacc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    float *dst = red + (b * 16 + q) * 64 + lane;
-                    *dst = w == 0 ? a[q] : *dst + a[q];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    float *sl = p.slabs[0] + (int64_t)blockIdx.x * (OB * 32) * WG_SLAB_COLS_F;
-    for (int b = wave; b < NB; b += 4) {
-        const int ob = b >> 1, ib = b & 1;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float v = red[(b * 16 + q) * 64 + lane];
-            if (b < 2 * OB) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = v;
-            else if (r < OB) sl[(32 * r + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;      // dbacc column r = bias gradients of block r
-        }
-    }
-}
-
-// ------------------------------------------------ wide softmax head, stage A, block-parallel form (the one that is launched)
-// mlp_bwd_wide_fused above gives every wave whole tiles and ALL dW_L blocks: 240 accumulator registers = one wave per SIMD, where a
-// lone wave issues a VALU instruction every 4 cycles (2 with a second wave) and nothing hides its waits - 0.70 ms, VALU 41 % /
-// waiting 38 %, with both passes rebuilding the probabilities for lack of registers.  Here the OUTPUT BLOCKS are spread over the
-// waves of a workgroup instead: wave ob (< OB) owns the 32 channels of block ob for EVERY tile of the workgroup - it rebuilds that
-// block once per tile (kept in registers between the passes), and accumulates dW_L[32 ob .. +31][:] (2 blocks + the bias block:
-// 48 accumulator registers) for the whole launch; one helper wave runs the W_L^T chain on the dz fragments the block waves leave
-// in LDS, applies the ReLU mask, writes the hidden gradient and stages the coming tiles.  What crosses waves per tile: the partial
-// <p, g> of each block (256 B per wave) and the dz B-fragments (2 KiB per wave).
+// the dW_L accumulators.  The [M, out_dim] softmax gradient (839 MB at M = 2.1 M, written once and read once before) never exists.
+//
+// The first form of this kernel gave every wave whole tiles and ALL dW_L blocks: 240 accumulator registers = one wave per SIMD,
+// where nothing hides a wave's waits - 0.70 ms, VALU 41 % / waiting 38 %, with both passes rebuilding the probabilities for lack
+// of registers.  Here the OUTPUT BLOCKS are spread over the waves of a workgroup instead: wave ob (< OB) owns the 32 channels of
+// block ob for EVERY tile of the workgroup - it rebuilds that block once per tile (kept in registers between the passes), and
+// accumulates dW_L[32 ob .. +31][:] (2 blocks + the bias block: 48 accumulator registers) for the whole launch; one helper wave
+// runs the W_L^T chain on the dz fragments the block waves leave in LDS (W_L^T itself stays in its registers), applies the ReLU
+// mask, writes the hidden gradient and stages the coming tiles.  What crosses waves per tile: the partial <p, g> of each block
+// (256 B per wave) and the dz B-fragments (2 KiB per wave).
 //
 // The three steps of a tile are SKEWED over three iterations so that ONE workgroup barrier per iteration orders everything and
 // every wave has two independent instruction streams between barriers:
 //     iteration it:   block waves   finish(it-1): <p,g> from the partials, dz -> LDS fragments, dW_L MFMAs
-//                                   rebuild(it) : probabilities of tile it, z = scaled gradient rows, partial <p,g> -> LDS
+//                                   rebuild(it) : probabilities of tile it, z = gradient rows, partial <p,g> -> LDS
 //                     helper wave   tiles it+1 (registers -> LDS) and it+2 (global -> registers) staged,
 //                                   chain(it-2) : W_L^T . dz, ReLU mask, hidden gradient of tile it-2 -> global
 // LDS rings: activations 4 deep (tiles it-2 .. it+1), dz fragments / partial dots / gradient rows 2 deep.  Tiles that do not exist
-// (the two drain iterations, tiles past the end) run with live = false: their dz is zero and their stores are predicated off.
-// OB + 1 = 8 waves per workgroup, one workgroup per CU: two waves per SIMD.
+// (the two drain iterations, tiles past the end) run with scale 0: their dz is zero, their stores go to a dump tile.
+// OB + 1 = 8 waves per workgroup, one workgroup per CU: two waves per SIMD.  0.43 ms; per-wave barrier waits (-DPAG_WB_PROF): the
+// block waves that share a SIMD with another block wave wait 4-30 %, the helper 5 % - the roles are balanced, what is left is the
+// issue time of two waves per SIMD.
+constexpr int WR_RS = 256;         // floats per staged gradient row
 #ifdef PAG_WB_PROF
-__device__ unsigned long long g_wb_prof[2][8];      // [0] cycles at the barrier, [1] loop cycles; per wave role, summed over workgroups
+__device__ unsigned long long g_wb_prof[2][8];      // [0] cycles at the barrier, [1] loop cycles (slots 0-3: helper segments on top); summed over workgroups
 #endif
 constexpr int WB_RMAX = 4;         // rays whose gradient rows are staged per tile; tiles spanning more read their rows from global
 template <int OB>
@@ -2051,19 +1790,20 @@ __global__ __launch_bounds__((OB + 1) * 64) void mlp_bwd_wide_blocks(BwdParams p
             for (int w = 0; w < OB; ++w) dot += dotp[w * 64 + lane];
             dot += __shfl_xor(dot, 32);
             const f32x2 sc2 = {gsc_c, gsc_c}, nd2 = {-gsc_c * dot, -gsc_c * dot};
-            f32x16 zz;
+            typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            unsigned int zp[8];          // dz rounded to bf16, channel pairs (2q, 2q+1): the helper's B fragments and the own transposed tile
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const f32x2 pb = {(float)(bf16_t)pf_c[q][0], (float)(bf16_t)pf_c[q][1]};
                 const f32x2 t = pb * (v_c[q] * sc2 + nd2);
-                zz[2 * q] = t[0];
-                zz[2 * q + 1] = t[1];
+                zp[q] = __builtin_bit_cast(unsigned int, bf16x2{(bf16_t)t[0], (bf16_t)t[1]});
             }
-            bf16x8 zb[2];
-            pack_block(zz, zb[0], zb[1]);
-            zbp[(ob * 2 + 0) * 64 + lane] = zb[0];
-            zbp[(ob * 2 + 1) * 64 + lane] = zb[1];
-            tw_put_block(Tz, 0, r, h, zz);
+            *reinterpret_cast<u32x4 *>(zbp + (ob * 2 + 0) * 64 + lane) = u32x4{zp[0], zp[1], zp[2], zp[3]};
+            *reinterpret_cast<u32x4 *>(zbp + (ob * 2 + 1) * 64 + lane) = u32x4{zp[4], zp[5], zp[6], zp[7]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2 *>(Tz + tw_off(r, 2 * g + h)) = u32x2{zp[2 * g], zp[2 * g + 1]};
         }
         // ---- rebuild(it): logits
 #pragma unroll
@@ -3016,7 +2756,7 @@ static int fused_kind(const pag_mlp_bwd_args *a) {
     if (a->n_layers != 2 && a->n_layers != 3) return -1;
     if (!a->x1 || a->x1_dtype != PAG_BF16) return -1;
     const bool rank1 = a->g_ray != nullptr;
-    if (a->out_dim > 32) {      // wide softmax head: stage A (output layer, mlp_bwd_wide_fused) + stage B (the two layers below it)
+    if (a->out_dim > 32) {      // wide softmax head: stage A (output layer, mlp_bwd_wide_blocks) + stage B (the two layers below it)
         if (a->out_dim <= 192 || a->out_dim > 224 || a->n_layers != 3 || !a->g_ray || !a->g_scale || !a->g_index || !a->g_ray_scale) return -1;
         if (a->out_act != PAG_ACT_SOFTMAX || !a->softmax_stats || !a->b_last || a->out_dtype != PAG_BF16 || !a->dx1 || a->dx1_dtype != PAG_BF16) return -1;
         if (!a->x1 || a->x1_dtype != PAG_BF16 || a->x1_layout != PAG_LAYOUT_XCD8 || a->k1 != 64 || a->x2 || a->dx1_col0_add || a->dx1_accumulate) return -1;
@@ -3128,6 +2868,8 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     if (fuse && kind == 3) {
         // ---- wide softmax head: stage A (output layer + dW_L) then stage B (layers 0, 1 as a 2-layer decoder whose upstream gradient is
         //      the hidden gradient stage A wrote)
+        PAG_CHECK_ARG(M <= PAG_MLP_FUSED_WIDE_MAX_M, "pag_mlp_bwd: the fused wide-head backward addresses [M,64] bf16 tensors with 32-bit byte offsets: M %lld > %lld, split the batch",
+                      (long long)M, (long long)PAG_MLP_FUSED_WIDE_MAX_M);
         const unsigned grid = fused_grid(M);
         float *ws = a->wgrad_workspace;
         float *slabA = ws;

@@ -441,7 +441,7 @@ class _FusedMLP(torch.autograd.Function):
         # kernel for this decoder shape: no dz tensors, no second pass over the activations.  d x2 (pose optimisation) is formed
         # from dz_0, so that case keeps the dz tensors and the separate weight-gradient launches.
         fused = False
-        if WGRAD_FUSED and M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 and not need_dx2:
+        if WGRAD_FUSED and 0 < M <= L.MLP_FUSED_WIDE_MAX_M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 and not need_dx2:
             a.x1, a.x1_dtype = L.ptr(x1), L.BF16
             if x2 is not None:
                 a.x2, a.k2p, a.x2_index = L.ptr(x2), k2p, L.ptr(x2_index)
