@@ -418,6 +418,51 @@ __device__ __forceinline__ void hidden_layer(const bf16_t *Ws, const float *bs, 
     }
 }
 
+// The same for the one-wave-per-SIMD fused backward kernels, with the instruction order PINNED.  Left to itself the scheduler emits
+// "ds_read fragment, s_waitcnt lgkmcnt(0), v_mfma" once per k-step - a full LDS round trip in front of every MFMA, and a lone wave
+// has nothing else to run meanwhile (20 such steps were half of a tile's time).  Here: every read of the first two k-steps first,
+// then per k-step its two MFMAs (independent accumulators) while the reads two steps ahead are in flight.
+template <int MBS, int NS, int LEAD_READS>
+__device__ __forceinline__ void mfma_chain_pinned(const bf16_t *Wt, int stride, const bf16x8 (&frag)[NS], int r, int h, f32x16 (&acc)[2]) {
+    bf16x8 a[MBS][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mb = 0; mb < MBS; ++mb) a[mb][s] = *reinterpret_cast<const bf16x8 *>(Wt + (32 * mb + r) * stride + 16 * s + 8 * h);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mb = 0; mb < MBS; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][s], frag[s], acc[mb], 0, 0, 0);
+    constexpr int AHEAD = NS < 2 ? NS : 2;
+    __builtin_amdgcn_sched_group_barrier(0x100, LEAD_READS + AHEAD * MBS, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MBS, 0);
+        if (s + AHEAD < NS) __builtin_amdgcn_sched_group_barrier(0x100, MBS, 0);
+    }
+}
+template <int NS>
+__device__ __forceinline__ void hidden_layer_pinned(const bf16_t *Ws, const float *bs, const bf16x8 (&frag)[NS], int r, int h, f32x16 (&acc)[2]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[mb][q] = bs[32 * mb + rho(q, h)];
+    mfma_chain_pinned<2, NS, 8>(Ws, RS, frag, r, h, acc);          // 8 leading reads: the bias blocks (4 x 16 bytes per block)
+    __builtin_amdgcn_sched_barrier(0);
+}
+// acc = W^T-layout weight . fragments, from zero
+template <int MBS, int NS>
+__device__ __forceinline__ void wt_chain_pinned(const bf16_t *Wt, int stride, const bf16x8 (&frag)[NS], int r, int h, f32x16 (&acc)[2]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < MBS; ++mb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
+    mfma_chain_pinned<MBS, NS, 0>(Wt, stride, frag, r, h, acc);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---------------------------------------------------------------------- swizzled tiles for the fused weight gradients
 // dW = dz^T . a sums over the SAMPLES, which sit on the lanes in every register layout of the backward kernel - both MFMA
 // operands need one transpose.  A wave keeps its 32-sample tiles ([32 samples][64 channels] bf16, 128-byte rows, 4 KiB) in LDS
@@ -1241,7 +1286,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
             tw_put_frags(Tx, xb, r, h);
             f32x16 ha[2];
             bf16x8 hf[4];
-            hidden_layer<4>(W0s, b0s, xb, 4, r, h, ha);
+            hidden_layer_pinned<4>(W0s, b0s, xb, r, h, ha);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -1250,7 +1295,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
                 if constexpr (NL == 3) pack_block(ha[mb], hf[2 * mb], hf[2 * mb + 1]);
             }
             if constexpr (NL == 3) {
-                hidden_layer<4>(W1s, b1s, hf, 4, r, h, ha);
+                hidden_layer_pinned<4>(W1s, b1s, hf, r, h, ha);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -1323,15 +1368,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         // ---- back through the output layer, masked by the saved ReLU output (read from its LDS image)
         f32x16 acc[2];
         bf16x8 hb[4];
+        wt_chain_pinned<2, 2 * OBL>(WLt, RSL, zb, r, h, acc);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 2 * OBL; ++s) {
-                bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLt + (32 * mb + r) * RSL + 16 * s + 8 * h);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[s], acc[mb], 0, 0, 0);
-            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const bf16x4 hv = *reinterpret_cast<const bf16x4 *>((NL == 3 ? Th1 : Th0) + tw_off(r, 8 * mb + 2 * g + h));
@@ -1348,15 +1387,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         wave_lds_sync();
         if constexpr (NL == 3) {
             bf16x8 hb2[4];
+            wt_chain_pinned<2, 4>(W1t, RS, hb, r, h, acc);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(W1t + (32 * mb + r) * RS + 16 * s + 8 * h);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
-                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(Th0 + tw_off(r, 8 * mb + 2 * g + h));
@@ -1374,15 +1407,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
         }
         // ---- dx1 = (W_0^T . dz_0)[0:k1]
+        wt_chain_pinned<(GRP ? 2 : 1), 4>(W0t, RS, hb, r, h, acc);
 #pragma unroll
         for (int mb = 0; mb < (GRP ? 2 : 1); ++mb) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 a = *reinterpret_cast<const bf16x8 *>(W0t + (32 * mb + r) * RS + 16 * s + 8 * h);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], acc[mb], 0, 0, 0);
-            }
             if constexpr (GRP) {      // XCD8: row 32mb + 8g + 4h + j of dx^T -> piece [4mb + g][m][4h + j]
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
