@@ -739,6 +739,291 @@ __global__ __launch_bounds__(256, (OBMAX > 2 ? PAG_FWD_WAVES_WIDE : PAG_FWD_WAVE
     }
 }
 
+// ------------------------------------------------------------------ forward, production decoder shapes: straight-line tile loops
+// mlp_fwd_mfma above serves every layout / dtype / activation through run-time branches: 62 branches per tile, and past every join the
+// compiler waits for ALL loads in flight (it no longer counts them) - the next tile's prefetch was waited for right after it was
+// issued; 45 - 58 % VALU-busy, the rest stalls.  The decoder shapes of the panoptic nef (pc_nerf/panoptic_nef.py:114-164: density-like,
+// colour-like, semantic-like, the wide instance head) get dedicated kernels, like their backward (mlp_bwd_fused): no branch in the tile
+// loop at all.  Every global access goes through a buffer descriptor - out-of-range lanes (rows past M, channels past out_dim, the
+// half-waves that hold no output channel) get an offset past the end: their loads return 0, their stores are dropped - the weight chains
+// use the pinned read-ahead order, and the element-wise arithmetic is written on pairs (packed fp32).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned BUF_OOB = 0x80000000u;         // added to an offset < 2^30: past any descriptor's range (tensors here are <= 2^30 bytes:
+constexpr unsigned BUF_OOB_ROW = 0x40000000u;     // M <= 2^24 rows of <= 64 bytes).  Dead PIECE + dead ROW = 0xC0000000: the sum must not wrap to 0
+
+__device__ __forceinline__ void out_block_pinned(const bf16_t *WLs, const float *bLs, int ob, const bf16x8 (&hb)[4], int r, int h, f32x16 &o) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[q] = bLs[32 * ob + rho(q, h)];
+    bf16x8 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], hb[s], o, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);          // 4 bias reads + 4 weight fragments, then the chain
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// relu + bf16 B fragments of the next layer
+__device__ __forceinline__ void relu_pack(f32x16 (&acc)[2], bf16x8 (&hb)[4]) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[mb][q] = fmaxf(acc[mb][q], 0.0f);
+        pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
+    }
+}
+// accumulator blocks (64 columns, 32 rows) -> row-major [M,64] bf16 through the wave's staging buffer; rows past M are dropped
+template <typename RS_T>
+__device__ __forceinline__ void tile64_store_buf(bf16_t *stg, RS_T rs, unsigned tile_off, int lane, int r, int h, const f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v = {(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
+            *reinterpret_cast<bf16x4 *>(stg + r * ST_RS + 32 * mb + 8 * g + 4 * h) = v;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + row * ST_RS + c);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, tile_off + row * (HID * 2) + c * 2, 0, 0);
+    }
+    wave_lds_sync();
+}
+
+// KIND 0: XCD8 bf16 input, no output activation, bf16 out, out_dim % 4 == 0 (<= 32)                 (density decoder)
+// KIND 1: bf16 x1 [M,16] + f32 x2 [R,32] through x2_index, sigmoid, f32 out, out_dim <= 4, col0_relu   (colour decoder)
+// KIND 2: XCD8 bf16 input, softmax, bf16 out, out_dim <= 8                                             (semantic head)
+// SAVE: write the hidden activations (hsave[0], and hsave[1] with three layers) - the backward that recomputes them passes none.
+template <int NL, int KIND, bool SAVE>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_fast(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool GRP = KIND != 1;
+    constexpr int NKS0 = GRP ? 4 : 3;
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16_t *W0s = reinterpret_cast<bf16_t *>(smem);                  // [64][RS] natural k
+    bf16_t *W1s = W0s + 64 * RS;                                     // [64][RS] permuted k (NL == 3)
+    bf16_t *WLs = W1s + (NL == 3 ? 64 * RS : 0);                     // [32][RS] permuted k
+    float *b0s = reinterpret_cast<float *>(WLs + 32 * RS);
+    float *b1s = b0s + 64;
+    float *bLs = b1s + 64;
+    bf16_t *stg = reinterpret_cast<bf16_t *>(bLs + 32) + (threadIdx.x >> 6) * (ST_BYTES / 2);      // wave-private staging tile
+    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
+    if (NL == 3) stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
+    stage_weight(WLs, RS, 32, 64, p.W[NL - 1], p.out_dim, HID, true);
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        b0s[e] = p.b[0][e];
+        b1s[e] = NL == 3 ? p.b[1][e] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b[NL - 1][e] : 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t M = p.M, ntiles = (M + 31) / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const auto rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x1), 0, (int)(GRP ? M * 128 : M * 32), 0x00020000);
+    const auto rs_xi = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(KIND == 1 ? p.x2_index : nullptr), 0, (int)(M * 4), 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(M * p.out_dim * (KIND == 1 ? 4 : 2)), 0x00020000);
+    const auto rs_c0 = __builtin_amdgcn_make_buffer_rsrc(KIND == 1 ? p.col0_relu : nullptr, 0, (int)(M * 4), 0x00020000);
+    const auto rs_h0 = __builtin_amdgcn_make_buffer_rsrc(SAVE ? p.hsave[0] : nullptr, 0, (int)(M * HID * 2), 0x00020000);
+    const auto rs_h1 = __builtin_amdgcn_make_buffer_rsrc(SAVE && NL == 3 ? p.hsave[1] : nullptr, 0, (int)(M * HID * 2), 0x00020000);
+    // loop-invariant lane offsets
+    unsigned xoff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xoff[s] = GRP ? (unsigned)(((int64_t)(2 * s + h) * M + r) * 16) : (unsigned)(r * 32 + h * 16);
+    unsigned ooff[4];            // per output piece of this lane; BUF_OOB when the piece is past out_dim
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if constexpr (KIND == 0) ooff[g] = (8 * g + 4 * h < p.out_dim) ? (unsigned)((r * p.out_dim + 8 * g + 4 * h) * 2) : BUF_OOB;
+        else ooff[g] = (4 * h + g < p.out_dim) ? (unsigned)((r * p.out_dim + 4 * h + g) * (KIND == 1 ? 4 : 2)) : BUF_OOB;
+    }
+    const unsigned c0off = h == 0 ? (unsigned)(r * 4) : BUF_OOB;
+
+    // the next tile's layer-0 fragments are requested before the current tile is computed (colour: the view-embedding row index
+    // runs one tile further ahead, so that the gather it addresses never waits for it inside an iteration)
+    auto row_live = [&](int64_t tile) __attribute__((always_inline)) { return tile * 32 + r < M; };
+    auto load_x = [&](int64_t tile, int ray, bf16x8 (&xf)[4]) __attribute__((always_inline)) {
+        const unsigned base = row_live(tile) ? (unsigned)(tile * 32) * (GRP ? 16u : 32u) : BUF_OOB;
+        if constexpr (GRP) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x1, xoff[s] + base, 0, 0));
+        } else {
+            xf[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x1, xoff[0] + base, 0, 0));
+            const float *row = p.x2 + (int64_t)ray * p.k2p + 8 * h;          // ray is a valid index for every lane (0 for rows past M)
+#pragma unroll
+            for (int s = 1; s < 3; ++s) xf[s] = load8(row + 16 * (s - 1));
+            xf[3] = zero8();
+        }
+    };
+    auto load_ray = [&](int64_t tile) __attribute__((always_inline)) {
+        if constexpr (KIND != 1) return 0;
+        else return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_xi, row_live(tile) ? (unsigned)(tile * 32 + r) * 4u : BUF_OOB, 0, 0);
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    int ray1 = load_ray(tile + tile_step);
+    bf16x8 xn[4];
+    load_x(tile, load_ray(tile), xn);
+
+    for (; tile < ntiles; tile += tile_step) {
+        const bool live = row_live(tile);
+        const unsigned row0 = (unsigned)(tile * 32);
+        bf16x8 xb[NKS0 < 4 ? 3 : 4];
+#pragma unroll
+        for (int s = 0; s < NKS0; ++s) xb[s] = xn[s];
+        load_x(tile + tile_step, ray1, xn);
+        ray1 = load_ray(tile + 2 * tile_step);
+        if constexpr (KIND == 1)      // density = relu(column 0 of the colour decoder's input)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf((float)xb[0][0], 0.0f)), rs_c0, live ? c0off + row0 * 4 : BUF_OOB, 0, 0);
+        f32x16 acc[2];
+        bf16x8 hb[4];
+        hidden_layer_pinned<NKS0>(W0s, b0s, xb, r, h, acc);
+        relu_pack(acc, hb);
+        if constexpr (SAVE) tile64_store_buf(stg, rs_h0, row0 * (HID * 2), lane, r, h, acc);
+        if constexpr (NL == 3) {
+            hidden_layer_pinned<4>(W1s, b1s, hb, r, h, acc);
+            relu_pack(acc, hb);
+            if constexpr (SAVE) tile64_store_buf(stg, rs_h1, row0 * (HID * 2), lane, r, h, acc);
+        }
+        f32x16 o;
+        out_block_pinned(WLs, bLs, 0, hb, r, h, o);
+        const unsigned obase = live ? row0 * (unsigned)(p.out_dim * (KIND == 1 ? 4 : 2)) : BUF_OOB_ROW;
+        if constexpr (KIND == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+                const u32x2 v = {__builtin_bit_cast(unsigned, bf16x2{(bf16_t)o[4 * g], (bf16_t)o[4 * g + 1]}),
+                                 __builtin_bit_cast(unsigned, bf16x2{(bf16_t)o[4 * g + 2], (bf16_t)o[4 * g + 3]})};
+                __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, ooff[g] + obase, 0, 0);
+            }
+        } else if constexpr (KIND == 1) {
+            // hardware exp2 / rcp (~1 ulp), as the generic kernel
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * o[j]));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs_out, ooff[j] + obase, 0, 0);
+            }
+        } else {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * h + j < p.out_dim) mx = fmaxf(mx, o[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mxs = mx * LOG2E;
+            float e[4], sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[j] = (4 * h + j < p.out_dim) ? __builtin_amdgcn_exp2f(fmaf(o[j], LOG2E, -mxs)) : 0.0f;
+                sum += e[j];
+            }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t y = (bf16_t)(e[j] * inv);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, y), rs_out, ooff[j] + obase, 0, 0);
+            }
+        }
+    }
+}
+
+// Wide softmax head (three layers, XCD8 input, 192 < out_dim <= 224), statistics only: the forward of the instance head writes the
+// per-sample (max logit * log2e, 1 / sum exp) and the last hidden layer; pag_head_composite_fwd and the backward rebuild the
+// probabilities from them.  One 32-channel block is live at a time (online softmax over the blocks); block k+1's MFMAs are issued
+// before block k's exponentials so that the matrix pipe runs under them.
+template <bool SAVE0>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_wide_stats(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int OB = 7;
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16_t *W0s = reinterpret_cast<bf16_t *>(smem);
+    bf16_t *W1s = W0s + 64 * RS;
+    bf16_t *WLs = W1s + 64 * RS;                                     // [OB*32][RS] permuted k
+    float *b0s = reinterpret_cast<float *>(WLs + OB * 32 * RS);
+    float *b1s = b0s + 64;
+    float *bLs = b1s + 64;
+    bf16_t *stg = reinterpret_cast<bf16_t *>(bLs + OB * 32) + (threadIdx.x >> 6) * (ST_BYTES / 2);
+    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
+    stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
+    stage_weight(WLs, RS, OB * 32, 64, p.W[2], p.out_dim, HID, true);
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        b0s[e] = p.b[0][e];
+        b1s[e] = p.b[1][e];
+    }
+    // padding channels: a bias of -1e30 makes their exponential exactly 0 and never the maximum
+    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b[2][e] : -1e30f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t M = p.M, ntiles = (M + 31) / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const auto rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x1), 0, (int)(M * 128), 0x00020000);
+    const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, (int)(M * 8), 0x00020000);
+    const auto rs_h0 = __builtin_amdgcn_make_buffer_rsrc(SAVE0 ? p.hsave[0] : nullptr, 0, (int)(M * HID * 2), 0x00020000);
+    const auto rs_h1 = __builtin_amdgcn_make_buffer_rsrc(p.hsave[1], 0, (int)(M * HID * 2), 0x00020000);
+    unsigned xoff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xoff[s] = (unsigned)(((int64_t)(2 * s + h) * M + r) * 16);
+    const unsigned soff = h == 0 ? (unsigned)(r * 8) : BUF_OOB;
+    auto row_live = [&](int64_t tile) __attribute__((always_inline)) { return tile * 32 + r < M; };
+    auto load_x = [&](int64_t tile, bf16x8 (&xf)[4]) __attribute__((always_inline)) {
+        const unsigned base = row_live(tile) ? (unsigned)(tile * 32) * 16u : BUF_OOB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x1, xoff[s] + base, 0, 0));
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    bf16x8 xn[4];
+    load_x(tile, xn);
+    for (; tile < ntiles; tile += tile_step) {
+        const bool live = row_live(tile);
+        const unsigned row0 = (unsigned)(tile * 32);
+        bf16x8 xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = xn[s];
+        load_x(tile + tile_step, xn);
+        f32x16 acc[2];
+        bf16x8 hb[4];
+        hidden_layer_pinned<4>(W0s, b0s, xb, r, h, acc);
+        relu_pack(acc, hb);
+        if constexpr (SAVE0) tile64_store_buf(stg, rs_h0, row0 * (HID * 2), lane, r, h, acc);
+        hidden_layer_pinned<4>(W1s, b1s, hb, r, h, acc);
+        relu_pack(acc, hb);
+        tile64_store_buf(stg, rs_h1, row0 * (HID * 2), lane, r, h, acc);
+        // online softmax statistics over the OB blocks
+        float mrun = -INFINITY, srun = 0.0f;
+        f32x16 o, on;
+        out_block_pinned(WLs, bLs, 0, hb, r, h, o);
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+            if (ob + 1 < OB) out_block_pinned(WLs, bLs, ob + 1, hb, r, h, on);
+            float bm = fmaxf(o[0], o[1]);
+#pragma unroll
+            for (int q = 2; q < 16; ++q) bm = fmaxf(bm, o[q]);
+            const float mn = fmaxf(mrun, bm);
+            const f32x2 l2 = {LOG2E, LOG2E}, nm2 = {-mn * LOG2E, -mn * LOG2E};
+            f32x2 bs2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x2 t = f32x2{o[2 * q], o[2 * q + 1]} * l2 + nm2;
+                bs2 += f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            }
+            srun = srun * __builtin_amdgcn_exp2f((mrun - mn) * LOG2E) + (bs2[0] + bs2[1]);
+            mrun = mn;
+            if (ob + 1 < OB) o = on;
+        }
+        const float mo = __shfl_xor(mrun, 32), so = __shfl_xor(srun, 32);
+        const float M_ = fmaxf(mrun, mo);
+        const float S_ = srun * __builtin_amdgcn_exp2f((mrun - M_) * LOG2E) + so * __builtin_amdgcn_exp2f((mo - M_) * LOG2E);
+        const u32x2 st2 = {__builtin_bit_cast(unsigned, M_ * LOG2E), __builtin_bit_cast(unsigned, 1.0f / S_)};
+        __builtin_amdgcn_raw_buffer_store_b64(st2, rs_st, live ? soff + row0 * 8 : BUF_OOB, 0, 0);
+    }
+}
+
 // ----------------------------------------------------------------------------------------- backward
 template <typename OutT, typename DxT, int NL, int OBMAX>
 // 2 waves per SIMD: without the bound the 3-layer narrow variants took 252 VGPRs + 36 AGPRs (1 wave per SIMD); asking for 2 makes them fit 254 with no
@@ -2688,6 +2973,49 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
         p.in_pad = 64;
     }
     hipStream_t st = (hipStream_t)stream;
+    // ---- the panoptic nef's decoder shapes on the bf16 path: dedicated straight-line kernels (PAG_NO_FAST_FWD: the generic one, for A/B runs)
+    static const bool no_fast = getenv("PAG_NO_FAST_FWD") != nullptr;
+    if (!no_fast && a->mode == PAG_MLP_MFMA_BF16 && a->x1_dtype == PAG_BF16 && M <= PAG_MLP_FUSED_WIDE_MAX_M) {
+        const bool grp = p.grp_L > 0;
+        const bool save_all = a->hidden_save[0] && (a->n_layers == 2 || a->hidden_save[1]);
+        const bool save_none = !a->hidden_save[0] && !a->hidden_save[1];
+        int kind = -1;
+        if (grp && a->out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_NONE && a->out_dim % 4 == 0 && a->out_dim <= 32) kind = 0;
+        else if (!grp && a->k1 == 16 && a->x2 && a->k2p == 32 && a->in_dim <= 48 && a->out && a->out_dtype == PAG_F32 && a->out_act == PAG_ACT_SIGMOID &&
+                 a->out_dim <= 4 && a->x1_col0_relu)
+            kind = 1;
+        else if (grp && a->out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_SOFTMAX && a->out_dim <= 8) kind = 2;
+        else if (grp && !a->out && a->n_layers == 3 && p.stats && a->out_act == PAG_ACT_SOFTMAX && a->out_dim > 192 && a->hidden_save[1]) kind = 3;
+        if (kind == 3) {
+            const size_t lds = (size_t)(128 + 224) * RS * sizeof(bf16_t) + (128 + 224) * sizeof(float) + 4 * ST_BYTES;
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr = true;
+            }
+            if (a->hidden_save[0]) hipLaunchKernelGGL((mlp_fwd_wide_stats<true>), dim3(mlp_grid(M)), dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((mlp_fwd_wide_stats<false>), dim3(mlp_grid(M)), dim3(256), lds, st, p);
+            PAG_CHECK_LAUNCH("pag_mlp_fwd (wide head statistics)");
+            return PAG_OK;
+        }
+        if (kind >= 0 && (save_all || save_none)) {
+            const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + 32) * RS * sizeof(bf16_t) + (128 + 32) * sizeof(float) + 4 * ST_BYTES;
+#define FWD_FAST(NL_, K_, S_) hipLaunchKernelGGL((mlp_fwd_fast<NL_, K_, S_>), dim3(mlp_grid(M)), dim3(256), lds, st, p)
+#define FWD_FAST_K(K_)                                                        \
+    do {                                                                      \
+        if (a->n_layers == 2) { if (save_all) FWD_FAST(2, K_, true); else FWD_FAST(2, K_, false); } \
+        else { if (save_all) FWD_FAST(3, K_, true); else FWD_FAST(3, K_, false); }                 \
+    } while (0)
+            if (kind == 0) FWD_FAST_K(0);
+            else if (kind == 1) FWD_FAST_K(1);
+            else FWD_FAST_K(2);
+#undef FWD_FAST_K
+#undef FWD_FAST
+            PAG_CHECK_LAUNCH("pag_mlp_fwd (straight-line)");
+            return PAG_OK;
+        }
+    }
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;
         const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + OB * 32) * RS * sizeof(bf16_t) + (128 + OB * 32) * sizeof(float) + 4 * ST_BYTES;
