@@ -1061,3 +1061,63 @@ def test_fused_weight_gradients_match_separate_kernels(gpu_device):
             bsep = run(fn, prms, False)
             for u, v in zip(a, bsep):
                 assert _rel_l2(u.float(), v.float()) < lim
+
+
+@pytest.mark.gpu
+def test_straight_line_forward_kernels(gpu_device):
+    """The dedicated forward kernels of the panoptic nef's decoder shapes (csrc/mlp.hip: mlp_fwd_fast, mlp_fwd_wide_stats - buffer-descriptor
+    addressing, no branch in the tile loop) against a plain fp32 torch evaluation on bf16-rounded operands: ragged last tiles, one tile per wave
+    and grid-strided launches (the cap is 1536 workgroups x 4 tiles), two and three layers, every output epilogue.  Tolerance: bf16 outputs
+    (2^-8 relative) of O(1) values + the bf16 hidden activations."""
+    from pagnerf_amd import ops, _lib as L
+    dev = gpu_device
+    rs = np.random.RandomState(5)
+
+    def ref(x, Ws, bs, act):
+        h = x
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            h = h.bfloat16().float() @ W.bfloat16().float().t() + b
+            if i < len(Ws) - 1:
+                h = torch.relu(h)
+        return torch.sigmoid(h) if act == L.ACT_SIGMOID else (torch.softmax(h, -1) if act == L.ACT_SOFTMAX else h)
+
+    def mk(dims):
+        W, b = _rand_mlp(rs, dims)
+        return [w.to(dev) for w in W], [v.to(dev) for v in b]
+
+    cols = ops.xcd8_columns(24, 2)
+    for M, N in ((5, 2), (1000, 7), (32 * 6144 + 37, 900)):
+        x1 = torch.from_numpy(rs.standard_normal(size=(M, 16)).astype(np.float32)).to(dev).bfloat16()
+        x2 = torch.zeros(N, 32, device=dev)
+        x2[:, :27] = torch.from_numpy(rs.standard_normal(size=(N, 27)).astype(np.float32)).to(dev)
+        idx = torch.from_numpy(np.sort(rs.randint(0, N, size=M)).astype(np.int32)).to(dev)
+        for dims in ((43, 64, 64, 3), (43, 64, 4)):
+            Ws, bs = mk(dims)
+            rgb, sigma = ops.colour_and_density(x1, Ws, bs, x2, idx, 43)
+            xin = torch.cat([x1.float(), x2[idx.long()][:, :27]], 1)
+            assert rgb.shape == (M, dims[-1]) and torch.equal(sigma, torch.relu(x1[:, 0].float()))
+            assert float((rgb - ref(xin, Ws, bs, L.ACT_SIGMOID)).abs().max()) < 2e-3, (M, dims)
+        x8 = torch.from_numpy(rs.standard_normal(size=(8, M, 8)).astype(np.float32)).to(dev)
+        x8[:, :, 6:] = 0
+        x8 = x8.bfloat16()
+        xin = torch.zeros(M, 48, device=dev)
+        for pos, c in enumerate(cols):
+            if c >= 0:
+                xin[:, c] = x8[pos // 8, :, pos % 8].float()
+        for dims, act, tol in (((48, 64, 16), L.ACT_NONE, 2e-2), ((48, 64, 64, 32), L.ACT_NONE, 2e-2), ((48, 64, 6), L.ACT_SOFTMAX, 4e-3),
+                               ((48, 64, 64, 8), L.ACT_SOFTMAX, 4e-3)):
+            Ws, bs = mk(dims)
+            out = ops.fused_mlp(x8, Ws, bs, in_dim=48, out_act=act, out_dtype=torch.bfloat16, x1_grouped=(24, 2))
+            assert out.shape == (M, dims[-1])
+            assert float((out.float() - ref(xin, Ws, bs, act)).abs().max()) < tol, (M, dims)
+        # the wide head: statistics + composite (pag_head_composite_fwd rebuilds the probabilities from them) against the dense evaluation
+        Ws, bs = mk((48, 64, 64, 200))
+        ridx = idx
+        counts = torch.bincount(ridx.long(), minlength=N)
+        pack_start = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(counts, 0)])
+        wts, alpha = torch.rand(M, device=dev), torch.rand(N, device=dev)
+        o = ops.head_composite(x8, Ws, bs, wts, alpha, ridx, pack_start, torch.arange(N, dtype=torch.int32, device=dev), N, in_dim=48,
+                               out_act=L.ACT_SOFTMAX, out_dtype=torch.bfloat16, x1_grouped=(24, 2))
+        dense = ref(xin, Ws, bs, L.ACT_SOFTMAX) * wts[:, None]
+        want = torch.zeros(N, 200, device=dev).index_add_(0, ridx.long(), dense) * alpha[:, None]
+        assert float((o.float() - want).abs().max()) < 2e-2 * max(1.0, float(want.abs().max())), M
