@@ -24,7 +24,9 @@ SOURCES = {
     "api.cpp": ["-x", "hip"],
     "encode.hip": ["-ffp-contract=off"],
     "render.hip": ["-ffp-contract=off"],
-    "mlp.hip": [],
+    # MFMA results in VGPRs wherever they fit: the fused backward kernels keep 224 accumulator registers in the AGPR half, and with the
+    # default (AGPR-form MFMAs for the whole function) every per-tile result paid a v_accvgpr_read per register - 160 of 520 VALU per tile
+    "mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "assign.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=off"],
 }
