@@ -40,16 +40,22 @@ def mlp(x, weights, biases, act=torch.relu):
 def nef_forward(feats, delta_feats, ray_d, params, channels,
                 view_multires=4, lod_weights=None,
                 sem_softmax=True, inst_softmax=True, sem_sigmoid=False, inst_sigmoid=False,
-                sem_normalize=False, inst_normalize=False, inst_soft_temperature=0.0):
-    """Everything of rgb_semantics() after the two grid interpolations.
+                sem_normalize=False, inst_normalize=False, inst_soft_temperature=0.0,
+                panoptic_features_type="delta", multiscale_sum_levels=0, coords=None, pos_multires=4):
+    """Everything of rgb_semantics() after the two grid interpolations (pc_nerf/panoptic_delta_nef.py:170-259).
 
     feats, delta_feats: [M, L*F] grid features (delta may be None when no panoptic channel).
     ray_d [M,3] per-sample view direction.  params: dict name -> (weights, biases).
+    panoptic_features_type: what the panoptic heads read (:210-234) - 'delta' (None in the reference), 'separate', 'appearance',
+    'pos_encoding' (the embedded sample position, coords [M,3] required) or 'position'.
+    multiscale_sum_levels = L: multiscale_type 'sum', the L levels' F features are summed (:172-173, :221-222).
     Returns dict with density [M,1], rgb [M,3], semantics [M,C], inst_embedding [M,I].
     """
     out = {}
     if lod_weights is not None:
         feats = feats * lod_weights
+    if multiscale_sum_levels:
+        feats = feats.reshape(-1, multiscale_sum_levels, feats.shape[-1] // multiscale_sum_levels).sum(-2)
     dfe = mlp(feats, *params["density"])
     out["density_feats"] = dfe
     out["density"] = torch.relu(dfe[..., 0:1])
@@ -57,8 +63,22 @@ def nef_forward(feats, delta_feats, ray_d, params, channels,
         pe = positional_embed(-ray_d, view_multires)
         out["rgb"] = torch.sigmoid(mlp(torch.cat([dfe, pe], dim=-1), *params["color"]))
     if "semantics" in channels or "inst_embedding" in channels:
-        d = delta_feats * lod_weights if lod_weights is not None else delta_feats
-        pan = feats.detach() + d
+        if panoptic_features_type in ("delta", "separate", None):
+            d = delta_feats * lod_weights if lod_weights is not None else delta_feats
+            if multiscale_sum_levels:
+                d = d.reshape(-1, multiscale_sum_levels, d.shape[-1] // multiscale_sum_levels).sum(-2)
+        if panoptic_features_type in ("delta", None):
+            pan = feats.detach() + d
+        elif panoptic_features_type == "separate":
+            pan = d
+        elif panoptic_features_type == "appearance":
+            pan = feats.detach()
+        elif panoptic_features_type == "pos_encoding":
+            pan = positional_embed(coords.reshape(-1, 3), pos_multires)
+        elif panoptic_features_type == "position":
+            pan = coords.reshape(-1, 3)
+        else:
+            raise ValueError(panoptic_features_type)
         if "semantics" in channels:
             s = mlp(pan, *params["semantics"])
             s = torch.sigmoid(s) if sem_sigmoid else s

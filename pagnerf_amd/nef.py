@@ -88,8 +88,10 @@ class PanopticDeltaNeF(nn.Module):
             raise NotImplementedError("fused decoders implement ReLU hidden activations (best.yaml)")
         if position_input:
             raise NotImplementedError                                   # panoptic_delta_nef.py:177
-        if panoptic_features_type not in (None, "delta", "separate", "appearance"):
-            raise NotImplementedError("panoptic_features_type '%s'" % panoptic_features_type)
+        if panoptic_features_type not in (None, "delta", "separate", "appearance", "pos_encoding", "position"):
+            raise ValueError('Panoptic feature type "%s" not implemented for PanopticDeltaNeF' % panoptic_features_type)   # :234
+        if multiscale_type not in ("cat", "sum"):
+            raise NotImplementedError("'%s' not supported by this neural field. supported options ['cat', 'sum']" % multiscale_type)
         self.grid_type, self.multiscale_type = grid_type, multiscale_type
         self.feature_dim, self.num_lods, self.base_lod = feature_dim, num_lods, base_lod
         self.hidden_dim, self.num_layers = hidden_dim, num_layers
@@ -115,17 +117,19 @@ class PanopticDeltaNeF(nn.Module):
             if isinstance(self.delta_grid, PermutoGridHIP) and panoptic_features_type in ("delta", "separate") \
                     and "delta_capacity_log_2" in kwargs:
                 self.delta_grid.set_capacity(kwargs["delta_capacity_log_2"])
-        # ---- embedder (panoptic_nef.py:72-77)
+        # ---- embedders (panoptic_nef.py:72-77; the position embedder of the panoptic branch: panoptic_delta_nef.py:46-53, always positional)
         self.view_embed_dim = 3 + 6 * view_multires if embedder_type == "positional" else 3
-        # ---- decoders (panoptic_nef.py:108-164)
+        self.pos_multires, self.pos_embed_dim = pos_multires, 3 + 6 * pos_multires
+        # ---- decoders (panoptic_nef.py:85-164): the panoptic heads read the grid features, the embedded position or the raw position
         eff = feature_dim * num_lods if multiscale_type == "cat" else feature_dim
+        pan_dim = {"position": 3, "pos_encoding": self.pos_embed_dim}.get(panoptic_features_type, eff)
         self.decoder_density = BasicDecoder(eff, 16, num_layers, hidden_dim)
         with torch.no_grad():
             self.decoder_density.lout.bias[0] = 1.0                      # panoptic_nef.py:123
         self.decoder_color = BasicDecoder(16 + self.view_embed_dim, 3, num_layers + 1, hidden_dim)
-        self.decoder_semantics = BasicDecoder(eff, num_classes, sem_num_layers or num_layers, sem_hidden_dim or hidden_dim)
+        self.decoder_semantics = BasicDecoder(pan_dim, num_classes, sem_num_layers or num_layers, sem_hidden_dim or hidden_dim)
         assert num_instances > 2
-        self.decoder_inst = BasicDecoder(eff, num_instances, inst_num_layers or num_layers, inst_hidden_dim or hidden_dim)
+        self.decoder_inst = BasicDecoder(pan_dim, num_instances, inst_num_layers or num_layers, inst_hidden_dim or hidden_dim)
         self._fns = [(self.rgb_semantics, {"density", "rgb", "semantics", "inst_embedding"})]
 
     # -------------------------------------------------------------------------------- configuration
@@ -186,9 +190,18 @@ class PanopticDeltaNeF(nn.Module):
 
     def _grouped(self):
         """(levels, feats) when the bf16 path can use the XCD-grouped feature layout, else None."""
-        if self.precision == "bf16" and ops.xcd8_supported(self.num_lods, self.feature_dim):
+        if self.precision == "bf16" and self.multiscale_type == "cat" and ops.xcd8_supported(self.num_lods, self.feature_dim):
             return (self.num_lods, self.feature_dim)
         return None
+
+    def _pan_grouped(self):
+        """The panoptic heads' input layout: the grid features' (see _grouped) unless they read positions."""
+        return None if self.panoptic_features_type in ("pos_encoding", "position") else self._grouped()
+
+    @staticmethod
+    def _pad8(x, dtype):
+        """[M,k] -> [M, k rounded up to 8] in the decoders' input dtype (the fused decoders take k % 8 == 0 and ignore columns >= in_dim)."""
+        return F.pad(x, (0, (-x.shape[1]) % 8)).to(dtype).contiguous()
 
     def _lod_weights_or_none(self):
         """None while every weight is 1 (the kernels then skip the multiply); the CPU-side check (three tensor ops, ~40 us -
@@ -201,8 +214,11 @@ class PanopticDeltaNeF(nn.Module):
 
     def _interp(self, grid, coords, addend=None):
         lw = self._lod_weights_or_none()
-        return grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None,
-                                       addend=addend)
+        feats = grid.interpolate_scaled(coords, lw, out_dtype=self.feat_dtype, layout="xcd8" if self._grouped() else None,
+                                        addend=addend)
+        if self.multiscale_type == "sum":                                          # :172-173, :221-222: levels summed, F columns left
+            feats = self._pad8(feats.float().reshape(-1, self.num_lods, self.feature_dim).sum(-2), self.feat_dtype)
+        return feats
 
     def prefetch_features(self, coords):
         """Queue the main grid's interpolation of `coords` NOW; rgb_semantics() called with the same tensor picks it up.
@@ -217,6 +233,10 @@ class PanopticDeltaNeF(nn.Module):
         """:210-236 - `feats.detach() + delta` ('delta'), delta alone ('separate') or the main features ('appearance').
         On the grouped bf16 path the sum is formed inside the delta grid's encode launch (same rounding as the tensor add)."""
         t = self.panoptic_features_type
+        if t == "pos_encoding":                                                    # :231 (the coordinates are NOT detached here)
+            return self._pad8(positional_embed(coords.reshape(-1, 3).float(), self.pos_multires), self.feat_dtype)
+        if t == "position":                                                        # :233
+            return self._pad8(coords.reshape(-1, 3).float(), self.feat_dtype)
         if t == "appearance":
             return feats_detached
         if t == "separate":
@@ -233,8 +253,6 @@ class PanopticDeltaNeF(nn.Module):
         if isinstance(compute_channels, str):
             compute_channels = {compute_channels}
         batch, num_samples, _ = coords.shape
-        if self.multiscale_type != "cat":
-            raise NotImplementedError("multiscale_type 'sum' with fused decoders")
         mode = self.mlp_mode
         pre = getattr(self, "_prefetched", None)
         self._prefetched = None
@@ -262,6 +280,7 @@ class PanopticDeltaNeF(nn.Module):
             out["density"] = density
         if "semantics" in compute_channels or "inst_embedding" in compute_channels:    # :210-236
             pan = self._panoptic_feats(feats.detach(), coords)
+            grp = self._pan_grouped()
             if "semantics" in compute_channels:                                        # :238-244
                 plain = not (self.sem_sigmoid or self.sem_normalize)
                 act = L.ACT_SOFTMAX if (self.sem_softmax and plain) else L.ACT_NONE
@@ -285,7 +304,7 @@ class PanopticDeltaNeF(nn.Module):
 
     def can_fuse_panoptic(self, channels):
         """True when the semantic / instance heads can run as decoder + compositing in one autograd node."""
-        if self.precision != "bf16" or self._grouped() is None:
+        if self.precision != "bf16" or self._pan_grouped() is None:
             return False
         ok = True
         if "semantics" in channels:

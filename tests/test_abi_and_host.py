@@ -287,3 +287,24 @@ def test_bench_launches_its_own_ranks_dry_run():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                         env=env2, timeout=600)
     assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]
+
+
+def test_nef_option_decoder_widths_and_guards():
+    """Decoder input widths per panoptic_features_type / multiscale_type (pc_nerf/panoptic_nef.py:78-105) and the option guards
+    (panoptic_delta_nef.py:177, :234) - host logic only."""
+    import pytest
+    import pagnerf_amd
+    kw = dict(grid_type="PermutoGrid", feature_dim=2, num_lods=24, num_classes=6, num_instances=200, capacity_log_2=8, delta_capacity_log_2=8)
+    for t, want, has_delta in ((None, 48, True), ("delta", 48, True), ("separate", 48, True), ("appearance", 48, False),
+                               ("pos_encoding", 27, False), ("position", 3, False)):
+        nef = pagnerf_amd.PanopticDeltaNeF(panoptic_features_type=t, **kw)
+        assert nef.decoder_semantics.input_dim == want and nef.decoder_inst.input_dim == want and nef.decoder_density.input_dim == 48
+        assert hasattr(nef, "delta_grid") == has_delta
+    nef = pagnerf_amd.PanopticDeltaNeF(multiscale_type="sum", **kw)
+    assert nef.decoder_density.input_dim == 2 and nef.decoder_inst.input_dim == 2 and nef._grouped() is None
+    with pytest.raises(ValueError):
+        pagnerf_amd.PanopticDeltaNeF(panoptic_features_type="nope", **kw)
+    with pytest.raises(NotImplementedError):
+        pagnerf_amd.PanopticDeltaNeF(position_input=True, **kw)
+    with pytest.raises(NotImplementedError):
+        pagnerf_amd.PanopticDeltaNeF(multiscale_type="max", **kw)

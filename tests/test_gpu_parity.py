@@ -1121,3 +1121,50 @@ def test_straight_line_forward_kernels(gpu_device):
         dense = ref(xin, Ws, bs, L.ACT_SOFTMAX) * wts[:, None]
         want = torch.zeros(N, 200, device=dev).index_add_(0, ridx.long(), dense) * alpha[:, None]
         assert float((o.float() - want).abs().max()) < 2e-2 * max(1.0, float(want.abs().max())), M
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("option", ["pos_encoding", "position", "separate", "appearance", "sum"])
+def test_nef_panoptic_feature_types_and_multiscale_sum(gpu_device, option):
+    """The nef options outside best.yaml (pc_nerf/panoptic_delta_nef.py:172-173, :210-234; decoder input widths panoptic_nef.py:78-105):
+    what the panoptic heads read - embedded position, raw position, the delta grid alone, the appearance features - and
+    multiscale_type 'sum'.  HIP nef against oracle.decoders.nef_forward on the nef's own grid features: fp32 path tight, bf16 path loose."""
+    import pagnerf_amd
+    from oracle import decoders as od
+    dev = gpu_device
+    torch.manual_seed(11)
+    M = 300
+    coords = (torch.rand(M, 1, 3, device=dev) * 1.6 - 0.8)
+    ray_d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev), dim=-1)
+    kw = dict(grid_type="PermutoGrid", feature_dim=2, num_lods=24, num_classes=6, num_instances=200, sem_num_layers=1, sem_softmax=True,
+              inst_num_layers=2, inst_softmax=True, capacity_log_2=12, delta_capacity_log_2=12)
+    if option == "sum":
+        kw.update(multiscale_type="sum", panoptic_features_type="delta")
+    else:
+        kw.update(panoptic_features_type=option)
+    for precision in ("fp32", "bf16"):
+        torch.manual_seed(5)
+        nef = pagnerf_amd.PanopticDeltaNeF(precision=precision, **kw)
+        for g in [nef.grid] + ([nef.delta_grid] if hasattr(nef, "delta_grid") else []):
+            g.init_from_scales()
+            g.tables.data.normal_(0, 0.5)
+        nef = nef.to(dev)
+        want_dim = {"pos_encoding": 27, "position": 3, "sum": 2}.get(option, 48)
+        assert nef.decoder_semantics.input_dim == want_dim and nef.decoder_inst.input_dim == want_dim
+        assert nef.decoder_density.input_dim == (2 if option == "sum" else 48)
+        chans = {"density", "rgb", "semantics", "inst_embedding"}
+        with torch.no_grad():
+            out = nef(coords=coords, ray_d=ray_d, channels=chans)
+            feats = nef.grid.interpolate(coords, None).reshape(M, -1).float().cpu()
+            dfe = nef.delta_grid.interpolate(coords, None).reshape(M, -1).float().cpu() if hasattr(nef, "delta_grid") else None
+        params = {k: tuple([t.detach().float().cpu() for t in lst] for lst in getattr(nef, "decoder_" + n).weights())
+                  for k, n in (("density", "density"), ("color", "color"), ("semantics", "semantics"), ("inst", "inst"))}
+        ref = od.nef_forward(feats, dfe, ray_d.cpu(), params, chans, panoptic_features_type="delta" if option == "sum" else option,
+                             multiscale_sum_levels=24 if option == "sum" else 0, coords=coords.cpu(), pos_multires=4)
+        tol = 2e-5 if precision == "fp32" else 3e-2
+        for ch, shape in (("density", (M, 1, 1)), ("rgb", (M, 1, 3)), ("semantics", (M, 6)), ("inst_embedding", (M, 200))):
+            got = out[ch].float().cpu().reshape(M, -1)
+            assert out[ch].shape == shape, (ch, out[ch].shape)
+            assert float((got - ref[ch].reshape(M, -1)).abs().max()) < tol * max(1.0, float(ref[ch].abs().max())), (option, precision, ch)
+    # the fused head + compositing path applies only when the heads read grouped grid features
+    assert nef.can_fuse_panoptic({"semantics", "inst_embedding"}) == (option in ("separate", "appearance"))
