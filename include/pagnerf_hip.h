@@ -364,6 +364,21 @@ int pag_raymarch_voxel_pack(const float *origins, const float *dirs, int64_t N, 
                             float *depths, float *deltas, uint8_t *boundary, int32_t *ridx_sample,
                             int64_t *ridx64, void *stream);
 
+/* The same two passes with ONE walk: pass 1 also records every kept nugget (t_in, t_out) and its cell, pass 2 turns them into the
+ * packed arrays in parallel (one wave per ray) instead of walking every ray a second time.  Outputs are bit-identical to
+ * pag_raymarch_voxel_count / _pack.
+ *   nugget_t     f32 [cap][N][2], nugget_cell i32 [cap][N]  caller-allocated scratch, cap = pag_raymarch_voxel_nugget_capacity(blas_level)
+ *                (3 * 2^blas_level + 3: the most cells a ray can cross) */
+int64_t pag_raymarch_voxel_nugget_capacity(int blas_level);
+int pag_raymarch_voxel_count_nuggets(const float *origins, const float *dirs, int64_t N, int samples_per_voxel,
+                                     float dist_min, float dist_max, const uint32_t *occupancy_bits,
+                                     const uint32_t *occupancy_coarse, int blas_level, float max_travel,
+                                     int32_t *counts, float *nugget_t, int32_t *nugget_cell, void *stream);
+int pag_raymarch_voxel_pack_nuggets(const float *origins, const float *dirs, int64_t N, int samples_per_voxel,
+                                    const int64_t *offsets, const float *nugget_t, const int32_t *nugget_cell,
+                                    int32_t *ridx, int32_t *pidx, float *samples, float *depths, float *deltas,
+                                    uint8_t *boundary, int32_t *ridx_sample, int64_t *ridx64, void *stream);
+
 /* Coarse occupancy for the voxel march: bit ((x/4)*RC + y/4)*RC + z/4 (RC = 2^blas_level / 4) is set iff any of the 64 fine
  * cells under it is.  pag_occupancy_coarse_bytes() = size of `coarse` in bytes, 0 when blas_level is outside [5,8]
  * (the march then runs without it).  Rebuild after every prune (pc_nerf/panoptic_delta_nef.py:98-104). */

@@ -791,6 +791,9 @@ def occupancy_coarse(occupancy_bits, blas_level):
     return coarse
 
 
+VOXEL_SCRATCH_MAX = 1 << 30      # bytes of nugget scratch raymarch_voxel() may allocate per call
+
+
 def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupancy_bits=None, blas_level=7, max_travel=None,
                    occupancy_coarse_bits=None, want_packs=False):
     """'voxel'-mode march (3-D DDA over the occupancy grid).  Returns per NUGGET ridx i32[M'], pidx i32[M'] and per sample
@@ -809,7 +812,16 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     coarse = L.ptr(occupancy_coarse_bits) if (occupancy_coarse_bits is not None and occupancy_bits is not None) else None
     travel = float("inf") if max_travel is None else float(max_travel)
     st = L.stream()
-    if N:
+    # one walk: pass 1 records the nuggets ([cap][N] scratch, 12 bytes each), pass 2 expands them in parallel; above VOXEL_SCRATCH_MAX
+    # bytes of scratch the rays are walked twice instead (pag_raymarch_voxel_count / _pack)
+    cap = int(L.load().pag_raymarch_voxel_nugget_capacity(blas_level))
+    nug_t = nug_cell = None
+    if N and cap * N * 12 <= VOXEL_SCRATCH_MAX:
+        nug_t = torch.empty(cap, N, 2, device=dev)
+        nug_cell = torch.empty(cap, N, device=dev, dtype=torch.int32)
+        _call("pag_raymarch_voxel_count_nuggets", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse,
+              blas_level, travel, L.ptr(counts), L.ptr(nug_t), L.ptr(nug_cell), st)
+    elif N:
         _call("pag_raymarch_voxel_count", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse, blas_level,
               travel, L.ptr(counts), st)
     pack_start = torch.empty(N + 1, device=dev, dtype=torch.int64)      # [i] = first SAMPLE of ray i, [N] = M' * k
@@ -833,7 +845,10 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     boundary = torch.empty(Mn * k, device=dev, dtype=torch.uint8)
     ridx_sample = torch.empty(Mn * k, device=dev, dtype=torch.int32) if want_packs else None
     ridx64 = torch.empty(Mn, device=dev, dtype=torch.int64) if want_packs else None
-    if Mn:
+    if Mn and nug_t is not None:
+        _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(pack_start), L.ptr(nug_t), L.ptr(nug_cell),
+              L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), L.ptr(ridx_sample), L.ptr(ridx64), st)
+    elif Mn:
         _call("pag_raymarch_voxel_pack", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse, blas_level,
               travel, L.ptr(pack_start), L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary),
               L.ptr(ridx_sample), L.ptr(ridx64), st)
