@@ -255,6 +255,16 @@ int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *args);
 #define PAG_MLP_FUSED_WIDE_MAX_M ((int64_t)1 << 24)
 int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *args, int64_t M);
 
+/* One affine map of the XCD8 features: the activation-free `decoder_delta_density` of pc_nerf/panoptic_dd_nef.py:49-56, :238
+ * (its layers composed to one [n_out, in_dim] matrix by the caller; n_out <= 8).
+ *   fwd     out f32 [M, n_out] = x . W^T + b        x: bf16 [8][M][8] (PAG_LAYOUT_XCD8 of x_levels x x_feats features), W f32 [n_out, in_dim]
+ *   bwd_dx  dx bf16 [8][M][8] = grad_out [M, n_out] . W   (padding positions 0)
+ * Weight gradients: pag_mlp_wgrad_batch with grad_out (bf16) as `dz` and x as `a1`. */
+int pag_affine_xcd8_fwd(const void *x, int64_t M, int x_levels, int x_feats, const float *W, const float *b, int n_out, int in_dim,
+                        float *out, void *stream);
+int pag_affine_xcd8_bwd_dx(const float *grad_out, int64_t M, int x_levels, int x_feats, const float *W, int n_out, int in_dim, void *dx,
+                           void *stream);
+
 /* Wide softmax head fused with the per-ray weighted sum of tracers/panoptic_packed_rf_tracer.py:197-205:
  *   out[ray][c] = alpha[ray] * sum_{i in pack} weights[i] * softmax(W_last . hidden[i] + b_last)[c]
  * from the forward's saved last hidden layer (bf16 [M,64]) and softmax_stats (pag_mlp_fwd with out = NULL): the

@@ -97,6 +97,8 @@ _SIGS = {
     "pag_raymarch_voxel_nugget_capacity": (c_i64, [c_i32]),
     "pag_raymarch_voxel_count_nuggets": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "pag_raymarch_voxel_pack_nuggets": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_affine_xcd8_fwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "pag_affine_xcd8_bwd_dx": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "pag_occupancy_coarse_bytes": (c_i64, [c_i32]),
     "pag_occupancy_coarse": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "pag_occupancy_update": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),

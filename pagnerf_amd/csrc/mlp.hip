@@ -2554,6 +2554,66 @@ __global__ __launch_bounds__(256) void head_composite_fwd_kernel(HeadCompParams 
     }
 }
 
+// ---------------------------------------------------------- one affine map of the XCD8 features (decoder without activations)
+// pc_nerf/panoptic_dd_nef.py:49-56 `decoder_delta_density` has no activation: any number of its layers compose to one [n_out, in_dim]
+// matrix (n_out = 1).  out[m][o] = b[o] + sum_p W[o][col(p)] x[p / 8][m][p % 8] on the encoders' bf16 [8][M][8] layout, one lane per
+// sample, 128 bytes in / 4 n_out bytes out per sample; backward-data is the transposed product, written back in the same layout.
+// (Weight gradients: pag_mlp_wgrad_batch with the upstream gradient as `dz`.)
+constexpr int AFF_MAX_OUT = 8;
+__global__ __launch_bounds__(256) void affine_xcd8_fwd_kernel(const bf16_t *__restrict__ x8, int64_t M, int grp_L, int grp_F, const float *__restrict__ W,
+                                                              const float *__restrict__ b, int n_out, int in_dim, float *__restrict__ out) {
+    __shared__ float Ws[AFF_MAX_OUT][64];
+    for (int e = threadIdx.x; e < n_out * 64; e += blockDim.x) {
+        const int o = e >> 6, col = grp_col(e & 63, grp_L, grp_F);
+        Ws[o][e & 63] = (col >= 0 && col < in_dim) ? W[(int64_t)o * in_dim + col] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float acc[AFF_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < AFF_MAX_OUT; ++o) acc[o] = o < n_out ? b[o] : 0.0f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x8 + ((int64_t)g * M + m) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xv = (float)v[e];
+#pragma unroll
+            for (int o = 0; o < AFF_MAX_OUT; ++o)
+                if (o < n_out) acc[o] = fmaf(xv, Ws[o][8 * g + e], acc[o]);
+        }
+    }
+    for (int o = 0; o < n_out; ++o) out[m * n_out + o] = acc[o];
+}
+__global__ __launch_bounds__(256) void affine_xcd8_bwd_dx_kernel(const float *__restrict__ gout, int64_t M, int grp_L, int grp_F, const float *__restrict__ W,
+                                                                 int n_out, int in_dim, bf16_t *__restrict__ dx8) {
+    __shared__ float Ws[AFF_MAX_OUT][64];
+    for (int e = threadIdx.x; e < n_out * 64; e += blockDim.x) {
+        const int o = e >> 6, col = grp_col(e & 63, grp_L, grp_F);
+        Ws[o][e & 63] = (col >= 0 && col < in_dim) ? W[(int64_t)o * in_dim + col] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float g[AFF_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < AFF_MAX_OUT; ++o) g[o] = o < n_out ? gout[m * n_out + o] : 0.0f;
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.0f;
+#pragma unroll
+            for (int o = 0; o < AFF_MAX_OUT; ++o)
+                if (o < n_out) a = fmaf(g[o], Ws[o][8 * gp + e], a);
+            v[e] = (bf16_t)a;
+        }
+        *reinterpret_cast<bf16x8 *>(dx8 + ((int64_t)gp * M + m) * 8) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------ FP32 parity path
 // One lane per sample.  Weights transposed in LDS ([k][j]) so the 64 outputs of a layer are 16
 // broadcast ds_read_b128; the per-sample activation column lives in LDS ([k][lane]).
@@ -3487,6 +3547,34 @@ extern "C" int pag_mlp_wgrad_batch(const pag_wgrad_layer *layers, int n_layers, 
     }
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(max_out, n_layers), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
     PAG_CHECK_LAUNCH("pag_mlp_wgrad_batch (finish)");
+    return PAG_OK;
+}
+
+extern "C" int pag_affine_xcd8_fwd(const void *x, int64_t M, int x_levels, int x_feats, const float *W, const float *b, int n_out, int in_dim,
+                                   float *out, void *stream) {
+    PAG_CHECK_ARG(M >= 0, "pag_affine_xcd8_fwd: M < 0");
+    PAG_CHECK_ARG(n_out >= 1 && n_out <= AFF_MAX_OUT, "pag_affine_xcd8_fwd: n_out %d not in [1,%d]", n_out, AFF_MAX_OUT);
+    PAG_CHECK_ARG(x_feats >= 1 && ((x_levels + 7) / 8) * x_feats <= 8 && in_dim == x_levels * x_feats, "pag_affine_xcd8_fwd: in_dim %d != levels %d * feats %d (or more than 8 values per group)",
+                  in_dim, x_levels, x_feats);
+    if (M == 0) return PAG_OK;
+    PAG_CHECK_ARG(x && W && b && out, "pag_affine_xcd8_fwd: NULL input/output");
+    hipLaunchKernelGGL(affine_xcd8_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, M, x_levels, x_feats, W, b,
+                       n_out, in_dim, out);
+    PAG_CHECK_LAUNCH("pag_affine_xcd8_fwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_affine_xcd8_bwd_dx(const float *grad_out, int64_t M, int x_levels, int x_feats, const float *W, int n_out, int in_dim, void *dx,
+                                      void *stream) {
+    PAG_CHECK_ARG(M >= 0, "pag_affine_xcd8_bwd_dx: M < 0");
+    PAG_CHECK_ARG(n_out >= 1 && n_out <= AFF_MAX_OUT, "pag_affine_xcd8_bwd_dx: n_out %d not in [1,%d]", n_out, AFF_MAX_OUT);
+    PAG_CHECK_ARG(x_feats >= 1 && ((x_levels + 7) / 8) * x_feats <= 8 && in_dim == x_levels * x_feats, "pag_affine_xcd8_bwd_dx: in_dim %d != levels %d * feats %d (or more than 8 values per group)",
+                  in_dim, x_levels, x_feats);
+    if (M == 0) return PAG_OK;
+    PAG_CHECK_ARG(grad_out && W && dx, "pag_affine_xcd8_bwd_dx: NULL input/output");
+    hipLaunchKernelGGL(affine_xcd8_bwd_dx_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_out, M, x_levels, x_feats, W, n_out, in_dim,
+                       (bf16_t *)dx);
+    PAG_CHECK_LAUNCH("pag_affine_xcd8_bwd_dx");
     return PAG_OK;
 }
 

@@ -46,12 +46,7 @@ class LinearChainDecoder(nn.Module):
         W, b = self.affine()
         if grouped is None:
             return F.linear(x.float(), W, b)
-        cols = ops.xcd8_columns(*grouped)
-        Wp = torch.zeros(W.shape[0], 64, device=W.device, dtype=W.dtype)
-        pos = [p for p, c in enumerate(cols) if c >= 0]
-        Wp[:, torch.tensor(pos, device=W.device)] = W[:, torch.tensor([cols[p] for p in pos], device=W.device)]
-        Wp = Wp.reshape(W.shape[0], 8, 8)                       # [out, g, e]
-        return torch.einsum("gme,oge->mo", x.float(), Wp) + b
+        return ops.affine_xcd8(x, W, b, grouped)          # one launch on the bf16 [8, M, 8] features (pag_affine_xcd8_fwd)
 
 
 class PanopticDDensityNeF(PanopticDeltaNeF):

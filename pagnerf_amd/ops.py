@@ -553,6 +553,45 @@ def _launch_wgrad(specs, M):
         _call("pag_mlp_wgrad_batch", layers, len(part), M, L.stream())
 
 
+class _AffineXCD8(torch.autograd.Function):
+    """out f32 [M, n_out] = x . W^T + b on the encoders' bf16 [8, M, 8] features (pag_affine_xcd8_fwd); backward: d x in the same
+    layout (pag_affine_xcd8_bwd_dx), d W / d b through the decoders' weight-gradient kernels (pag_mlp_wgrad_batch)."""
+
+    @staticmethod
+    def forward(ctx, x8, W, b, grouped):
+        _check_gpu(x8, W, b)
+        M, (n_out, in_dim) = x8.shape[1], W.shape
+        Wc, bc = W.detach().float().contiguous(), b.detach().float().contiguous()
+        out = torch.empty(M, n_out, device=x8.device)
+        _call("pag_affine_xcd8_fwd", L.ptr(x8), M, grouped[0], grouped[1], L.ptr(Wc), L.ptr(bc), n_out, in_dim, L.ptr(out), L.stream())
+        ctx.save_for_backward(x8, Wc)
+        ctx.grouped = grouped
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x8, Wc = ctx.saved_tensors
+        M, (n_out, in_dim) = x8.shape[1], Wc.shape
+        g = g.float().contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x8)
+            _call("pag_affine_xcd8_bwd_dx", L.ptr(g), M, ctx.grouped[0], ctx.grouped[1], L.ptr(Wc), n_out, in_dim, L.ptr(dx), L.stream())
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dW, db = torch.empty(n_out, in_dim, device=g.device), torch.empty(n_out, device=g.device)
+            if M:
+                _launch_wgrad([dict(dz=g.to(torch.bfloat16), n_out=n_out, a1=x8, a1_dtype=L.BF16, a1_layout=L.LAYOUT_XCD8, k1=64, n_in=64,
+                                    a2=None, k2p=0, a2_index=None, levels=ctx.grouped[0], feats=ctx.grouped[1], w=dW, b=db)], M)
+            else:
+                dW.zero_(), db.zero_()
+        return dx, dW, db, None
+
+
+def affine_xcd8(x8, W, b, grouped):
+    """x8 bf16 [8, M, 8] (grouped = (levels, feats)), W [n_out, levels*feats], b [n_out] -> f32 [M, n_out]."""
+    return _AffineXCD8.apply(x8, W, b, grouped)
+
+
 class _ColourDensity(_FusedMLP):
     """The colour decoder on cat(density_feats, PE) AND the density sigma = relu(density_feats[:, 0]) that
     pc_nerf/panoptic_delta_nef.py:188 reads off its x1, as one autograd node: the gradient of sigma is added to column 0 of

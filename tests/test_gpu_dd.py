@@ -156,3 +156,41 @@ def test_batch_render_chunks_match_single_pass(gpu_device):
     for ch in ("rgb", "alpha", "depth", "semantics", "hit"):
         assert torch.equal(getattr(full, ch), getattr(parts, ch)), ch
     assert parts.rgb.shape == (N, 3)
+
+
+@pytest.mark.gpu
+def test_affine_xcd8_matches_dense_evaluation(gpu_device):
+    """pag_affine_xcd8_fwd / _bwd_dx + the weight-gradient kernels (ops.affine_xcd8: the activation-free decoder_delta_density of
+    pc_nerf/panoptic_dd_nef.py:49-56 as ONE affine map of the bf16 [8,M,8] features) against a dense fp32 evaluation and its autograd."""
+    from pagnerf_amd import ops
+    dev = gpu_device
+    rs = np.random.RandomState(9)
+    cols = ops.xcd8_columns(24, 2)
+    for M, n_out in ((5, 1), (1000, 1), (70001, 3)):
+        x8 = torch.from_numpy(rs.standard_normal(size=(8, M, 8)).astype(np.float32)).to(dev)
+        x8[:, :, 6:] = 0
+        x8 = x8.bfloat16().requires_grad_(True)
+        W = torch.from_numpy((rs.standard_normal(size=(n_out, 48)) / 7).astype(np.float32)).to(dev).requires_grad_(True)
+        b = torch.from_numpy(rs.standard_normal(size=(n_out,)).astype(np.float32)).to(dev).requires_grad_(True)
+        g = torch.from_numpy(rs.standard_normal(size=(M, n_out)).astype(np.float32)).to(dev)
+        out = ops.affine_xcd8(x8, W, b, (24, 2))
+        (out * g).sum().backward()
+        xin = torch.zeros(M, 48, device=dev)
+        for pos, c in enumerate(cols):
+            if c >= 0:
+                xin[:, c] = x8.detach()[pos // 8, :, pos % 8].float()
+        xin.requires_grad_(True)
+        W2, b2 = W.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+        ref = xin @ W2.t() + b2
+        (ref * g).sum().backward()
+        assert float((out - ref).detach().abs().max()) < 1e-4 * max(1.0, float(ref.detach().abs().max()))
+        dx = torch.zeros(M, 48, device=dev)
+        for pos, c in enumerate(cols):
+            if c >= 0:
+                dx[:, c] = x8.grad[pos // 8, :, pos % 8].float()
+            else:
+                assert float(x8.grad[pos // 8, :, pos % 8].float().abs().max()) == 0.0
+        assert float((dx - xin.grad).abs().max()) < 1e-2 * max(1.0, float(xin.grad.abs().max()))          # bf16 output
+        scale = float(W2.grad.abs().max())
+        assert float((W.grad - W2.grad).abs().max()) < 1e-2 * scale, (M, n_out)                                # bf16 upstream gradient in the GEMM
+        assert float((b.grad - b2.grad).abs().max()) < 1e-2 * max(1.0, float(b2.grad.abs().max()))
