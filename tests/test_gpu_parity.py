@@ -1110,6 +1110,15 @@ def test_straight_line_forward_kernels(gpu_device):
             out = ops.fused_mlp(x8, Ws, bs, in_dim=48, out_act=act, out_dtype=torch.bfloat16, x1_grouped=(24, 2))
             assert out.shape == (M, dims[-1])
             assert float((out.float() - ref(xin, Ws, bs, act)).abs().max()) < tol, (M, dims)
+            # the variant that also writes the hidden activations (a backward that does not recompute them): same outputs, bit for bit
+            fused_was = ops.WGRAD_FUSED
+            try:
+                ops.WGRAD_FUSED = False
+                out_s = ops.fused_mlp(x8, [w.clone().requires_grad_(True) for w in Ws], bs, in_dim=48, out_act=act, out_dtype=torch.bfloat16,
+                                      x1_grouped=(24, 2))
+            finally:
+                ops.WGRAD_FUSED = fused_was
+            assert out_s.requires_grad and torch.equal(out_s.detach(), out), (M, dims)
         # the wide head: statistics + composite (pag_head_composite_fwd rebuilds the probabilities from them) against the dense evaluation
         Ws, bs = mk((48, 64, 64, 200))
         ridx = idx
