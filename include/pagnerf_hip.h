@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 2
+#define PAG_ABI_VERSION 3
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -193,7 +193,7 @@ int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
  *           (bf16 in MFMA mode, f32 in FP32 mode); dz of the last layer is [M, out_dim]
  *   dx1     [M, k1] (dx1_dtype) or NULL
  * Weight gradients are dz[i]^T @ input_i - a plain GEMM left to the caller's BLAS. */
-typedef struct {
+typedef struct pag_mlp_bwd_args {
     const void *grad_out; const void *out; int out_dtype; int out_act;   /* grad_out has out's dtype */
     int k1; int in_dim; int n_layers; int out_dim;
     int x1_layout; int x1_levels; int x1_feats;   /* as in pag_mlp_fwd_args: dx1 is then written as bf16 [8][M][8] */
@@ -235,6 +235,12 @@ typedef struct {
      * layer at M = 2.1 M.  Needs the hidden layers' biases b[0 .. n_layers-2]; hidden_save[] may be NULL except, for the wide
      * softmax head, the LAST hidden layer's (the probabilities are rebuilt from it). */
     const float *b[3];
+    /* Optional, wide softmax head with wgrad_workspace only: a second decoder on the SAME XCD8 input - a two-layer softmax head with
+     * out_dim <= 8 (the semantic head next to the instance head), filled in as for its own pag_mlp_bwd call (fused workspace, dW, db,
+     * b[0], rank-1 gradient, dx1 = this decoder's dx1 with dx1_accumulate = 1).  Its backward then runs inside this call, in the launch of
+     * the layers below the wide output layer: one read of the input and one write of the summed input gradient for both decoders.
+     * The caller does not call pag_mlp_bwd for it. */
+    const struct pag_mlp_bwd_args *pair;
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
 /* 1 when pag_mlp_bwd has a fused weight-gradient kernel for these (fully filled in, wgrad_workspace aside) arguments.  Three
@@ -254,6 +260,9 @@ int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *args);
  * (PAG_ERR_ARG; callers split the batch or leave wgrad_workspace NULL). */
 #define PAG_MLP_FUSED_WIDE_MAX_M ((int64_t)1 << 24)
 int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *args, int64_t M);
+/* 1 when `pair` (fully filled in) can ride in args' call as pag_mlp_bwd_args.pair: args is a wide softmax head, pair a two-layer narrow
+ * softmax head on the same XCD8 input that accumulates into args->dx1. */
+int pag_mlp_bwd_pair_supported(const pag_mlp_bwd_args *args, const pag_mlp_bwd_args *pair);
 
 /* One affine map of the XCD8 features: the activation-free `decoder_delta_density` of pc_nerf/panoptic_dd_nef.py:49-56, :238
  * (its layers composed to one [n_out, in_dim] matrix by the caller; n_out <= 8).

@@ -16,7 +16,7 @@ MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
 LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
 ENC_HALF_COORDS = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 MLP_FUSED_WIDE_MAX_M = 1 << 24      # PAG_MLP_FUSED_WIDE_MAX_M
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -48,7 +48,10 @@ class WgradLayer(ctypes.Structure):
 
 
 class MlpBwdArgs(ctypes.Structure):
-    _fields_ = [("grad_out", c_vp), ("out", c_vp), ("out_dtype", c_i32), ("out_act", c_i32),
+    pass
+
+
+MlpBwdArgs._fields_ = [("grad_out", c_vp), ("out", c_vp), ("out_dtype", c_i32), ("out_act", c_i32),
                 ("k1", c_i32), ("in_dim", c_i32), ("n_layers", c_i32), ("out_dim", c_i32),
                 ("x1_layout", c_i32), ("x1_levels", c_i32), ("x1_feats", c_i32),
                 ("W", c_vp * 3),
@@ -61,7 +64,8 @@ class MlpBwdArgs(ctypes.Structure):
                 ("dx1_col0_gate", c_vp), ("g_ray_scale", c_vp),
                 ("x1", c_vp), ("x1_dtype", c_i32), ("x2", c_vp), ("k2p", c_i32), ("x2_index", c_vp),
                 ("wgrad_workspace", c_vp), ("wgrad_workspace_bytes", c_i64),
-                ("dW", c_vp * 3), ("db", c_vp * 3), ("b", c_vp * 3)]
+                ("dW", c_vp * 3), ("db", c_vp * 3), ("b", c_vp * 3),
+                ("pair", ctypes.POINTER(MlpBwdArgs))]
 
 
 _SIGS = {
@@ -82,6 +86,7 @@ _SIGS = {
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd_fused_supported": (c_i32, [ctypes.POINTER(MlpBwdArgs)]),
     "pag_mlp_bwd_fused_workspace_bytes": (c_i64, [ctypes.POINTER(MlpBwdArgs), c_i64]),
+    "pag_mlp_bwd_pair_supported": (c_i32, [ctypes.POINTER(MlpBwdArgs), ctypes.POINTER(MlpBwdArgs)]),
     "pag_head_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_mlp_wgrad_blocks": (c_i32, [c_i64]),
     "pag_mlp_wgrad_batch": (c_i32, [ctypes.POINTER(WgradLayer), c_i32, c_i64, c_vp]),

@@ -1790,6 +1790,331 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     });
 }
 
+// ------------------------------------------------ two decoders on the same XCD8 input, backward in one launch (panoptic heads)
+// The semantic head and the two layers below the instance head's output layer read the same panoptic features and their input
+// gradients are summed.  As two launches (stage B of the instance head writes dx, the semantic head reads it back and adds) the
+// pair moved 1.6 GB at 3.5 - 4.4 TB/s; here a wave runs both decoders on ITS tile - one read of the features, one write of the
+// summed gradient (396 B per sample instead of 780) - with both decoders' weight gradients as accumulators (240 registers).
+//   .i  two layers, dense bf16 upstream gradient [M,64] (the hidden gradient stage A wrote), 64-wide "output" layer, no activation
+//   .s  two layers, rank-1 upstream gradient, softmax with saved bf16 probabilities, out_dim <= 8
+// Same tile images, fragments and instruction sequences as mlp_bwd_fused<2, 0, false, 2> and <2, 2, *>: the weight gradients are
+// bit-identical to the two launches, dx differs by one bf16 rounding less (the sum is formed in fp32).
+struct PairParams {
+    BwdParams i, s;
+};
+__global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
+    const BwdParams &pi = pp.i, &ps = pp.s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RSLI = 72, RSLS = 40;
+    bf16_t *WLtI = reinterpret_cast<bf16_t *>(smem);             // [64][72]  k = the 64 outputs of .i's upper layer (permuted)
+    bf16_t *W0tI = WLtI + 64 * RSLI;                             // [64 input positions][RS]
+    bf16_t *W0sI = W0tI + 64 * RS;                               // [64][RS] natural k (forward recompute)
+    bf16_t *WLtS = W0sI + 64 * RS;                               // [64][40]
+    bf16_t *W0tS = WLtS + 64 * RSLS;
+    bf16_t *W0sS = W0tS + 64 * RS;
+    float *b0I = reinterpret_cast<float *>(W0sS + 64 * RS);
+    float *b0S = b0I + 64;
+    stage_weight_t(WLtI, RSLI, 64, 64, pi.W[1], pi.out_dim, HID);
+    stage_weight_t(W0tI, RS, 64, 64, pi.W[0], HID, pi.in_dim, pi.grp_L, pi.grp_F);
+    stage_weight(W0sI, RS, 64, 64, pi.W[0], HID, pi.in_dim, false, pi.grp_L, pi.grp_F);
+    stage_weight_t(WLtS, RSLS, 64, 32, ps.W[1], ps.out_dim, HID);
+    stage_weight_t(W0tS, RS, 64, 64, ps.W[0], HID, ps.in_dim, ps.grp_L, ps.grp_F);
+    stage_weight(W0sS, RS, 64, 64, ps.W[0], HID, ps.in_dim, false, ps.grp_L, ps.grp_F);
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        b0I[e] = pi.b[0][e];
+        b0S[e] = ps.b[0][e];
+    }
+    bf16_t *Tx = reinterpret_cast<bf16_t *>(b0S + 64) + (threadIdx.x >> 6) * (4 * TW_ELEMS);      // wave-private swizzled tiles
+    bf16_t *ThI = Tx + TW_ELEMS, *ThS = ThI + TW_ELEMS, *Tz = ThS + TW_ELEMS;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t M = pi.M, ntiles = (M + 31) / 32, nfull = M / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const bf16_t *x1b = reinterpret_cast<const bf16_t *>(pi.x1);
+    const int32_t *ridx = ps.g_index;
+
+    // ---- registers of the NEXT tile (requested one tile ahead; the per-ray row index two tiles ahead)
+    bf16x8 xn[4];
+    bf16x4 gz[2][4];
+    float gs[4], gy[4], gsc = 0.0f;
+    int ray1 = 0, ray2 = 0;
+    auto row_of = [&](int64_t tile) __attribute__((always_inline)) { return min(min(tile, ntiles - 1) * 32 + r, M - 1); };
+    auto prefetch = [&](int64_t tile_raw, int ray) __attribute__((always_inline)) {
+        const int64_t tile = min(tile_raw, ntiles - 1);
+        const int64_t m = min(tile * 32 + r, M - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xn[s] = load8(x1b + ((int64_t)(2 * s + h) * M + m) * 8);
+        const bf16_t *gop = reinterpret_cast<const bf16_t *>(pi.grad_out) + m * HID;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gz[ob][g] = *reinterpret_cast<const bf16x4 *>(gop + 32 * ob + 8 * g + 4 * h);
+        gsc = __fmul_rn(ps.g_scale[m], ps.g_ray_scale[ray]);
+        const float *grow = ps.g_ray + (int64_t)ray * ps.out_dim;
+        const bf16_t *yop = reinterpret_cast<const bf16_t *>(ps.out) + m * ps.out_dim;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (4 * h + j) < ps.out_dim ? (4 * h + j) : 0;
+            gs[j] = grow[c];
+            gy[j] = (float)yop[c];
+        }
+    };
+
+    // ---- weight-gradient accumulators (the whole launch): .i upper layer [64 x 64], .i layer 0, .s output layer [32 x 64], .s layer 0, biases
+    f32x16 awLI[2][2], aw0I[2][2], awLS[1][2], aw0S[2][2], dbacc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        dbacc[q] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            awLS[0][i][q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) awLI[i][j][q] = aw0I[i][j][q] = aw0S[i][j][q] = 0.0f;
+        }
+    }
+    auto ones_col = [&](int j) __attribute__((always_inline)) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(r == j ? 1.0f : 0.0f);
+        return o;
+    };
+    auto wgrad_tile = [&](const bf16_t *Tin, auto &aw, int dbcol) __attribute__((always_inline)) {      // aw: f32x16 [out blocks][2]
+        constexpr int NOB = (int)(sizeof(aw) / sizeof(aw[0]));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[2], afr[NOB];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) bfr[ib] = tw_frag(Tin, ib, ks, lane);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) afr[ob] = tw_frag(Tz, ob, ks, lane);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) aw[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ob], bfr[ib], aw[ob][ib], 0, 0, 0);
+                if (dbcol >= 0) dbacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ob], ones_col(dbcol + ob), dbacc, 0, 0, 0);
+            }
+        }
+    };
+    // dx of tile t is stored at the top of tile t+1 (see mlp_bwd_fused)
+    bf16x4 pend[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pend[mb][g] = bf16x4{(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
+    int64_t pend_m = min((int64_t)blockIdx.x * 4 * 32 + (int64_t)wave * 32 + r, M - 1);
+    auto flush = [&](bool pred) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16_t *dst = reinterpret_cast<bf16_t *>(pi.dx1) + ((int64_t)(4 * mb + g) * M + pend_m) * 8 + 4 * h;
+                if (pred) *reinterpret_cast<bf16x4 *>(dst) = pend[mb][g];
+            }
+    };
+    // masked by the saved ReLU output (read from its LDS image), then: fragments of the next chain + the transposed image for dW
+    auto mask_pack_put = [&](const bf16_t *Th, bool live, f32x16 (&acc)[2], bf16x8 (&hb)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(Th + tw_off(r, 8 * mb + 2 * g + h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] = ((float)hv[j] > 0.0f && live) ? acc[mb][4 * g + j] : 0.0f;
+            }
+            pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
+        }
+        tw_put_block(Tz, 0, r, h, acc[0]);
+        tw_put_block(Tz, 1, r, h, acc[1]);
+    };
+    auto body = [&](int64_t tile, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int64_t m = tile * 32 + r;
+        const bool live = FULL || m < M;
+        // ---- the tile's input and both decoders' recomputed hidden activations become LDS images (kept for the whole tile)
+        wave_lds_sync();
+        {
+            bf16x8 xb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xb[s] = xn[s];
+            if (h == 1) xb[3][7] = (bf16_t)1.0f;      // column 63 := 1 (weight 0 in both forwards): its dW columns are the layer-0 bias gradients
+            tw_put_frags(Tx, xb, r, h);
+            f32x16 ha[2];
+            hidden_layer_pinned<4>(W0sI, b0I, xb, r, h, ha);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ha[mb][q] = fmaxf(ha[mb][q], 0.0f);
+                tw_put_block(ThI, mb, r, h, ha[mb]);
+            }
+            hidden_layer_pinned<4>(W0sS, b0S, xb, r, h, ha);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ha[mb][q] = fmaxf(ha[mb][q], 0.0f);
+                tw_put_block(ThS, mb, r, h, ha[mb]);
+            }
+        }
+        // ---- upstream gradients of this tile
+        f32x16 zi[2];
+        float zs4[4];          // the softmax head's dz: 4 channels per lane, kept small until its phase
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zi[ob][4 * g + j] = (float)gz[ob][g][j];
+        {
+            float zr[4], yv[4], dot = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = 4 * h + j < ps.out_dim;
+                zr[j] = ok ? gsc * gs[j] : 0.0f;
+                yv[j] = ok ? gy[j] : 0.0f;
+                dot += zr[j] * yv[j];
+            }
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zs4[j] = (FULL || live) ? yv[j] * (zr[j] - dot) : 0.0f;
+        }
+        // ---- the previous tile's dx goes out, then everything of the next tile is requested
+        flush(true);
+        prefetch(tile + tile_step, ray1);
+        ray1 = ray2;
+        ray2 = ridx[row_of(tile + 3 * tile_step)];
+        f32x16 acc[2];
+        bf16x8 hb[4];
+        // ================================================================ .i : upper layer (64 wide), layer 0
+        {
+            bf16x8 zb[4];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                if constexpr (!FULL) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) zi[ob][q] = live ? zi[ob][q] : 0.0f;
+                }
+                pack_block(zi[ob], zb[2 * ob], zb[2 * ob + 1]);
+                tw_put_block(Tz, ob, r, h, zi[ob]);
+            }
+            wave_lds_sync();
+            wgrad_tile(ThI, awLI, 0);
+            wave_lds_sync();
+            wt_chain_pinned<2, 4>(WLtI, RSLI, zb, r, h, acc);
+        }
+        mask_pack_put(ThI, live, acc, hb);
+        wave_lds_sync();
+        wgrad_tile(Tx, aw0I, -1);
+        wave_lds_sync();
+        wt_chain_pinned<2, 4>(W0tI, RS, hb, r, h, acc);
+        // .i's input gradient waits in bf16 (the rounding the two-launch form applies when it stores it): 8 registers instead of 32
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pend[mb][g] = bf16x4{(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
+        // ================================================================ .s : softmax output layer, layer 0
+        {
+            bf16x8 zb[2];
+            f32x16 zs;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) zs[q] = q < 4 ? zs4[q] : 0.0f;
+            pack_block(zs, zb[0], zb[1]);
+            tw_put_block(Tz, 0, r, h, zs);
+            wave_lds_sync();
+            wgrad_tile(ThS, awLS, 2);
+            wave_lds_sync();
+            wt_chain_pinned<2, 2>(WLtS, RSLS, zb, r, h, acc);
+        }
+        mask_pack_put(ThS, live, acc, hb);
+        wave_lds_sync();
+        wgrad_tile(Tx, aw0S, -1);
+        wave_lds_sync();
+        wt_chain_pinned<2, 4>(W0tS, RS, hb, r, h, acc);
+        // ---- dx = both decoders' input gradients: row 32mb + 8g + 4h + j of dx^T -> piece [4mb + g][m][4h + j]
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sum = {acc[mb][4 * g] + (float)pend[mb][g][0], acc[mb][4 * g + 1] + (float)pend[mb][g][1], acc[mb][4 * g + 2] + (float)pend[mb][g][2],
+                                   acc[mb][4 * g + 3] + (float)pend[mb][g][3]};
+                pend[mb][g] = bf16x4{(bf16_t)sum[0], (bf16_t)sum[1], (bf16_t)sum[2], (bf16_t)sum[3]};
+            }
+        pend_m = min(m, M - 1);
+    };
+
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int ray0 = ridx[row_of(tile)];
+    ray1 = ridx[row_of(tile + tile_step)];
+    ray2 = ridx[row_of(tile + 2 * tile_step)];
+    prefetch(tile, ray0);
+    const bool any_tile = tile < ntiles;
+    bool last_ragged = false;
+    for (; tile < nfull; tile += tile_step) body(tile, std::true_type{});
+    if (tile < ntiles) {      // the ragged last tile (one wave of the launch)
+        body(tile, std::false_type{});
+        last_ragged = true;
+    }
+    if (any_tile) flush(!last_ragged || (nfull * 32 + r) < M);
+
+    // ---- the four waves' accumulators are summed through LDS, then one slab per workgroup and layer (see mlp_bwd_fused)
+    constexpr int NBLK = 4 + 4 + 2 + 4 + 1;      // .i upper | .i layer 0 | .s output | .s layer 0 | db
+    auto blk = [&](auto bi) -> const f32x16 & {
+        constexpr int bb = decltype(bi)::value;
+        if constexpr (bb < 4) return awLI[bb >> 1][bb & 1];
+        else if constexpr (bb < 8) return aw0I[(bb - 4) >> 1][(bb - 4) & 1];
+        else if constexpr (bb < 10) return awLS[0][bb - 8];
+        else if constexpr (bb < 14) return aw0S[(bb - 10) >> 1][(bb - 10) & 1];
+        else return dbacc;
+    };
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);                      // [NBLK][16 q][64 lanes]
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            static_for<NBLK>([&](auto bi) {
+                constexpr int bb = decltype(bi)::value;
+                const f32x16 &a = blk(bi);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float *dst = red + (bb * 16 + q) * 64 + lane;
+                    *dst = w == 0 ? a[q] : *dst + a[q];
+                }
+            });
+        }
+        __syncthreads();
+    }
+    static_for<NBLK>([&](auto bi) {
+        constexpr int bb = decltype(bi)::value;
+        if ((bb & 3) != wave) return;
+        const float *src = red + bb * 16 * 64 + lane;
+        if constexpr (bb < 4 || (bb >= 8 && bb < 10)) {               // output-layer blocks: rows = output channels
+            constexpr bool S = bb >= 8;
+            constexpr int ob = S ? 0 : (bb >> 1), ib = S ? (bb - 8) : (bb & 1);
+            float *sl = (S ? ps.slabs[1] + (int64_t)blockIdx.x * 32 * WG_SLAB_COLS_F : pi.slabs[1] + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = src[q * 64];
+        } else if constexpr (bb < 14) {                               // layer-0 blocks; input column 63 (the ones column) = db of layer 0
+            constexpr bool S = bb >= 10;
+            constexpr int k = S ? bb - 10 : bb - 4, ob = k >> 1, ib = k & 1;
+            float *sl = (S ? ps.slabs[0] : pi.slabs[0]) + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float v = src[q * 64];
+                sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = v;
+                if (ib == 1 && r == 31) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
+            }
+        } else {      // dbacc: columns 0, 1 -> .i upper layer's blocks; column 2 -> .s output layer
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float v = src[q * 64];
+                if (r < 2) pi.slabs[1][((int64_t)blockIdx.x * 64 + 32 * r + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
+                if (r == 2) ps.slabs[1][((int64_t)blockIdx.x * 32 + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
+            }
+        }
+    });
+}
+
 // -------------------------------------------- wide softmax head: output layer backward + its weight gradient (one launch)
 // Stage A of the fused backward of a decoder whose last layer is wide (the 200-way instance head): per 32-sample tile the
 // probabilities are rebuilt from the saved last hidden layer and the forward's softmax statistics (as mlp_bwd_wide_mfma does),
@@ -3199,6 +3524,14 @@ static int fused_kind(const pag_mlp_bwd_args *a) {
 
 extern "C" int pag_mlp_bwd_fused_supported(const pag_mlp_bwd_args *a) { return fused_kind(a) >= 0 ? 1 : 0; }
 
+extern "C" int pag_mlp_bwd_pair_supported(const pag_mlp_bwd_args *a, const pag_mlp_bwd_args *b) {
+    if (!a || !b || fused_kind(a) != 3 || fused_kind(b) != 2 || b->n_layers != 2) return 0;
+    return (b->x1 == a->x1 && b->x1_layout == PAG_LAYOUT_XCD8 && b->x1_levels == a->x1_levels && b->x1_feats == a->x1_feats && b->in_dim == a->in_dim &&
+            a->dx1 && b->dx1 == a->dx1 && b->dx1_accumulate && !a->dx1_accumulate)
+               ? 1
+               : 0;
+}
+
 extern "C" int64_t pag_mlp_bwd_fused_workspace_bytes(const pag_mlp_bwd_args *a, int64_t M) {
     const int kind = fused_kind(a);
     if (kind < 0 || M < 1) return 0;
@@ -3309,6 +3642,42 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
             hipFuncSetAttribute((const void *)mlp_bwd_fused<2, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attrA = true;
         }
+        // ---- a companion head on the same input (args->pair): validated before anything is launched
+        const pag_mlp_bwd_args *b = a->pair;
+        BwdParams ps{};
+        float *slabS0 = nullptr, *slabS1 = nullptr;
+        if (b) {
+            PAG_CHECK_ARG(b->wgrad_workspace && fused_kind(b) == 2 && b->n_layers == 2 && !b->pair, "pag_mlp_bwd: pair must be a two-layer narrow softmax head with a fused workspace");
+            PAG_CHECK_ARG(b->x1 == a->x1 && b->x1_layout == PAG_LAYOUT_XCD8 && b->x1_levels == a->x1_levels && b->x1_feats == a->x1_feats && b->in_dim == a->in_dim,
+                          "pag_mlp_bwd: pair must read the same XCD8 input");
+            PAG_CHECK_ARG(b->dx1 == a->dx1 && b->dx1_accumulate && a->dx1 && !a->dx1_accumulate, "pag_mlp_bwd: pair must accumulate into this decoder's dx1");
+            PAG_CHECK_ARG(b->wgrad_workspace_bytes >= pag_mlp_bwd_fused_workspace_bytes(b, M), "pag_mlp_bwd: pair wgrad_workspace too small");
+            PAG_CHECK_ARG(b->W[0] && b->W[1] && b->b[0] && b->dW[0] && b->dW[1] && b->db[0] && b->db[1] && b->out && b->g_ray && b->g_scale && b->g_index && b->g_ray_scale,
+                          "pag_mlp_bwd: pair: NULL weight / bias / gradient / saved output");
+            ps.g_ray = b->g_ray;
+            ps.g_scale = b->g_scale;
+            ps.g_ray_scale = b->g_ray_scale;
+            ps.g_index = b->g_index;
+            ps.out = b->out;
+            ps.grad_out = b->out;
+            ps.k1 = 64;
+            ps.in_dim = b->in_dim;
+            ps.in_pad = 64;
+            ps.out_dim = b->out_dim;
+            ps.act = PAG_ACT_SOFTMAX;
+            ps.W[0] = b->W[0];
+            ps.W[1] = b->W[1];
+            ps.b[0] = b->b[0];
+            ps.M = M;
+            ps.grp_L = p.grp_L;
+            ps.grp_F = p.grp_F;
+            ps.x1 = a->x1;
+            ps.dx1 = a->dx1;
+            slabS0 = b->wgrad_workspace;
+            slabS1 = slabS0 + (int64_t)grid * 64 * WG_SLAB_COLS;
+            ps.slabs[0] = slabS0;
+            ps.slabs[1] = slabS1;
+        }
         hipLaunchKernelGGL((mlp_bwd_wide_blocks<OBW>), dim3(grid), dim3((OBW + 1) * 64), ldsA, st, pa);
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, wide head)");
 #ifdef PAG_WB_PROF
@@ -3338,14 +3707,31 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         pb.hsave[1] = nullptr;
         pb.slabs[0] = slabB0;
         pb.slabs[1] = slabB1;
-        const size_t ldsB = (size_t)(64 * (64 + 8) + 2 * 64 * RS) * sizeof(bf16_t) + 128 * sizeof(float) + (size_t)4 * 3 * TW_ELEMS * sizeof(bf16_t);
-        hipLaunchKernelGGL((mlp_bwd_fused<2, 0, false, 2>), dim3(grid), dim3(256), ldsB, st, pb);
-        PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, layers below the wide head)");
         FinishBatch fb{};
         fb.p[0] = FinishParams{slabB0, (int)grid, HID, 64, a->in_dim, p.grp_L, p.grp_F, a->dW[0], a->db[0]};
         fb.p[1] = FinishParams{slabB1, (int)grid, HID, 64, HID, 0, 0, a->dW[1], a->db[1]};
         fb.p[2] = FinishParams{slabA, (int)grid, a->out_dim, 224, HID, 0, 0, a->dW[2], a->db[2]};
-        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(a->out_dim, 3), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
+        int n_fin = 3;
+        if (b) {
+            // the companion head runs in the same launch as the layers below the wide head: one read of the input, one write of the summed gradient
+            const size_t ldsP = (size_t)(64 * 72 * 5 + 64 * 40) * sizeof(bf16_t) + 128 * sizeof(float) + (size_t)4 * 4 * TW_ELEMS * sizeof(bf16_t);
+            static bool attrP = false;
+            if (!attrP) {
+                hipFuncSetAttribute((const void *)mlp_bwd_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attrP = true;
+            }
+            PairParams pp{pb, ps};
+            hipLaunchKernelGGL(mlp_bwd_pair, dim3(grid), dim3(256), ldsP, st, pp);
+            PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, layers below the wide head + companion head)");
+            fb.p[3] = FinishParams{slabS0, (int)grid, HID, 64, b->in_dim, p.grp_L, p.grp_F, b->dW[0], b->db[0]};
+            fb.p[4] = FinishParams{slabS1, (int)grid, b->out_dim, 32, HID, 0, 0, b->dW[1], b->db[1]};
+            n_fin = 5;
+        } else {
+            const size_t ldsB = (size_t)(64 * (64 + 8) + 2 * 64 * RS) * sizeof(bf16_t) + 128 * sizeof(float) + (size_t)4 * 3 * TW_ELEMS * sizeof(bf16_t);
+            hipLaunchKernelGGL((mlp_bwd_fused<2, 0, false, 2>), dim3(grid), dim3(256), ldsB, st, pb);
+            PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, layers below the wide head)");
+        }
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(a->out_dim, n_fin), dim3(WF_SPLITS * WG_SLAB_COLS), 0, st, fb);
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, finish)");
         return PAG_OK;
     }

@@ -388,9 +388,13 @@ class _FusedMLP(torch.autograd.Function):
         return _FusedMLP._backward_impl(ctx, g, None)
 
     @staticmethod
-    def _backward_impl(ctx, g, rank1, dx1_into=None, col0_add=None, col0_gate=None, wgrad_queue=None):
+    def _backward_impl(ctx, g, rank1, dx1_into=None, col0_add=None, col0_gate=None, wgrad_queue=None, dx1_out=None, hold=None,
+                       pair_hold=None):
         """rank1 = (g_ray f32 [N,out], g_scale f32 [M], g_index i32 [M]) replaces the dense upstream gradient g.
-        dx1_into: an XCD8 gradient tensor of another decoder on the same input - this one's d x1 is added to it in place."""
+        dx1_into: an XCD8 gradient tensor of another decoder on the same input - this one's d x1 is added to it in place.
+        dx1_out: write d x1 into this tensor instead of a new one.
+        hold (dict): a fused launch is PREPARED, not issued - args and everything they point to are parked in the dict, to ride in the
+        call of the other decoder of a pair (pair_hold = that dict; pag_mlp_bwd_args.pair) or to be issued by the caller."""
         lib = L.load()
         in_dim, out_act, mode, n_layers, k1, grouped = ctx.cfg
         saved = ctx.saved_tensors
@@ -405,7 +409,8 @@ class _FusedMLP(torch.autograd.Function):
         out_dtype = ctx.out_dtype
         need_dx = ctx.needs_input_grad[0]
         need_dx2 = ctx.needs_input_grad[1] and x2 is not None
-        dx1 = (dx1_into if dx1_into is not None else torch.empty(x1.shape, device=dev, dtype=x1.dtype)) if need_dx else None
+        dx1 = (dx1_into if dx1_into is not None else (dx1_out if dx1_out is not None else torch.empty(x1.shape, device=dev, dtype=x1.dtype))) \
+            if need_dx else None
         k2p = x2.shape[1] if x2 is not None else 0
         a = L.MlpBwdArgs()
         if rank1 is None:
@@ -464,7 +469,14 @@ class _FusedMLP(torch.autograd.Function):
             dz = [torch.empty(M, 64, device=dev, dtype=zdt) for _ in range(n_layers - 1)] + [torch.empty(M, out_dim, device=dev, dtype=zdt)]
             for i in range(n_layers):
                 a.dz[i] = L.ptr(dz[i])
-        if M:
+        if M and hold is not None:
+            hold["args"], hold["M"], hold["fused"] = a, M, fused       # issued later: inside the pair's other call or by the caller
+            hold["keep"] = [v for v in locals().values() if isinstance(v, (torch.Tensor, list, tuple))]
+        elif M:
+            if pair_hold is not None and fused and pair_hold.get("fused") \
+                    and lib.pag_mlp_bwd_pair_supported(ctypes.byref(a), ctypes.byref(pair_hold["args"])) == 1:
+                a.pair = ctypes.pointer(pair_hold["args"])
+                pair_hold["taken"] = True
             _call("pag_mlp_bwd", ctypes.byref(a), M, L.stream())
         if col0_add is not None and need_dx and not fuse_col0:
             dx1[:, 0] += col0_add.to(dx1.dtype)          # parity path: same sum with torch ops
@@ -1113,11 +1125,11 @@ class _HeadComposite(_FusedMLP):
         return (dx1, None, None, None, None, None, None, None, None, None, None, *gwb)
 
     @staticmethod
-    def _backward_pair(ctx, g, dx1_into, wgrad_queue=None):
+    def _backward_pair(ctx, g, dx1_into, wgrad_queue=None, **kw):
         weights_w, alpha, ridx = ctx.hc
         # upstream gradient in rank-1 form: alpha[ray] * w_m * g[ray] (detached weights, :148-155); the kernel forms the product
         grads = _FusedMLP._backward_impl(ctx, None, (g.contiguous().float(), weights_w.contiguous(), ridx.contiguous(), alpha.contiguous()),
-                                         dx1_into, wgrad_queue=wgrad_queue)
+                                         dx1_into, wgrad_queue=wgrad_queue, **kw)
         return grads[0], grads[8:]
 
 
@@ -1151,10 +1163,16 @@ class _HeadCompositePair(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_a, g_b):
         sub_a, sub_b = ctx.subs
-        # wide head first (it writes dx1), the narrow one accumulates
+        # wide head first (it writes dx1), the narrow one accumulates.  Where the library can, the narrow head's backward rides in the wide
+        # head's call (pag_mlp_bwd_args.pair: one read of the features, one write of the summed gradient): it is prepared first and parked.
         queue = []
-        ga = _HeadComposite._backward_pair(sub_a, g_a, None, queue)
-        gb = _HeadComposite._backward_pair(sub_b, g_b, ga[0], queue)
+        x1 = sub_a.saved_tensors[0]
+        dx = torch.empty(x1.shape, device=x1.device, dtype=x1.dtype) if sub_a.needs_input_grad[0] else None
+        hold = {}
+        gb = _HeadComposite._backward_pair(sub_b, g_b, dx, queue, hold=hold if dx is not None else None)
+        ga = _HeadComposite._backward_pair(sub_a, g_a, None, queue, dx1_out=dx, pair_hold=hold)
+        if hold.get("args") is not None and not hold.get("taken"):          # not paired after all: the narrow head's own launch, after the wide one
+            _call("pag_mlp_bwd", ctypes.byref(hold["args"]), hold["M"], L.stream())
         if queue:                                   # both heads' weight gradients: one narrow + one wide + one finish launch
             _launch_wgrad(queue, queue[0]["dz"].shape[0])
         return (ga[0], None, None, None, None, None, None, None, None, None, None, *ga[1], *gb[1])
