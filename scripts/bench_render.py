@@ -12,9 +12,9 @@ from pagnerf_amd import ops
 
 rays_n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 samples = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-args = types.SimpleNamespace(rays=rays_n, samples=samples, grid="permuto", precision="bf16")
+args = bench.parse(["--rays", str(rays_n), "--samples", str(samples), "--grid", "permuto", "--precision", "bf16"])
 dev = torch.device("cuda:0")
-nef, tracer = bench.make_model(args, dev, 0)
+nef, tracer = bench.make_model(args, dev, 0), bench.make_tracer(args)
 rays, _ = bench.make_rays(rays_n, dev, 1)
 cases = (["rgb", "semantics", "inst_embedding", "depth"], ["rgb", "depth"])
 if os.environ.get("RENDER_ONLY_ALL"):

@@ -13,9 +13,9 @@ import bench
 from pagnerf_amd import ops
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-args = types.SimpleNamespace(rays=4096, samples=512, grid="permuto", precision="bf16")
+args = bench.parse(["--rays", "4096", "--samples", "512", "--grid", "permuto", "--precision", "bf16"])
 dev = torch.device("cuda:0")
-nef, tracer = bench.make_model(args, dev, 0)
+nef, tracer = bench.make_model(args, dev, 0), bench.make_tracer(args)
 rays, gt = bench.make_rays(args.rays, dev, 1)
 opt = bench.make_optimizer(nef)
 chans = ["rgb", "semantics", "inst_embedding"]

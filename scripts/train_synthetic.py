@@ -41,8 +41,8 @@ def scene_rays(n, gen, dev):
 
 
 def run(precision, a, dev):
-    args = types.SimpleNamespace(rays=a.rays, samples=a.samples, grid=a.grid, precision=precision)
-    nef, tracer = bench.make_model(args, dev, seed=0)
+    args = bench.parse(["--rays", str(a.rays), "--samples", str(a.samples), "--grid", a.grid, "--precision", precision])
+    nef, tracer = bench.make_model(args, dev, seed=0), bench.make_tracer(args)
     opt = bench.make_optimizer(nef)
     chans = ["rgb", "semantics", "inst_embedding"]
     gen = torch.Generator().manual_seed(123)
