@@ -167,7 +167,7 @@ int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int 
  *             activations of hidden layer i, or NULL when no backward will follow
  *   mode      PAG_MLP_MFMA_BF16: bf16 operands, fp32 accumulate on the matrix cores;
  *             PAG_MLP_FP32: fp32 FMA chain in k order (parity path) */
-typedef struct {
+typedef struct pag_mlp_fwd_args {
     const void *x1; int x1_dtype; int k1;
     int x1_layout; int x1_levels; int x1_feats;   /* PAG_LAYOUT_XCD8: x1 is the encoders' bf16 [8][M][8]
                                                      output for (levels, feats); k1 = 64, in_dim = levels*feats */
@@ -184,8 +184,13 @@ typedef struct {
     float *x1_col0_relu;    /* optional (MFMA mode, strided bf16 x1, out_dim <= 64): f32 [M] = relu(x1[m][0]) written by the
                                same launch - the density pc_nerf/panoptic_delta_nef.py:188 reads off column 0 of the density
                                decoder's output, which is this (colour) decoder's x1 */
+    /* Optional, statistics-only wide softmax head only (out NULL): a second decoder on the SAME XCD8 input - two layers, softmax,
+     * out_dim <= 8, bf16 out, no hidden_save (the semantic head next to the instance head) - evaluated in this call's launch while the
+     * tile is in registers.  The caller does not call pag_mlp_fwd for it.  pag_mlp_fwd_pair_supported() tells whether the pair qualifies. */
+    const struct pag_mlp_fwd_args *pair;
 } pag_mlp_fwd_args;
 int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
+int pag_mlp_fwd_pair_supported(const pag_mlp_fwd_args *args, const pag_mlp_fwd_args *pair);
 
 /* Data gradients of pag_mlp_fwd.  grad_out is d loss / d (activated output); `out` is the
  * activated output saved from the forward (needed for sigmoid / softmax).  Writes

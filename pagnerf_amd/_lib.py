@@ -26,7 +26,10 @@ c_fp = ctypes.POINTER(ctypes.c_float)
 
 
 class MlpFwdArgs(ctypes.Structure):
-    _fields_ = [("x1", c_vp), ("x1_dtype", c_i32), ("k1", c_i32),
+    pass
+
+
+MlpFwdArgs._fields_ = [("x1", c_vp), ("x1_dtype", c_i32), ("k1", c_i32),
                 ("x1_layout", c_i32), ("x1_levels", c_i32), ("x1_feats", c_i32),
                 ("x2", c_vp), ("k2p", c_i32), ("x2_index", c_vp),
                 ("in_dim", c_i32), ("n_layers", c_i32), ("out_dim", c_i32),
@@ -35,7 +38,7 @@ class MlpFwdArgs(ctypes.Structure):
                 ("out", c_vp), ("out_dtype", c_i32),
                 ("hidden_save", c_vp * 2),
                 ("mode", c_i32),
-                ("softmax_stats", c_vp), ("x1_col0_relu", c_vp)]
+                ("softmax_stats", c_vp), ("x1_col0_relu", c_vp), ("pair", ctypes.POINTER(MlpFwdArgs))]
 
 
 class WgradLayer(ctypes.Structure):
@@ -83,6 +86,7 @@ _SIGS = {
     "pag_permuto_encode_fwd_add": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_i32, c_vp]),
     "pag_encode_bwd_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32, c_i64]),
     "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
+    "pag_mlp_fwd_pair_supported": (c_i32, [ctypes.POINTER(MlpFwdArgs), ctypes.POINTER(MlpFwdArgs)]),
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd_fused_supported": (c_i32, [ctypes.POINTER(MlpBwdArgs)]),
     "pag_mlp_bwd_fused_workspace_bytes": (c_i64, [ctypes.POINTER(MlpBwdArgs), c_i64]),

@@ -62,6 +62,11 @@ struct FwdParams {
     int grp_L, grp_F;      // x1 in PAG_LAYOUT_XCD8 (bf16 [8][M][8]) when grp_L > 0
     float *stats;          // optional f32 [M,2]: (max logit * log2e, 1 / sum exp) of the output softmax
     float *col0_relu;      // optional f32 [M]: relu(x1[m][0]) (strided bf16 x1) - the density read off the colour decoder's input
+    // companion head of mlp_fwd_wide_stats<.., PAIR = true>: a two-layer softmax decoder (out2_dim <= 8, bf16 out2 [M, out2_dim]) on the same x1
+    const float *W2[2];
+    const float *b2[2];
+    void *out2;
+    int out2_dim;
 };
 
 struct BwdParams {
@@ -935,21 +940,35 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fast(FwdParams p) {
 // per-sample (max logit * log2e, 1 / sum exp) and the last hidden layer; pag_head_composite_fwd and the backward rebuild the
 // probabilities from them.  One 32-channel block is live at a time (online softmax over the blocks); block k+1's MFMAs are issued
 // before block k's exponentials so that the matrix pipe runs under them.
-template <bool SAVE0>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_wide_stats(FwdParams p) {
+// PAIR: a second, narrow softmax decoder on the same input (the semantic head next to the instance head: both read the panoptic
+// features) is evaluated on the tile while it is in registers - its own launch was one more 268 MB read of the features.  The weights
+// of both decoders then take 66 KiB: 8 waves share them (512 threads, one workgroup per CU) instead of two 4-wave workgroups.
+template <bool SAVE0, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void mlp_fwd_wide_stats(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OB = 7;
     constexpr float LOG2E = 1.4426950408889634f;
+    const int NW = blockDim.x >> 6;
     bf16_t *W0s = reinterpret_cast<bf16_t *>(smem);
     bf16_t *W1s = W0s + 64 * RS;
     bf16_t *WLs = W1s + 64 * RS;                                     // [OB*32][RS] permuted k
-    float *b0s = reinterpret_cast<float *>(WLs + OB * 32 * RS);
+    bf16_t *W0s2 = WLs + OB * 32 * RS;                               // PAIR: [64][RS] natural k, [32][RS] permuted k
+    bf16_t *WLs2 = W0s2 + (PAIR ? 64 * RS : 0);
+    float *b0s = reinterpret_cast<float *>(WLs2 + (PAIR ? 32 * RS : 0));
     float *b1s = b0s + 64;
     float *bLs = b1s + 64;
-    bf16_t *stg = reinterpret_cast<bf16_t *>(bLs + OB * 32) + (threadIdx.x >> 6) * (ST_BYTES / 2);
+    float *b0s2 = bLs + OB * 32;
+    float *bLs2 = b0s2 + (PAIR ? 64 : 0);
+    bf16_t *stg = reinterpret_cast<bf16_t *>(bLs2 + (PAIR ? 32 : 0)) + (threadIdx.x >> 6) * (ST_BYTES / 2);
     stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
     stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
     stage_weight(WLs, RS, OB * 32, 64, p.W[2], p.out_dim, HID, true);
+    if constexpr (PAIR) {
+        stage_weight(W0s2, RS, 64, 64, p.W2[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
+        stage_weight(WLs2, RS, 32, 64, p.W2[1], p.out2_dim, HID, true);
+        for (int e = threadIdx.x; e < 64; e += blockDim.x) b0s2[e] = p.b2[0][e];
+        for (int e = threadIdx.x; e < 32; e += blockDim.x) bLs2[e] = e < p.out2_dim ? p.b2[1][e] : 0.0f;
+    }
     for (int e = threadIdx.x; e < 64; e += blockDim.x) {
         b0s[e] = p.b[0][e];
         b1s[e] = p.b[1][e];
@@ -961,9 +980,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_wide_stats(FwdParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t M = p.M, ntiles = (M + 31) / 32;
-    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const int64_t tile_step = (int64_t)gridDim.x * NW;
     const auto rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x1), 0, (int)(M * 128), 0x00020000);
     const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, (int)(M * 8), 0x00020000);
+    const auto rs_o2 = __builtin_amdgcn_make_buffer_rsrc(PAIR ? p.out2 : nullptr, 0, (int)(M * (PAIR ? p.out2_dim : 0) * 2), 0x00020000);
+    unsigned ooff2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ooff2[j] = (PAIR && 4 * h + j < p.out2_dim) ? (unsigned)((r * p.out2_dim + 4 * h + j) * 2) : BUF_OOB;
     const auto rs_h0 = __builtin_amdgcn_make_buffer_rsrc(SAVE0 ? p.hsave[0] : nullptr, 0, (int)(M * HID * 2), 0x00020000);
     const auto rs_h1 = __builtin_amdgcn_make_buffer_rsrc(p.hsave[1], 0, (int)(M * HID * 2), 0x00020000);
     unsigned xoff[4];
@@ -976,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_wide_stats(FwdParams p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x1, xoff[s] + base, 0, 0));
     };
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    int64_t tile = (int64_t)blockIdx.x * NW + wave;
     bf16x8 xn[4];
     load_x(tile, xn);
     for (; tile < ntiles; tile += tile_step) {
@@ -988,6 +1011,32 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_wide_stats(FwdParams p) {
         load_x(tile + tile_step, xn);
         f32x16 acc[2];
         bf16x8 hb[4];
+        if constexpr (PAIR) {      // the companion head: hidden layer, <= 8 logits, softmax (as mlp_fwd_fast<2, 2, false>)
+            f32x16 o2;
+            hidden_layer_pinned<4>(W0s2, b0s2, xb, r, h, acc);
+            relu_pack(acc, hb);
+            out_block_pinned(WLs2, bLs2, 0, hb, r, h, o2);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * h + j < p.out2_dim) mx = fmaxf(mx, o2[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mxs = mx * LOG2E;
+            float e[4], sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[j] = (4 * h + j < p.out2_dim) ? __builtin_amdgcn_exp2f(fmaf(o2[j], LOG2E, -mxs)) : 0.0f;
+                sum += e[j];
+            }
+            sum += __shfl_xor(sum, 32);
+            const float inv2 = 1.0f / sum;
+            const unsigned obase = live ? row0 * (unsigned)(p.out2_dim * 2) : BUF_OOB_ROW;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t y = (bf16_t)(e[j] * inv2);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, y), rs_o2, ooff2[j] + obase, 0, 0);
+            }
+        }
         hidden_layer_pinned<4>(W0s, b0s, xb, r, h, acc);
         relu_pack(acc, hb);
         if constexpr (SAVE0) tile64_store_buf(stg, rs_h0, row0 * (HID * 2), lane, r, h, acc);
@@ -3307,6 +3356,17 @@ inline unsigned mlp_grid(int64_t M) {
         else MLP_FWD_OB(X1T, OutT, 3);                               \
     } while (0)
 
+extern "C" int pag_mlp_fwd_pair_supported(const pag_mlp_fwd_args *a, const pag_mlp_fwd_args *b) {
+    if (!a || !b || b->pair) return 0;
+    const bool wide = a->mode == PAG_MLP_MFMA_BF16 && a->x1_dtype == PAG_BF16 && a->x1_layout == PAG_LAYOUT_XCD8 && !a->out && a->n_layers == 3 &&
+                      a->softmax_stats && a->out_act == PAG_ACT_SOFTMAX && a->out_dim > 192 && a->out_dim <= 224 && a->hidden_save[1] && !a->hidden_save[0];
+    const bool narrow = b->mode == PAG_MLP_MFMA_BF16 && b->x1 == a->x1 && b->x1_dtype == PAG_BF16 && b->x1_layout == PAG_LAYOUT_XCD8 && b->x1_levels == a->x1_levels &&
+                        b->x1_feats == a->x1_feats && b->in_dim == a->in_dim && b->n_layers == 2 && b->out && b->out_dtype == PAG_BF16 &&
+                        b->out_act == PAG_ACT_SOFTMAX && b->out_dim >= 1 && b->out_dim <= 8 && !b->hidden_save[0] && !b->hidden_save[1] && !b->x2 &&
+                        !b->x1_col0_relu && b->W[0] && b->W[1] && b->b[0] && b->b[1];
+    return wide && narrow ? 1 : 0;
+}
+
 extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a, "pag_mlp_fwd: args is NULL");
     PAG_CHECK_ARG(M >= 0, "pag_mlp_fwd: M < 0");
@@ -3341,6 +3401,9 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(!a->x1_col0_relu || (a->mode == PAG_MLP_MFMA_BF16 && a->x1_dtype == PAG_BF16 && a->x1_layout != PAG_LAYOUT_XCD8 && a->out_dim <= 64),
                   "pag_mlp_fwd: x1_col0_relu needs MFMA mode, a strided bf16 x1 and out_dim <= 64");
     p.col0_relu = a->x1_col0_relu;
+    p.W2[0] = p.W2[1] = p.b2[0] = p.b2[1] = nullptr;
+    p.out2 = nullptr;
+    p.out2_dim = 0;
     for (int l = 0; l < 3; ++l) {
         p.W[l] = l < a->n_layers ? a->W[l] : nullptr;
         p.b[l] = l < a->n_layers ? a->b[l] : nullptr;
@@ -3371,16 +3434,31 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
             kind = 1;
         else if (grp && a->out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_SOFTMAX && a->out_dim <= 8) kind = 2;
         else if (grp && !a->out && a->n_layers == 3 && p.stats && a->out_act == PAG_ACT_SOFTMAX && a->out_dim > 192 && a->hidden_save[1]) kind = 3;
+        PAG_CHECK_ARG(!a->pair || (kind == 3 && pag_mlp_fwd_pair_supported(a, a->pair) == 1), "pag_mlp_fwd: pair is not supported for these arguments (pag_mlp_fwd_pair_supported)");
         if (kind == 3) {
-            const size_t lds = (size_t)(128 + 224) * RS * sizeof(bf16_t) + (128 + 224) * sizeof(float) + 4 * ST_BYTES;
             static bool attr = false;
             if (!attr) {
-                hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr = true;
             }
-            if (a->hidden_save[0]) hipLaunchKernelGGL((mlp_fwd_wide_stats<true>), dim3(mlp_grid(M)), dim3(256), lds, st, p);
-            else hipLaunchKernelGGL((mlp_fwd_wide_stats<false>), dim3(mlp_grid(M)), dim3(256), lds, st, p);
+            if (a->pair) {
+                const pag_mlp_fwd_args *b = a->pair;
+                p.W2[0] = b->W[0];
+                p.W2[1] = b->W[1];
+                p.b2[0] = b->b[0];
+                p.b2[1] = b->b[1];
+                p.out2 = b->out;
+                p.out2_dim = b->out_dim;
+                const size_t lds = (size_t)(128 + 224 + 96) * RS * sizeof(bf16_t) + (128 + 224 + 96) * sizeof(float) + 8 * ST_BYTES;
+                const unsigned grid = (mlp_grid(M) + 1) / 2;       // 8 waves per workgroup
+                hipLaunchKernelGGL((mlp_fwd_wide_stats<false, true>), dim3(grid), dim3(512), lds, st, p);
+            } else {
+                const size_t lds = (size_t)(128 + 224) * RS * sizeof(bf16_t) + (128 + 224) * sizeof(float) + 4 * ST_BYTES;
+                if (a->hidden_save[0]) hipLaunchKernelGGL((mlp_fwd_wide_stats<true, false>), dim3(mlp_grid(M)), dim3(256), lds, st, p);
+                else hipLaunchKernelGGL((mlp_fwd_wide_stats<false, false>), dim3(mlp_grid(M)), dim3(256), lds, st, p);
+            }
             PAG_CHECK_LAUNCH("pag_mlp_fwd (wide head statistics)");
             return PAG_OK;
         }
@@ -3401,6 +3479,7 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
             return PAG_OK;
         }
     }
+    PAG_CHECK_ARG(!a->pair, "pag_mlp_fwd: pair rides only in the straight-line wide-head launch (M <= %lld, PAG_NO_FAST_FWD unset)", (long long)PAG_MLP_FUSED_WIDE_MAX_M);
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;
         const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + OB * 32) * RS * sizeof(bf16_t) + (128 + OB * 32) * sizeof(float) + 4 * ST_BYTES;

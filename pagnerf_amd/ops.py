@@ -309,6 +309,9 @@ def _recompute_hidden(x1, x2, x2_index, Wc, bc, in_dim, k1, grouped, mode, hidde
     return full
 
 
+_NO_FAST_FWD = os.environ.get("PAG_NO_FAST_FWD") is not None
+
+
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, x2_index, in_dim, out_act, mode, out_dtype, grouped, *wb):
@@ -369,7 +372,17 @@ class _FusedMLP(torch.autograd.Function):
                 and out_dim <= 64 and M:
             ctx.col0_relu = torch.empty(M, device=x1.device)           # _ColourDensity: sigma from the same launch
             a.x1_col0_relu = L.ptr(ctx.col0_relu)
-        if M:
+        # A pair of decoders on one input (_HeadCompositePair): the narrow one's launch is PREPARED and parked (ctx.fwd_hold) and rides
+        # in the wide one's call (ctx.fwd_pair -> pag_mlp_fwd_args.pair) where the library can; else the caller issues it.
+        hold, pair_hold = getattr(ctx, "fwd_hold", None), getattr(ctx, "fwd_pair", None)
+        if M and hold is not None:
+            hold["args"], hold["M"] = a, M
+            hold["keep"] = [v for v in locals().values() if isinstance(v, (torch.Tensor, list, tuple))]
+        elif M:
+            if pair_hold is not None and pair_hold.get("args") is not None and M <= L.MLP_FUSED_WIDE_MAX_M and not _NO_FAST_FWD \
+                    and L.load().pag_mlp_fwd_pair_supported(ctypes.byref(a), ctypes.byref(pair_hold["args"])) == 1:
+                a.pair = ctypes.pointer(pair_hold["args"])
+                pair_hold["taken"] = True
             _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
         ctx.cfg = (in_dim, out_act, mode, n_layers, k1, grouped)
         ctx.x2_packs = None
@@ -1095,8 +1108,16 @@ class _HeadComposite(_FusedMLP):
 
     @staticmethod
     def forward(ctx, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dim, out_act, out_dtype, grouped, *wb):
+        probs = _HeadComposite._decode(ctx, x1, in_dim, out_act, out_dtype, grouped, *wb)
+        return _HeadComposite._composite(ctx, probs, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, grouped, *wb)
+
+    @staticmethod
+    def _decode(ctx, x1, in_dim, out_act, out_dtype, grouped, *wb):
         ctx.stats_only = HEAD_REBUILD
-        probs = _FusedMLP.forward(ctx, x1, None, None, in_dim, out_act, L.MLP_MFMA_BF16, out_dtype, grouped, *wb)
+        return _FusedMLP.forward(ctx, x1, None, None, in_dim, out_act, L.MLP_MFMA_BF16, out_dtype, grouped, *wb)
+
+    @staticmethod
+    def _composite(ctx, probs, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, grouped, *wb):
         C = wb[len(wb) // 2 - 1].shape[0]
         P = ray_of_pack.shape[0]
         M = x1.shape[1] if grouped is not None else x1.shape[0]
@@ -1151,14 +1172,22 @@ class _HeadCompositePair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dims, out_dtype, grouped, n_a, *wb):
-        subs, outs = [], []
-        for i, part in enumerate((wb[:n_a], wb[n_a:])):
-            sub = _SubCtx(ctx.needs_input_grad[0])
-            outs.append(_HeadComposite.forward(sub, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dims[i], L.ACT_SOFTMAX,
-                                               out_dtype, grouped, *part))
-            subs.append(sub)
-        ctx.subs, ctx.n_a = subs, n_a
-        return outs[0], outs[1]
+        sub_a, sub_b = _SubCtx(ctx.needs_input_grad[0]), _SubCtx(ctx.needs_input_grad[0])
+        part_a, part_b = wb[:n_a], wb[n_a:]
+        # the second (narrow) decoder is prepared first and parked: where the library can, it is evaluated inside the first one's launch
+        # (pag_mlp_fwd_args.pair: the features are read once); its compositing pass follows either way
+        hold = {}
+        sub_b.fwd_hold = hold
+        probs_b = _HeadComposite._decode(sub_b, x1, in_dims[1], L.ACT_SOFTMAX, out_dtype, grouped, *part_b)
+        sub_a.fwd_pair = hold
+        out_a = _HeadComposite.forward(sub_a, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dims[0], L.ACT_SOFTMAX, out_dtype,
+                                       grouped, *part_a)
+        if hold.get("args") is not None and not hold.get("taken"):
+            _call("pag_mlp_fwd", ctypes.byref(hold["args"]), hold["M"], L.stream())
+        sub_a.fwd_pair = sub_b.fwd_hold = None
+        out_b = _HeadComposite._composite(sub_b, probs_b, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, grouped, *part_b)
+        ctx.subs, ctx.n_a = [sub_a, sub_b], n_a
+        return out_a, out_b
 
     @staticmethod
     def backward(ctx, g_a, g_b):
