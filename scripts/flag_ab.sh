@@ -6,7 +6,7 @@ for round in 1 2; do
   for fl in "$1" "$2"; do
     export PAG_EXTRA_FLAGS="$fl"
     out=gpurun_out/ab_tmp; rm -rf $out; mkdir -p $out
-    rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux > $out/bench.json 2> $out/err
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux $BENCH_ARGS > $out/bench.json 2> $out/err
     f=$(find $out -name "*kernel_stats.csv" | head -1)
     echo "[$fl] $(python3 - $f "$pat" <<'PY'
 import csv,sys,re
