@@ -507,6 +507,34 @@ __device__ __forceinline__ void tw_put_block(bf16_t *T, int mb, int r, int h, co
         *reinterpret_cast<bf16x4 *>(T + tw_off(r, 8 * mb + 2 * g + h)) = v;
     }
 }
+// dz of a hidden layer from a W^T chain's accumulators: ReLU mask (the layer's saved bf16 activation > 0, read from its image Th) and
+// bf16 rounding on PAIRS - a post-ReLU half-word is 0 or positive, so min(max(h as i16, 0), 1) is its 0 / 1 mask (a -0 counts as not
+// positive, like the float compare) and a 16-bit multiply applies it: 4 instructions per pair instead of 7, and ONE conversion serves
+// both outputs - the next chain's B fragments hb[] and the transposed-read image Tz (blocks 0, 1).  Bit-identical to mask-in-fp32.
+__device__ __forceinline__ void relu_mask_pack_put(const bf16_t *Th, bf16_t *Tz, int r, int h, bool live, const f32x16 (&acc)[2], bf16x8 (&hb)[4]) {
+    typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        unsigned zp[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x2_t hv = *reinterpret_cast<const u32x2_t *>(Th + tw_off(r, 8 * mb + 2 * g + h));
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const bf16x2_t a2 = {(bf16_t)acc[mb][4 * g + 2 * d], (bf16_t)acc[mb][4 * g + 2 * d + 1]};
+                unsigned m, o;
+                asm("v_pk_max_i16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(m) : "v"(hv[d]), "s"(0u), "s"(0x00010001u));
+                asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o) : "v"(__builtin_bit_cast(unsigned, a2)), "v"(m));
+                zp[2 * g + d] = live ? o : 0u;
+            }
+            *reinterpret_cast<u32x2_t *>(Tz + tw_off(r, 8 * mb + 2 * g + h)) = u32x2_t{zp[2 * g], zp[2 * g + 1]};
+        }
+        hb[2 * mb] = __builtin_bit_cast(bf16x8, u32x4_t{zp[0], zp[1], zp[2], zp[3]});
+        hb[2 * mb + 1] = __builtin_bit_cast(bf16x8, u32x4_t{zp[4], zp[5], zp[6], zp[7]});
+    }
+}
 __device__ __forceinline__ void tw_get_raw(const bf16_t *T, int r, int h, bf16x4 (&raw)[2][4]) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -1703,18 +1731,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         f32x16 acc[2];
         bf16x8 hb[4];
         wt_chain_pinned<2, 2 * OBL>(WLt, RSL, zb, r, h, acc);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bf16x4 hv = *reinterpret_cast<const bf16x4 *>((NL == 3 ? Th1 : Th0) + tw_off(r, 8 * mb + 2 * g + h));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] = ((float)hv[j] > 0.0f && live) ? acc[mb][4 * g + j] : 0.0f;
-            }
-            pack_block(acc[mb], hb[2 * mb], hb[2 * mb + 1]);
-        }
-        tw_put_block(Tz, 0, r, h, acc[0]);
-        tw_put_block(Tz, 1, r, h, acc[1]);
+        relu_mask_pack_put(NL == 3 ? Th1 : Th0, Tz, r, h, live, acc, hb);
         wave_lds_sync();
         if constexpr (NL == 3) wgrad_tile(Th0, awM, OBL);
         else wgrad_tile(Tx, aw0, -1);
@@ -1722,18 +1739,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         if constexpr (NL == 3) {
             bf16x8 hb2[4];
             wt_chain_pinned<2, 4>(W1t, RS, hb, r, h, acc);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const bf16x4 hv = *reinterpret_cast<const bf16x4 *>(Th0 + tw_off(r, 8 * mb + 2 * g + h));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mb][4 * g + j] = ((float)hv[j] > 0.0f && live) ? acc[mb][4 * g + j] : 0.0f;
-                }
-                pack_block(acc[mb], hb2[2 * mb], hb2[2 * mb + 1]);
-            }
-            tw_put_block(Tz, 0, r, h, acc[0]);
-            tw_put_block(Tz, 1, r, h, acc[1]);
+            relu_mask_pack_put(Th0, Tz, r, h, live, acc, hb2);
             wave_lds_sync();
             wgrad_tile(Tx, aw0, -1);
             wave_lds_sync();
@@ -1964,6 +1970,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
     };
     // masked by the saved ReLU output (read from its LDS image), then: fragments of the next chain + the transposed image for dW
     auto mask_pack_put = [&](const bf16_t *Th, bool live, f32x16 (&acc)[2], bf16x8 (&hb)[4]) __attribute__((always_inline)) {
+        // (the packed form of relu_mask_pack_put costs this kernel 8 bytes of scratch: 256 + 256 registers are all taken)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
