@@ -1725,29 +1725,29 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
             tw_put_block(Tz, ob, r, h, zv[ob]);
         }
         wave_lds_sync();
-        wgrad_tile(NL == 3 ? Th1 : Th0, awL, 0);
-        wave_lds_sync();
-        // ---- back through the output layer, masked by the saved ReLU output (read from its LDS image)
+        // ---- back through the output layer, masked by the saved ReLU output (read from its LDS image).  Every W^T chain (fragments in
+        // registers, weights from LDS) is issued BEFORE the weight-gradient MFMAs of the same dz: their transposed reads of the image just
+        // written then land under the chain instead of being waited for by the only wave of the SIMD.
         f32x16 acc[2];
         bf16x8 hb[4];
         wt_chain_pinned<2, 2 * OBL>(WLt, RSL, zb, r, h, acc);
-        relu_mask_pack_put(NL == 3 ? Th1 : Th0, Tz, r, h, live, acc, hb);
+        wgrad_tile(NL == 3 ? Th1 : Th0, awL, 0);
         wave_lds_sync();
-        if constexpr (NL == 3) wgrad_tile(Th0, awM, OBL);
-        else wgrad_tile(Tx, aw0, -1);
+        relu_mask_pack_put(NL == 3 ? Th1 : Th0, Tz, r, h, live, acc, hb);
         wave_lds_sync();
         if constexpr (NL == 3) {
             bf16x8 hb2[4];
             wt_chain_pinned<2, 4>(W1t, RS, hb, r, h, acc);
-            relu_mask_pack_put(Th0, Tz, r, h, live, acc, hb2);
+            wgrad_tile(Th0, awM, OBL);
             wave_lds_sync();
-            wgrad_tile(Tx, aw0, -1);
+            relu_mask_pack_put(Th0, Tz, r, h, live, acc, hb2);
             wave_lds_sync();
 #pragma unroll
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
         }
-        // ---- dx1 = (W_0^T . dz_0)[0:k1]
+        // ---- dx1 = (W_0^T . dz_0)[0:k1], then layer 0's weight gradient
         wt_chain_pinned<(GRP ? 2 : 1), 4>(W0t, RS, hb, r, h, acc);
+        wgrad_tile(Tx, aw0, -1);
 #pragma unroll
         for (int mb = 0; mb < (GRP ? 2 : 1); ++mb) {
             if constexpr (GRP) {      // XCD8: row 32mb + 8g + 4h + j of dx^T -> piece [4mb + g][m][4h + j]
@@ -1970,7 +1970,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
     };
     // masked by the saved ReLU output (read from its LDS image), then: fragments of the next chain + the transposed image for dW
     auto mask_pack_put = [&](const bf16_t *Th, bool live, f32x16 (&acc)[2], bf16x8 (&hb)[4]) __attribute__((always_inline)) {
-        // (the packed form of relu_mask_pack_put costs this kernel 8 bytes of scratch: 256 + 256 registers are all taken)
+        // (the packed form of relu_mask_pack_put, and issuing the chains before the weight-gradient MFMAs as mlp_bwd_fused does, cost this
+        // kernel 8 / 120 bytes of scratch for no gain: 256 + 256 registers are all taken)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
