@@ -972,7 +972,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fast(FwdParams p) {
 // features) is evaluated on the tile while it is in registers - its own launch was one more 268 MB read of the features.  The weights
 // of both decoders then take 66 KiB: 8 waves share them (512 threads, one workgroup per CU) instead of two 4-wave workgroups.
 template <bool SAVE0, bool PAIR>
-__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void mlp_fwd_wide_stats(FwdParams p) {
+#ifndef PAG_WIDE_FWD_PAIR_THREADS
+#define PAG_WIDE_FWD_PAIR_THREADS 1024
+#endif
+__global__ __launch_bounds__(PAIR ? PAG_WIDE_FWD_PAIR_THREADS : 256, PAIR ? 1 : 2) void mlp_fwd_wide_stats(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OB = 7;
     constexpr float LOG2E = 1.4426950408889634f;
@@ -3459,9 +3462,10 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
                 p.b2[1] = b->b[1];
                 p.out2 = b->out;
                 p.out2_dim = b->out_dim;
-                const size_t lds = (size_t)(128 + 224 + 96) * RS * sizeof(bf16_t) + (128 + 224 + 96) * sizeof(float) + 8 * ST_BYTES;
-                const unsigned grid = (mlp_grid(M) + 1) / 2;       // 8 waves per workgroup
-                hipLaunchKernelGGL((mlp_fwd_wide_stats<false, true>), dim3(grid), dim3(512), lds, st, p);
+                constexpr int NWP = PAG_WIDE_FWD_PAIR_THREADS / 64;      // waves per workgroup (one workgroup per CU shares the 66 KiB of weights)
+                const size_t lds = (size_t)(128 + 224 + 96) * RS * sizeof(bf16_t) + (128 + 224 + 96) * sizeof(float) + NWP * ST_BYTES;
+                const unsigned grid = (mlp_grid(M) * 4 + NWP - 1) / NWP;
+                hipLaunchKernelGGL((mlp_fwd_wide_stats<false, true>), dim3(grid), dim3(PAG_WIDE_FWD_PAIR_THREADS), lds, st, p);
             } else {
                 const size_t lds = (size_t)(128 + 224) * RS * sizeof(bf16_t) + (128 + 224) * sizeof(float) + 4 * ST_BYTES;
                 if (a->hidden_save[0]) hipLaunchKernelGGL((mlp_fwd_wide_stats<true, false>), dim3(mlp_grid(M)), dim3(256), lds, st, p);
