@@ -27,11 +27,20 @@ def positional_embed(x, num_freq):
     return torch.cat([x, torch.sin(w), torch.cos(w)], dim=-1)
 
 
-def mlp(x, weights, biases, act=torch.relu):
+def bf16_operands(t):
+    """Straight-through bf16 rounding: the value a bf16 matrix-core operand carries, the gradient of the identity.  Passed as
+    `operand_round` it turns the fp32 chain below into the arithmetic of a bf16-operand / fp32-accumulate implementation (weights,
+    layer inputs and stored activations rounded, sums and epilogues in fp32) - used by the tests to separate rounding noise from
+    real differences; the default (None) is the reference's fp32 arithmetic."""
+    return t + (t.bfloat16().float() - t).detach()
+
+
+def mlp(x, weights, biases, act=torch.relu, operand_round=None):
     """weights[i] is [out,in] (nn.Linear layout); activation after every layer but the last."""
+    r = operand_round if operand_round is not None else (lambda t: t)
     h = x
     for i, (W, b) in enumerate(zip(weights, biases)):
-        h = F.linear(h, W, b)
+        h = F.linear(r(h), r(W), b)
         if i + 1 < len(weights):
             h = act(h)
     return h
@@ -41,7 +50,7 @@ def nef_forward(feats, delta_feats, ray_d, params, channels,
                 view_multires=4, lod_weights=None,
                 sem_softmax=True, inst_softmax=True, sem_sigmoid=False, inst_sigmoid=False,
                 sem_normalize=False, inst_normalize=False, inst_soft_temperature=0.0,
-                panoptic_features_type="delta", multiscale_sum_levels=0, coords=None, pos_multires=4):
+                panoptic_features_type="delta", multiscale_sum_levels=0, coords=None, pos_multires=4, operand_round=None):
     """Everything of rgb_semantics() after the two grid interpolations (pc_nerf/panoptic_delta_nef.py:170-259).
 
     feats, delta_feats: [M, L*F] grid features (delta may be None when no panoptic channel).
@@ -52,23 +61,27 @@ def nef_forward(feats, delta_feats, ray_d, params, channels,
     Returns dict with density [M,1], rgb [M,3], semantics [M,C], inst_embedding [M,I].
     """
     out = {}
+    rnd = operand_round if operand_round is not None else (lambda t: t)      # stored tensors of a reduced-precision implementation
+    kw = dict(operand_round=operand_round)
     if lod_weights is not None:
         feats = feats * lod_weights
     if multiscale_sum_levels:
         feats = feats.reshape(-1, multiscale_sum_levels, feats.shape[-1] // multiscale_sum_levels).sum(-2)
-    dfe = mlp(feats, *params["density"])
+    feats = rnd(feats)
+    dfe = rnd(mlp(feats, *params["density"], **kw))
     out["density_feats"] = dfe
     out["density"] = torch.relu(dfe[..., 0:1])
     if "rgb" in channels:
         pe = positional_embed(-ray_d, view_multires)
-        out["rgb"] = torch.sigmoid(mlp(torch.cat([dfe, pe], dim=-1), *params["color"]))
+        out["rgb"] = torch.sigmoid(mlp(torch.cat([dfe, pe], dim=-1), *params["color"], **kw))
     if "semantics" in channels or "inst_embedding" in channels:
         if panoptic_features_type in ("delta", "separate", None):
             d = delta_feats * lod_weights if lod_weights is not None else delta_feats
             if multiscale_sum_levels:
                 d = d.reshape(-1, multiscale_sum_levels, d.shape[-1] // multiscale_sum_levels).sum(-2)
+            d = rnd(d)
         if panoptic_features_type in ("delta", None):
-            pan = feats.detach() + d
+            pan = rnd(feats.detach() + d)
         elif panoptic_features_type == "separate":
             pan = d
         elif panoptic_features_type == "appearance":
@@ -80,13 +93,13 @@ def nef_forward(feats, delta_feats, ray_d, params, channels,
         else:
             raise ValueError(panoptic_features_type)
         if "semantics" in channels:
-            s = mlp(pan, *params["semantics"])
+            s = mlp(pan, *params["semantics"], **kw)
             s = torch.sigmoid(s) if sem_sigmoid else s
             s = F.normalize(s, dim=-1) if sem_normalize else s
             s = F.softmax(s, dim=-1) if sem_softmax else s
             out["semantics"] = s
         if "inst_embedding" in channels:
-            e = mlp(pan, *params["inst"])
+            e = mlp(pan, *params["inst"], **kw)
             e = torch.sigmoid(e) if inst_sigmoid else e
             e = F.normalize(e, dim=-1) if inst_normalize else e
             e = e / inst_soft_temperature if inst_soft_temperature > 0.0 else e

@@ -104,7 +104,8 @@ class PanopticDDensityNeF(PanopticDeltaNeF):
         words = max(1, (g.num_cells + 31) // 32)
         keep = torch.zeros(words, dtype=torch.int32, device=dev)
         for grid, channel in ((self.grid, "density"), (self.delta_grid, "panoptic_density")):
-            density = self.forward(coords=samples[:, None], ray_d=views, channels=channel)
+            with self.grid.fp32_coords(), self.delta_grid.fp32_coords():      # outside the trainer's autocast region (grids.rounds_coords)
+                density = self.forward(coords=samples[:, None], ray_d=views, channels=channel)
             grid.occupancy = grid.occupancy.to(dev).float().contiguous()
             bits = torch.empty(words, dtype=torch.int32, device=dev)
             ops.occupancy_update(density.reshape(-1).float(), grid.occupancy, bits, density_decay, min_density)

@@ -92,7 +92,7 @@ class OccupancyBLAS(nn.Module):
         w = (mask.reshape(-1, 32).long() << torch.arange(32, device=mask.device)).sum(1)
         w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
         self.blas_bits = w.to(self.blas_bits.device)
-        self._all_occupied = bool(mask.all())
+        self._refresh_derived()              # also drops the coarse-occupancy and pack caches keyed on the old tensor
 
     def blas_init_bits(self, bits):
         """Adopt a packed bitfield produced on the device (ops.occupancy_update)."""
@@ -160,10 +160,38 @@ class _GridBase(OccupancyBLAS):
     def _coords(self, coords):
         return coords.reshape(-1, 3)
 
+    def rounds_coords(self):
+        """Whether interpolate() rounds the coordinates to fp16 in THIS call.  The reference's `custom_fwd(cast_inputs=torch.half)`
+        (grids/permuto_grid.py:65, grids/hash_grid_tinycudann.py:36) acts only inside the train step's `torch.cuda.amp.autocast()`
+        (pc_nerf/trainer.py:429); validate() / evaluate_metrics() (pipeline.eval(), no autocast: trainer.py:630,944) and nef.prune()
+        see fp32 coordinates.  half_coords=True follows that: rounding under autocast, or in training mode outside fp32_coords()
+        (training mode stands for "inside the train step" for callers that do not open an autocast region); "always" / False
+        force it on / off."""
+        hc = self.half_coords
+        if hc == "always":
+            return True
+        if not hc:
+            return False
+        return torch.is_autocast_enabled() or (self.training and not getattr(self, "_fp32_coords", False))
+
+    def fp32_coords(self):
+        """Context manager: interpolate() keeps fp32 coordinates even in training mode (nef.prune(), panoptic_delta_nef.py:63-104,
+        runs outside the trainer's autocast region)."""
+        grid = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.prev, grid._fp32_coords = getattr(grid, "_fp32_coords", False), True
+
+            def __exit__(self, *exc):
+                grid._fp32_coords = self.prev
+        return _Ctx()
+
     def interpolate_scaled(self, coords, feat_scale=None, out_dtype=torch.float32, layout=None, addend=None):
         """interpolate() with the nef's lod_weights folded into the kernel; layout="xcd8" returns the bf16
         [8, M, 8] XCD-grouped features the fused decoders consume (ops.encode); addend: see ops.encode."""
-        return ops.encode(self._coords(coords), self.tables, self._spec, feat_scale, out_dtype, False, layout=layout, addend=addend)
+        return ops.encode(self._coords(coords), self.tables, self._spec, feat_scale, out_dtype, False, layout=layout, addend=addend,
+                          half_coords=self.rounds_coords())
 
 
 class HashGridHIP(_GridBase):
@@ -173,7 +201,7 @@ class HashGridHIP(_GridBase):
         super().__init__(feature_dim, **kwargs)
         self.codebook_bitwidth = int(codebook_bitwidth)
         # grids/hash_grid_tinycudann.py:36 rounds the coordinates to fp16 under autocast; grids/hash_grid_torch.py does not (Appendix E.6)
-        self.half_coords = bool(half_coords)
+        self.half_coords = half_coords if half_coords == "always" else bool(half_coords)
 
     @staticmethod
     def level_resolutions(base_resolution, finest_resolution, n_levels):
@@ -197,7 +225,7 @@ class HashGridHIP(_GridBase):
         dev = self.blas_bits.device
         t = torch.empty(self.num_lods, T, self.feature_dim, device=dev).uniform_(-1e-4, 1e-4)   # hash_grid_torch.py:65
         self.tables = nn.Parameter(t.to(self.table_dtype))
-        self._spec = ops.hash_spec(res, self.codebook_bitwidth, self.feature_dim, half_coords=self.half_coords)
+        self._spec = ops.hash_spec(res, self.codebook_bitwidth, self.feature_dim, half_coords=bool(self.half_coords))
 
     def init_from_geometric(self, min_width, max_width, num_lods):
         """wisp HashGrid.init_from_geometric (config_parser.py:733): int(1 + floor(min * b**l))."""
@@ -222,7 +250,7 @@ class PermutoGridHIP(_GridBase):
         self.capacity = 2 ** int(capacity_log_2)
         # permuto_grid.py:65,71 - under the trainer's autocast the coordinates are rounded to fp16 before the encoder sees them
         # (PAG_ENC_HALF_COORDS: done inside the kernels).  On by default because that is how the reference trains.
-        self.half_coords = bool(half_coords)
+        self.half_coords = half_coords if half_coords == "always" else bool(half_coords)
 
     def set_capacity(self, capacity_log_2):
         self.capacity = 2 ** int(capacity_log_2)
@@ -248,7 +276,7 @@ class PermutoGridHIP(_GridBase):
 
     def _build_spec(self):
         self._spec = ops.permuto_spec(self.scale_factors(self.resolutions), self.random_shift_per_level, self.capacity,
-                                      self.feature_dim, half_coords=self.half_coords)
+                                      self.feature_dim, half_coords=bool(self.half_coords))
 
     def _refresh_derived(self):
         super()._refresh_derived()

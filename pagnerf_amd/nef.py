@@ -353,7 +353,8 @@ class PanopticDeltaNeF(nn.Module):
         samples = (points.float() + jitter) / res * 2.0 - 1.0
         views = torch.zeros(points.shape[0], 3, device=dev)
         views[:, 2] = 1.0
-        density = self.forward(coords=samples[:, None], ray_d=views, channels="density")
+        with g.fp32_coords():          # prune() runs outside the trainer's autocast region: fp32 coordinates (grids.rounds_coords)
+            density = self.forward(coords=samples[:, None], ray_d=views, channels="density")
         g.occupancy = g.occupancy.to(dev).float().contiguous()
         bits = torch.empty(max(1, (g.num_cells + 31) // 32), dtype=torch.int32, device=dev)
         ops.occupancy_update(density.reshape(-1), g.occupancy, bits, density_decay, min_density)   # EMA-max + threshold + pack

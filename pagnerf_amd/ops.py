@@ -123,25 +123,26 @@ def _layout_args(t):
     return t.stride(0), t.stride(1), L.LAYOUT_STRIDED
 
 
-def _encode_fwd(spec, xyz, tables, feat_scale, out, addend=None):
+def _encode_fwd(spec, xyz, tables, feat_scale, out, addend=None, flags=None):
     M = xyz.shape[0]
+    flags = spec.flags if flags is None else flags
     fs = L.host_floats(feat_scale)
     sm, sc, lay = _layout_args(out)
     if addend is not None:                    # out = bf16(addend + bf16(features)), XCD8 layout only
         assert lay == L.LAYOUT_XCD8 and addend.shape == out.shape and addend.dtype == torch.bfloat16 and addend.is_contiguous()
         if spec.kind == "hash":
             _call("pag_hash_encode_fwd_add", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T, spec.res, fs,
-                  L.ptr(addend), out.data_ptr(), spec.flags, L.stream())
+                  L.ptr(addend), out.data_ptr(), flags, L.stream())
         else:
             _call("pag_permuto_encode_fwd_add", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity, spec.sf,
-                  spec.shift, fs, L.ptr(addend), out.data_ptr(), spec.flags, L.stream())
+                  spec.shift, fs, L.ptr(addend), out.data_ptr(), flags, L.stream())
         return
     if spec.kind == "hash":
         _call("pag_hash_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.log2_T,
-              spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, spec.flags, L.stream())
+              spec.res, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, flags, L.stream())
     else:
         _call("pag_permuto_encode_fwd", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), spec.L, spec.F, spec.capacity,
-              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, spec.flags, L.stream())
+              spec.sf, spec.shift, fs, out.data_ptr(), L.dtype_code(out), sm, sc, lay, flags, L.stream())
 
 
 _DTYPE_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
@@ -149,9 +150,10 @@ _DTYPE_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF1
 BWD_ALGO = "binned"     # "binned": atomic-free two-pass scatter (default); "atomic": per-vertex fp32 global atomics
 
 
-def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False):
+def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False, flags=None):
     """overwrite: grad_tables is uninitialised memory that the binned reduce pass fills completely (pag_*_encode_bwd_set)."""
     lib = L.load()
+    flags = spec.flags if flags is None else flags
     M = xyz.shape[0]
     fs = L.host_floats(feat_scale)
     sm, sc, lay = _layout_args(grad_out)
@@ -164,33 +166,35 @@ def _encode_bwd(spec, xyz, grad_out, feat_scale, grad_tables, overwrite=False):
     suffix = "_set" if overwrite else ""
     if spec.kind == "hash":
         _call("pag_hash_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
-              spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, spec.flags, L.stream())
+              spec.log2_T, spec.res, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, flags, L.stream())
     else:
         _call("pag_permuto_encode_bwd" + suffix, L.ptr(xyz), M, grad_out.data_ptr(), L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F,
-              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, spec.flags, L.stream())
+              spec.capacity, spec.sf, spec.shift, fs, L.ptr(grad_tables), ws_ptr, ws_bytes, flags, L.stream())
 
 
-def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale):
+def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale, flags=None):
     """d loss / d xyz f32 [M,3] (pose optimisation: ba_pipeline.py:85-92)."""
     M = xyz.shape[0]
+    flags = spec.flags if flags is None else flags
     fs = L.host_floats(feat_scale)
     sm, sc, lay = _layout_args(grad_out)
     d_xyz = torch.empty(M, 3, device=xyz.device)
     ws = torch.empty(8 * M * 3, device=xyz.device)
     if spec.kind == "hash":
         _call("pag_hash_encode_bwd_xyz", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), grad_out.data_ptr(), L.dtype_code(grad_out),
-              sm, sc, lay, spec.L, spec.F, spec.log2_T, spec.res, fs, L.ptr(d_xyz), L.ptr(ws), ws.numel() * 4, spec.flags, L.stream())
+              sm, sc, lay, spec.L, spec.F, spec.log2_T, spec.res, fs, L.ptr(d_xyz), L.ptr(ws), ws.numel() * 4, flags, L.stream())
     else:
         _call("pag_permuto_encode_bwd_xyz", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), grad_out.data_ptr(),
               L.dtype_code(grad_out), sm, sc, lay, spec.L, spec.F, spec.capacity, spec.sf, spec.shift, fs, L.ptr(d_xyz), L.ptr(ws),
-              ws.numel() * 4, spec.flags, L.stream())
+              ws.numel() * 4, flags, L.stream())
     return d_xyz
 
 
 class _Encode(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, tables, spec, feat_scale, out_dtype, feature_major, addend=None):
+    def forward(ctx, xyz, tables, spec, feat_scale, out_dtype, feature_major, addend=None, flags=None):
         _check_gpu(xyz, tables)
+        ctx.flags = flags
         xyz = xyz.detach().contiguous().float()
         M, C = xyz.shape[0], spec.L * spec.F
         if tables.shape != (spec.L, spec.rows(), spec.F):
@@ -203,7 +207,7 @@ class _Encode(torch.autograd.Function):
             out = torch.empty(M, C, device=xyz.device, dtype=out_dtype)
         tc = tables.detach().contiguous()
         if M:
-            _encode_fwd(spec, xyz, tc, feat_scale, out, addend.detach() if addend is not None else None)
+            _encode_fwd(spec, xyz, tc, feat_scale, out, addend.detach() if addend is not None else None, flags=flags)
         ctx.spec, ctx.feat_scale = spec, feat_scale
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(xyz, tc)           # d/d xyz needs the table rows again
@@ -225,22 +229,25 @@ class _Encode(torch.autograd.Function):
             binned = BWD_ALGO == "binned" or g.dim() == 3
             if xyz.shape[0] and binned:       # the reduce pass writes every row: no zero fill, no read-modify-write
                 gt = torch.empty(ctx.tshape, device=xyz.device, dtype=torch.float32)
-                _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt, overwrite=True)
+                _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt, overwrite=True, flags=ctx.flags)
             else:
                 gt = torch.zeros(ctx.tshape, device=xyz.device, dtype=torch.float32)
                 if xyz.shape[0]:
-                    _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt)
+                    _encode_bwd(ctx.spec, xyz, g, ctx.feat_scale, gt, flags=ctx.flags)
             gt = gt.to(ctx.tdtype)
         if need_x:
-            d_xyz = _encode_bwd_xyz(ctx.spec, xyz, ctx.saved_tensors[1], g, ctx.feat_scale) if xyz.shape[0] else torch.zeros_like(xyz)
-        return d_xyz, gt, None, None, None, None, None
+            d_xyz = _encode_bwd_xyz(ctx.spec, xyz, ctx.saved_tensors[1], g, ctx.feat_scale, flags=ctx.flags) if xyz.shape[0] \
+                else torch.zeros_like(xyz)
+        return d_xyz, gt, None, None, None, None, None, None
 
 
-def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None, addend=None):
+def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None, addend=None, half_coords=None):
     """Grid features [M, L*F] (column = level*F + f); layout="xcd8" returns the bf16 [8, M, 8] XCD-grouped tensor the
     fused decoders consume directly.  Differentiable w.r.t. tables and (when xyz.requires_grad) xyz.
-    addend (xcd8 only, treated as a constant): the result is bf16(addend + bf16(features)) in the same launch."""
-    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major, addend)
+    addend (xcd8 only, treated as a constant): the result is bf16(addend + bf16(features)) in the same launch.
+    half_coords: None = as the spec says; True / False override it for this call (forward and both gradients)."""
+    flags = None if half_coords is None else (L.ENC_HALF_COORDS if half_coords else 0)
+    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major, addend, flags)
 
 
 def xcd8_supported(n_levels, n_feat):

@@ -143,6 +143,9 @@ class PanopticPackedRFTracer(nn.Module):
                 outputs[ch] = ops.composite_feats(feats[ch].reshape(-1, feats[ch].shape[-1]), w, alpha_d, pack_start, ray_of_pack, N)
         extra_outputs = {}
         for ch in extra_channels:                                                          # :184-192
+            # the reference composites extra channels with the LIVE alpha / transmittance (:192 passes the tensors of :135-138, not
+            # the detached panoptic ones): their loss reaches the density through the weights as well as the channel itself
             f = nef(coords=samples, ray_d=rays.dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx, channels=ch)
-            extra_outputs[ch] = ops.composite_feats(f.reshape(-1, f.shape[-1]), w, alpha_d, pack_start, ray_of_pack, N)
+            extra_outputs[ch] = ops.composite_features(sigma, deltas.reshape(-1), f.reshape(-1, f.shape[-1]), ridx32, pack_start,
+                                                       ray_of_pack, N)[0]
         return RenderBuffer(**outputs, **extra_outputs)

@@ -219,6 +219,24 @@ def test_half_coords_flag_equals_rounding_the_input(gpu_device):
     assert g.half_coords and np.array_equal(g.interpolate(torch.from_numpy(x).to(dev)[:, None]).detach().cpu().numpy(), ref)
     h = pagnerf_amd.HashGridHIP(2, codebook_bitwidth=14, blas_level=3)
     assert not h.half_coords
+    # when the rounding applies (grids.rounds_coords): the reference casts only under the train step's autocast (trainer.py:429);
+    # validate() / evaluate_metrics() run pipeline.eval() without autocast (trainer.py:630,944) and nef.prune() runs outside it.
+    xg = torch.from_numpy(x).to(dev)[:, None]
+    plain, _, _ = op.permuto_encode(x, tab, shifts, sf)
+    g.eval()
+    assert not g.rounds_coords() and np.array_equal(g.interpolate(xg).detach().cpu().numpy(), plain)
+    with torch.autocast("cuda"):
+        assert g.rounds_coords() and np.array_equal(g.interpolate(xg).detach().float().cpu().numpy(), ref)
+    g.train()
+    with g.fp32_coords():
+        assert not g.rounds_coords() and np.array_equal(g.interpolate(xg).detach().cpu().numpy(), plain)
+    assert g.rounds_coords()
+    g.half_coords = "always"
+    g.eval()
+    assert np.array_equal(g.interpolate(xg).detach().cpu().numpy(), ref)
+    g.half_coords = False
+    g.train()
+    assert np.array_equal(g.interpolate(xg).detach().cpu().numpy(), plain)
 
 
 def _xcd8_to_strided(g8, Lv, F):
