@@ -63,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--occupancy", type=float, default=0.1, help="voxel mode: fraction of occupied 128^3 cells after the synthetic prune")
     ap.add_argument("--pose-opt", action="store_true", help="BAPipeline: rays from learnable camera extrinsics (configs[3])")
     ap.add_argument("--images", type=int, default=6, help="--pose-opt: images per step (rays are split evenly over them)")
+    ap.add_argument("--table-dtype", default="fp32", choices=["fp32", "fp16"], help="grid tables (BASELINE configs[4]: fp16 features)")
     ap.add_argument("--fp32-coords", action="store_true", help="permuto grids: skip the fp16 coordinate rounding of the reference's autocast")
     ap.add_argument("--sustain-steps", type=int, default=300, help="extra timed region after the K steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,14 +111,15 @@ def spawn_ranks(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ workload
-def make_model(args, dev, seed, grid=None, num_lods=None, log2T=None, finest=None):
+def make_model(args, dev, seed, grid=None, num_lods=None, log2T=None, finest=None, table_dtype=None):
     import torch
     import pagnerf_amd
     grid = grid or args.grid
     torch.manual_seed(seed)
+    tdt = torch.float16 if (table_dtype or args.table_dtype) == "fp16" else torch.float32
     common = dict(feature_dim=2, num_classes=6, num_instances=200, sem_num_layers=1, sem_softmax=True, inst_num_layers=2,
                   inst_softmax=True, panoptic_features_type="delta", hidden_dim=64, num_layers=1, view_multires=4,
-                  precision=args.precision, blas_level=7)
+                  precision=args.precision, blas_level=7, table_dtype=tdt)
     if grid == "permuto":        # configs/bup20/best.yaml:47-65
         cap = log2T or 18
         nef = pagnerf_amd.PanopticDeltaNeF(grid_type="PermutoGrid", num_lods=24, capacity_log_2=cap, delta_capacity_log_2=cap,
@@ -129,7 +131,7 @@ def make_model(args, dev, seed, grid=None, num_lods=None, log2T=None, finest=Non
         nef = pagnerf_amd.PanopticDeltaNeF(grid_type="HashGridTorch", num_lods=L_, codebook_bitwidth=log2T or 19, **common)
         for g in (nef.grid, nef.delta_grid):
             g.init_from_resolutions([16] * (L_ - 1) + [finest or 2048])
-            g.tables.data.normal_(0, 1e-2)
+            g.tables.data.copy_((torch.randn(g.tables.shape) * 1e-2).to(g.tables.dtype))
     return nef.to(dev)
 
 
@@ -172,6 +174,11 @@ def make_rays(n, dev, seed):
     d = torch.nn.functional.normalize(d, dim=-1)
     gt = dict(rgb=torch.rand(n, 3, generator=g), sem=torch.randint(0, 6, (n,), generator=g),
               inst=torch.randint(0, 200, (n,), generator=g))
+    # per-ray gt instance ids for the linear-assignment loss: ~24 'plants' per image (id > 0) tiled over the rays' footprint, the
+    # rest stuff (id 0); stuff mask = semantic class is a stuff class (trainer.py:493-494)
+    cell = ((o[:, 0] + 0.3) / 0.6 * 6).long().clamp(0, 5) * 6 + ((o[:, 1] + 0.3) / 0.6 * 6).long().clamp(0, 5)
+    gt["inst_ids"] = torch.where(cell % 3 != 0, cell + 1000, torch.zeros_like(cell))
+    gt["stuff"] = gt["sem"] < 2
     return pagnerf_amd.Rays(o.to(dev), d.to(dev), dist_min=0.0, dist_max=1.9), {k: v.to(dev) for k, v in gt.items()}
 
 
@@ -208,6 +215,8 @@ def make_optimizer(nef, extra=()):
     grid_params = [p for n, p in nef.named_parameters() if "grid" in n]
     rest = [p for n, p in nef.named_parameters() if "grid" not in n]
     groups = [dict(params=grid_params, lr=1e-3 * 100), dict(params=rest, lr=1e-3)]     # best.yaml:103,108 ; trainer.py:272-281
+    if any(p.dtype == torch.float16 for p in grid_params):
+        groups[0]["eps"] = 1e-4       # fp16 tables keep fp16 Adam state: the reference's eps = 1e-15 underflows to 0 there (0 / 0 on untouched rows)
     if extra:
         groups.append(dict(params=list(extra), lr=1e-4))
     try:
@@ -216,7 +225,40 @@ def make_optimizer(nef, extra=()):
         return torch.optim.Adam(groups, eps=1e-15)
 
 
-def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None):
+class ReferenceFormulationThingsLoss:
+    """loss/lin_assignment_things.py:23-82 as the reference writes it, on device tensors: one masked sum and one device-to-host
+    copy PER gt label for the cost matrix (:31-33), one masked assignment per label for the relabelling (:47-50).  Here only to time
+    that formulation beside pagnerf_amd.loss.LinAssignmentThingsLoss (one pag_label_sums launch, one [K,199] copy, one table lookup);
+    both produce the same virtual labels (tests/test_gpu_loss.py pins the device form to the reference's golden labels)."""
+
+    def __call__(self, inst_probabilities, labels_gt, stuff_mask):
+        import numpy as np
+        import scipy.optimize
+        import torch
+        import torch.nn.functional as F
+        loss = torch.zeros_like(inst_probabilities[..., 0])
+        for i, (p, gt, m) in enumerate(zip(inst_probabilities, labels_gt, stuff_mask)):
+            valid = torch.logical_or(m, gt > 0)
+            gt_v, p_v = gt[valid], p[valid]
+            with torch.no_grad():
+                things = gt_v > 0
+                tg, tp = gt_v[things], p_v[things][..., 1:]
+                labels = sorted(torch.unique(tg).cpu().tolist())[:tp.shape[-1]]
+                cost = np.zeros([len(labels), tp.shape[-1]])
+                for k, lab in enumerate(labels):
+                    cost[k, :] = -(tp[tg == lab, :].sum(dim=0) / ((tg == lab).sum() + 1e-4)).cpu().numpy()
+                rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))
+                tl = torch.zeros_like(tg)
+                for a, r in enumerate(rows):
+                    tl[tg == labels[r]] = int(cols[a])
+                virt = torch.zeros_like(gt_v)
+                virt[things] = tl + 1
+            if torch.any(virt != p_v.argmax(dim=-1)):
+                loss[i][valid] = F.nll_loss(torch.log(p_v + 1e-27), virt, reduction="none")
+        return loss
+
+
+def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assign=None):
     import torch
     import torch.nn.functional as F
     opt.zero_grad(set_to_none=True)
@@ -232,6 +274,12 @@ def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None):
         if "semantics" in channels:
             loss = loss + 0.1 * F.nll_loss(torch.log(rb.semantics + 1e-27), gt["sem"], reduction="mean")
             loss = loss + 1000.0 * F.nll_loss(torch.log(rb.inst_embedding + 1e-27), gt["inst"], reduction="mean")
+    elif "semantics" in channels and lin_assign is not None:
+        # the instance term as the trainer forms it late in training (trainer.py:483-520, best.yaml inst_loss linear_assignment_things):
+        # per-image Hungarian relabelling of the rendered instance probabilities, then the NLL against the virtual labels
+        loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1))
+        inst = rb.inst_embedding.float().reshape(1, -1, rb.inst_embedding.shape[-1])
+        loss = loss + 1000.0 * lin_assign(inst, gt["inst_ids"][None], gt["stuff"][None]).mean()
     elif "semantics" in channels:
         loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1),
                               NllTerm(rb.inst_embedding, gt["inst"], weight=1000.0))
@@ -244,14 +292,18 @@ def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None):
     return loss
 
 
-def cpu_baseline(n_rays, n_samples, budget_s=20.0):
-    """The oracle's torch-CPU restatement of the reference's hash_grid_torch path, forward + backward."""
+def cpu_baseline(n_rays, n_samples, budget_s=9.0, points=((256, 64), (4096, 64)), point_budget_s=14.0):
+    """The oracle's torch-CPU restatement of the reference's hash_grid_torch path on this host's cores (kind "port").
+    `value`: full train step (forward + backward + Adam, rgb L1 x 10) on a bounded sample of the headline workload's shape
+    (n_rays x n_samples).  `points`: the configurations BASELINE.md section 3 names - (256 rays x 64 samples) = BASELINE.json
+    configs[0], (4096 x 64) - each in its three modes: encode forward, encode + decoders + compositing forward, full train step."""
     import numpy as np
     import torch
     from oracle import hash_encode as oh, decoders as od, render as orr
     # torch-CPU ops on these small tensors scale badly past a few dozen threads (256 threads on the GPU
-    # box's host ran 400x slower than 8): use at most 32 and report the count actually used.
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    # box's host ran 400x slower than 8): use at most 32 and report both the count used and the count available.
+    cores_available = os.cpu_count() or 1
+    torch.set_num_threads(min(32, cores_available))
     rs = np.random.RandomState(0)
     L_, log2T = 16, 19
     res = oh.level_resolutions(16, 2048, L_)
@@ -262,73 +314,144 @@ def cpu_baseline(n_rays, n_samples, budget_s=20.0):
         W = [torch.from_numpy((rs.standard_normal(size=(d[i + 1], d[i])) / np.sqrt(d[i])).astype(np.float32)).requires_grad_(True) for i in range(len(d) - 1)]
         b = [torch.zeros(d[i + 1], requires_grad=True) for i in range(len(d) - 1)]
         params[k] = (W, b)
-    o = torch.cat([(torch.rand(n_rays, 2) - 0.5) * 0.6, torch.full((n_rays, 1), 0.95)], 1)
-    dr = torch.nn.functional.normalize(torch.cat([(torch.rand(n_rays, 2) - 0.5) * 0.7, -torch.ones(n_rays, 1)], 1), dim=-1)
-    gt = torch.rand(n_rays, 3)
+    leaves = [tables] + [t for W, b in params.values() for t in W + b]
+    opt = torch.optim.Adam([dict(params=[tables], lr=1e-1), dict(params=leaves[1:], lr=1e-3)], eps=1e-15)      # trainer.py:272-281, best.yaml:103,108
 
-    def step():
-        ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_ray(o, dr, 0.0, 1.9, n_samples, torch.rand(n_rays, n_samples))
-        feats, _ = oh.hash_encode(samples[:, 0], tables, res, log2T)
-        out = od.nef_forward(feats, None, dr[ridx], params, {"rgb"})
-        comp = orr.composite(n_rays, ridx, boundary, out["density"], deltas, rgb=out["rgb"])
-        loss = 10.0 * torch.abs(comp["rgb"] - gt).mean()
-        loss.backward()
-    t_w = time.perf_counter()
-    step()                                   # warm-up (also sizes the budget)
-    t_w = time.perf_counter() - t_w
+    def scene(nr):
+        o = torch.cat([(torch.rand(nr, 2) - 0.5) * 0.6, torch.full((nr, 1), 0.95)], 1)
+        dr = torch.nn.functional.normalize(torch.cat([(torch.rand(nr, 2) - 0.5) * 0.7, -torch.ones(nr, 1)], 1), dim=-1)
+        return o, dr, torch.rand(nr, 3)
+
+    def step(sc, ns, mode):
+        o, dr, gt = sc
+        nr = o.shape[0]
+        with torch.set_grad_enabled(mode == "train"):
+            ridx, pidx, samples, depths, deltas, boundary = orr.raymarch_ray(o, dr, 0.0, 1.9, ns, torch.rand(nr, ns))
+            feats, _ = oh.hash_encode(samples[:, 0], tables, res, log2T)
+            if mode == "encode":
+                return
+            out = od.nef_forward(feats, None, dr[ridx], params, {"rgb"})
+            comp = orr.composite(nr, ridx, boundary, out["density"], deltas, rgb=out["rgb"])
+            if mode == "forward":
+                return
+            opt.zero_grad(set_to_none=True)
+            loss = 10.0 * torch.abs(comp["rgb"] - gt).mean()
+            loss.backward()
+            opt.step()
+
+    def timed(sc, ns, mode, budget, max_steps=50):
+        t_w = time.perf_counter()
+        step(sc, ns, mode)                       # warm-up (also sizes the budget)
+        t_w = time.perf_counter() - t_w
+        if t_w > budget:                         # pathological host: report the single step rather than overrun
+            return t_w, 1, True
+        t0, n = time.perf_counter(), 0
+        while True:
+            step(sc, ns, mode)
+            n += 1
+            if time.perf_counter() - t0 > budget or n >= max_steps:
+                break
+        return (time.perf_counter() - t0) / n, n, False
+
+    main_scene = scene(n_rays)
+    dt, n, warm_only = timed(main_scene, n_samples, "train", budget_s)
     note = ("DIFFERENT WORKLOAD from the GPU line: %d rays x %d samples, HASH grid L=16 T=2^19 (the reference's CPU-runnable "
             "grids/hash_grid_torch.py, restated op for op in oracle/), density+colour decoders only (no panoptic heads, no delta grid), "
-            "compositing, rgb L1, forward+backward, torch-CPU" % (n_rays, n_samples))
-    if t_w > budget_s:                       # pathological host: report the single step rather than overrun
-        return dict(value=n_rays / t_w, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                    sample=note + "; 1 step of %.1f s (warm-up only; host too slow for more)" % t_w)
-    t0, n = time.perf_counter(), 0
-    while True:
-        step()
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 50:
-            break
-    dt = (time.perf_counter() - t0) / n
-    return dict(value=n_rays / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=note + "; %d timed steps of %.2f s" % (n, dt))
+            "compositing, rgb L1, forward+backward+Adam, torch-CPU, %d of %d host threads; %s" %
+            (n_rays, n_samples, torch.get_num_threads(), cores_available,
+             ("1 step of %.1f s (warm-up only; host too slow for more)" % dt) if warm_only else ("%d timed steps of %.2f s" % (n, dt))))
+    pts = []
+    per = point_budget_s / max(1, 3 * len(points))
+    for nr, ns in points:
+        sc = scene(nr)
+        for mode in ("encode", "forward", "train"):
+            d, k, cold = timed(sc, ns, mode, per, max_steps=20)
+            pts.append(dict(rays=nr, samples_per_ray=ns, mode={"encode": "encode forward", "forward": "encode + decoders + compositing forward",
+                                                               "train": "train step (forward + backward + Adam)"}[mode],
+                            s_per_step=round(d, 4), rays_s=round(nr / d, 1), samples_s=round(nr * ns / d, 1), steps=k, first_call_only=cold))
+    return dict(value=n_rays / dt, unit="rays/s", cores=torch.get_num_threads(), cores_available=cores_available, kind="port", sample=note,
+                torch=torch.__version__, points=pts)
 
 
 # -------------------------------------------------------------------------- algorithmic bytes / flops per entry point
+DECODER_MACS = dict(density=48 * 64 + 64 * 16, colour=43 * 64 + 64 * 64 + 64 * 3, sem=48 * 64 + 64 * 6, inst=48 * 64 + 64 * 64 + 64 * 200)
+
+
 def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16):
-    """Per C-ABI entry point and STEP: (algorithmic HBM bytes, useful MFMA flops).  Bytes = every tensor the launch must read or write
-    once at the dtypes of the production path (SURVEY 8d per-sample figures x M); tables count as gathered bytes (rows x F x 4)."""
+    """Per C-ABI entry point and STEP: dict(bytes=algorithmic HBM bytes, flops=useful matrix-core FLOPs, parts={launch: bytes per sample}).
+    Bytes = every tensor a launch of the PRODUCTION path (bf16 features in the XCD8 layout, fused backward kernels: DESIGN 4.3b / 4.4b)
+    must read or write once; table rows count as gathered bytes (rows x F x 4).  The per-sample figures are the table of DESIGN section 5
+    (pinned by tests/test_abi_and_host.py::test_bench_byte_model_matches_design_table) and are what `kernels.*.pmc_bytes` - the rocprofv3
+    FETCH_SIZE / WRITE_SIZE passes committed under profiles/ - is compared with in the bench line."""
     s = 2 if bf16 else 4
     C = L_ * F_
+    feat = 128 if bf16 else C * 4               # XCD8: 8 groups x 16-byte piece per sample (zero padded), else the fp32 [M, C] row
     gather = L_ * verts * F_ * 4
     pan = "semantics" in channels
-    enc_bwd = (12 + C * s + 2 * gather) * M * (2 if pan else 1)                                  # SURVEY 8d: grad row + xyz + RMW of the gathered rows
-    # decoders (34 560 MAC per sample with C=6, I=200 - SURVEY a8): density 48->64->16, colour 43->64->64->3, sem 48->64->6, inst 48->64->64->200
-    mac = dict(density=C * 64 + 64 * 16, colour=43 * 64 + 64 * 64 + 64 * 3, sem=C * 64 + 64 * 6, inst=C * 64 + 64 * 64 + 64 * 200)
+    mac = dict(DECODER_MACS, density=C * 64 + 64 * 16, sem=C * 64 + 64 * 6, inst=C * 64 + 64 * 64 + 64 * 200)
     used = ["density", "colour"] + (["sem", "inst"] if pan else [])
-    flops_fwd = 2 * M * sum(mac[k] for k in used)
-    # forward traffic: inputs + outputs + the hidden activations saved for the backward ([M,64] per hidden layer)
-    io = dict(density=(C + 16 + 64) * s, colour=(16 + 64 + 64) * s + 3 * 4 + 4, sem=(C + 64) * s + 8, inst=(C + 64 + 64) * s + 8)
-    mlp_fwd = M * sum(io[k] for k in used)
-    # backward-data: reads saved activations + upstream gradient, writes dz per layer (+ dx for density / heads)
-    iob = dict(density=(64 + 16 + 64 + 16 + C) * s, colour=(64 + 64 + 3 + 64 + 64 + 3 + 16) * s, sem=(64 + 64 + 6 + C) * s + 8,
-               inst=(64 + 64 + 64 + 64 + 200 + C) * s + 8)
-    mlp_bwd = M * sum(iob[k] for k in used)
-    # weight gradients: every layer streams its dz and its input once
-    iow = dict(density=(C + 64 + 64 + 16) * s, colour=(16 + 64 + 64 + 64 + 64 + 3) * s, sem=(C + 64 + 64 + 6) * s,
-               inst=(C + 64 + 64 + 64 + 64 + 200) * s)
-    wgrad = M * sum(iow[k] for k in used)
-    comp = M * (4 + 4 + 4 + 12 + 4) + N * 24
-    return {
-        "pag_%s_encode_fwd" % grid: ((12 + gather + C * s) * M, 0),
-        "pag_%s_encode_fwd_add" % grid: ((12 + gather + 2 * C * s) * M, 0),
-        "pag_%s_encode_bwd_set" % grid: (enc_bwd, 0),
-        "pag_mlp_fwd": (mlp_fwd, flops_fwd),
-        "pag_mlp_bwd": (mlp_bwd, flops_fwd),            # dX = dZ W: the same MACs as the forward (first-layer dx of the colour decoder's PE excluded)
-        "pag_mlp_wgrad_batch": (wgrad, flops_fwd),      # dW = dZ^T A: the same MACs again
-        "pag_composite_fwd": (comp, 0),
-        "pag_composite_bwd": (comp + M * 16, 0),
-        "pag_head_composite_fwd": (M * (64 * s + 8 + 4) * 1 + N * 206 * 4, 2 * M * 64 * 200),
+    macs_fwd = sum(mac[k] for k in used)
+    # backward: dX = W^T dZ of every layer whose input gradient is needed (the colour decoder's first layer only towards its 16
+    # density features) + dW = dZ^T A of every layer; the hidden activations the fused kernels recompute are not counted as useful
+    macs_bwd_data = dict(density=mac["density"], colour=64 * 3 + 64 * 64 + 16 * 64, sem=mac["sem"], inst=mac["inst"])
+    macs_bwd = sum(macs_bwd_data[k] + mac[k] for k in used)
+    fwd_parts = dict(density=feat + 16 * s,                                   # features in, [M,16] density features out
+                     colour=16 * s + 4 + 12 + 4)                               # x1, per-sample ray index, rgb f32, sigma f32 (view embedding: per ray)
+    bwd_parts = dict(density=feat + 16 * s + feat,                             # features (recompute), upstream gradient, d features
+                     colour=16 * s + 4 + 12 + 4 + 4 + 16 * s)                  # x1, ray index, d rgb, d sigma, sigma gate, d x1 (per-wave weight-gradient slabs: 11 - 45 MB per launch, not per sample)
+    if pan:
+        fwd_parts["inst_stats+sem"] = feat + 64 * s + 8 + 6 * s                # features, last hidden layer out, softmax statistics, semantic probabilities
+        bwd_parts["inst_stage_A"] = 64 * s + 8 + 64 * s                        # hidden layer, statistics, hidden gradient out (rank-1 upstream gradient: per ray)
+        bwd_parts["inst_stage_B+sem"] = feat + 64 * s + 6 * s + feat           # features, hidden gradient in, semantic probabilities, summed d features
+    out = {
+        "pag_mlp_fwd": dict(bytes=M * sum(fwd_parts.values()), flops=2 * M * macs_fwd, parts=fwd_parts),
+        "pag_mlp_bwd": dict(bytes=M * sum(bwd_parts.values()), flops=2 * M * macs_bwd, parts=bwd_parts),
+        "pag_composite_fwd": dict(bytes=M * (4 + 4 + 4 + 12 + 4) + N * 24, flops=0),
+        "pag_composite_bwd": dict(bytes=M * (4 + 4 + 4 + 12 + 4 + 4 + 12) + N * 24, flops=0),
     }
+    # the encoders: SURVEY 8d accounting.  forward = xyz + gathered rows + the feature row written (C x s useful bytes of the 128-byte piece);
+    # `_add` also reads the other grid's row; backward = xyz + gradient row + read-modify-write of the gathered rows (the binned kernels
+    # replace the RMW by a sort through a workspace: their minimum is xyz + gradient row + the table written once, `bytes_min`)
+    out["pag_%s_encode_fwd" % grid] = dict(bytes=(12 + gather + C * s) * M, flops=0)
+    out["pag_%s_encode_fwd_add" % grid] = dict(bytes=(12 + gather + 2 * C * s) * M, flops=0)
+    rows = (1 << 18) if grid == "permuto" else (1 << 19)
+    out["pag_%s_encode_bwd_set" % grid] = dict(bytes=(12 + C * s + 2 * gather) * M * (2 if pan else 1), flops=0,
+                                               bytes_min=((12 + C * s) * M + L_ * rows * F_ * 4) * (2 if pan else 1))
+    if pan:
+        out["pag_head_composite_fwd"] = dict(bytes=M * (64 * s + 8 + 4) + N * 200 * 4, flops=0, rebuild_flops=2 * M * 64 * 200)
+        out["pag_composite_feats_fwd"] = dict(bytes=M * (6 * s + 4) + N * 6 * 4, flops=0)
+    return out
+
+
+# C-ABI entry point -> substrings of the kernel names rocprofv3 reports for it (profiles/*_pmc_traffic_per_launch.json keys)
+PMC_KERNELS = {
+    "pag_permuto_encode_fwd": ["permuto_fwd_kernel"], "pag_permuto_encode_fwd_add": ["permuto_fwd_add_kernel"],
+    "pag_permuto_encode_bwd_set": ["bin_kernel", "reduce_kernel"],
+    "pag_mlp_fwd": ["mlp_fwd_fast<2, 0", "mlp_fwd_fast<3, 1", "mlp_fwd_wide_stats"],
+    "pag_mlp_bwd": ["mlp_bwd_fused<2, 0", "mlp_bwd_fused<3, 1", "mlp_bwd_wide_blocks", "mlp_bwd_pair", "wgrad_finish_kernel"],
+    "pag_head_composite_fwd": ["head_composite_fwd_kernel"], "pag_composite_fwd": ["composite_fwd_kernel"],
+    "pag_composite_bwd": ["composite_bwd_kernel"], "pag_composite_feats_fwd": ["composite_feats_small_fwd_kernel"],
+}
+
+
+def pmc_bytes_per_step(blob, entry, calls_per_step):
+    """HBM bytes per STEP of one entry point from a committed per-launch PMC file: the sum over its kernels of bytes per launch x the
+    launches of that kernel per call (1) x calls per step of the kernels that belong to ONE call each (encode backward: 2 grids)."""
+    names = PMC_KERNELS.get(entry)
+    if not names:
+        return None
+    total, found = 0.0, 0
+    for sub in names:
+        for k, v in blob.items():
+            if isinstance(v, dict) and sub in k and "hbm_bytes_per_launch_corrected" in v and not (sub == "permuto_fwd_kernel" and "fwd_add" in k):
+                total += v["hbm_bytes_per_launch_corrected"]
+                found += 1
+                break
+    if not found:
+        return None
+    if entry.endswith("encode_bwd_set") or entry.endswith("encode_fwd") or entry.endswith("encode_fwd_add"):
+        total *= calls_per_step           # one bin + one reduce launch (or one encode launch) per call
+    return int(total)
 
 
 # -------------------------------------------------------------------------------------------------- dry run (CPU, gloo)
@@ -457,13 +580,15 @@ def run_rank(args):
             else:
                 self.rays, self.gt = make_rays(rays_n, dev, seed=1000 + rank)      # per-rank ray shard
             self.opt = make_optimizer(self.nef, extra)
+            self.lin_assign = None
             self.sync = None
             if world > 1:
                 early = [self.nef.delta_grid.tables] if hasattr(self.nef, "delta_grid") else []
                 self.sync = shard.GradSync(list(self.nef.parameters()) + list(extra), early=early)
 
         def step(self, channels=None):
-            return train_step(self.nef, self.tracer, self.opt, self.rays, self.gt, channels or self.channels, world, self.sync)
+            return train_step(self.nef, self.tracer, self.opt, self.rays, self.gt, channels or self.channels, world, self.sync,
+                              lin_assign=self.lin_assign)
 
         def timed(self, n_steps, channels=None, profile=None):
             barrier()
@@ -501,7 +626,8 @@ def run_rank(args):
     L_, F_ = (24, 2) if args.grid == "permuto" else (16, 2)
     verts = 4 if args.grid == "permuto" else 8
     out_bytes = 2 if args.precision == "bf16" else 4
-    bytes_per_sample = 12 + L_ * verts * F_ * 4 + L_ * F_ * out_bytes       # xyz + table gathers + feature row
+    table_bytes = 2 if args.table_dtype == "fp16" else 4
+    bytes_per_sample = 12 + L_ * verts * F_ * table_bytes + L_ * F_ * out_bytes       # xyz + table gathers + feature row
     # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, KB
     # units, FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes) - measured offline on this exact configuration and
     # committed under profiles/ (file name and the commit it was taken at are stamped next to the number); null otherwise.
@@ -536,7 +662,7 @@ def run_rank(args):
                               M, "+".join(sorted(channels)), ", pose-opt" if args.pose_opt else "",
                               ", RCCL grad all-reduce" if world > 1 else ""),
                     rays_per_gpu=args.rays, samples_per_ray=args.samples, grid=args.grid, channels=sorted(channels),
-                    raymarch=args.raymarch, half_coords=(args.grid == "permuto" and not args.fp32_coords),
+                    raymarch=args.raymarch, half_coords=(args.grid == "permuto" and not args.fp32_coords), table_dtype=args.table_dtype,
                     parallelism="ray-sharded data parallel x%d" % world),
         rccl_ranks_seen=ranks_seen, backend=backend, roofline=roofline)
 
@@ -549,25 +675,42 @@ def run_rank(args):
             job.step()
         prof_all = ops.profile_stop()
         model = algorithmic_model(args.grid, M, args.rays, channels, L_, F_, verts, args.precision == "bf16")
+        pmc_blob = json.load(open(os.path.join(pdir, cands[-1]))) if (cands and traffic_src is not None) else None
         kernels, mfma_ms, mfma_flops = {}, 0.0, 0.0
         for k, v in sorted(prof_all.items()):
             ms = float(np.sum(v)) / n_bd
             ent = dict(calls_per_step=len(v) / n_bd, ms_per_step=round(ms, 4))
             if k in model and ms > 0:
-                by, fl = model[k]
+                md = model[k]
+                by, fl = md["bytes"], md["flops"]
                 ent.update(algorithmic_bytes=int(by), hbm_frac=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                if "bytes_min" in md:
+                    ent["algorithmic_bytes_min"] = int(md["bytes_min"])
+                if "parts" in md:
+                    ent["bytes_per_sample"] = md["parts"]
+                if pmc_blob is not None:
+                    pb = pmc_bytes_per_step(pmc_blob, k, ent["calls_per_step"])
+                    if pb:
+                        ent.update(pmc_bytes=pb, pmc_hbm_frac=round(pb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
                 if fl:
                     ent.update(mfma_tflops=round(fl / (ms * 1e-3) / 1e12, 2), mfma_frac=round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5))
                     mfma_ms += ms
                     mfma_flops += fl
+                if md.get("rebuild_flops"):
+                    mfma_ms += ms          # the head's probabilities are rebuilt on the matrix cores: device time of the decoders, no useful FLOPs credited
             kernels[k.replace("pag_", "")] = ent
         line["kernels"] = kernels
+        if pmc_blob is not None:
+            line["kernels_pmc_source"] = traffic_src
         if mfma_ms:
             line["mfma_util"] = dict(
                 algorithmic_tflops=round(mfma_flops / (mfma_ms * 1e-3) / 1e12, 2), peak_tflops=MFMA_PEAK_TFLOPS,
                 frac=round(mfma_flops / (mfma_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5), decoder_ms_per_step=round(mfma_ms, 4),
-                note="useful decoder MACs (34 560 / sample x fwd, bwd-data, wgrad) over the decoder entry points' device time; K <= 64 "
-                     "MLPs are activation-traffic bound (see kernels.*.hbm_frac); PMC MFMA-busy cycles: profiles/README.md")
+                useful_mac_per_sample=dict(fwd=int(model["pag_mlp_fwd"]["flops"] / (2 * M)), bwd_data_and_wgrad=int(model["pag_mlp_bwd"]["flops"] / (2 * M))),
+                note="useful decoder MACs per sample (forward; backward = input gradients + every weight gradient, which pag_mlp_bwd forms in "
+                     "the same launches) x 2 FLOP over the device time of pag_mlp_fwd + pag_mlp_bwd + pag_head_composite_fwd, against the dense "
+                     "bf16 MFMA peak; recomputed activations / rebuilt probabilities are not counted as useful.  K <= 64 MLPs are bound by "
+                     "activation traffic and per-tile VALU work (kernels.*.hbm_frac, DESIGN 4.3b / 4.4b), not by the matrix pipe")
         # ---- sustained: >= 2 s of the same step; the clocks / temperature of a 0.14 s burst are not what training sees
         if args.sustain_steps > 0:
             half = args.sustain_steps // 2
@@ -586,6 +729,22 @@ def run_rank(args):
             line["rgb_only"] = dict(workload="same scene, channels {rgb} only (epochs < 601, best.yaml:89)",
                                     value=round(world * args.rays * n_aux / dt_rgb, 1), unit="rays/s", ms_per_step=round(dt_rgb / n_aux * 1e3, 3))
         default_cfg = (args.grid, args.rays, args.samples, args.raymarch, args.pose_opt, args.channels) == ("permuto", 4096, 512, "ray", False, "all")
+        if args.channels == "all" and world == 1:
+            # ---- the late-training step as the trainer runs it: instance term = LinAssignmentThingsLoss on the rendered probabilities
+            from pagnerf_amd.loss import LinAssignmentThingsLoss
+            la = {}
+            for tag, mod in (("device_cost_matrix", LinAssignmentThingsLoss()), ("reference_formulation", ReferenceFormulationThingsLoss())):
+                job.lin_assign = mod
+                for _ in range(2):
+                    job.step()
+                n_la = max(3, args.steps // 2)
+                d_la, _ = job.timed(n_la)
+                la[tag] = dict(ms_per_step=round(d_la / n_la * 1e3, 3), rays_s=round(args.rays * n_la / d_la, 1))
+            job.lin_assign = None
+            la["labels_per_image"] = int((torch.unique(job.gt["inst_ids"]) > 0).sum())
+            la["note"] = ("same step with the instance term of trainer.py:483-520 (per-image Hungarian relabelling + NLL); device_cost_matrix = "
+                          "pag_label_sums + one [K,199] copy + SciPy; reference_formulation = one masked sum and one device-to-host copy per label")
+            line["with_lin_assignment"] = la
         job.close()
         del job
         torch.cuda.empty_cache()
@@ -600,8 +759,10 @@ def run_rank(args):
             ms = d / n_steps * 1e3
             e = p.get("pag_%s_encode_fwd" % kw["grid"], [])
             lv, vt = (24, 4) if kw["grid"] == "permuto" else (kw.get("num_lods") or 16, 8)
-            bps = 12 + lv * vt * 2 * 4 + lv * 2 * out_bytes
+            tb = 2 if (kw.get("table_dtype") or args.table_dtype) == "fp16" else 4
+            bps = 12 + lv * vt * 2 * tb + lv * 2 * out_bytes
             ent = dict(name=name, ms_per_step=round(ms, 3), rays_s=round(rays_total / ms * 1e3, 1), samples_per_step=int(m), steps=n_steps,
+                       encode_bytes_per_sample=bps,
                        encode_frac=round(bps * m / (float(np.mean(e)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if e else None)
             if kw.get("raymarch") == "voxel":
                 ent["occupied_fraction"] = round(j.occupied, 4)
@@ -619,10 +780,12 @@ def run_rank(args):
                                   rays_n=4096, samples=512, grid="hash", channels=all_ch))
             cfgs.append(short_run("configs[3] on ONE GPU: 6 images x 4096 rays, ba_pipeline pose-opt, permuto, all channels", 5, 2,
                                   rays_n=24576, samples=512, grid="permuto", channels=all_ch, pose=True))
-            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, rgb", 10, 3,
+            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp16 tables + bf16 features, rgb", 10, 3,
+                                  rays_n=131072, samples=64, grid="permuto", channels={"rgb"}, table_dtype="fp16"))
+            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp32 tables, rgb", 10, 3,
                                   rays_n=131072, samples=64, grid="permuto", channels={"rgb"}))
-            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, hash L=16 T=2^19 res 16..1024, rgb", 10, 3,
-                                  rays_n=131072, samples=64, grid="hash", channels={"rgb"}, finest=1024))
+            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, hash L=16 T=2^19 res 16..1024, fp16 tables, rgb", 10, 3,
+                                  rays_n=131072, samples=64, grid="hash", channels={"rgb"}, finest=1024, table_dtype="fp16"))
             cfgs.append(short_run("post-prune regime (f3): voxel march, %.0f %% occupancy, 2 samples per voxel, permuto, all channels"
                                   % (100 * args.occupancy), 20, 5, rays_n=4096, samples=2, grid="permuto", channels=all_ch, raymarch="voxel"))
             line["configs"] = cfgs

@@ -614,7 +614,7 @@ def _oracle_render(nef, rays, occ, jitter, S, channels):
 
     def enc(grid):
         sf = grid.scale_factors(grid.resolutions).numpy()
-        f, _, _ = op.permuto_encode(xyz, grid.tables.detach().cpu().numpy(), grid.random_shift_per_level.cpu().numpy(), sf)
+        f, _, _ = op.permuto_encode(xyz, grid.tables.detach().float().cpu().numpy(), grid.random_shift_per_level.cpu().numpy(), sf)
         return torch.from_numpy(f)
     params = {}
     for short in ("density", "color", "semantics", "inst"):
