@@ -126,6 +126,11 @@ _lib = None
 
 
 def library_path():
+    """The in-tree library; PAG_LIB_VARIANT=<tag> (kernel experiments only, scripts/build_variant.sh) loads lib/libpagnerf_hip_<tag>.so -
+    the same sources built with extra -D flags - so that variants can be A/B-timed on one box without rebuilding there."""
+    tag = os.environ.get("PAG_LIB_VARIANT")
+    if tag:
+        return os.path.join(os.path.dirname(_build.LIB), "libpagnerf_hip_%s.so" % tag)
     return _build.LIB
 
 
