@@ -276,24 +276,46 @@ def _mm_f32(a, b):
         return (a @ b).float()
 
 
-def _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, stats_only):
-    """Forward-time guess of pag_mlp_bwd_fused_supported(): shapes whose backward recomputes the hidden activations."""
+def _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, stats_only, M, out_act, out_dtype, rank1_expected, col0):
+    """Forward-time mirror of csrc/mlp.hip::fused_kind() - the shapes whose backward (pag_mlp_bwd with wgrad_workspace) recomputes the hidden
+    activations, so that the forward need not write them.  Every condition fused_kind() checks that is knowable at forward time is
+    checked here (batch bound, layout, widths, output activation / dtype per kernel kind, whether the upstream gradient will be dense or
+    rank-1); a mismatch that still slips through (e.g. a _ColourDensity backward that receives no sigma gradient) takes
+    _recompute_hidden(), which is correct but costs a second forward - it warns once."""
     if not WGRAD_FUSED or mode != L.MLP_MFMA_BF16 or x1.dtype != torch.bfloat16 or not ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        return False
+    if not (0 < M <= L.MLP_FUSED_WIDE_MAX_M) or n_layers not in (2, 3):
         return False
     if grouped is not None:
         levels, feats = grouped
+        if levels < 1 or feats < 1 or ((levels + 7) // 8) * feats > 8:
+            return False
         j = 7 // feats
         if j < (levels + 7) // 8 and 7 + 8 * j < levels:      # staged position 63 is a real feature: no room for the bias column
             return False
         if x2 is not None:
             return False
-        return out_dim <= 32 or (stats_only and n_layers == 3 and 192 < out_dim <= 224)
-    return x2 is not None and k1 == 16 and x2.shape[1] == 32 and in_dim <= 48 and out_dim <= 4
+        if out_dim > 32:                                      # wide softmax head: stage A + stage B (rank-1 gradient, statistics-only forward)
+            return stats_only and n_layers == 3 and 192 < out_dim <= 224 and out_act == L.ACT_SOFTMAX and out_dtype == torch.bfloat16
+        if rank1_expected:                                    # semantic-like: composited softmax head
+            return out_act == L.ACT_SOFTMAX and out_dim <= 8 and out_dtype == torch.bfloat16
+        return out_act == L.ACT_NONE and out_dim % 4 == 0 and out_dtype == torch.bfloat16      # density-like: dense bf16 gradient
+    return (x2 is not None and k1 == 16 and x2.shape[1] == 32 and in_dim <= 48 and out_dim <= 4 and out_act == L.ACT_SIGMOID
+            and out_dtype == torch.float32 and col0 and not rank1_expected)
+
+
+_WARNED_RECOMPUTE = False
 
 
 def _recompute_hidden(x1, x2, x2_index, Wc, bc, in_dim, k1, grouped, mode, hidden):
     """Fill the missing entries of `hidden` by re-running the forward (pag_mlp_fwd with hidden_save) - the fallback for a backward
     that the fused kernels cannot serve although the forward did not save the activations."""
+    global _WARNED_RECOMPUTE
+    if not _WARNED_RECOMPUTE:
+        _WARNED_RECOMPUTE = True
+        import warnings
+        warnings.warn("pagnerf_amd: a decoder backward could not use the fused kernels although its forward skipped the hidden activations; "
+                      "re-running the forward for them (correct, but one extra launch and an [M, out] scratch per backward)")
     M = x1.shape[1] if grouped is not None else x1.shape[0]
     n_layers = len(Wc)
     dev = x1.device
@@ -344,7 +366,9 @@ class _FusedMLP(torch.autograd.Function):
         # decoder they will serve does not write them: 268 MB per hidden layer at M = 2.1 M, in launches that run at the HBM rate.
         # Wide head: the LAST hidden layer is kept (the probabilities are rebuilt from it).  A backward that turns out not to be
         # fusable (no column-0 gradient, d x2 requested, ...) re-runs the forward for them (_recompute_hidden: rare, slow, correct).
-        recompute = need_grad and M > 0 and _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, stats_only)
+        recompute = need_grad and M > 0 and _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, stats_only, M, out_act,
+                                                          out_dtype, bool(getattr(ctx, "rank1_expected", False)),
+                                                          bool(getattr(ctx, "want_col0_relu", False)))
         hidden = []
         if need_grad or stats_only:
             for i in range(n_layers - 1):
@@ -1121,6 +1145,7 @@ class _HeadComposite(_FusedMLP):
     @staticmethod
     def _decode(ctx, x1, in_dim, out_act, out_dtype, grouped, *wb):
         ctx.stats_only = HEAD_REBUILD
+        ctx.rank1_expected = True            # the backward hands the decoder its gradient in rank-1 form (_backward_pair)
         return _FusedMLP.forward(ctx, x1, None, None, in_dim, out_act, L.MLP_MFMA_BF16, out_dtype, grouped, *wb)
 
     @staticmethod

@@ -22,14 +22,71 @@ def world_info():
     return 0, 1
 
 
+_AVG_OK = {}        # backend -> bool: ReduceOp.AVG verified on this process group (first use)
+
+
+def _avg_supported():
+    """RCCL's ReduceOp.AVG, checked ONCE per backend with a tiny all-reduce of rank-valued numbers before any gradient depends on it:
+    the averaging collective has no CPU (gloo) counterpart to test against, so the first use on a node verifies it and anything other
+    than the exact mean - or an exception - sends every later call down the sum-then-divide path."""
+    be = dist.get_backend()
+    if be not in _AVG_OK:
+        ok = False
+        if be == "nccl":
+            try:
+                rank, world = dist.get_rank(), dist.get_world_size()
+                t = torch.full((4,), float(rank + 1), device=torch.device("cuda", torch.cuda.current_device()))
+                dist.all_reduce(t, op=dist.ReduceOp.AVG)
+                ok = bool(torch.allclose(t.cpu(), torch.full((4,), (world + 1) / 2.0)))
+            except Exception:
+                ok = False
+            flag = torch.tensor([1.0 if ok else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)             # every rank takes the same branch
+            ok = bool(flag.item() > 0.5)
+        _AVG_OK[be] = ok
+    return _AVG_OK[be]
+
+
 def _reduce_op(average):
     """(op, divide afterwards?) - RCCL averages inside the collective (ReduceOp.AVG: no separate pass over a 50 MB table
-    gradient); gloo (the CPU tests) has no AVG, so there the sum is divided by the world size afterwards."""
+    gradient) once _avg_supported() has verified it; gloo (the CPU tests) has no AVG: there the sum is divided by the world size."""
     if not average:
         return dist.ReduceOp.SUM, False
-    if dist.get_backend() == "nccl":
+    if _avg_supported():
         return dist.ReduceOp.AVG, False
     return dist.ReduceOp.SUM, True
+
+
+class _DirectReduce:
+    """All-reduce of ONE large gradient as two direct exchanges in a reduced message dtype with fp32 accumulation:
+         1. all_to_all_single: the gradient is cut in `world` chunks, rank r receives everyone's chunk r (bf16 on the wire),
+         2. each rank sums its `world` received chunks in FP32 (and divides), rounds ONCE to the message dtype,
+         3. all_gather_into_tensor: every rank receives every reduced chunk.
+    Why this shape on MI355X: xGMI is a point-to-point mesh (7 links per GPU) - both phases send 1/world of the tensor to each peer
+    over its own link at the same time, where a ring all-reduce is bound by one link; and the sum over ranks is formed in fp32, not in
+    the message dtype hop by hop.  A 50.3 MB fp32 table gradient travels as 2 x 22 MB per rank at 8 ranks instead of 2 x 44 MB.
+    Error per element: every rank's value rounded once to bf16 (2^-8 relative) + one rounding of the mean: |err| <= 2^-7 mean_r |g_r|
+    (tests/test_shard_gloo.py checks the bound element by element)."""
+
+    def __init__(self, grad, comm_dtype, average):
+        _, world = world_info()
+        self.grad, self.average, self.world = grad, average, world
+        n = grad.numel()
+        self.n, self.chunk = n, (n + world - 1) // world
+        send = torch.zeros(world * self.chunk, device=grad.device, dtype=comm_dtype)
+        send[:n] = grad.reshape(-1).to(comm_dtype)
+        self.send = send
+        self.recv = torch.empty_like(send)
+        self.handle = dist.all_to_all_single(self.recv, self.send, async_op=True)
+
+    def finish(self):
+        self.handle.wait()
+        red = self.recv.reshape(self.world, self.chunk).float().sum(0)          # fp32 accumulate
+        if self.average:
+            red /= self.world
+        out = torch.empty(self.world * self.chunk, device=red.device, dtype=self.send.dtype)
+        dist.all_gather_into_tensor(out, red.to(self.send.dtype))
+        self.grad.copy_(out[:self.n].reshape(self.grad.shape))
 
 
 def shard_bounds(n, rank, world):
@@ -75,9 +132,10 @@ def all_gather_render(rb, n_total, channels=None):
     return RenderBuffer(**res)
 
 
-def allreduce_grads(params, average=True, big=1 << 20):
+def allreduce_grads(params, average=True, big=1 << 20, comm_dtype=None):
     """Gradients of >= `big` elements (the tables, ~50 MB each) are all-reduced in place, one message each; everything
-    smaller (decoders, poses: ~0.14 MB) travels as ONE flat all_reduce.  No staging copy of the large tensors."""
+    smaller (decoders, poses: ~0.14 MB) travels as ONE flat all_reduce.  No staging copy of the large tensors.
+    comm_dtype (e.g. torch.bfloat16): the large gradients go through _DirectReduce (reduced-precision messages, fp32 accumulation)."""
     rank, world = world_info()
     if world == 1:
         return
@@ -87,7 +145,12 @@ def allreduce_grads(params, average=True, big=1 << 20):
     large = [g for g in grads if g.numel() >= big and g.is_contiguous()]
     small = [g for g in grads if not (g.numel() >= big and g.is_contiguous())]
     op, divide = _reduce_op(average)
-    handles = [dist.all_reduce(g, op=op, async_op=True) for g in large]
+    if comm_dtype is not None and comm_dtype != torch.float32:
+        direct = [_DirectReduce(g, comm_dtype, average) for g in large]
+        handles = []
+    else:
+        direct = []
+        handles = [dist.all_reduce(g, op=op, async_op=True) for g in large]
     if small:
         flat = torch.cat([g.reshape(-1).float() for g in small])
         dist.all_reduce(flat, op=op)
@@ -97,6 +160,8 @@ def allreduce_grads(params, average=True, big=1 << 20):
         for g in small:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
+    for d in direct:
+        d.finish()
     for g, h in zip(large, handles):
         h.wait()
         if divide:
@@ -111,9 +176,13 @@ class GradSync:
     finish() waits for them, exchanges everything else as one flat all-reduce and averages.  On the xGMI mesh the 50 MB
     early message therefore travels while the GPU still computes; only the main table (produced last) is exposed."""
 
-    def __init__(self, params, early=(), average=True):
+    def __init__(self, params, early=(), average=True, comm_dtype=None, big=1 << 20):
+        """comm_dtype=torch.bfloat16: table-sized gradients travel as bf16 messages with fp32 accumulation (_DirectReduce): half the
+        bytes of the fp32 all-reduce and direct per-link transfers; the default (None) keeps RCCL's fp32 all-reduce."""
         self.params = list(params)
         self.average = average
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
+        self.big = big
         self.early = [p for p in early]
         self._early_ids = {id(p) for p in self.early}
         self._handles = []
@@ -124,7 +193,11 @@ class GradSync:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._launch))
 
     def _launch(self, p):
-        if p.grad is not None:
+        if p.grad is None:
+            return
+        if self.comm_dtype is not None and p.grad.numel() >= self.big and p.grad.is_contiguous():
+            self._handles.append((p, _DirectReduce(p.grad, self.comm_dtype, self.average), None))      # phase 1 in flight under the backward
+        else:
             op, divide = _reduce_op(self.average)
             self._handles.append((p, dist.all_reduce(p.grad, op=op, async_op=True), divide))
 
@@ -133,8 +206,11 @@ class GradSync:
         if world == 1:
             return
         rest = [p for p in self.params if id(p) not in self._early_ids or not any(q is p for q, _, _ in self._handles)]
-        allreduce_grads(rest, average=self.average)
+        allreduce_grads(rest, average=self.average, big=self.big, comm_dtype=self.comm_dtype)
         for p, h, divide in self._handles:
+            if isinstance(h, _DirectReduce):
+                h.finish()
+                continue
             h.wait()
             if divide:
                 p.grad /= world

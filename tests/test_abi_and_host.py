@@ -278,6 +278,13 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["warmup"] == 1
+    # the driver's largest launch: 8 ranks (gloo here), once with the fp32 all-reduce and once with bf16 messages + fp32 accumulation
+    for extra in ([], ["--grad-sync", "bf16"]):
+        r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"] + extra,
+                            capture_output=True, text=True, env=dict(env, OMP_NUM_THREADS="1"), timeout=900)
+        assert r8.returncode == 0, r8.stderr[-2000:]
+        d8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][0])
+        assert d8["n_gpus"] == 8 and d8["rccl_ranks_seen"] == 8 and d8["grad_sync"] == (extra[1] if extra else "fp32")
     # N = 1 dry run: no spawn, same schema
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
                         capture_output=True, text=True, env=env, timeout=600)
@@ -308,3 +315,28 @@ def test_nef_option_decoder_widths_and_guards():
         pagnerf_amd.PanopticDeltaNeF(position_input=True, **kw)
     with pytest.raises(NotImplementedError):
         pagnerf_amd.PanopticDeltaNeF(multiscale_type="max", **kw)
+
+
+def test_bench_byte_model_matches_design_table():
+    """bench.algorithmic_model() - the per-launch algorithmic bytes the `kernels` block of the bench line is computed from - against the
+    table of DESIGN.md section 5 (production path: bf16 features in the XCD8 layout, fused backward kernels), and against the committed
+    PMC traffic of profiles/ within 1.3x for every streaming decoder kernel."""
+    import json
+    import os
+    import bench
+    M, N = 4096 * 512, 4096
+    m = bench.algorithmic_model("permuto", M, N, {"rgb", "depth", "semantics", "inst_embedding"}, 24, 2, 4, True)
+    per = {k: v["bytes"] / M for k, v in m.items()}
+    assert m["pag_mlp_fwd"]["parts"] == {"density": 160, "colour": 52, "inst_stats+sem": 276} and per["pag_mlp_fwd"] == 488
+    assert m["pag_mlp_bwd"]["parts"] == {"density": 288, "colour": 88, "inst_stage_A": 264, "inst_stage_B+sem": 396} and per["pag_mlp_bwd"] == 1036
+    assert per["pag_permuto_encode_fwd"] == 876 and per["pag_permuto_encode_fwd_add"] == 972 and per["pag_permuto_encode_bwd_set"] == 2 * 1644
+    assert m["pag_mlp_fwd"]["flops"] == 2 * M * 34560 and m["pag_mlp_bwd"]["flops"] == 2 * M * (34560 + 32832)
+    rgb = bench.algorithmic_model("permuto", M, N, {"rgb"}, 24, 2, 4, True)
+    assert rgb["pag_mlp_fwd"]["bytes"] / M == 212 and rgb["pag_permuto_encode_bwd_set"]["bytes"] / M == 1644 and "pag_head_composite_fwd" not in rgb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pdir = os.path.join(root, "profiles")
+    newest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic_per_launch.json"))[-1]
+    blob = json.load(open(os.path.join(pdir, newest)))
+    for entry in ("pag_mlp_fwd", "pag_mlp_bwd", "pag_head_composite_fwd", "pag_composite_fwd"):
+        pmc = bench.pmc_bytes_per_step(blob, entry, 1)
+        assert pmc is not None and 1 / 1.3 < pmc / m[entry]["bytes"] < 1.3, (entry, pmc, m[entry]["bytes"])

@@ -73,6 +73,29 @@ def _worker(rank, world, port, n, q):
             assert torch.allclose(a.grad, torch.full((4, 2), mean_a)) and torch.allclose(b.grad, torch.full((3,), mean_b)), step
             assert c.grad is None
         sync.remove()
+        # reduced-precision exchange (GradSync(comm_dtype=bf16)): direct all_to_all + fp32 accumulate + all_gather.  Error bound per
+        # element: each rank's value rounded to bf16 (8 significant bits: 2^-8 relative) and the mean rounded once more:
+        # |err| <= 2^-7 * mean_r |g_r| (+ fp32 noise)
+        gen = torch.Generator().manual_seed(100 + rank)
+        n_big = 3 * 1000 + 7                                   # not a multiple of the world size: the last chunk is padded
+        gtab = torch.randn(n_big, 2, generator=gen) * (10.0 ** torch.randint(-3, 3, (n_big, 1), generator=gen).float())
+        all_g = [torch.empty_like(gtab) for _ in range(world)]
+        dist.all_gather(all_g, gtab)
+        exact = torch.stack(all_g).double().mean(0)
+        bound = torch.stack(all_g).abs().double().mean(0) * 2.0 ** -7 + 1e-12
+        for early in (True, False):
+            tab, small = torch.nn.Parameter(torch.zeros(n_big, 2)), torch.nn.Parameter(torch.zeros(5))
+            sync = shard.GradSync([tab, small], early=[tab] if early else [], comm_dtype=torch.bfloat16, big=1000)
+            ((tab * gtab).sum() + (small * (rank + 1.0)).sum()).backward()
+            sync.finish()
+            err = (tab.grad.double() - exact).abs()
+            assert bool((err <= bound).all()), (early, float((err / bound).max()))
+            assert tab.grad.dtype == torch.float32 and torch.allclose(small.grad, torch.full((5,), sum(range(1, world + 1)) / world))
+            sync.remove()
+        # every rank ends with the SAME reduced tensor (the all_gather distributes one rounded value per element)
+        chk = [torch.empty_like(tab.grad) for _ in range(world)]
+        dist.all_gather(chk, tab.grad.detach())
+        assert all(torch.equal(chk[0], c) for c in chk[1:])
         q.put((rank, "ok"))
     except Exception as e:          # surface the failure in the parent
         q.put((rank, repr(e)))
