@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 3
+#define PAG_ABI_VERSION 4
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -283,11 +283,13 @@ int pag_affine_xcd8_bwd_dx(const float *grad_out, int64_t M, int x_levels, int x
  *   out[ray][c] = alpha[ray] * sum_{i in pack} weights[i] * softmax(W_last . hidden[i] + b_last)[c]
  * from the forward's saved last hidden layer (bf16 [M,64]) and softmax_stats (pag_mlp_fwd with out = NULL): the
  * [M, out_dim] probabilities are rebuilt tile by tile and never stored.  64 < out_dim <= 224; out f32 [N,out_dim]
- * (rows of rays that have a pack are overwritten). */
+ * (rows of rays that have a pack are overwritten).  n_samples = pack_start[P] as the host knows it (0 = unknown): short packs
+ * (fewer than ~5 tiles of 32 samples on average: the voxel march after the first prune) are processed one per wave instead of
+ * one per workgroup - same sums in the same order per pack, a speed hint only. */
 int pag_head_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
                            const void *hidden, const float *W_last, const float *b_last, int out_dim,
                            const float *softmax_stats, const float *weights, const float *alpha,
-                           float *out, void *stream);
+                           float *out, int64_t n_samples, void *stream);
 
 /* Weight and bias gradients of one Linear layer of pag_mlp_fwd (MFMA mode):
  *   dW[o][i] = sum_m dz[m][o] * a[m][i],  db[o] = sum_m dz[m][o]

@@ -729,9 +729,13 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
     // segment per wave-iteration left two thirds of the lanes idle.  Instead the segments of 64 consecutive tiles are
     // treated as ONE concatenated stream: lane l takes stream element 64*c + l, finds its tile by a 6-step binary search
     // over the wave's exclusive prefix of segment lengths (shuffles) and reads that tile's region at the right offset.
-    for (int64_t t0 = (int64_t)wave * 64; t0 < lay.ntiles; t0 += (int64_t)nwaves * 64) {
+    // With few tiles (small batches: the post-prune voxel regime has ~300) groups of 64 would leave most of the 16 waves without any:
+    // the group shrinks so that every wave gets tiles (lanes >= G hold empty segments; the search below is unchanged).
+    const int G = (int)min((int64_t)64, max((int64_t)1, (lay.ntiles + nwaves - 1) / nwaves));
+    for (int64_t t0 = (int64_t)wave * G; t0 < lay.ntiles; t0 += (int64_t)nwaves * G) {
         const int64_t tl = t0 + lane;
-        const uint32_t mb = tl < lay.ntiles ? hb[tl] : 0u, me = tl < lay.ntiles ? he[tl] : 0u;
+        const bool has = lane < G && tl < lay.ntiles;
+        const uint32_t mb = has ? hb[tl] : 0u, me = has ? he[tl] : 0u;
         uint32_t incl = me - mb;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {

@@ -1165,7 +1165,7 @@ class _HeadComposite(_FusedMLP):
             ctx.fwd_state = None
             if P and M:
                 _call("pag_head_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(hidden_last), L.ptr(W_last),
-                      L.ptr(b_last), C, L.ptr(stats), L.ptr(weights_w), L.ptr(alpha), L.ptr(out), L.stream())
+                      L.ptr(b_last), C, L.ptr(stats), L.ptr(weights_w), L.ptr(alpha), L.ptr(out), int(M), L.stream())
         elif P and M:
             _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights_w), L.ptr(alpha),
                   L.ptr(probs), L.dtype_code(probs), C, L.ptr(out), L.stream())
