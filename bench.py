@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--sustain-steps", type=int, default=300, help="extra timed region after the K steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the rgb-only / sustained / configs / strong measurements")
+    ap.add_argument("--graphs", default="on", choices=["on", "off"],
+                    help="PanopticPackedRFTracer(use_graphs=...): replay the post-march part of the step as HIP graphs (N = 1, no pose-opt)")
     ap.add_argument("--grad-sync", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1: table gradients as RCCL fp32 all-reduce (default) or bf16 messages with fp32 accumulation (shard._DirectReduce)")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: process group, shard collectives, timing and JSON plumbing only")
@@ -140,9 +142,10 @@ def make_model(args, dev, seed, grid=None, num_lods=None, log2T=None, finest=Non
 def make_tracer(args, raymarch=None, samples=None):
     import pagnerf_amd
     rm = raymarch or args.raymarch
+    g = args.graphs == "on"
     if rm == "voxel":            # after trainer.py:362-366: 2 samples per intersected occupied voxel (best.yaml:31), ray_max_travel 6 x scale
-        return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="voxel", num_steps=2, bg_color="white", ray_max_travel=6.0)
-    return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=samples or args.samples, bg_color="white")
+        return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="voxel", num_steps=2, bg_color="white", ray_max_travel=6.0, use_graphs=g)
+    return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=samples or args.samples, bg_color="white", use_graphs=g)
 
 
 def synthetic_prune(nef, fraction, seed=0):
@@ -596,6 +599,11 @@ def run_rank(args):
                               lin_assign=self.lin_assign)
 
         def timed(self, n_steps, channels=None, profile=None):
+            """profile (a set of C-ABI entry points): HIP events around those calls - which only exist on the EAGER path (a graph replay
+            issues no per-kernel host call), so a profiled region runs with the tracer's graphs switched off."""
+            was = self.tracer.use_graphs
+            if profile is not None:
+                self.tracer.use_graphs = False
             barrier()
             if profile is not None:
                 ops.profile_start(only=profile)
@@ -605,7 +613,12 @@ def run_rank(args):
             barrier()
             dt = time.perf_counter() - t0
             prof = ops.profile_stop() if profile is not None else None
+            self.tracer.use_graphs = was
             return max_over_ranks(dt), prof
+
+        def graph_stats(self):
+            g = getattr(self.tracer, "_graphs", None)
+            return None if g is None else dict(captures=g.captures, replays=g.replays, overflows=g.overflows)
 
         def samples_per_step(self):
             with torch.no_grad():
@@ -624,8 +637,16 @@ def run_rank(args):
 
     for _ in range(args.warmup):
         job.step()
-    # HIP events around the roofline kernel only; the full per-entry-point breakdown comes from a separate pass
-    dt, prof = job.timed(args.steps, profile=None if os.environ.get("PAG_BENCH_PROFILE_ALL") else {enc_name})
+    # The K timed steps.  With graphs on (default at N = 1) a step issues the ray march and two graph replays, so no per-kernel host
+    # call exists to bracket with events: the roofline kernel's duration is then measured over K further EAGER steps right after the
+    # timed region (same process, same inputs, HIP events on the launch stream around its C-ABI call).  With --graphs off the events
+    # sit inside the timed region itself, as in rounds 1 - 2.
+    graphs_on = job.tracer.use_graphs and world == 1 and not args.pose_opt
+    if graphs_on:
+        dt, _ = job.timed(args.steps)
+        _, prof = job.timed(args.steps, profile={enc_name})
+    else:
+        dt, prof = job.timed(args.steps, profile=None if os.environ.get("PAG_BENCH_PROFILE_ALL") else {enc_name})
 
     M = job.samples_per_step() if (args.raymarch == "voxel" or args.pose_opt) else args.rays * args.samples
     L_, F_ = (24, 2) if args.grid == "permuto" else (16, 2)
@@ -653,7 +674,10 @@ def run_rank(args):
         roofline = dict(bound="hbm", kernel=enc_name.replace("pag_", "") + "_kernel", achieved=round(achieved, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                         traffic_source=traffic_src, launches=len(enc_ms), avg_launch_ms=round(mean_ms, 4),
-                        algorithmic_bytes_per_launch=bytes_per_sample * M)
+                        algorithmic_bytes_per_launch=bytes_per_sample * M,
+                        timing=("HIP events around the kernel's C-ABI call in %d eager steps run right after the timed region (the timed steps "
+                                "replay HIP graphs: no per-launch host call to bracket)" % args.steps) if graphs_on else
+                               "HIP events around the kernel's C-ABI call inside the timed steps")
 
     line = dict(
         metric="rays/sec (train step) on BUP20-shape scene", value=round(world * args.rays * args.steps / dt, 1), unit="rays/s",
@@ -668,17 +692,21 @@ def run_rank(args):
                               ", RCCL grad all-reduce" if world > 1 else ""),
                     rays_per_gpu=args.rays, samples_per_ray=args.samples, grid=args.grid, channels=sorted(channels),
                     raymarch=args.raymarch, half_coords=(args.grid == "permuto" and not args.fp32_coords), table_dtype=args.table_dtype,
+                    hip_graphs=bool(graphs_on),
                     parallelism="ray-sharded data parallel x%d" % world),
-        rccl_ranks_seen=ranks_seen, backend=backend, grad_sync=(args.grad_sync if world > 1 else None), roofline=roofline)
+        rccl_ranks_seen=ranks_seen, backend=backend, grad_sync=(args.grad_sync if world > 1 else None), roofline=roofline,
+        graphs=job.graph_stats())
 
     if not args.no_aux:
         # ---- per-entry-point device time: a separate, untimed pass with events around every C-ABI call
         n_bd = max(1, min(5, args.steps))
         barrier()
+        was_graphs, job.tracer.use_graphs = job.tracer.use_graphs, False       # per-kernel events need the eager path
         ops.profile_start()
         for _ in range(n_bd):
             job.step()
         prof_all = ops.profile_stop()
+        job.tracer.use_graphs = was_graphs
         model = algorithmic_model(args.grid, M, args.rays, channels, L_, F_, verts, args.precision == "bf16")
         pmc_blob = json.load(open(os.path.join(pdir, cands[-1]))) if (cands and traffic_src is not None) else None
         kernels, mfma_ms, mfma_flops = {}, 0.0, 0.0
@@ -725,6 +753,16 @@ def run_rank(args):
                                      ms_per_step=round((d1 + d2) / args.sustain_steps * 1e3, 3),
                                      ms_per_step_last_half=round(d2 / max(half, 1) * 1e3, 3),
                                      value_last_half=round(world * args.rays * half / d2, 1), unit="rays/s")
+        # ---- the same step without graphs (what rounds 1 - 2 measured)
+        if graphs_on:
+            job.tracer.use_graphs = False
+            for _ in range(2):
+                job.step()
+            n_e = max(3, args.steps // 2)
+            d_e, _ = job.timed(n_e)
+            job.tracer.use_graphs = True
+            line["eager"] = dict(ms_per_step=round(d_e / n_e * 1e3, 3), rays_s=round(world * args.rays * n_e / d_e, 1),
+                                 note="PanopticPackedRFTracer(use_graphs=False): every kernel launched from Python, host waits for the sample count")
         # ---- rgb-only regime (epochs < 601, best.yaml:89)
         if args.channels == "all":
             for _ in range(2):
@@ -756,9 +794,10 @@ def run_rank(args):
 
         def short_run(name, n_steps, warm, **kw):
             j = Job(**kw)
-            for _ in range(warm):
+            for _ in range(max(warm, 3)):                       # graphs: step 0 learns the sample count, step 1 captures
                 j.step()
-            d, p = j.timed(n_steps, profile={"pag_%s_encode_fwd" % kw["grid"]})
+            d, _ = j.timed(n_steps)
+            _, p = j.timed(min(n_steps, 5), profile={"pag_%s_encode_fwd" % kw["grid"]})      # eager pass: events around the encode launch
             m = j.samples_per_step() if (kw.get("raymarch") == "voxel" or kw.get("pose")) else kw["rays_n"] * kw["samples"]
             rays_total = kw.get("total_rays") or kw["rays_n"] * world
             ms = d / n_steps * 1e3
@@ -771,6 +810,7 @@ def run_rank(args):
                        encode_frac=round(bps * m / (float(np.mean(e)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if e else None)
             if kw.get("raymarch") == "voxel":
                 ent["occupied_fraction"] = round(j.occupied, 4)
+            ent["hip_graphs"] = j.graph_stats()
             j.close()
             del j
             torch.cuda.empty_cache()

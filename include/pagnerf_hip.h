@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 4
+#define PAG_ABI_VERSION 5
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -348,6 +348,17 @@ int pag_raymarch_count(const float *origins, const float *dirs, int64_t N, int S
  * total_host (optional): device-accessible PINNED HOST memory that also receives pack_start[N] (system-scope release store):
  * a host that preset it to a negative value can poll it instead of issuing a stream-synchronising read-back. */
 int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, int64_t *total_host, void *stream);
+/* Pad a packed batch to `capacity` samples (a multiple of samples_per_entry) WITHOUT the host knowing the sample count: the
+ * M = pack_start[N] real samples are followed by filler samples that belong to no pack (coordinates 0, depth 0, delta 0, ray index
+ * N - 1; pack_start is not modified).  Per-ray kernels never touch them; per-sample kernels compute on them and the results are
+ * ignored; with the per-sample gradient tensors of the compositing backward zero-filled past M they carry zero gradient.  The step
+ * after the march then has shapes that do not depend on device data and can be replayed as a HIP graph (pagnerf_amd/graphs.py - the
+ * reference's boolean-mask indexing, wisp OctreeAS.raymarch, forces a host read-back instead).
+ * M > capacity: nothing is written (the caller learns M from pag_pack_offsets' total_host and falls back to exact shapes).
+ * ridx_sample i32 [capacity] / ridx_entry i32 [capacity / k] / ridx64 i64 [capacity / k] may be NULL; pidx i32 [capacity / k]. */
+int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capacity, int samples_per_entry, float *samples, float *depths,
+                   float *deltas, int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx,
+                   uint8_t *boundary, void *stream);
 
 /* View-direction embedding of the colour decoder (wisp PositionalEmbedder on -ray_d, pc_nerf/panoptic_delta_nef.py:196-200):
  * out f32 [R, width] = (-d, sin(-d 2^k) for k < n_freq, cos(-d 2^k) for k < n_freq), frequency-major, zero padded;

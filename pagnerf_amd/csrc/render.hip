@@ -608,6 +608,34 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__res
     }
 }
 
+// Pad a packed batch up to a fixed capacity (pagnerf_amd/graphs.py: HIP graphs need shapes that do not depend on device data).  The
+// M = pack_start[N] real samples are followed by capacity - M filler samples that belong to NO pack (pack_start is left alone): the
+// per-ray kernels never see them, the per-sample kernels (encoders, decoders) compute on them and their results are ignored; the caller
+// zero-fills the per-sample gradient tensors the compositing backward produces, so the fillers carry exactly zero gradient.
+// Coordinates (0,0,0) are inside the volume, ray index = the last ray.  One workgroup.  M > capacity: nothing is touched (the caller
+// sees the true count in its mailbox and falls back to exact shapes).  k = samples per nugget (voxel mode: the per-nugget arrays are
+// padded up to capacity / k).
+__global__ __launch_bounds__(1024) void pad_packed_kernel(const int64_t *__restrict__ pack_start, int64_t N, int64_t capacity, int k, float *__restrict__ samples,
+                                                          float *__restrict__ depths, float *__restrict__ deltas, int32_t *__restrict__ ridx_sample,
+                                                          int32_t *__restrict__ ridx_nugget, int64_t *__restrict__ ridx64, int32_t *__restrict__ pidx,
+                                                          uint8_t *__restrict__ boundary) {
+    const int64_t M = pack_start[N];
+    if (M > capacity) return;
+    const int32_t last = (int32_t)(N - 1);
+    for (int64_t i = M + threadIdx.x; i < capacity; i += blockDim.x) {
+        samples[i * 3] = 0.0f, samples[i * 3 + 1] = 0.0f, samples[i * 3 + 2] = 0.0f;
+        depths[i] = 0.0f;
+        deltas[i] = 0.0f;
+        boundary[i] = 0;
+        if (ridx_sample) ridx_sample[i] = last;
+    }
+    for (int64_t g = M / k + threadIdx.x; g < capacity / k; g += blockDim.x) {
+        if (ridx_nugget) ridx_nugget[g] = last;
+        if (ridx64) ridx64[g] = last;
+        pidx[g] = 0;
+    }
+}
+
 // wisp PositionalEmbedder on the NEGATED ray directions (pc_nerf/panoptic_delta_nef.py:196-200): out[r] = (-d, sin(-d 2^k) k<F,
 // cos(-d 2^k) k<F), frequency-major, zero padded to `width` columns.  One launch instead of the ten of the tensor-op form.
 __global__ __launch_bounds__(256) void view_embed_kernel(const float *__restrict__ dirs, int64_t R, int n_freq, int width,
@@ -634,6 +662,17 @@ extern "C" int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_
     PAG_CHECK_ARG(N >= 0 && pack_start && (N == 0 || counts), "pag_pack_offsets: bad arguments");
     hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, pack_start, total_host);
     PAG_CHECK_LAUNCH("pag_pack_offsets");
+    return PAG_OK;
+}
+
+extern "C" int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capacity, int samples_per_entry, float *samples, float *depths, float *deltas,
+                              int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx, uint8_t *boundary, void *stream) {
+    PAG_CHECK_ARG(N >= 1 && capacity >= 0 && samples_per_entry >= 1 && capacity % samples_per_entry == 0,
+                  "pag_pad_packed: N %lld, capacity %lld must be a multiple of samples_per_entry %d", (long long)N, (long long)capacity, samples_per_entry);
+    PAG_CHECK_ARG(pack_start && samples && depths && deltas && pidx && boundary, "pag_pad_packed: NULL buffer");
+    hipLaunchKernelGGL(pad_packed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack_start, N, capacity, samples_per_entry, samples, depths, deltas,
+                       ridx_sample, ridx_entry, ridx64, pidx, boundary);
+    PAG_CHECK_LAUNCH("pag_pad_packed");
     return PAG_OK;
 }
 

@@ -952,6 +952,80 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     return ridx, pidx, samples, depths, deltas, boundary.view(torch.bool)
 
 
+class MarchBuffers:
+    """Upper-bound packed-sample buffers of one march configuration, for the graph path (pagnerf_amd/graphs.py): the march kernels write
+    into them without the host knowing the sample count, pad_to() appends inert samples up to a fixed capacity, and the first
+    `capacity` elements are the STATIC tensors a captured HIP graph reads.  mode 'ray': per_ray = samples per ray (k = 1);
+    mode 'voxel': per_ray = pag_raymarch_voxel_nugget_capacity(level), k = samples per nugget."""
+
+    def __init__(self, mode, N, per_ray, k, dev):
+        self.mode, self.N, self.k = mode, int(N), int(k)
+        ne = self.N * int(per_ray)                 # entries (nuggets; = samples in 'ray' mode)
+        self.cap = ne * self.k                     # samples
+        self.samples = torch.zeros(self.cap, 3, device=dev)
+        self.depths = torch.zeros(self.cap, device=dev)
+        self.deltas = torch.zeros(self.cap, device=dev)
+        self.boundary = torch.zeros(self.cap, device=dev, dtype=torch.uint8)
+        self.ridx_entry = torch.zeros(ne, device=dev, dtype=torch.int32)
+        self.ridx_sample = self.ridx_entry if self.k == 1 else torch.zeros(self.cap, device=dev, dtype=torch.int32)
+        self.ridx64 = torch.zeros(ne, device=dev, dtype=torch.int64)
+        self.pidx = torch.zeros(ne, device=dev, dtype=torch.int32)
+        self.counts = torch.zeros(self.N, device=dev, dtype=torch.int32)
+        self.pack_start = torch.zeros(self.N + 1, device=dev, dtype=torch.int64)
+        if mode == "voxel":
+            self.nug_t = torch.empty(int(per_ray), self.N, 2, device=dev)
+            self.nug_cell = torch.empty(int(per_ray), self.N, device=dev, dtype=torch.int32)
+
+    def pad_to(self, capacity):
+        """Queue pag_pad_packed: samples [M, capacity) become filler samples outside every pack (pack_start is left alone)."""
+        assert 0 < capacity <= self.cap and capacity % self.k == 0
+        _call("pag_pad_packed", L.ptr(self.pack_start), self.N, int(capacity), self.k, L.ptr(self.samples), L.ptr(self.depths), L.ptr(self.deltas),
+              L.ptr(self.ridx_sample) if self.k > 1 else None, L.ptr(self.ridx_entry), L.ptr(self.ridx64), L.ptr(self.pidx), L.ptr(self.boundary),
+              L.stream())
+
+
+def march_into(buf, origins, dirs, dist_min, dist_max, num_samples, jitter=None, occupancy_bits=None, blas_level=7, max_travel=None,
+               occupancy_coarse_bits=None):
+    """The ray march of raymarch_ray() / raymarch_voxel() written into `buf` (MarchBuffers) WITHOUT waiting for the sample count:
+    count -> offsets (+ pinned mailbox) -> pack are queued back to back.  -> the mailbox (poll it with _poll_count() when convenient;
+    give it back with _release_mailbox()) or None when polling is disabled (the caller then reads buf.pack_start[N] itself)."""
+    _check_gpu(origins, dirs)
+    dev = origins.device
+    N = origins.shape[0]
+    assert N == buf.N
+    origins = origins.detach().contiguous().float()
+    dirs = dirs.detach().contiguous().float()
+    occ = L.ptr(occupancy_bits) if occupancy_bits is not None else None
+    st = L.stream()
+    mailbox = _count_mailbox() if POLL_SAMPLE_COUNT else None
+    if mailbox is not None:
+        mailbox[1][0] = -1
+    mb_ptr = mailbox[0].data_ptr() if mailbox is not None else None
+    if buf.mode == "ray":
+        S = int(num_samples)
+        if jitter is None:
+            jitter = torch.rand(N, S, device=dev)
+        jitter = jitter.contiguous().float()
+        tvals = _tvals(S, dev)
+        _call("pag_raymarch_count", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min), float(dist_max), occ,
+              blas_level, L.ptr(buf.counts), st)
+        _call("pag_pack_offsets", L.ptr(buf.counts), N, L.ptr(buf.pack_start), mb_ptr, st)
+        _call("pag_raymarch_pack", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min), float(dist_max), occ,
+              blas_level, L.ptr(buf.pack_start), L.ptr(buf.ridx_entry), L.ptr(buf.pidx), L.ptr(buf.samples), L.ptr(buf.depths),
+              L.ptr(buf.deltas), L.ptr(buf.boundary), L.ptr(buf.ridx64), st)
+    else:
+        k = buf.k
+        coarse = L.ptr(occupancy_coarse_bits) if (occupancy_coarse_bits is not None and occupancy_bits is not None) else None
+        travel = float("inf") if max_travel is None else float(max_travel)
+        _call("pag_raymarch_voxel_count_nuggets", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse,
+              blas_level, travel, L.ptr(buf.counts), L.ptr(buf.nug_t), L.ptr(buf.nug_cell), st)
+        _call("pag_pack_offsets", L.ptr(buf.counts), N, L.ptr(buf.pack_start), mb_ptr, st)
+        _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(buf.pack_start), L.ptr(buf.nug_t), L.ptr(buf.nug_cell),
+              L.ptr(buf.ridx_entry), L.ptr(buf.pidx), L.ptr(buf.samples), L.ptr(buf.depths), L.ptr(buf.deltas), L.ptr(buf.boundary),
+              L.ptr(buf.ridx_sample), L.ptr(buf.ridx64), st)
+    return mailbox, jitter
+
+
 def packs_from_boundary(ridx, boundary):
     """(pack_start i64[P+1], ray_of_pack i32[P]) from kaolin-style (ridx, boundary) arrays."""
     starts = torch.nonzero(boundary).reshape(-1)
@@ -984,7 +1058,8 @@ class _Composite(torch.autograd.Function):
         deltas = deltas.detach().contiguous().float()
         rgbc = rgb.detach().contiguous().float() if rgb is not None else None
         depc = depths.detach().contiguous().float() if depths is not None else None
-        w = torch.empty(M, device=dev)
+        w = (torch.zeros if TAIL_ZERO else torch.empty)(M, device=dev)
+        ctx.tail_zero = TAIL_ZERO
         if M and _one_pack_per_ray(ray_of_pack, N):      # the kernel writes every ray (background for empty packs): no fills
             alpha = torch.empty(N, device=dev)
             hit = torch.empty(N, device=dev, dtype=torch.uint8)
@@ -1009,7 +1084,7 @@ class _Composite(torch.autograd.Function):
     def backward(ctx, g_alpha, _g_hit, g_rgb, g_depth, _g_w):
         sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha = ctx.saved_tensors
         M, P = sigma.shape[0], ray_of_pack.shape[0]
-        mk = torch.empty if P and M else torch.zeros          # all samples are covered by packs: kernels write every element
+        mk = torch.empty if (P and M and not ctx.tail_zero) else torch.zeros          # all samples are covered by packs: kernels write every element
         d_sigma = mk(M, device=sigma.device)
         d_rgb = mk(M, 3, device=sigma.device) if rgbc is not None else None
         gc = lambda t: t.contiguous().float() if t is not None else None
@@ -1044,6 +1119,7 @@ class _CompositeFeats(torch.autograd.Function):
                                                 L.ptr(feats), L.dtype_code(feats), C, L.ptr(out), L.stream())
         ctx.save_for_backward(weights, alpha, pack_start, ray_of_pack)
         ctx.shape, ctx.fdtype = feats.shape, feats.dtype
+        ctx.tail_zero = TAIL_ZERO
         return out
 
     @staticmethod
@@ -1052,7 +1128,7 @@ class _CompositeFeats(torch.autograd.Function):
         M, C = ctx.shape
         P = ray_of_pack.shape[0]
         # every packed sample belongs to a pack, so the kernel writes every row: no zero fill of the [M,C] buffer
-        d = torch.empty(M, C, device=weights.device, dtype=ctx.fdtype) if P else torch.zeros(M, C, device=weights.device, dtype=ctx.fdtype)
+        d = torch.empty(M, C, device=weights.device, dtype=ctx.fdtype) if (P and not ctx.tail_zero) else torch.zeros(M, C, device=weights.device, dtype=ctx.fdtype)
         if P and M:
             _call("pag_composite_feats_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights), L.ptr(alpha),
                   L.ptr(g.contiguous().float()), C, L.ptr(d), L.dtype_code(d), L.stream())
@@ -1130,6 +1206,8 @@ def composite_features(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N):
 
 
 HEAD_REBUILD = True      # wide softmax heads under head_composite(): statistics-only forward + rebuilt probabilities
+TAIL_ZERO = False        # graphs.py: batches carry filler samples past pack_start[N] - per-sample tensors written pack by pack start as zeros
+SAMPLES_HINT = None      # graphs.py: the REAL sample count expected in a padded batch (pag_head_composite_fwd picks its per-pack work split from it)
 
 
 class _HeadComposite(_FusedMLP):
@@ -1165,7 +1243,8 @@ class _HeadComposite(_FusedMLP):
             ctx.fwd_state = None
             if P and M:
                 _call("pag_head_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(hidden_last), L.ptr(W_last),
-                      L.ptr(b_last), C, L.ptr(stats), L.ptr(weights_w), L.ptr(alpha), L.ptr(out), int(M), L.stream())
+                      L.ptr(b_last), C, L.ptr(stats), L.ptr(weights_w), L.ptr(alpha), L.ptr(out),
+                      int(M if SAMPLES_HINT is None else SAMPLES_HINT), L.stream())
         elif P and M:
             _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(weights_w), L.ptr(alpha),
                   L.ptr(probs), L.dtype_code(probs), C, L.ptr(out), L.stream())

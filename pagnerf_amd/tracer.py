@@ -22,8 +22,14 @@ _TRACE_PARAMS = {}      # per tracer class: trace()'s parameters (inspect.signat
 
 class PanopticPackedRFTracer(nn.Module):
     def __init__(self, ray_sparcity_reg=0.0, ray_max_travel=6.0, raymarch_type="voxel", num_steps=64, step_size=1.0,
-                 bg_color="white", **kwargs):
+                 bg_color="white", use_graphs=None, **kwargs):
+        """use_graphs (this build's addition, default: the PAG_GRAPHS environment variable, else off): training-time traces replay the
+        post-march part of the step - forward and backward - as HIP graphs over static, padded sample buffers (pagnerf_amd/graphs.py).
+        Same channels, same values; what changes is that the host neither waits for the sample count nor issues ~35 launches per step."""
         super().__init__()
+        import os
+        self.use_graphs = bool(int(os.environ.get("PAG_GRAPHS", "0"))) if use_graphs is None else bool(use_graphs)
+        self._graphs = None
         self.raymarch_type, self.num_steps, self.step_size, self.bg_color = raymarch_type, num_steps, step_size, bg_color
         self.render_channels = {"depth", "alpha", "hit"}
         self.base_channels = {"rgb", "density"}
@@ -77,6 +83,15 @@ class PanopticPackedRFTracer(nn.Module):
         dev = rays.origins.device
         if lod_idx is None:
             lod_idx = nef.grid.num_lods - 1
+        gkey = None
+        if self.use_graphs and type(self).shade is PanopticPackedRFTracer.shade and raymarch_type in ("ray", "voxel"):
+            from .graphs import GraphRunner
+            if GraphRunner.eligible(self, nef, channels, extra_channels, rays, stage):
+                if self._graphs is None:
+                    self._graphs = GraphRunner()
+                rb, gkey, jitter = self._graphs.run(self, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage, jitter)
+                if rb is not None:
+                    return rb           # else: no capacity known yet, or this batch overflowed it - the eager path below, same jitter
         kw = {"jitter": jitter} if jitter is not None else {}
         # voxel mode: grids of this package apply the travel filter of :88-108 inside the walk (pag_raymarch_voxel_*: same
         # strict `<` on the same fp32 difference) and hand back one pack per ray - no unique / repeat_interleave / mask passes
@@ -99,26 +114,38 @@ class PanopticPackedRFTracer(nn.Module):
             boundary = boundary.reshape(depths.shape)[valid_mask].reshape(-1)
             ridx, pidx, samples, depths = ridx[valid_mask], pidx[valid_mask], samples[valid_mask], depths[valid_mask]
         k = samples.shape[1] if samples.dim() == 3 else 1                                   # samples per pack entry
+        if gkey is not None:
+            self._graphs.observe(gkey, samples.shape[0] * k)
         cache = getattr(nef.grid, "_pack_cache", None)
         if cache is not None and cache[0] is ridx:
             _, ridx32, pack_start, ray_of_pack = cache
         else:                                                                              # :114
             ridx32 = ridx.int() if k == 1 else ridx.int().repeat_interleave(k)            # one entry per SAMPLE
             pack_start, ray_of_pack = ops.packs_from_boundary(ridx32, boundary)
+        outputs = self.shade(nef, channels, extra_channels, rays.dirs, N, ridx, ridx32, pidx, samples, depths, deltas, pack_start,
+                             ray_of_pack, lod_idx, bg_color, stage)
+        return RenderBuffer(**outputs)
+
+    def shade(self, nef, channels, extra_channels, ray_dirs, N, ridx, ridx32, pidx, samples, depths, deltas, pack_start, ray_of_pack,
+              lod_idx, bg_color, stage):
+        """Everything of trace() after the ray march (:117-205): the nef on the packed samples, compositing, the panoptic heads.
+        -> dict channel -> tensor.  A function of tensors only (no host synchronisation, no shape that depends on device data), so
+        that pagnerf_amd.graphs can capture it - forward and backward - into HIP graphs over static sample buffers."""
+        dev = samples.device
         outputs = {}
         sample_channels = set(channels - self.render_channels)                             # :121-124
         sample_channels.update(["density"])
         # The panoptic channels use detached weights (:148-155), so they can be evaluated AFTER compositing, fused with
         # their per-ray weighted sum (nef.panoptic_composited): the [M, C] probabilities' gradient is never materialised.
-        pan_req = [c for c in channels if c in self.panoptic_channels]
+        pan_req = [c for c in sorted(channels) if c in self.panoptic_channels]
         fuse_pan = bool(pan_req) and getattr(nef, "accepts_ray_index", False) and nef.can_fuse_panoptic(pan_req)
         if fuse_pan:
             sample_channels -= self.panoptic_channels
         if getattr(nef, "accepts_ray_index", False):      # per-ray view embedding gathered through ridx (no [M,3] dirs)
-            feats = nef(coords=samples, ridx=ridx32, ray_dirs=rays.dirs, pidx=pidx, lod_idx=lod_idx, channels=sample_channels,
+            feats = nef(coords=samples, ridx=ridx32, ray_dirs=ray_dirs, pidx=pidx, lod_idx=lod_idx, channels=sample_channels,
                         ray_packs=(pack_start, ray_of_pack))
         else:                                              # :117,:124
-            feats = nef(coords=samples, ray_d=rays.dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx,
+            feats = nef(coords=samples, ray_d=ray_dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx,
                         channels=sample_channels)
         sigma = feats["density"].reshape(-1)
         if self.ray_sparcity_reg > 0.0 and stage == "train":                               # :127-130
@@ -141,11 +168,10 @@ class PanopticPackedRFTracer(nn.Module):
         else:
             for ch in pan_req:                                                              # :148-155,:178-182
                 outputs[ch] = ops.composite_feats(feats[ch].reshape(-1, feats[ch].shape[-1]), w, alpha_d, pack_start, ray_of_pack, N)
-        extra_outputs = {}
         for ch in extra_channels:                                                          # :184-192
             # the reference composites extra channels with the LIVE alpha / transmittance (:192 passes the tensors of :135-138, not
             # the detached panoptic ones): their loss reaches the density through the weights as well as the channel itself
-            f = nef(coords=samples, ray_d=rays.dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx, channels=ch)
-            extra_outputs[ch] = ops.composite_features(sigma, deltas.reshape(-1), f.reshape(-1, f.shape[-1]), ridx32, pack_start,
-                                                       ray_of_pack, N)[0]
-        return RenderBuffer(**outputs, **extra_outputs)
+            f = nef(coords=samples, ray_d=ray_dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx, channels=ch)
+            outputs[ch] = ops.composite_features(sigma, deltas.reshape(-1), f.reshape(-1, f.shape[-1]), ridx32, pack_start,
+                                                 ray_of_pack, N)[0]
+        return outputs
