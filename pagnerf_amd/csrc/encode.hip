@@ -450,6 +450,16 @@ __device__ __forceinline__ void seg_step(float (&v)[F], int &f) {
     }
     f |= fp;
 }
+// max over the wave on DPP moves; the result is valid in lane 63 (row_shr inside the 16-lane rows, row_bcast across them)
+__device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
+    v = max(v, (uint32_t)dpp_i<0x111, 0xF>((int)v));
+    v = max(v, (uint32_t)dpp_i<0x112, 0xF>((int)v));
+    v = max(v, (uint32_t)dpp_i<0x114, 0xF>((int)v));
+    v = max(v, (uint32_t)dpp_i<0x118, 0xF>((int)v));
+    v = max(v, (uint32_t)dpp_i<0x142, 0xA>((int)v));
+    v = max(v, (uint32_t)dpp_i<0x143, 0xC>((int)v));
+    return v;
+}
 template <int F>
 __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[F], bool &emit, int lane) {
     const uint32_t prev = (uint32_t)dpp_i<0x138, 0xF>((int)key);             // wave_shr:1
@@ -464,6 +474,30 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[
         return;
     }
 #endif
+    if constexpr (F == 2) {
+        // The production width.  The head flag travels as nf = 1.0 (no head between source and this lane) / 0.0, which turns one step
+        // into v += dpp(v) * nf ; nf *= dpp(nf): three DPP-form instructions (v_fmac_f32_dpp / v_mul_f32_dpp) instead of a DPP move,
+        // a compare and an add + select per feature.  The multiplier is exactly 1 or 0, so the sums round like the plain additions
+        // of seg_step.  No bound_ctrl: a lane whose source is outside its row (or masked rows of the row_bcast steps) keeps v and nf.
+        // Every DPP source was written at least three instructions earlier (the two wait states the hardware wants); the leading
+        // s_nop covers values the compiler produced right before the block.
+        float nf = same ? 1.0f : 0.0f;
+#define PAG_SEG_STEP(ctl) \
+        "v_fmac_f32_dpp %0, %0, %2 " ctl "\n\tv_fmac_f32_dpp %1, %1, %2 " ctl "\n\tv_mul_f32_dpp %2, %2, %2 " ctl "\n\t"
+        asm("s_nop 4\n\t"
+            PAG_SEG_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+            PAG_SEG_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+            PAG_SEG_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+            PAG_SEG_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+            PAG_SEG_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+            "v_fmac_f32_dpp %0, %0, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %1, %2 row_bcast:31 row_mask:0xc bank_mask:0xf"
+            : "+v"(v[0]), "+v"(v[1]), "+v"(nf));
+#undef PAG_SEG_STEP
+        const bool next_same2 = (m >> ((lane + 1) & 63)) & 1ull;
+        emit = live && (lane == 63 || !next_same2);
+        return;
+    }
     int f = same ? 0 : 1;                 // run head
     seg_step<F, 0x111, 0xF>(v, f);        // row_shr:1
     seg_step<F, 0x112, 0xF>(v, f);        // row_shr:2
@@ -563,9 +597,8 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
             for (int f = 0; f < F; ++f) mx = fmaxf(mx, (live && lv) ? fabsf(gv[f]) : 0.0f);
             uint32_t mb = __float_as_uint(mx);
             if (mx != mx) mb = 0x7FC00000u;   // NaN poisons the level
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, d));
-            if (lane == 0 && mb) atomicMax(&cnt[j][NS_MAX + 1], mb);     // LDS, one per wave
+            mb = wave_max_to_lane63(mb);
+            if (lane == 63 && mb) atomicMax(&cnt[j][NS_MAX + 1], mb);    // LDS, one per wave
         }
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
