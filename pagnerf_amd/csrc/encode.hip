@@ -677,10 +677,10 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
 // overflow.  Integer addition is associative: the result does not depend on arrival order (bitwise
 // reproducible).  Rows that several lanes share (coarse levels) are first summed across the wave.
 template <int F>
-__device__ __forceinline__ void lds_accumulate(unsigned long long *acc, uint32_t key, const long long (&val)[F], bool valid, int lane) {
+__device__ __forceinline__ void lds_accumulate(unsigned long long *acc, uint32_t key, const long long (&val)[F], bool valid, int lane, bool distinct) {
     unsigned long long active = __ballot(valid);
 #pragma unroll 1
-    for (int it = 0; it < 8 && active; ++it) {
+    for (int it = 0; it < 8 && active && !distinct; ++it) {
         const int leader = __ffsll((long long)active) - 1;
         const uint32_t lk = __shfl(key, leader);
         const unsigned long long m = __ballot(valid && key == lk) & active;
@@ -764,6 +764,12 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
     // over the wave's exclusive prefix of segment lengths (shuffles) and reads that tile's region at the right offset.
     // With few tiles (small batches: the post-prune voxel regime has ~300) groups of 64 would leave most of the 16 waves without any:
     // the group shrinks so that every wave gets tiles (lanes >= G hold empty segments; the search below is unchanged).
+    // Where the segments are long (the fine levels, which hold most of the entries: ~64 per segment) a 64-element chunk of the stream
+    // crosses at most a few tile boundaries, and the search collapses to three compares against the next boundaries, read with
+    // wave-uniform LDS addresses from a per-wave copy of the prefix (s_excl) and of  tile * region + begin - prefix  (s_adj: position
+    // + s_adj = offset of the element inside the group's regions).  `ts` (uniform) is a tile at or before the chunk's first
+    // element; chunks with a fourth boundary (short segments: the coarse levels) take the binary search.
+    __shared__ uint32_t s_excl[16][72], s_adj[16][72];
     const int G = (int)min((int64_t)64, max((int64_t)1, (lay.ntiles + nwaves - 1) / nwaves));
     for (int64_t t0 = (int64_t)wave * G; t0 < lay.ntiles; t0 += (int64_t)nwaves * G) {
         const int64_t tl = t0 + lane;
@@ -778,18 +784,42 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         const uint32_t excl = incl - (me - mb);
         const uint32_t total = (uint32_t)__shfl((int)incl, 63);
         const int64_t region0 = ((int64_t)level * lay.ntiles + t0) * (TS * NV);
+        s_excl[wave][lane] = excl;
+        s_adj[wave][lane] = (uint32_t)lane * (uint32_t)(TS * NV) + mb - excl;      // modulo 2^32: only position + s_adj is used
+        if (lane < 8) s_excl[wave][64 + lane] = 0xFFFFFFFFu;                        // "no further boundary"
+        // entries of one (tile, slice) segment that survived the run merge with ~64 per segment come from a level without repeats:
+        // the wave-wide pre-summation of shared rows (lds_accumulate's leader loop) has nothing to find there
+        const int tiles_here = (int)min((int64_t)G, lay.ntiles - t0);
+        const bool distinct = total >= 60u * (uint32_t)tiles_here;
+        int ts = 0;
         auto fetch = [&](uint32_t c0, uint32_t &key, float (&val)[F]) __attribute__((always_inline)) {
             const uint32_t i = c0 + lane;
             const bool ok = i < total;
-            int t = 0;
+            const uint32_t *pe = &s_excl[wave][ts];
+            const uint32_t b1 = pe[1], b2 = pe[2], b3 = pe[3], b4 = pe[4];           // identical in every lane
+            int64_t pos;
+            int t;
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)b4) >= c0 + 64u) {
+                const uint32_t *pa = &s_adj[wave][ts];
+                uint32_t a = pa[0];
+                a = i >= b1 ? pa[1] : a;
+                a = i >= b2 ? pa[2] : a;
+                a = i >= b3 ? pa[3] : a;
+                t = ts + (i >= b1 ? 1 : 0) + (i >= b2 ? 1 : 0) + (i >= b3 ? 1 : 0);
+                pos = region0 + (int64_t)(uint32_t)(i + a);
+            } else {
+                t = 0;
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int cand = t + step;
-                const uint32_t pe = (uint32_t)__shfl((int)excl, cand & 63);
-                if (pe <= i) t = cand;                       // cand <= 63 always: t + step never exceeds 63
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int cand = t + step;
+                    const uint32_t pc = (uint32_t)__shfl((int)excl, cand & 63);
+                    if (pc <= i) t = cand;                   // cand <= 63 always: t + step never exceeds 63
+                }
+                const uint32_t bt = (uint32_t)__shfl((int)mb, t), et = (uint32_t)__shfl((int)excl, t);
+                pos = region0 + (int64_t)t * (TS * NV) + bt + (i - et);
             }
-            const uint32_t bt = (uint32_t)__shfl((int)mb, t), et = (uint32_t)__shfl((int)excl, t);
-            if (ok) load_entry<F, PACK>(lay, region0 + (int64_t)t * (TS * NV) + bt + (i - et), key, val);
+            ts = __builtin_amdgcn_readlane(t, 63);           // a tile at or before the next chunk's first element (only used when one follows)
+            if (ok) load_entry<F, PACK>(lay, pos, key, val);
             return ok;
         };
         uint32_t key_n = 0;
@@ -802,7 +832,7 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
             for (int f = 0; f < F; ++f) val[f] = ok_n ? to_fixed<PACK>(val_n[f], S) : 0ll;
             const bool ok = ok_n;
             ok_n = (c0 + 64 < total) ? fetch(c0 + 64, key_n, val_n) : false;      // next chunk in flight during the accumulate
-            lds_accumulate<F>(acc, key, val, ok, lane);
+            lds_accumulate<F>(acc, key, val, ok, lane, distinct);
         }
     }
     __syncthreads();
