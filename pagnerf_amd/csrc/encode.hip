@@ -701,16 +701,31 @@ __device__ __forceinline__ void lds_accumulate(unsigned long long *acc, uint32_t
     }
 }
 
+// One entry as it sits in registers while its load is in flight: the packed form stays raw (decoding it would wait for the load)
 template <int F, bool PACK>
-__device__ __forceinline__ void load_entry(const BinLayout &lay, int64_t pos, uint32_t &key, float (&val)[F]) {
-    if constexpr (PACK) {
-        unpack_entry(reinterpret_cast<const uint64_t *>(lay.vals)[pos], key, val[0], val[F - 1]);
-    } else {
-        key = lay.keys[pos];
+struct RawEntry {
+    uint64_t e;
+    uint32_t key_;
+    float val_[PACK ? 1 : F];
+    __device__ __forceinline__ void load(const BinLayout &lay, int64_t pos) {
+        if constexpr (PACK) {
+            e = reinterpret_cast<const uint64_t *>(lay.vals)[pos];
+        } else {
+            key_ = lay.keys[pos];
 #pragma unroll
-        for (int f = 0; f < F; ++f) val[f] = lay.vals[pos * F + f];
+            for (int f = 0; f < F; ++f) val_[f] = lay.vals[pos * F + f];
+        }
     }
-}
+    __device__ __forceinline__ void decode(uint32_t &key, float (&val)[F]) const {
+        if constexpr (PACK) {
+            unpack_entry(e, key, val[0], val[F - 1]);
+        } else {
+            key = key_;
+#pragma unroll
+            for (int f = 0; f < F; ++f) val[f] = val_[f];
+        }
+    }
+};
 
 // value -> 2^-S fixed point.  Exact 64-bit conversion on the fp32-gradient path; on the packed bf16 path (entries already
 // rounded to 18 mantissa bits) a 32-bit convert of v * 2^(S-14) followed by a 14-bit shift: the quantum becomes
@@ -792,7 +807,7 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         const int tiles_here = (int)min((int64_t)G, lay.ntiles - t0);
         const bool distinct = total >= 60u * (uint32_t)tiles_here;
         int ts = 0;
-        auto fetch = [&](uint32_t c0, uint32_t &key, float (&val)[F]) __attribute__((always_inline)) {
+        auto fetch = [&](uint32_t c0, RawEntry<F, PACK> &raw) __attribute__((always_inline)) {
             const uint32_t i = c0 + lane;
             const bool ok = i < total;
             const uint32_t *pe = &s_excl[wave][ts];
@@ -819,20 +834,35 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
                 pos = region0 + (int64_t)t * (TS * NV) + bt + (i - et);
             }
             ts = __builtin_amdgcn_readlane(t, 63);           // a tile at or before the next chunk's first element (only used when one follows)
-            if (ok) load_entry<F, PACK>(lay, pos, key, val);
+            raw.load(lay, ok ? pos : region0);               // lanes past the end read the group's first entry (always inside the workspace) and ignore it: no branch around the load
             return ok;
         };
-        uint32_t key_n = 0;
-        float val_n[F];
-        bool ok_n = total ? fetch(0, key_n, val_n) : false;
-        for (uint32_t c0 = 0; c0 < total; c0 += 64) {
-            const uint32_t key = key_n;
+        // TWO chunks in flight: the kernel is latency-bound (VALU ~45 % busy at the full 8 waves per SIMD, 70 % of the wave cycles waiting),
+        // and one iteration of accumulate work did not cover the latency of the next chunk's load.  Ping-pong between two named
+        // registers sets (a rotation by copies would wait for the newer load at the copy) and every refill is issued unconditionally
+        // (past the end it re-reads the group's first entry): the wait counts stay exact at every join.
+        RawEntry<F, PACK> raw_a, raw_b;
+        bool ok_a = fetch(0, raw_a);
+        bool ok_b = fetch(64, raw_b);
+        auto stage = [&](RawEntry<F, PACK> &raw, bool &ok_r, uint32_t c_next) __attribute__((always_inline)) {
+            uint32_t key;
+            float fv[F];
+            raw.decode(key, fv);
+            const bool ok = ok_r;
+            // decode first, for real (the empty asm pins the decoded values and, with its memory clobber, keeps the refill below it):
+            // the refill then reuses the raw registers instead of landing in new ones that are copied - after a full wait - at the loop edge
+            asm volatile("" : "+v"(key) : : "memory");
+#pragma unroll
+            for (int f = 0; f < F; ++f) asm volatile("" : "+v"(fv[f]) : : "memory");
+            ok_r = fetch(c_next, raw);
             long long val[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) val[f] = ok_n ? to_fixed<PACK>(val_n[f], S) : 0ll;
-            const bool ok = ok_n;
-            ok_n = (c0 + 64 < total) ? fetch(c0 + 64, key_n, val_n) : false;      // next chunk in flight during the accumulate
+            for (int f = 0; f < F; ++f) val[f] = ok ? to_fixed<PACK>(fv[f], S) : 0ll;
             lds_accumulate<F>(acc, key, val, ok, lane, distinct);
+        };
+        for (uint32_t c0 = 0; c0 < total; c0 += 128) {
+            stage(raw_a, ok_a, c0 + 128);
+            stage(raw_b, ok_b, c0 + 192);          // past the end: ok_b is false, nothing is added
         }
     }
     __syncthreads();
