@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 5
+#define PAG_ABI_VERSION 6
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -36,7 +36,8 @@ enum { PAG_MLP_MFMA_BF16 = 0, PAG_MLP_FP32 = 1 };
 enum { PAG_BG_BLACK = 0, PAG_BG_WHITE = 1 };
 /* feature-tensor layouts of the encoders / decoder inputs:
  *   PAG_LAYOUT_STRIDED  [M, L*F] addressed through (stride_m, stride_c); column = level*F + f
- *   PAG_LAYOUT_XCD8     bf16 [8][M][8]: group g = level % 8, element e = (level / 8)*F + f, zero padded
+ *   PAG_LAYOUT_XCD8     bf16 [8][M][8]: element e = j*F + f of group g holds level 8j + g (j even) or 8j + 7 - g (j odd) - every group,
+ *                       i.e. every XCD of the encoders' launches, gets a mix of coarse and fine levels - zero padded (ABI 6; before: 8j + g)
  *                       (requires ceil(L/8)*F <= 8).  Strides are ignored. */
 enum { PAG_LAYOUT_STRIDED = 0, PAG_LAYOUT_XCD8 = 1 };
 /* `flags` of the encode entry points:

@@ -6,6 +6,12 @@
 #include <stdio.h>
 #include "../../include/pagnerf_hip.h"
 
+// PAG_LAYOUT_XCD8: which level sits in slot j of XCD group g.  "Snake" order - even bands of 8 levels ascend with g, odd bands descend -
+// so that every group (= every XCD: workgroup b of the encoders lands on XCD b % 8) holds a mix of cheap coarse and expensive fine
+// levels.  With band j simply ascending, group 7 of the 24-level permutohedral grid held the finest level of every band and the forward
+// waited for that one XCD: 0.458 -> 0.386 ms per launch (scripts/bench_encode_levels.py).  Levels >= n_levels are padding.
+__host__ __device__ __forceinline__ int xcd8_level(int g, int j) { return (j & 1) ? 8 * j + 7 - g : 8 * j + g; }
+
 #define PAG_WAVE 64
 
 typedef __bf16 bf16_t;

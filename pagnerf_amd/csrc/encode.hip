@@ -19,7 +19,7 @@ using namespace pag_enc;
 
 namespace {
 
-// XCD-grouped feature layout (PAG_LAYOUT_XCD8): out[g][m][8] bf16, g = level % 8, element e = (level / 8) * F + f
+// XCD-grouped feature layout (PAG_LAYOUT_XCD8): out[g][m][8] bf16, element e = j * F + f holds level xcd8_level(g, j) (common.h)
 // (zero padded): each lane stores ONE aligned 16-byte piece holding all the levels it computed, a wave
 // stores 1 KiB contiguously - instead of LPX*F scattered 2-byte pieces per sample in a [M, L*F] row
 // (measured 8x write amplification).  The decoders read the same pieces as MFMA B fragments.
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
     for (int q = 0; q < (LPX * F <= 8 ? LPX * F : 1); ++q) gvals[q] = 0.0f;
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        int l = g + 8 * j;
+        int l = xcd8_level(g, j);
         int le = l < p.L ? l : p.L - 1;
         uint32_t idx[8];
         hash_cell(x, p.res[le], p.log2T, idx, w[j]);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
     }
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        int l = g + 8 * j;
+        int l = xcd8_level(g, j);
         if (l >= p.L) break;
         const float wx = w[j][0], wy = w[j][1], wz = w[j][2];
         const float ox = __fsub_rn(1.0f, wx), oy = __fsub_rn(1.0f, wy), oz = __fsub_rn(1.0f, wz);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void hash_bwd_kernel(const float *__restrict__
     const int64_t T = (int64_t)1 << p.log2T;
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        int l = g + 8 * j;
+        int l = xcd8_level(g, j);
         if (l >= p.L) break;
         uint32_t idx[8];
         float w[3];
@@ -169,7 +169,7 @@ __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, 
     for (int q = 0; q < (LPX * F <= 8 ? LPX * F : 1); ++q) gvals[q] = 0.0f;
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        int l = g + 8 * j;
+        int l = xcd8_level(g, j);
         int le = l < p.L ? l : p.L - 1;
         uint32_t idx[4];
 #ifdef PAG_DBG_ONLY_J      // experiment: only the j-th level of every XCD group (what a level-phased launch would run per phase)
@@ -200,7 +200,7 @@ __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, 
     }
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        int l = g + 8 * j;
+        int l = xcd8_level(g, j);
         if (l >= p.L) break;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(const float *__restric
     load_xyz(xyz, i, p.half_coords, x);
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        int l = g + 8 * j;
+        int l = xcd8_level(g, j);
         if (l >= p.L) break;
         uint32_t idx[4];
         float bary[4];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void xyz_grad_kernel(const float *__restrict__
     int slot[LPX][4];        // permuto: 3 - rank
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        const int l = g + 8 * j;
+        const int l = xcd8_level(g, j);
         const int le = l < L ? l : L - 1;
         const TableT *tab = tables + (int64_t)le * rows * F;
         if constexpr (KIND == 0) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void xyz_grad_kernel(const float *__restrict__
     float dx[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        const int l = g + 8 * j;
+        const int l = xcd8_level(g, j);
         if (l >= L) break;
         float gv[F];
 #pragma unroll
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
     uint32_t rank[LPX][NV];
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        const int level = grouped ? (int)blockIdx.y + 8 * j : (int)blockIdx.y;
+        const int level = grouped ? xcd8_level((int)blockIdx.y, j) : (int)blockIdx.y;
         const bool lv = level < L;
         const int lc = lv ? level : L - 1;
         float w[NV];
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
-        const int level = grouped ? (int)blockIdx.y + 8 * j : (int)blockIdx.y;
+        const int level = grouped ? xcd8_level((int)blockIdx.y, j) : (int)blockIdx.y;
         if (level >= L) break;
         const int64_t region = ((int64_t)level * lay.ntiles + tile) * (TS * NV);
         if constexpr (STAGE) {

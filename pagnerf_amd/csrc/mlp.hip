@@ -45,7 +45,7 @@ __device__ __forceinline__ int swap23(int a) { return (a & ~12) | ((a & 4) << 1)
 __device__ __forceinline__ int grp_col(int pos, int L, int F) {
     const int g = pos >> 3, e = pos & 7;
     const int j = e / F, f = e - j * F;
-    const int level = g + 8 * j;
+    const int level = xcd8_level(g, j);
     return (j < (L + 7) / 8 && level < L) ? level * F + f : -1;
 }
 
@@ -3605,13 +3605,13 @@ static int fused_kind(const pag_mlp_bwd_args *a) {
         if (!a->x1 || a->x1_dtype != PAG_BF16 || a->x1_layout != PAG_LAYOUT_XCD8 || a->k1 != 64 || a->x2 || a->dx1_col0_add || a->dx1_accumulate) return -1;
         if (a->x1_levels < 1 || a->x1_feats < 1 || ((a->x1_levels + 7) / 8) * a->x1_feats > 8) return -1;
         const int j = 7 / a->x1_feats;
-        if (j < (a->x1_levels + 7) / 8 && 7 + 8 * j < a->x1_levels) return -1;
+        if (j < (a->x1_levels + 7) / 8 && xcd8_level(7, j) < a->x1_levels) return -1;
         return 3;
     }
     if (a->x1_layout == PAG_LAYOUT_XCD8) {
         if (a->k1 != 64 || a->x1_levels < 1 || a->x1_feats < 1 || ((a->x1_levels + 7) / 8) * a->x1_feats > 8) return -1;
         const int j = 7 / a->x1_feats;                            // staged position 63 = group 7, element 7: must be padding
-        if (j < (a->x1_levels + 7) / 8 && 7 + 8 * j < a->x1_levels) return -1;
+        if (j < (a->x1_levels + 7) / 8 && xcd8_level(7, j) < a->x1_levels) return -1;
         if (a->x2 || a->dx1_col0_add) return -1;
         if (!rank1 && a->grad_out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_NONE && a->out_dim % 4 == 0 && !a->dx1_accumulate) return 0;
         if (rank1 && a->g_scale && a->g_index && a->g_ray_scale && a->out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_SOFTMAX &&

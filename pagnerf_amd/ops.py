@@ -254,13 +254,18 @@ def xcd8_supported(n_levels, n_feat):
     return ((n_levels + 7) // 8) * n_feat <= 8
 
 
+def xcd8_level(g, j):
+    """Level in slot j of XCD group g (csrc/common.h xcd8_level): even bands of 8 levels ascend with g, odd bands descend."""
+    return 8 * j + 7 - g if j & 1 else 8 * j + g
+
+
 def xcd8_columns(n_levels, n_feat):
     """staged position p = 8*g + e  ->  feature column level*F + f (or -1 for padding), as a list of 64."""
     cols = []
     for p in range(64):
         g, e = p >> 3, p & 7
         j, f = divmod(e, n_feat)
-        level = g + 8 * j
+        level = xcd8_level(g, j)
         cols.append(level * n_feat + f if (j < (n_levels + 7) // 8 and level < n_levels) else -1)
     return cols
 
@@ -291,7 +296,7 @@ def _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, sta
         if levels < 1 or feats < 1 or ((levels + 7) // 8) * feats > 8:
             return False
         j = 7 // feats
-        if j < (levels + 7) // 8 and 7 + 8 * j < levels:      # staged position 63 is a real feature: no room for the bias column
+        if j < (levels + 7) // 8 and xcd8_level(7, j) < levels:      # staged position 63 is a real feature: no room for the bias column
             return False
         if x2 is not None:
             return False
