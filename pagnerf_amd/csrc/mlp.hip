@@ -2845,9 +2845,13 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
 }
 
-__global__ __launch_bounds__(256) void head_composite_fwd_kernel(HeadCompParams p) {
+// OBT = 7 (193 - 224 outputs: the 200-instance head): the block loop is compile-time, so the output blocks' MFMA chains are issued one block
+// AHEAD of the exponentials that consume them (the run-time `ob < OB` guards of the generic form, OBT = 0, end a scheduling region per block
+// and every block ran as reads -> 4 chained MFMAs -> 16 exponentials, nothing overlapping at two waves per SIMD).
+template <int OBT>
+__global__ __launch_bounds__(256, 2) void head_composite_fwd_kernel(HeadCompParams p) {      // two waves per SIMD: 256 registers
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int OB = (p.out_dim + 31) / 32;
+    const int OB = OBT ? OBT : (p.out_dim + 31) / 32;
     bf16_t *WLs = reinterpret_cast<bf16_t *>(smem);                  // [OB*32][RS] permuted k (forward layout)
     float *bLs = reinterpret_cast<float *>(WLs + OB * 32 * RS);      // [OB*32]
     float *red = bLs + OB * 32;                                      // [4][OB*32]
@@ -2902,23 +2906,38 @@ __global__ __launch_bounds__(256) void head_composite_fwd_kernel(HeadCompParams 
                 pack_block(hv, hb[2 * mb], hb[2 * mb + 1]);
             }
             const float Ms = st2.x, sw = st2.y * wcur;       // 1/sum folded into the sample weight (0 for lanes past the pack's end)
+            auto logits = [&](int ob) __attribute__((always_inline)) {
+                f32x16 o;
 #pragma unroll
-            for (int ob = 0; ob < 7; ++ob) {
-                if (ob < OB) {
-                    f32x16 o;
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bLs + 32 * ob + 8 * g + 4 * h);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bLs + 32 * ob + 8 * g + 4 * h);
+                    for (int j = 0; j < 4; ++j) o[4 * g + j] = b4[j];
+                }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[4 * g + j] = b4[j];
-                    }
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], o, 0, 0, 0);
+                }
+                return o;
+            };
+            if constexpr (OBT != 0) {
+                f32x16 o_next = logits(0);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(WLs + (32 * ob + r) * RS + 16 * s + 8 * h);
-                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[s], o, 0, 0, 0);
-                    }
+                for (int ob = 0; ob < OBT; ++ob) {
+                    const f32x16 o = o_next;
+                    if (ob + 1 < OBT) o_next = logits(ob + 1);        // in the matrix pipe while the exponentials below issue
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[ob][q] = fmaf(sw, __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -Ms)), acc[ob][q]);
+                }
+            } else {
+#pragma unroll
+                for (int ob = 0; ob < 7; ++ob) {
+                    if (ob < OB) {
+                        const f32x16 o = logits(ob);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc[ob][q] = fmaf(sw, __builtin_amdgcn_exp2f(fmaf(o[q], LOG2E, -Ms)), acc[ob][q]);
+                    }
                 }
             }
         }
@@ -2926,15 +2945,32 @@ __global__ __launch_bounds__(256) void head_composite_fwd_kernel(HeadCompParams 
 #pragma unroll
         for (int ob = 0; ob < 7; ++ob) {
             if (ob < OB) {
+                // step by step over all 16 values: consecutive DPP adds are independent (a chain per value would put two wait states
+                // between every pair - 459 s_nop in the first listing of this epilogue)
+                // (written as asm blocks of 16 v_add_f32_dpp: left to itself the compiler pairs the values into v_pk_add_f32 fed by two DPP moves
+                // each - 1.5 instructions per value and step instead of 1.  Inside a block every DPP source was written 16 instructions earlier.)
+                float v[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    float v = acc[ob][q];
-                    v = dpp_add<0x111, 0xF>(v);      // row_shr:1
-                    v = dpp_add<0x112, 0xF>(v);      // row_shr:2
-                    v = dpp_add<0x114, 0xF>(v);      // row_shr:4
-                    v = dpp_add<0x118, 0xF>(v);      // row_shr:8   -> lane 15 of every 16-lane row holds the row sum
-                    v = dpp_add<0x142, 0xA>(v);      // row_bcast:15 into rows 1, 3 -> lanes 31 / 63 hold the half's sum
-                    if (r == 31) red[wave * OB * 32 + 32 * ob + rho(q, h)] = v;
+                for (int q = 0; q < 16; ++q) v[q] = acc[ob][q];
+#define PAG_DPP_ADD16(ctl)                                                                                                         \
+                asm("s_nop 1\n\t"                                                                                                   \
+                    "v_add_f32_dpp %0, %0, %0 " ctl "\n\tv_add_f32_dpp %1, %1, %1 " ctl "\n\tv_add_f32_dpp %2, %2, %2 " ctl "\n\t"   \
+                    "v_add_f32_dpp %3, %3, %3 " ctl "\n\tv_add_f32_dpp %4, %4, %4 " ctl "\n\tv_add_f32_dpp %5, %5, %5 " ctl "\n\t"   \
+                    "v_add_f32_dpp %6, %6, %6 " ctl "\n\tv_add_f32_dpp %7, %7, %7 " ctl "\n\tv_add_f32_dpp %8, %8, %8 " ctl "\n\t"   \
+                    "v_add_f32_dpp %9, %9, %9 " ctl "\n\tv_add_f32_dpp %10, %10, %10 " ctl "\n\tv_add_f32_dpp %11, %11, %11 " ctl "\n\t" \
+                    "v_add_f32_dpp %12, %12, %12 " ctl "\n\tv_add_f32_dpp %13, %13, %13 " ctl "\n\tv_add_f32_dpp %14, %14, %14 " ctl "\n\t" \
+                    "v_add_f32_dpp %15, %15, %15 " ctl                                                                             \
+                    : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),     \
+                      "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+                PAG_DPP_ADD16("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+                PAG_DPP_ADD16("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+                PAG_DPP_ADD16("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+                PAG_DPP_ADD16("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");      // lane 15 of every 16-lane row holds the row sum
+                PAG_DPP_ADD16("row_bcast:15 row_mask:0xa bank_mask:0xf");                // into rows 1, 3: lanes 31 / 63 hold the half's sum
+#undef PAG_DPP_ADD16
+                if (r == 31) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) red[wave * OB * 32 + 32 * ob + rho(q, h)] = v[q];
                 }
             }
         }
@@ -4076,14 +4112,21 @@ extern "C" int pag_head_composite_fwd(const int64_t *pack_start, const int32_t *
     PAG_CHECK_ARG(pack_start && ray_of_pack && hidden && W_last && b_last && softmax_stats && weights && alpha && out,
                   "pag_head_composite_fwd: NULL input/output");
     HeadCompParams p{pack_start, ray_of_pack, P, (const bf16_t *)hidden, W_last, b_last, out_dim, softmax_stats, 0, weights, alpha, out};
-    p.per_wave = (samples_hint > 0 && samples_hint < 160 * P) ? 1 : 0;      // fewer than ~5 tiles per pack on average: one wave per pack
+#ifndef PAG_HC_PER_WAVE_P
+#define PAG_HC_PER_WAVE_P 2048
+#endif
+    // one wave per pack when packs are short (fewer than ~5 tiles on average) - and whenever there are enough packs to fill the chip that way
+    // (2048 = 512 workgroups of 4 waves): the lane reduction of the 7 x 16 partial sums at the end of a pack costs as much as two tiles, and four
+    // waves sharing a pack each pay it
+    p.per_wave = ((samples_hint > 0 && samples_hint < 160 * P) || P >= PAG_HC_PER_WAVE_P) ? 1 : 0;
     const int OB = (out_dim + 31) / 32;
     const size_t lds = (size_t)OB * 32 * RS * sizeof(bf16_t) + (size_t)5 * OB * 32 * sizeof(float) + 4 * ST_BYTES;
 #ifndef PAG_HC_GRID
 #define PAG_HC_GRID 512
 #endif
     const unsigned grid = (unsigned)std::min<int64_t>(p.per_wave ? (P + 3) / 4 : P, PAG_HC_GRID);
-    hipLaunchKernelGGL(head_composite_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    if (OB == 7) hipLaunchKernelGGL(head_composite_fwd_kernel<7>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(head_composite_fwd_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     PAG_CHECK_LAUNCH("pag_head_composite_fwd");
     return PAG_OK;
 }
