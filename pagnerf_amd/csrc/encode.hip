@@ -797,7 +797,8 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
             if (lane >= d) incl += up;
         }
         const uint32_t excl = incl - (me - mb);
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total == 0u) continue;          // nothing of this slice in these tiles (small batches: most groups) - before any load is issued
         const int64_t region0 = ((int64_t)level * lay.ntiles + t0) * (TS * NV);
         s_excl[wave][lane] = excl;
         s_adj[wave][lane] = (uint32_t)lane * (uint32_t)(TS * NV) + mb - excl;      // modulo 2^32: only position + s_adj is used
