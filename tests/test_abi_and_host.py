@@ -340,3 +340,27 @@ def test_bench_byte_model_matches_design_table():
     for entry in ("pag_mlp_fwd", "pag_mlp_bwd", "pag_head_composite_fwd", "pag_composite_fwd"):
         pmc = bench.pmc_bytes_per_step(blob, entry, 1)
         assert pmc is not None and 1 / 1.3 < pmc / m[entry]["bytes"] < 1.3, (entry, pmc, m[entry]["bytes"])
+
+
+def test_xcd8_layout_is_the_snake_permutation():
+    """PAG_LAYOUT_XCD8 (C ABI 6): element j*F + f of group g holds level 8j + g for even j, 8j + 7 - g for odd j.  The host-side map
+    (what tests and callers unpack the tensor with) must be a bijection onto the L*F feature columns, pad everything else, and put
+    the 24-level grid's levels where DESIGN.md section 4.1 says (g, 15 - g, 16 + g)."""
+    from pagnerf_amd import ops
+    assert [ops.xcd8_level(g, 0) for g in range(8)] == list(range(8))
+    assert [ops.xcd8_level(g, 1) for g in range(8)] == list(range(15, 7, -1))
+    assert [ops.xcd8_level(g, 2) for g in range(8)] == list(range(16, 24))
+    for L_, F_ in ((24, 2), (16, 2), (20, 2), (16, 4), (12, 4), (7, 2), (1, 1), (32, 2), (64, 1), (8, 8)):
+        assert ops.xcd8_supported(L_, F_)
+        cols = ops.xcd8_columns(L_, F_)
+        assert len(cols) == 64
+        real = sorted(c for c in cols if c >= 0)
+        assert real == list(range(L_ * F_)), (L_, F_)
+        for pos, c in enumerate(cols):
+            if c >= 0:
+                g, e = pos >> 3, pos & 7
+                assert c == ops.xcd8_level(g, e // F_) * F_ + e % F_
+    assert not ops.xcd8_supported(33, 2) and not ops.xcd8_supported(24, 4)
+    # the cheap / expensive pairing the order exists for: every group of the 24-level grid sums to the same level total
+    sums = {sum(ops.xcd8_level(g, j) for j in range(2)) for g in range(8)}
+    assert sums == {15}
