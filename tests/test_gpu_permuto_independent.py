@@ -354,3 +354,52 @@ def test_checkpoint_round_trip_renders_identically(gpu_device):
         third = pipe(channels=chans, rays=rays, jitter=jitter.to(dev))
     for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding", "hit"):
         assert torch.equal(getattr(third, ch), getattr(rb, ch)), ch
+
+
+@pytest.mark.parametrize("kind", ["permuto", "hash"])
+def test_binned_table_gradients_at_ragged_sizes(gpu_device, kind):
+    """The reduce pass reads the (tile, slice) segments of up to 64 tiles as one stream, two 64-entry chunks in flight, with a three-compare
+    tile search where segments are long and a binary search where they are short, and skips tile groups that hold nothing of its slice.
+    Sizes that put every one of those branches at its edge: a single sample, one chunk exactly, fewer tiles than waves, a last group with
+    one tile, tile counts that are not multiples of the group size, and whole-ray as well as shuffled (no repeats: every level
+    'distinct') sample orders - binned == per-vertex atomics, and bitwise reproducible."""
+    ops, L = _ops()
+    from pagnerf_amd import grids
+    dev = gpu_device
+    gen = torch.Generator().manual_seed(5)
+    if kind == "permuto":
+        Lv, F, rows, ts = 24, 2, 1 << 18, 1024
+        spec = ops.permuto_spec(grids.PermutoGridHIP.scale_factors(np.geomspace(1.0, 1e-4, Lv)), torch.randn(Lv, 3, generator=gen) * 10, rows, F,
+                                half_coords=True)
+    else:
+        Lv, F, rows, ts = 16, 2, 1 << 19, 512
+        from oracle import hash_encode as oh
+        spec = ops.hash_spec(oh.level_resolutions(16, 2048, Lv), 19, F)
+    for M, shuffled in ((1, False), (63, False), (64, True), (65, False), (ts - 1, False), (ts, True), (ts + 1, False), (3 * ts + 5, True),
+                        (17 * ts + 1, False), (64 * ts, False), (65 * ts + 13, True), (130 * ts + 700, False)):
+        n_rays = max(1, M // 200)
+        o = (torch.rand(n_rays, 1, 3, generator=gen) - 0.5) * 0.8
+        d = torch.nn.functional.normalize(torch.randn(n_rays, 1, 3, generator=gen), dim=-1)
+        per = (M + n_rays - 1) // n_rays
+        t = torch.linspace(0, 1, per)[None, :, None] * 0.9
+        x = (o + d * t).reshape(-1, 3)[:M]
+        if shuffled:
+            x = x[torch.randperm(M, generator=gen)]
+        x = x.contiguous().to(dev)
+        g8 = (torch.randn(8, M, 8, generator=gen) * torch.exp(torch.randn(1, M, 1, generator=gen))).to(dev).bfloat16()
+        gs = _xcd8_to_strided(g8, Lv, F)
+        binned = torch.full((Lv, rows, F), float("nan"), device=dev)
+        ops._encode_bwd(spec, x, g8, None, binned, overwrite=True)          # overwrite: every row of the table is written, NaNs must be gone
+        ops.BWD_ALGO = "atomic"
+        try:
+            atomic = torch.zeros(Lv, rows, F, device=dev)
+            ops._encode_bwd(spec, x, gs, None, atomic)
+        finally:
+            ops.BWD_ALGO = "binned"
+        assert torch.isfinite(binned).all(), (kind, M)
+        for l in range(Lv):
+            a, b = binned[l].double(), atomic[l].double()
+            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, (kind, M, shuffled, l)
+        again = torch.empty_like(binned)
+        ops._encode_bwd(spec, x, g8, None, again, overwrite=True)
+        assert torch.equal(again, binned), (kind, M)
