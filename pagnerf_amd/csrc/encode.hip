@@ -575,7 +575,12 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
         } else {
             uint32_t id4[4];
             float b4[4];
-            permuto_simplex(x, pp.shift[lc], pp.sf[lc], pp.capacity, pp.pow2mask, id4, b4);
+#ifndef PAG_BIN_NO_LDS_SORT
+            if constexpr (STAGE)      // the staging tile is idle until the placement phase: 32 bytes of it per lane serve the rank sort
+                permuto_simplex_lds(x, pp.shift[lc], pp.sf[lc], pp.capacity, pp.pow2mask, id4, b4, reinterpret_cast<float *>(stage) + tid * 8);
+            else
+#endif
+                permuto_simplex(x, pp.shift[lc], pp.sf[lc], pp.capacity, pp.pow2mask, id4, b4);
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 idx[j][k] = id4[k & 3];

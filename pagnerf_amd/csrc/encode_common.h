@@ -94,9 +94,13 @@ __device__ __forceinline__ float lerp_ref(float a, float b, float w, float omw) 
 // oracle/permuto_encode.py lattice_simplex() + vertex_indices(), one level, d = 3.
 // slot[a] = 3 - rank[a]: coordinate a of the elevated point adds +delta_a to bary[slot] and -delta_a to bary[slot+1]
 // (bary[4] folds into bary[0]) - what d bary / d x needs.
+// LDS_SORT (the VALU-bound bin pass): the two rank-indexed selections below - the barycentric deltas sorted by rank and the hash
+// constant of the coordinate that holds each rank, 12 compares + 21 selects of the expensive VOP3 kind - become four 2-dword LDS
+// writes at slot rank[a] of a lane-private 32-byte record and two 16-byte reads: the same values moved, not recomputed.
+template <bool LDS_SORT = false>
 __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float (&sh)[3], const float (&sf)[3],
                                                 uint32_t capacity, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4],
-                                                int (&slot_out)[4]) {
+                                                int (&slot_out)[4], float *lane_slots = nullptr) {
     float cf[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) cf[a] = __fmul_rn(__fadd_rn(x[a], sh[a]), sf[a]);
@@ -122,9 +126,10 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
         const float dn = floorf(E[a] * 0.25f) * 4.0f, up = dn + 4.0f;
         const float d_up = __fsub_rn(up, E[a]), d_dn = __fsub_rn(E[a], dn);
         const bool take_up = d_up < d_dn;
-        rem0[a] = (int)dn + (take_up ? 4 : 0);
+        const float rf = take_up ? up : dn;         // the chosen remainder-0 point, exact in fp32
+        rem0[a] = (int)rf;
         sum += rem0[a];
-        resid[a] = take_up ? -d_up : d_dn;
+        resid[a] = __fsub_rn(E[a], rf);             // = -d_up or d_dn bit for bit (fl(E - up) = -fl(up - E)): one subtraction instead of a select + add
     }
     sum >>= 2;   // exact: every rem0 is a multiple of 4
     // rank_a = #{b : resid_b > resid_a} + #{b < a : resid_b == resid_a} (the oracle's pairwise rule: for a < b, `lt = resid_a <
@@ -158,8 +163,28 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
         d[a] = __fsub_rn(E[a], (float)rem0[a]) * 0.25f;
         slot_out[a] = 3 - rank[a];
     }
+    constexpr uint32_t m1 = 2531011u, m2 = m1 * m1, m3 = m2 * m1;
+    constexpr uint32_t step = m3 + m2 + m1;
+    constexpr uint32_t A[4] = {4u * m3, 4u * m2, 4u * m1, 0u};
+    uint32_t B[4];      // LDS_SORT: holds step - 4*m^(3-a) (the increment itself), else 4*m^(3-a)
+    if constexpr (LDS_SORT) {
+        // record: dwords 0-3 = delta of rank 0..3, dwords 4-7 = 4*m^(3-a) of the coordinate a with rank 0..3 (0 for a = 3)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dr[r] = rank[0] == r ? d[0] : (rank[1] == r ? d[1] : (rank[2] == r ? d[2] : d[3]));
+        for (int a = 0; a < 4; ++a) {
+            lane_slots[rank[a]] = d[a];
+            lane_slots[4 + rank[a]] = __uint_as_float(step - A[a]);
+        }
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v0 = *reinterpret_cast<const f4 *>(lane_slots), v1 = *reinterpret_cast<const f4 *>(lane_slots + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dr[r] = v0[r];
+            B[r] = __float_as_uint(v1[r]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dr[r] = rank[0] == r ? d[0] : (rank[1] == r ? d[1] : (rank[2] == r ? d[2] : d[3]));
+    }
     bary[0] = __fadd_rn(dr[3], __fsub_rn(1.0f, dr[0]));
     bary[1] = __fsub_rn(dr[2], dr[3]);
     bary[2] = __fsub_rn(dr[1], dr[2]);
@@ -167,18 +192,16 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
     // Vertex hashes.  k = ((key0*m + key1)*m + key2)*m is linear in the keys (mod 2^32) and
     // key_a(r) = rem0_a + r - 4*[rank_a > 3-r], so k(r) = k(rem0) + r*(m^3+m^2+m) - sum_a [rank_a >= 4-r] * 4*m^(3-a):
     // three multiplies per level instead of twelve.
-    constexpr uint32_t m1 = 2531011u, m2 = m1 * m1, m3 = m2 * m1;
-    constexpr uint32_t step = m3 + m2 + m1;
-    constexpr uint32_t A[3] = {4u * m3, 4u * m2, 4u * m1};
     const uint32_t h0 = (((uint32_t)rem0[0] * m1 + (uint32_t)rem0[1]) * m1 + (uint32_t)rem0[2]) * m1;
     // the sets {a: rank_a >= 4-r} are nested in r and at most one coordinate holds each rank: B[q] = 4*m^(3-a) of the
     // coordinate a < 3 with rank q (the compares are the ones the delta sort above already made)
-    uint32_t B[4];
+    if constexpr (!LDS_SORT) {
 #pragma unroll
-    for (int q = 1; q < 4; ++q) B[q] = rank[0] == q ? A[0] : (rank[1] == q ? A[1] : (rank[2] == q ? A[2] : 0u));
+        for (int q = 1; q < 4; ++q) B[q] = rank[0] == q ? A[0] : (rank[1] == q ? A[1] : (rank[2] == q ? A[2] : 0u));
+    }
     idx[0] = h0;
 #pragma unroll
-    for (int r = 1; r < 4; ++r) idx[r] = idx[r - 1] + (step - B[4 - r]);
+    for (int r = 1; r < 4; ++r) idx[r] = idx[r - 1] + (LDS_SORT ? B[4 - r] : step - B[4 - r]);
     if (pow2mask) {      // one wave-uniform branch for the four vertices
 #pragma unroll
         for (int r = 0; r < 4; ++r) idx[r] &= pow2mask;
@@ -191,7 +214,12 @@ __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float
 __device__ __forceinline__ void permuto_simplex(const float (&x)[3], const float (&sh)[3], const float (&sf)[3],
                                                 uint32_t capacity, uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4]) {
     int unused[4];
-    permuto_simplex(x, sh, sf, capacity, pow2mask, idx, bary, unused);
+    permuto_simplex<false>(x, sh, sf, capacity, pow2mask, idx, bary, unused);
+}
+__device__ __forceinline__ void permuto_simplex_lds(const float (&x)[3], const float (&sh)[3], const float (&sf)[3], uint32_t capacity,
+                                                    uint32_t pow2mask, uint32_t (&idx)[4], float (&bary)[4], float *lane_slots) {
+    int unused[4];
+    permuto_simplex<true>(x, sh, sf, capacity, pow2mask, idx, bary, unused, lane_slots);
 }
 
 }  // namespace pag_enc
