@@ -615,7 +615,7 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
 #else
             run_combine<F>(lk ? idx[j][k] : 0xFFFFFFFFu, lk, ev[j][k], emit[j][k], lane);
 #endif
-            rank[j][k] = emit[j][k] ? atomicAdd(&cnt[j][idx[j][k] >> lay.shift], 1u) : 0u;
+            if (emit[j][k]) rank[j][k] = atomicAdd(&cnt[j][idx[j][k] >> lay.shift], 1u);      // read only where emit is set
         }
     }
     __syncthreads();
