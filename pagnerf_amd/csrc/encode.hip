@@ -808,10 +808,10 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         s_excl[wave][lane] = excl;
         s_adj[wave][lane] = (uint32_t)lane * (uint32_t)(TS * NV) + mb - excl;      // modulo 2^32: only position + s_adj is used
         if (lane < 8) s_excl[wave][64 + lane] = 0xFFFFFFFFu;                        // "no further boundary"
-        // entries of one (tile, slice) segment that survived the run merge with ~64 per segment come from a level without repeats:
+        // segments that still hold (nearly) every entry a tile can have for one slice - TS * NV / NS: 64 permutohedral, 32 hash - come from a level without repeats:
         // the wave-wide pre-summation of shared rows (lds_accumulate's leader loop) has nothing to find there
         const int tiles_here = (int)min((int64_t)G, lay.ntiles - t0);
-        const bool distinct = total >= 60u * (uint32_t)tiles_here;
+        const bool distinct = total * 16u >= 15u * (uint32_t)((TS * NV) / lay.NS) * (uint32_t)tiles_here;      // >= 15/16 of a tile's entries per slice
         int ts = 0;
         auto fetch = [&](uint32_t c0, RawEntry<F, PACK> &raw) __attribute__((always_inline)) {
             const uint32_t i = c0 + lane;
