@@ -637,6 +637,13 @@ def run_rank(args):
 
     for _ in range(args.warmup):
         job.step()
+    # Graph capture is one-time set-up (an eager step that observes the sample count, then the capture): with fewer warm-up steps than that
+    # takes it would land inside the K timed steps.  Extra UNTIMED steps until a graph has replayed; reported as graphs.priming_steps.
+    priming = 0
+    if job.tracer.use_graphs and world == 1 and not args.pose_opt:
+        while priming < 4 and not ((job.graph_stats() or {}).get("replays", 0) > 0):
+            job.step()
+            priming += 1
     # The K timed steps.  With graphs on (default at N = 1) a step issues the ray march and two graph replays, so no per-kernel host
     # call exists to bracket with events: the roofline kernel's duration is then measured over K further EAGER steps right after the
     # timed region (same process, same inputs, HIP events on the launch stream around its C-ABI call).  With --graphs off the events
@@ -695,7 +702,7 @@ def run_rank(args):
                     hip_graphs=bool(graphs_on),
                     parallelism="ray-sharded data parallel x%d" % world),
         rccl_ranks_seen=ranks_seen, backend=backend, grad_sync=(args.grad_sync if world > 1 else None), roofline=roofline,
-        graphs=job.graph_stats())
+        graphs=(dict(job.graph_stats(), priming_steps=priming) if job.graph_stats() is not None else None))
 
     if not args.no_aux:
         # ---- per-entry-point device time: a separate, untimed pass with events around every C-ABI call
