@@ -224,6 +224,130 @@ __global__ __launch_bounds__(256) void voxel_march_kernel(MarchArgs a, int k, fl
     if (!PACK) counts[ray] = n * k;
 }
 
+// ---- the walk in two phases (pag_raymarch_voxel_count_nuggets).  voxel_march_kernel's loop carries two chains: the DDA state (a few fp32
+// adds and compares per step) and, behind every cell the coarse grid calls occupied, a dependent L2 read of the fine occupancy word - and a
+// wave of 64 rays pays that round trip in every step in which ANY of its rays needs it: 0.10 ms for 4096 rays on 64 waves, most of it waiting.
+// The occupancy does not steer the walk (it only decides what is emitted), so:
+//   phase 1 (voxel_walk_kernel)    one lane per ray, arithmetic only: every step with t_out > t_in is recorded as a candidate (t_in, t_out, cell)
+//                                  at [step][ray] of the nugget arrays (capacity 3R + 3 = the walk's iteration bound), candidates per ray -> counts;
+//   phase 2 (voxel_select_kernel)  one wave per ray, a lane per candidate: occupancy bit (an independent gather), the travel filter against the
+//                                  first kept candidate's depth, ordered in-place compaction (ballot prefix) -> the ray's nuggets and counts.
+// Same fp32 expressions on the same operands in the same order as voxel_march_kernel: identical nuggets (tests/test_gpu_edges.py, test_gpu_parity.py
+// compare both forms and the oracle).  The travel filter is monotone (depths grow along the ray), so "the first nugget that fails ends the walk"
+// and "drop every candidate that fails" select the same set.
+__global__ __launch_bounds__(64) void voxel_walk_kernel(MarchArgs a, int32_t *__restrict__ counts, float2 *__restrict__ cand_t,
+                                                        int32_t *__restrict__ cand_cell) {
+    const int R = 1 << a.level;
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= a.N) return;
+    const float cs = __fdiv_rn(2.0f, (float)R);
+    const float o[3] = {a.origins[ray * 3], a.origins[ray * 3 + 1], a.origins[ray * 3 + 2]};
+    const float d[3] = {a.dirs[ray * 3], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2]};
+    float t0 = a.dmin, t1 = a.dmax;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (d[ax] != 0.0f) {
+            const float ta = __fdiv_rn(__fsub_rn(-1.0f, o[ax]), d[ax]), tb = __fdiv_rn(__fsub_rn(1.0f, o[ax]), d[ax]);
+            const float lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+            t0 = t0 >= lo ? t0 : lo;
+            t1 = t1 <= hi ? t1 : hi;
+        } else if (o[ax] < -1.0f || o[ax] > 1.0f) {
+            t1 = -1.0f;
+        }
+    }
+    int n = 0;
+    if (t0 < t1) {
+        const float tm = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), 1e-6f));
+        int c0, c1, c2, s0 = 0, s1 = 0, s2 = 0;
+        float n0 = INFINITY, n1 = INFINITY, n2 = INFINITY, e0 = INFINITY, e1 = INFINITY, e2 = INFINITY;
+        auto setup = [&](int ax, int &c, int &st, float &tn, float &td) {
+            const float pa = __fadd_rn(__fmul_rn(d[ax], tm), o[ax]);
+            int ci = (int)floorf(__fdiv_rn(__fadd_rn(pa, 1.0f), cs));
+            c = min(max(ci, 0), R - 1);
+            if (d[ax] > 0.0f) {
+                st = 1;
+                tn = __fdiv_rn(__fsub_rn(__fadd_rn(-1.0f, __fmul_rn((float)(c + 1), cs)), o[ax]), d[ax]);
+                td = __fdiv_rn(cs, d[ax]);
+            } else if (d[ax] < 0.0f) {
+                st = -1;
+                tn = __fdiv_rn(__fsub_rn(__fadd_rn(-1.0f, __fmul_rn((float)c, cs)), o[ax]), d[ax]);
+                td = __fdiv_rn(cs, -d[ax]);
+            }
+        };
+        setup(0, c0, s0, n0, e0);
+        setup(1, c1, s1, n1, e1);
+        setup(2, c2, s2, n2, e2);
+        // straight-line step (selects instead of the three-way branch of voxel_march_kernel: a divergent branch costs the wave both sides and
+        // a dozen exec-mask instructions on the loop-carried path); a lane that has left the walk stays in the loop inactive
+        float t = t0;
+        bool active = true;
+        int64_t off = ray;                    // [n][ray]
+        for (int it = 0; it < 3 * R + 3; ++it) {
+            const bool a0 = n0 <= n1 && n0 <= n2, a1 = !a0 && n1 <= n2, a2 = !a0 && !a1;
+            const float tn = a0 ? n0 : (a1 ? n1 : n2);
+            const float tout = tn <= t1 ? tn : t1;
+            const bool rec = active && tout > t;
+            if (rec) {
+                cand_t[off] = float2{t, tout};
+                cand_cell[off] = (c0 * R + c1) * R + c2;
+            }
+            off += rec ? a.N : 0;
+            n += rec ? 1 : 0;
+            const bool last = tout >= t1;
+            t = tout;
+            c0 += a0 ? s0 : 0;
+            c1 += a1 ? s1 : 0;
+            c2 += a2 ? s2 : 0;
+            const float m0 = __fadd_rn(n0, e0), m1 = __fadd_rn(n1, e1), m2 = __fadd_rn(n2, e2);
+            n0 = a0 ? m0 : n0;
+            n1 = a1 ? m1 : n1;
+            n2 = a2 ? m2 : n2;
+            const int cm = a0 ? c0 : (a1 ? c1 : c2);
+            active = active && !last && (unsigned)cm < (unsigned)R;
+            if (__ballot(active) == 0ull) break;
+        }
+    }
+    counts[ray] = n;
+}
+
+__global__ __launch_bounds__(256) void voxel_select_kernel(const uint32_t *__restrict__ occ, int64_t N, int k, float max_travel, int32_t *counts,
+                                                           float2 *nug_t, int32_t *nug_cell) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= N) return;
+    const int ncand = counts[ray];
+    const float fr0 = __fdiv_rn(0.5f, (float)k);
+    float first = 0.0f;
+    bool have_first = false;
+    int n = 0;
+    for (int j0 = 0; j0 < ncand; j0 += 64) {
+        const int j = j0 + lane;
+        float2 tt = float2{0.0f, 0.0f};
+        int32_t cell = 0;
+        bool keep = false;
+        if (j < ncand) {
+            tt = nug_t[(int64_t)j * N + ray];
+            cell = nug_cell[(int64_t)j * N + ray];
+            keep = occ ? ((occ[cell >> 5] >> (cell & 31)) & 1u) : true;
+        }
+        const float dep0 = __fadd_rn(tt.x, __fmul_rn(__fsub_rn(tt.y, tt.x), fr0));
+        unsigned long long m = __ballot(keep);
+        if (!have_first && m) {             // depth of the ray's first sample = first kept candidate (wave-uniform)
+            first = __shfl(dep0, __ffsll((long long)m) - 1);
+            have_first = true;
+        }
+        keep = keep && (__fsub_rn(dep0, first) < max_travel);
+        m = __ballot(keep);
+        if (keep) {                          // in place: the target index never exceeds the candidate's own, and this chunk is already in registers
+            const int dst = n + __popcll(m & ((1ull << lane) - 1ull));
+            nug_t[(int64_t)dst * N + ray] = tt;
+            nug_cell[(int64_t)dst * N + ray] = cell;
+        }
+        n += __popcll(m);
+    }
+    if (lane == 0) counts[ray] = n * k;
+}
+
 // The packed outputs of a ray from the nuggets its (single) walk recorded: one wave per ray, a lane per nugget - the second sequential walk of
 // voxel_march_kernel<true> (0.12 ms for 4096 rays: 64 waves on the whole chip, every step a dependent occupancy read) becomes a parallel
 // copy.  Same fp32 expressions on the same (t_in, t_out) -> the same bits.
@@ -835,10 +959,18 @@ extern "C" int pag_raymarch_voxel_count_nuggets(const float *origins, const floa
     if (N == 0) return PAG_OK;
     PAG_CHECK_ARG(origins && dirs && counts && nugget_t && nugget_cell, "pag_raymarch_voxel_count_nuggets: NULL input/output");
     MarchArgs a{origins, dirs, nullptr, nullptr, occupancy_bits, N, 0, blas_level, dist_min, dist_max};
+#ifdef PAG_VOXEL_ONE_PHASE      // the single sequential walk (kept for A/B measurements)
     const size_t lds = occupancy_coarse ? voxel_coarse_lds(blas_level) : 0;
     hipLaunchKernelGGL((voxel_march_kernel<false>), dim3((unsigned)((N + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a, samples_per_voxel,
                        max_travel, occupancy_coarse, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                        reinterpret_cast<float2 *>(nugget_t), nugget_cell);
+#else
+    (void)occupancy_coarse;      // the walk no longer reads the occupancy: the coarse grid has nothing to shortcut
+    hipLaunchKernelGGL(voxel_walk_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a, counts,
+                       reinterpret_cast<float2 *>(nugget_t), nugget_cell);
+    hipLaunchKernelGGL(voxel_select_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, occupancy_bits, N, samples_per_voxel,
+                       max_travel, counts, reinterpret_cast<float2 *>(nugget_t), nugget_cell);
+#endif
     PAG_CHECK_LAUNCH("pag_raymarch_voxel_count_nuggets");
     return PAG_OK;
 }
