@@ -71,12 +71,24 @@ class _GraphedFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         r = ctx.runner
-        for static, g in zip(r.gouts, grads):
-            if static is not None:
-                if g is None:
-                    static.zero_()
-                elif static.data_ptr() != g.data_ptr():
-                    static.copy_(g)
+        # upstream gradients -> the backward graph's static inputs: ONE multi-tensor copy (they were five ~3 us launches in a 1.4 ms step);
+        # an output the loss does not use arrives as None: its static gradient is zeroed once and stays zero (the graph only reads it)
+        dst, src, zero = [], [], []
+        for i, (static, g) in enumerate(zip(r.gouts, grads)):
+            if static is None:
+                continue
+            if g is None:
+                if i not in r.zeroed:
+                    zero.append(static)
+                    r.zeroed.add(i)
+            elif static.data_ptr() != g.data_ptr():
+                dst.append(static)
+                src.append(g if (g.dtype == static.dtype and g.shape == static.shape) else g.to(static.dtype).reshape(static.shape))
+                r.zeroed.discard(i)
+        if zero:
+            torch._foreach_zero_(zero)
+        if dst:
+            torch._foreach_copy_(dst, src)
         r.bwd.replay()
         return (None,) + tuple(g.detach() if g is not None else None for g in r.gins)
 
@@ -118,6 +130,7 @@ class _Graphed:
         with torch.cuda.graph(self.fwd, pool=pool):
             self.outs, req = run()
         self.gouts = [torch.zeros_like(o) if o.requires_grad else None for o in self.outs]
+        self.zeroed = set()             # indices of gouts known to hold zeros (set by _GraphedFn.backward)
         with torch.cuda.graph(self.bwd, pool=pool):
             self.gins = torch.autograd.grad(req, leaves, [g for g in self.gouts if g is not None], allow_unused=True)
         torch.cuda.synchronize()

@@ -1,5 +1,6 @@
 """Print the kernel sequence of the LAST training step of a rocprofv3 --kernel-trace csv (start-ordered, with the idle gap before
-each launch).  usage: python3 scripts/step_timeline.py <kernel_trace.csv> [marker-substring]   (default marker: the fused Adam)"""
+each launch).  usage: python3 scripts/step_timeline.py <kernel_trace.csv> [marker-substring] [steps-back]   (default marker: the fused Adam;
+steps-back k: the step k before the last one - bench.py ends with K eager steps for the roofline kernel, the graph-replayed ones come before them)"""
 import csv
 import sys
 
@@ -9,7 +10,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ends = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 # a step ends with the last optimizer launch of a burst
 bursts = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] - i > 8]
-lo, hi = bursts[-2] + 1, bursts[-1] + 1
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+lo, hi = bursts[-2 - back] + 1, bursts[-1 - back] + 1
 prev_end = int(rows[lo - 1]["End_Timestamp"])
 t0 = int(rows[lo]["Start_Timestamp"])
 busy = 0
