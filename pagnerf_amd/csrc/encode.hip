@@ -461,12 +461,17 @@ __device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
     return v;
 }
 template <int F>
-__device__ __forceinline__ void run_combine(uint32_t key, bool live, float (&v)[F], bool &emit, int lane) {
+// pair = this lane and its predecessor both carry an entry (live && lane > 0; consecutive lanes are consecutive samples, so a live lane's
+// predecessor is live), pairmask = its ballot: hoisted by the caller.  The ballot of the bare compare is the compare's own result
+// register; the ballot of a conjunction costs a select and a second compare.
+__device__ __forceinline__ void run_combine(uint32_t key, bool pair, unsigned long long pairmask, bool live, float (&v)[F], bool &emit, int lane) {
     const uint32_t prev = (uint32_t)dpp_i<0x138, 0xF>((int)key);             // wave_shr:1
-    const bool same = live && lane > 0 && prev == key;
-    const unsigned long long m = __ballot(same);
+    const bool eq = prev == key;
+    const unsigned long long m = __ballot(eq) & pairmask;
+    const bool same = eq && pair;
     emit = live;
-    if (__popcll(m) < 8) return;
+    // 32-bit counts: the scalar unit has no ordered 64-bit compare, and a 64-bit popcount compare ends up on the vector unit
+    if (__builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32)) < 8) return;
 #ifdef PAG_BIN_FAKE_COMBINE
     {
         const bool ns = (m >> ((lane + 1) & 63)) & 1ull;
@@ -605,6 +610,8 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
             mb = wave_max_to_lane63(mb);
             if (lane == 63 && mb) atomicMax(&cnt[j][NS_MAX + 1], mb);    // LDS, one per wave
         }
+        const bool pair_l = live && lv && lane > 0;
+        const unsigned long long pair_m = __ballot(pair_l);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
 #ifdef PAG_BIN_NO_COMBINE
             emit[j][k] = lk;
 #else
-            run_combine<F>(lk ? idx[j][k] : 0xFFFFFFFFu, lk, ev[j][k], emit[j][k], lane);
+            run_combine<F>(idx[j][k], pair_l, pair_m, lk, ev[j][k], emit[j][k], lane);
 #endif
             if (emit[j][k]) rank[j][k] = atomicAdd(&cnt[j][idx[j][k] >> lay.shift], 1u);      // read only where emit is set
         }
