@@ -205,7 +205,8 @@ typedef struct pag_mlp_bwd_args {
     int x1_layout; int x1_levels; int x1_feats;   /* as in pag_mlp_fwd_args: dx1 is then written as bf16 [8][M][8] */
     const float *W[3];
     const void *hidden_save[2];
-    void *dz[3];
+    void *dz[3];          /* with wgrad_workspace (fused weight gradients) no dz tensor is written - except dz[0] (bf16 [M,64], optional) by the
+                           * colour-like kernel: the caller sums it per ray for the gradient of the per-ray input x2 (pose optimisation) */
     void *dx1; int dx1_dtype;
     int mode;
     /* Optional rank-1 upstream gradient (MFMA mode): grad_out[m][c] = g_scale[m] * g_ray[g_index[m]][c] with

@@ -1479,7 +1479,9 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
 //   KIND 2  semantic-like: XCD8 bf16 input, rank-1 gradient, softmax with saved bf16 probabilities (out_dim <= 8), XCD8 bf16 dx
 //                          (DXACC: added to the other head's gradient in place)
 // Full 32-sample tiles run in the main loop; a ragged last tile runs once after it with predicated stores.
-template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */>
+// DZ0: also write dz_0 (the gradient at the first hidden layer's pre-activation) as a bf16 [M,64] tensor (p.dz[0]) - what the caller sums per ray
+// and multiplies by W_0[:, k1:] for the gradient of the per-ray x2 (the view embedding: pose optimisation, pc_nerf/ba_pipeline.py:89-90).
+template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */, bool DZ0 = false>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     static_assert(OBL == 1 || KIND == 0, "a 64-wide output layer exists for the dense-gradient form only");
     constexpr bool GRP = KIND != 1;
@@ -1514,6 +1516,23 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     const int64_t tile_step = (int64_t)gridDim.x * 4;
     const bf16_t *x1b = reinterpret_cast<const bf16_t *>(p.x1);
     const int32_t *ridx = KIND == 1 ? p.x2_index : p.g_index;      // per-sample row of the per-ray tables
+    const auto rs_dz0 = __builtin_amdgcn_make_buffer_rsrc(DZ0 ? p.dz[0] : nullptr, 0, (int)(DZ0 ? M * HID * 2 : 0), 0x00020000);
+    // the masked dz_0 of the tile sits in the Tz image (row = sample, 4-unit chunks in natural order): whole rows leave as 16-byte pieces;
+    // rows past M fall outside the buffer's bounds and are dropped
+    auto store_dz0 = [&](int64_t tile) __attribute__((always_inline)) {
+        if constexpr (DZ0) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned voff = (unsigned)(tile * (32 * HID * 2)) + (unsigned)((lane >> 3) * (HID * 2) + (lane & 7) * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rowl = k * 8 + (lane >> 3), ch = (lane & 7) * 2;
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(Tz + tw_off(rowl, ch));
+                const u32x2 hi = *reinterpret_cast<const u32x2 *>(Tz + tw_off(rowl, ch + 1));
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, rs_dz0, voff + k * (8 * HID * 2), 0, 0);
+            }
+        }
+    };
 
     // ---- registers of the NEXT tile (requested one tile ahead; the per-ray row index two tiles ahead)
     bf16x8 xn[4];
@@ -1748,6 +1767,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
         }
+        store_dz0(tile);
         // ---- dx1 = (W_0^T . dz_0)[0:k1], then layer 0's weight gradient
         wt_chain_pinned<(GRP ? 2 : 1), 4>(W0t, RS, hb, r, h, acc);
         wgrad_tile(Tx, aw0, -1);
@@ -3894,7 +3914,19 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         hipLaunchKernelGGL((mlp_bwd_fused<NL_, KIND_, ACC_>), dim3(grid), dim3(256), lds, st, p);                                     \
     } while (0)
         const bool acc = a->dx1_accumulate != 0;
-        if (a->n_layers == 2) {
+        p.dz[0] = kind == 1 ? a->dz[0] : nullptr;
+        if (kind == 1 && a->dz[0]) {      // colour-like with the per-ray input's gradient requested: dz_0 is written as well
+            static bool attr2 = false, attr3 = false;
+            if (a->n_layers == 2) {
+                if (!attr2) hipFuncSetAttribute((const void *)mlp_bwd_fused<2, 1, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2 = true;
+                hipLaunchKernelGGL((mlp_bwd_fused<2, 1, false, 1, true>), dim3(grid), dim3(256), lds, st, p);
+            } else {
+                if (!attr3) hipFuncSetAttribute((const void *)mlp_bwd_fused<3, 1, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr3 = true;
+                hipLaunchKernelGGL((mlp_bwd_fused<3, 1, false, 1, true>), dim3(grid), dim3(256), lds, st, p);
+            }
+        } else if (a->n_layers == 2) {
             if (kind == 0) MLP_BWD_FUSED(2, 0, false);
             else if (kind == 1) MLP_BWD_FUSED(2, 1, false);
             else if (acc) MLP_BWD_FUSED(2, 2, true);

@@ -287,7 +287,9 @@ def _recompute_ok(ctx, x1, x2, k1, in_dim, n_layers, out_dim, mode, grouped, sta
     checked here (batch bound, layout, widths, output activation / dtype per kernel kind, whether the upstream gradient will be dense or
     rank-1); a mismatch that still slips through (e.g. a _ColourDensity backward that receives no sigma gradient) takes
     _recompute_hidden(), which is correct but costs a second forward - it warns once."""
-    if not WGRAD_FUSED or mode != L.MLP_MFMA_BF16 or x1.dtype != torch.bfloat16 or not ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+    if not WGRAD_FUSED or mode != L.MLP_MFMA_BF16 or x1.dtype != torch.bfloat16 or not ctx.needs_input_grad[0]:
+        return False
+    if ctx.needs_input_grad[1] and grouped is not None:       # only the colour-like kernel hands out dz_0 for the per-ray input's gradient
         return False
     if not (0 < M <= L.MLP_FUSED_WIDE_MAX_M) or n_layers not in (2, 3):
         return False
@@ -495,11 +497,16 @@ class _FusedMLP(torch.autograd.Function):
         # kernel for this decoder shape: no dz tensors, no second pass over the activations.  d x2 (pose optimisation) is formed
         # from dz_0, so that case keeps the dz tensors and the separate weight-gradient launches.
         fused = False
-        if WGRAD_FUSED and 0 < M <= L.MLP_FUSED_WIDE_MAX_M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 and not need_dx2:
+        dz0_fused = None
+        if WGRAD_FUSED and 0 < M <= L.MLP_FUSED_WIDE_MAX_M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 \
+                and (not need_dx2 or grouped is None):
             a.x1, a.x1_dtype = L.ptr(x1), L.BF16
             if x2 is not None:
                 a.x2, a.k2p, a.x2_index = L.ptr(x2), k2p, L.ptr(x2_index)
             fused = lib.pag_mlp_bwd_fused_supported(ctypes.byref(a)) == 1
+            if fused and need_dx2:        # colour-like kernel: dz_0 comes out as a tensor too (pag_mlp_bwd_args.dz[0]), d x2 is formed from it below
+                dz0_fused = torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
+                a.dz[0] = L.ptr(dz0_fused)
         if not fused and any(h is None for h in hidden):      # the forward counted on the fused kernels: rebuild what it skipped
             hidden = _recompute_hidden(x1, x2, x2_index, Wc, bc, in_dim, k1, grouped, mode, hidden)
         for i, h in enumerate(hidden):
@@ -569,6 +576,8 @@ class _FusedMLP(torch.autograd.Function):
                 gW.append(w)
                 gb.append(z.sum(0, dtype=torch.float32))
         dx2 = None
+        if need_dx2 and dz0_fused is not None:
+            dz = [dz0_fused]
         if need_dx2:
             # d x2[r] = (sum of dz_0 over the samples that gathered row r) @ W_0[:, k1:]  - the per-ray view embedding's
             # gradient (pose optimisation: the view direction depends on the camera rotation, ba_pipeline.py:89-90)

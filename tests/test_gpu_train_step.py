@@ -323,3 +323,73 @@ def test_extra_channel_keeps_the_gradient_of_the_compositing_weights(gpu_device,
             assert float((got - want).abs().max()) / (float(want.abs().max()) + 1e-20) < 2e-3, name
         else:
             assert T._rel_l2(got, want) < 4e-2, (name, T._rel_l2(got, want))
+
+
+@pytest.mark.gpu
+def test_colour_decoder_view_embedding_gradient_fused_vs_unfused(gpu_device):
+    """Pose optimisation: the colour decoder's per-ray input (the view embedding) needs a gradient.  The fused backward kernel then also writes
+    dz_0 (pag_mlp_bwd_args.dz[0]) and d x2 = (per-ray sum of dz_0) @ W_0[:, 16:] is formed from it - against the unfused path (dz tensors +
+    separate weight-gradient launches, ops.WGRAD_FUSED = False): same dz_0 arithmetic, so d x2 / d x1 / dW agree to bf16 rounding of the
+    different summation orders, and against fp32 torch on the bf16-rounded operands."""
+    from pagnerf_amd import ops
+    L = ops.L
+    dev = gpu_device
+    gen = torch.Generator().manual_seed(23)
+    N, per = 300, 37                      # ragged: the last 32-sample tile is partial, tiles span up to two rays
+    M = N * per - 11
+    ridx = torch.arange(N).repeat_interleave(per)[:M].int().to(dev)
+    counts = torch.bincount(ridx.long(), minlength=N)
+    pack_start = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts.cumsum(0)]).contiguous()
+    ray_of_pack = torch.arange(N, dtype=torch.int32, device=dev)
+    Ws = [(torch.randn(64, 43, generator=gen) * 0.3), (torch.randn(64, 64, generator=gen) * 0.2), (torch.randn(3, 64, generator=gen) * 0.3)]
+    bs = [torch.randn(64, generator=gen) * 0.1, torch.randn(64, generator=gen) * 0.1, torch.randn(3, generator=gen) * 0.1]
+    x1_0 = (torch.randn(M, 16, generator=gen)).bfloat16()
+    x2_0 = torch.randn(N, 32, generator=gen)
+    x2_0[:, 27:] = 0.0
+    g_rgb = torch.randn(M, 3, generator=gen).to(dev)
+    g_sig = torch.randn(M, generator=gen).to(dev)
+    res = {}
+    launched = []
+    real_call = ops._call
+
+    def spy(name, *args):
+        launched.append(name)
+        return real_call(name, *args)
+    for fusedflag in (True, False):
+        ops.WGRAD_FUSED = fusedflag
+        ops._call = spy
+        del launched[:]
+        try:
+            x1 = x1_0.to(dev).requires_grad_(True)
+            x2 = x2_0.to(dev).requires_grad_(True)
+            W = [w.to(dev).requires_grad_(True) for w in Ws]
+            b = [v.to(dev).requires_grad_(True) for v in bs]
+            rgb, sigma = ops.colour_and_density(x1, W, b, x2, ridx, 43, out_act=L.ACT_SIGMOID, mode=L.MLP_MFMA_BF16,
+                                                x2_packs=(pack_start, ray_of_pack))
+            ((rgb * g_rgb).sum() + (sigma * g_sig).sum()).backward()
+            res[fusedflag] = dict(rgb=rgb.detach().float().cpu(), x1=x1.grad.float().cpu(), x2=x2.grad.float().cpu(),
+                                  W=[w.grad.float().cpu() for w in W], b=[v.grad.float().cpu() for v in b])
+            # the fused form: one backward launch, no separate weight-gradient launches; the unfused form needs them
+            assert ("pag_mlp_wgrad_batch" in launched) == (not fusedflag), launched
+        finally:
+            ops.WGRAD_FUSED = True
+            ops._call = real_call
+    a, c = res[True], res[False]
+    assert torch.equal(a["rgb"], c["rgb"])
+    assert float(a["x2"][:, 27:].abs().max()) == 0.0 and float(a["x2"].abs().max()) > 0
+    for k in ("x1", "x2"):
+        assert T._rel_l2(a[k], c[k]) < 1e-2, (k, T._rel_l2(a[k], c[k]))
+    for l in range(3):
+        assert T._rel_l2(a["W"][l], c["W"][l]) < 1e-2 and T._rel_l2(a["b"][l], c["b"][l]) < 1e-2, l
+    # fp32 torch on the bf16-rounded operands
+    r16 = lambda t: t.bfloat16().float()
+    x1r = x1_0.float().requires_grad_(True)
+    x2r = x2_0.clone().requires_grad_(True)
+    Wr = [r16(w).requires_grad_(True) for w in Ws]
+    xin = torch.cat([x1r, r16(x2r)[ridx.long().cpu()][:, :27]], 1)
+    h0 = torch.relu(xin @ Wr[0].t() + bs[0])
+    h1 = torch.relu(r16(h0) @ Wr[1].t() + bs[1])
+    out = torch.sigmoid(r16(h1) @ Wr[2].t() + bs[2])
+    ((out * g_rgb.cpu()).sum() + (torch.relu(x1r[:, 0]) * g_sig.cpu()).sum()).backward()
+    assert T._rel_l2(a["x2"][:, :27], x2r.grad[:, :27]) < 3e-2, T._rel_l2(a["x2"][:, :27], x2r.grad[:, :27])
+    assert T._rel_l2(a["x1"], x1r.grad) < 3e-2
