@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 6
+#define PAG_ABI_VERSION 7
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -458,6 +458,12 @@ int pag_composite_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int
                       const float *rgb, int bg_color, const float *weights,
                       const float *out_alpha, const float *g_rgb, const float *g_depth,
                       const float *g_alpha, float *d_sigma, float *d_rgb, void *stream);
+
+/* Pose optimisation (pc_nerf/ba_pipeline.py:85-92): gradients of samples[m] = origins[ray] + dirs[ray] * depths[m] with respect to the rays -
+ * out f32 [N,6], row r = (sum of grad_samples over ray r's pack | sum of grad_samples * depth); rows of rays without a pack are NOT written
+ * (the caller zero-fills when packs do not cover every ray).  One pass over grad_samples f32 [M,3] and depths f32 [M].  (ABI 7) */
+int pag_ray_sample_grad(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *grad_samples, const float *depths,
+                        float *out, void *stream);
 
 /* Per-ray weighted feature sums (tracer :197-205): out[ray, c] = alpha[ray] * sum_i w_i f[i, c].
  *   feats [M,C] row-major (feat_dtype F32 or BF16); out f32 [N,C] (rows of rays with a pack) */

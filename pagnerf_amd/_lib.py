@@ -16,7 +16,7 @@ MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
 LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
 ENC_HALF_COORDS = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 MLP_FUSED_WIDE_MAX_M = 1 << 24      # PAG_MLP_FUSED_WIDE_MAX_M
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -107,6 +107,7 @@ _SIGS = {
     "pag_raymarch_voxel_nugget_capacity": (c_i64, [c_i32]),
     "pag_raymarch_voxel_count_nuggets": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "pag_raymarch_voxel_pack_nuggets": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_ray_sample_grad": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "pag_affine_xcd8_fwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "pag_affine_xcd8_bwd_dx": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "pag_occupancy_coarse_bytes": (c_i64, [c_i32]),

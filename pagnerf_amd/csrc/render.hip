@@ -856,6 +856,45 @@ extern "C" int pag_composite_bwd(const int64_t *pack_start, const int32_t *ray_o
     return PAG_OK;
 }
 
+// d loss / d origins and d loss / d dirs of samples = origins[ray] + dirs[ray] * depth (pose optimisation, pc_nerf/ba_pipeline.py:85-92 through wisp's
+// addcmul): per-ray sums of g and g * depth over the ray's pack.  One wave per pack, one pass over g [M,3] and depths [M] - the tensor-op form
+// wrote a [M,6] concatenation, a weights-of-ones vector and ran the generic feature compositing on them.
+__global__ __launch_bounds__(256) void ray_sample_grad_kernel(const int64_t *__restrict__ pack_start, const int32_t *__restrict__ ray_of_pack, int64_t P,
+                                                              const float *__restrict__ g, const float *__restrict__ depths, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pk >= P) return;
+    const int64_t beg = pack_start[pk], end = pack_start[pk + 1];
+    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t i = beg + lane; i < end; i += 64) {
+        const float dep = depths[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = g[i * 3 + c];
+            a[c] += v;
+            a[3 + c] += v * dep;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a[c] = wave_sum(a[c]);
+    if (lane == 0) {
+        float *o = out + (int64_t)ray_of_pack[pk] * 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) o[c] = a[c];
+    }
+}
+
+extern "C" int pag_ray_sample_grad(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *grad_samples, const float *depths,
+                                   float *out, void *stream) {
+    PAG_CHECK_ARG(P >= 0, "pag_ray_sample_grad: P < 0");
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(pack_start && ray_of_pack && grad_samples && depths && out, "pag_ray_sample_grad: NULL input/output");
+    hipLaunchKernelGGL(ray_sample_grad_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pack_start, ray_of_pack, P, grad_samples,
+                       depths, out);
+    PAG_CHECK_LAUNCH("pag_ray_sample_grad");
+    return PAG_OK;
+}
+
 extern "C" int pag_composite_feats_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *weights,
                                        const float *alpha, const void *feats, int feat_dtype, int C, float *out, void *stream) {
     PAG_CHECK_ARG(P >= 0, "pag_composite_feats_fwd: P < 0");

@@ -867,10 +867,15 @@ class _RaySamples(torch.autograd.Function):
     def backward(ctx, g):
         depths, pack_start, ray_of_pack = ctx.saved_tensors
         N = ctx.N
-        g = g.reshape(-1, 3).float()
-        M = g.shape[0]
-        both = torch.cat([g, g * depths.reshape(-1, 1)], dim=1).contiguous()           # [M,6]: d/d origin | d/d dir
-        seg = composite_feats(both, torch.ones(M, device=g.device), torch.ones(N, device=g.device), pack_start, ray_of_pack, N)
+        g = g.reshape(-1, 3).float().contiguous()
+        P = ray_of_pack.shape[0]
+        # [N,6]: d/d origin | d/d dir, one launch (pag_ray_sample_grad); every ray has a pack on the one-pack-per-ray layout
+        seg = (torch.empty if (P and _one_pack_per_ray(ray_of_pack, N)) else torch.zeros)(N, 6, device=g.device)
+        if P and g.shape[0]:
+            _call("pag_ray_sample_grad", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(g), L.ptr(depths.reshape(-1).float().contiguous()),
+                  L.ptr(seg), L.stream())
+        elif P:
+            seg.zero_()
         return seg[:, :3], seg[:, 3:], None, None, None, None
 
 

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_argument_validation_without_gpu(lib):
