@@ -150,9 +150,23 @@ class _State:
 class GraphRunner:
     """Per-tracer cache of march buffers and captured graphs, keyed by everything that is baked into a capture."""
 
+    MAX_STATES = 4      # configurations (key below) kept alive at once: each owns march buffers and graphs worth GBs at full size
+
     def __init__(self):
-        self.states = {}
+        self.states = collections.OrderedDict()
         self.replays = self.captures = self.overflows = 0
+
+    def _state(self, key):
+        """The state of `key`, most recently used last; the least recently used configuration is dropped (buffers, graphs and their
+        memory pool) when a new one would exceed MAX_STATES - e.g. after the tables were replaced or the optimiser re-created the leaves."""
+        st = self.states.get(key)
+        if st is None:
+            while len(self.states) >= self.MAX_STATES:
+                self.states.popitem(last=False)
+            st = self.states[key] = _State()
+        else:
+            self.states.move_to_end(key)
+        return st
 
     @staticmethod
     def eligible(tracer, nef, channels, extra_channels, rays, stage):
@@ -176,12 +190,12 @@ class GraphRunner:
 
     def observe(self, key, count):
         """An eager step of this configuration saw `count` samples: the first capacities are chosen from it."""
-        self.states.setdefault(key, _State()).counts.append(int(count))
+        self._state(key).counts.append(int(count))
 
     def run(self, tracer, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage, jitter):
         """-> (RenderBuffer | None, key, jitter used).  None: take the eager path (and call observe(key, M) afterwards)."""
         key = self._key(tracer, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage)
-        st = self.states.setdefault(key, _State())
+        st = self._state(key)
         if not st.counts:
             return None, key, jitter
         g = nef.grid

@@ -105,3 +105,33 @@ def test_graph_training_tracks_eager_training(gpu_device):
         if use:
             assert tr._graphs.replays >= 15, (tr._graphs.replays, tr._graphs.captures, tr._graphs.overflows)
     np.testing.assert_allclose(losses[True], losses[False], rtol=2e-3)
+
+
+def test_graph_states_are_bounded(gpu_device):
+    """Every configuration (channel set, precision, tables, ...) owns march buffers and two graphs; a runner keeps at most MAX_STATES of
+    them and drops the least recently used - a long training that changes configuration now and then must not accumulate captures."""
+    import pagnerf_amd
+    from pagnerf_amd.graphs import GraphRunner
+    dev = gpu_device
+    nef, _, rays, occ, jitter = T._make_scene(dev, "bf16", N=64, S=16, cap_log2=10)
+    nef.train()
+    tr = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=16, bg_color="white", use_graphs=True)
+    sets = [{"rgb"}, {"rgb", "depth"}, {"rgb", "semantics"}, {"rgb", "inst_embedding"}, {"rgb", "depth", "semantics"},
+            {"rgb", "depth", "semantics", "inst_embedding"}]
+    for ch in sets:
+        for _ in range(3):          # eager (observes the count), capture, replay
+            rb = tr(nef, channels=ch, rays=rays, stage="train")
+            rb.rgb.sum().backward()
+    g = tr._graphs
+    assert g.captures == len(sets) and len(g.states) == GraphRunner.MAX_STATES
+    # the oldest configuration was evicted: it is observed and captured again, results as the eager path gives them
+    before = g.captures
+    for _ in range(3):
+        rb = tr(nef, channels=sets[0], rays=rays, stage="train")
+    assert g.captures == before + 1 and len(g.states) == GraphRunner.MAX_STATES
+    eager = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=16, bg_color="white")
+    torch.manual_seed(1)
+    j = torch.rand(64, 16, device=dev)
+    a = tr(nef, channels=sets[0], rays=rays, stage="train", jitter=j).rgb
+    b = eager(nef, channels=sets[0], rays=rays, stage="train", jitter=j).rgb
+    assert torch.equal(a, b)
