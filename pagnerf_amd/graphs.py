@@ -62,6 +62,7 @@ class _GraphedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, *params):
         ctx.runner = runner
+        ctx.set_materialize_grads(False)      # outputs the loss does not use arrive as None in backward(), not as zero tensors filled per step
         runner.fwd.replay()
         outs = tuple(o.detach() for o in runner.outs)
         ctx.mark_non_differentiable(*[o for o, s in zip(outs, runner.outs) if not s.requires_grad])
