@@ -68,8 +68,9 @@ def parse(argv=None):
     ap.add_argument("--sustain-steps", type=int, default=300, help="extra timed region after the K steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the rgb-only / sustained / configs / strong measurements")
-    ap.add_argument("--graphs", default="on", choices=["on", "off"],
-                    help="PanopticPackedRFTracer(use_graphs=...): replay the post-march part of the step as HIP graphs (N = 1, no pose-opt)")
+    ap.add_argument("--graphs", default="on", choices=["on", "off", "static"],
+                    help="PanopticPackedRFTracer(use_graphs=...): on = replay the post-march part of the step as HIP graphs (N = 1, no pose-opt; at N > 1 "
+                         "the tracer takes the 'static' form); static = static padded buffers + optimistic count check with eager launches; off = eager")
     ap.add_argument("--grad-sync", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1: table gradients as RCCL fp32 all-reduce (default) or bf16 messages with fp32 accumulation (shard._DirectReduce)")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: process group, shard collectives, timing and JSON plumbing only")
@@ -142,7 +143,10 @@ def make_model(args, dev, seed, grid=None, num_lods=None, log2T=None, finest=Non
 def make_tracer(args, raymarch=None, samples=None):
     import pagnerf_amd
     rm = raymarch or args.raymarch
-    g = args.graphs == "on"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # at N > 1 the backward stays an ordinary autograd pass (shard.GradSync's early all-reduce hangs on gradient hooks): the static-buffer
+    # eager form keeps the graph path's other gain - the host never waits for the sample count
+    g = {"on": (True if world == 1 else "static"), "static": "static", "off": False}[args.graphs]
     if rm == "voxel":            # after trainer.py:362-366: 2 samples per intersected occupied voxel (best.yaml:31), ray_max_travel 6 x scale
         return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="voxel", num_steps=2, bg_color="white", ray_max_travel=6.0, use_graphs=g)
     return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=samples or args.samples, bg_color="white", use_graphs=g)
@@ -699,7 +703,7 @@ def run_rank(args):
                               ", RCCL grad all-reduce" if world > 1 else ""),
                     rays_per_gpu=args.rays, samples_per_ray=args.samples, grid=args.grid, channels=sorted(channels),
                     raymarch=args.raymarch, half_coords=(args.grid == "permuto" and not args.fp32_coords), table_dtype=args.table_dtype,
-                    hip_graphs=bool(graphs_on),
+                    hip_graphs=bool(graphs_on and job.tracer.use_graphs is True), static_buffers=bool(job.tracer.use_graphs == "static"),
                     parallelism="ray-sharded data parallel x%d" % world),
         rccl_ranks_seen=ranks_seen, backend=backend, grad_sync=(args.grad_sync if world > 1 else None), roofline=roofline,
         graphs=(dict(job.graph_stats(), priming_steps=priming) if job.graph_stats() is not None else None))

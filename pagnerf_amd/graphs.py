@@ -177,8 +177,9 @@ class GraphRunner:
             return False
         if not getattr(nef, "accepts_ray_index", False) or not getattr(nef.grid, "accepts_max_travel", False):
             return False
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            return False
+        if tracer.use_graphs != "static" and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            return False            # captured backward: the gradient hooks of shard.GradSync would all fire after the whole graph (no overlap)
         return True
 
     def _key(self, tracer, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage):
@@ -223,6 +224,25 @@ class GraphRunner:
         if st.dirs.data_ptr() != rays.dirs.data_ptr():
             st.dirs.copy_(rays.dirs)
         args = (buf.samples[:cap], buf.depths[:cap], buf.deltas[:cap], st.dirs)
+        if tracer.use_graphs == "static":
+            # same static, padded buffers and optimistic count check - but the post-march part runs as ordinary eager launches: what the graph
+            # path gains by never waiting for the sample count (the host runs ahead of the device) without a capture, for callers whose
+            # backward must stay an ordinary autograd pass (gradient hooks: the early all-reduce of shard.GradSync at N > 1)
+            mod = st.buckets.get(("static", cap))
+            if mod is None:
+                mod = st.buckets[("static", cap)] = _PostMarch(nef, tracer, buf, cap, channels, lod_idx, bg_color, stage)
+            ops.SAMPLES_HINT, ops.TAIL_ZERO = max(st.counts), True
+            try:
+                outs = mod(*args)
+            finally:
+                ops.SAMPLES_HINT, ops.TAIL_ZERO = None, False
+            self.replays += 1
+            M = self._count(mailbox, buf)
+            st.counts.append(M)
+            if M > cap:
+                self.overflows += 1
+                return None, key, jitter
+            return RenderBuffer(**dict(zip(mod.names, outs))), key, jitter
         graphed = st.buckets.get(cap)
         if graphed is None:
             # the count must be known to be <= cap before the capture's warm-up runs shade() on these buffers for real

@@ -28,7 +28,11 @@ class PanopticPackedRFTracer(nn.Module):
         Same channels, same values; what changes is that the host neither waits for the sample count nor issues ~35 launches per step."""
         super().__init__()
         import os
-        self.use_graphs = bool(int(os.environ.get("PAG_GRAPHS", "0"))) if use_graphs is None else bool(use_graphs)
+        if use_graphs is None:
+            use_graphs = os.environ.get("PAG_GRAPHS", "0")
+            use_graphs = "static" if use_graphs == "static" else bool(int(use_graphs))
+        # True: HIP graphs; "static": the graph path's static padded buffers and optimistic sample-count check with eager launches (no capture)
+        self.use_graphs = "static" if use_graphs == "static" else bool(use_graphs)
         self._graphs = None
         self.raymarch_type, self.num_steps, self.step_size, self.bg_color = raymarch_type, num_steps, step_size, bg_color
         self.render_channels = {"depth", "alpha", "hit"}
