@@ -644,7 +644,7 @@ def run_rank(args):
     # Graph capture is one-time set-up (an eager step that observes the sample count, then the capture): with fewer warm-up steps than that
     # takes it would land inside the K timed steps.  Extra UNTIMED steps until a graph has replayed; reported as graphs.priming_steps.
     priming = 0
-    if job.tracer.use_graphs and world == 1 and not args.pose_opt:
+    if job.tracer.use_graphs and not args.pose_opt:      # (every rank takes the same number of steps: the count is a function of the step index)
         while priming < 4 and not ((job.graph_stats() or {}).get("replays", 0) > 0):
             job.step()
             priming += 1
@@ -652,7 +652,9 @@ def run_rank(args):
     # call exists to bracket with events: the roofline kernel's duration is then measured over K further EAGER steps right after the
     # timed region (same process, same inputs, HIP events on the launch stream around its C-ABI call).  With --graphs off the events
     # sit inside the timed region itself, as in rounds 1 - 2.
-    graphs_on = job.tracer.use_graphs and world == 1 and not args.pose_opt
+    # (N > 1 runs the static-buffer form, use_graphs = "static": its launches are eager, but a profiled region switches the tracer to the plain
+    # eager path - so there, too, the events are taken after the timed region.)
+    graphs_on = job.tracer.use_graphs and not args.pose_opt
     if graphs_on:
         dt, _ = job.timed(args.steps)
         _, prof = job.timed(args.steps, profile={enc_name})
@@ -766,12 +768,12 @@ def run_rank(args):
                                      value_last_half=round(world * args.rays * half / d2, 1), unit="rays/s")
         # ---- the same step without graphs (what rounds 1 - 2 measured)
         if graphs_on:
-            job.tracer.use_graphs = False
+            was_mode, job.tracer.use_graphs = job.tracer.use_graphs, False
             for _ in range(2):
                 job.step()
             n_e = max(3, args.steps // 2)
             d_e, _ = job.timed(n_e)
-            job.tracer.use_graphs = True
+            job.tracer.use_graphs = was_mode
             line["eager"] = dict(ms_per_step=round(d_e / n_e * 1e3, 3), rays_s=round(world * args.rays * n_e / d_e, 1),
                                  note="PanopticPackedRFTracer(use_graphs=False): every kernel launched from Python, host waits for the sample count")
         # ---- rgb-only regime (epochs < 601, best.yaml:89)
