@@ -42,9 +42,12 @@ __device__ __forceinline__ int rho(int q, int h) { return (q & 3) + 8 * (q >> 2)
 __device__ __forceinline__ int swap23(int a) { return (a & ~12) | ((a & 4) << 1) | ((a & 8) >> 1); }
 
 // staged position (8*g + e) of the XCD8 layout -> column level*F + f of the [M, L*F] feature row, or -1 (padding)
+// (a / d for the wave-uniform divisors of the staging loops: a shift when d is a power of two - the feature width and the pad sizes always
+// are - instead of the ~40-instruction software division; the loops below were bound by those: 25 k of a launch's clocks per workgroup)
+__device__ __forceinline__ int udiv_uniform(int a, int d) { return (d & (d - 1)) == 0 ? a >> (31 - __clz(d)) : a / d; }
 __device__ __forceinline__ int grp_col(int pos, int L, int F) {
     const int g = pos >> 3, e = pos & 7;
-    const int j = e / F, f = e - j * F;
+    const int j = udiv_uniform(e, F), f = e - j * F;
     const int level = xcd8_level(g, j);
     return (j < (L + 7) / 8 && level < L) ? level * F + f : -1;
 }
@@ -100,23 +103,52 @@ struct BwdParams {
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
 // optional bit-2/3 swap of the column index (see header).
+// Every decoder kernel starts with 3 - 8 of these matrices.  As a loop of one element per iteration (a predicated load, then its store) the
+// prologue ran at one L2 round trip per element - 80 dependent round trips per thread, 23 - 27 k clocks = 10 us per launch whatever the batch
+// (-DPAG_FUSED_PROF).  Here eight loads are issued back to back - unconditionally, from clamped addresses, so that no branch separates them -
+// and the padding is applied to the values afterwards.
+constexpr int STAGE_BATCH = 8;
 __device__ void stage_weight(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in,
                              bool permute, int grp_L = 0, int grp_F = 0) {
-    for (int e = threadIdx.x; e < rows_pad * cols_pad; e += blockDim.x) {
-        int o = e / cols_pad, a = e - o * cols_pad;
-        int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
-        float v = (o < n_out && col >= 0 && col < n_in) ? W[(int64_t)o * n_in + col] : 0.0f;
-        dst[o * stride + (permute ? swap23(a) : a)] = (bf16_t)v;
+    const int total = rows_pad * cols_pad, step = (int)blockDim.x, last = n_out * n_in - 1;
+    for (int e0 = threadIdx.x; e0 < total; e0 += STAGE_BATCH * step) {
+        float v[STAGE_BATCH];
+        int at[STAGE_BATCH];
+#pragma unroll
+        for (int k = 0; k < STAGE_BATCH; ++k) {
+            const int e = e0 + k * step;
+            const int o = udiv_uniform(e, cols_pad), a = e - o * cols_pad;
+            const int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
+            const bool ok = e < total && o < n_out && col >= 0 && col < n_in;
+            at[k] = e < total ? o * stride + (permute ? swap23(a) : a) : -1;
+            v[k] = W[min(max(o * n_in + col, 0), last)];
+            v[k] = ok ? v[k] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < STAGE_BATCH; ++k)
+            if (at[k] >= 0) dst[at[k]] = (bf16_t)v[k];
     }
 }
 // Stage W^T: dst[row = input a][col = output o (permuted)]
 __device__ void stage_weight_t(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in,
                                int grp_L = 0, int grp_F = 0) {
-    for (int e = threadIdx.x; e < rows_pad * cols_pad; e += blockDim.x) {
-        int a = e / cols_pad, o = e - a * cols_pad;
-        int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
-        float v = (o < n_out && col >= 0 && col < n_in) ? W[(int64_t)o * n_in + col] : 0.0f;
-        dst[a * stride + swap23(o)] = (bf16_t)v;
+    const int total = rows_pad * cols_pad, step = (int)blockDim.x, last = n_out * n_in - 1;
+    for (int e0 = threadIdx.x; e0 < total; e0 += STAGE_BATCH * step) {
+        float v[STAGE_BATCH];
+        int at[STAGE_BATCH];
+#pragma unroll
+        for (int k = 0; k < STAGE_BATCH; ++k) {
+            const int e = e0 + k * step;
+            const int a = udiv_uniform(e, cols_pad), o = e - a * cols_pad;
+            const int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
+            const bool ok = e < total && o < n_out && col >= 0 && col < n_in;
+            at[k] = e < total ? a * stride + swap23(o) : -1;
+            v[k] = W[min(max(o * n_in + col, 0), last)];
+            v[k] = ok ? v[k] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < STAGE_BATCH; ++k)
+            if (at[k] >= 0) dst[at[k]] = (bf16_t)v[k];
     }
 }
 
@@ -1481,8 +1513,14 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
 // Full 32-sample tiles run in the main loop; a ragged last tile runs once after it with predicated stores.
 // DZ0: also write dz_0 (the gradient at the first hidden layer's pre-activation) as a bf16 [M,64] tensor (p.dz[0]) - what the caller sums per ray
 // and multiplies by W_0[:, k1:] for the gradient of the per-ray x2 (the view embedding: pose optimisation, pc_nerf/ba_pipeline.py:89-90).
+#ifdef PAG_FUSED_PROF      // debug build: where a workgroup of mlp_bwd_fused spends its clocks outside the tile loop (printed per launch by pag_mlp_bwd)
+__device__ unsigned long long g_fused_prof[8];      // shader clocks summed over workgroups: [0] staging, [1] tile loop, [2] cross-wave sum, [4] workgroups
+#endif
 template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */, bool DZ0 = false>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
+#ifdef PAG_FUSED_PROF
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
     static_assert(OBL == 1 || KIND == 0, "a 64-wide output layer exists for the dense-gradient form only");
     constexpr bool GRP = KIND != 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1509,6 +1547,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     bf16_t *Tx = reinterpret_cast<bf16_t *>(b1s + 64) + (threadIdx.x >> 6) * ((NL + 1) * TW_ELEMS);      // wave-private swizzled tiles
     bf16_t *Th0 = Tx + TW_ELEMS, *Th1 = Th0 + (NL == 3 ? TW_ELEMS : 0), *Tz = Th1 + TW_ELEMS;
     __syncthreads();
+#ifdef PAG_FUSED_PROF
+    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -1820,7 +1861,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
         else return dbacc;
     };
     __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);                      // [NBLK][16 q][64 lanes]
+#ifdef PAG_FUSED_PROF
+    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+#endif
+    float *red = reinterpret_cast<float *>(smem);                      // [NBLK][4][64 lanes] x 4 floats
 #pragma unroll 1
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -1828,39 +1872,52 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
                 constexpr int bb = decltype(bi)::value;
                 const f32x16 &a = blk(bi);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    float *dst = red + (bb * 16 + q) * 64 + lane;
-                    *dst = w == 0 ? a[q] : *dst + a[q];
+                for (int q4 = 0; q4 < 4; ++q4) {      // four values per LDS access (the sum was 2 x 176 four-byte accesses per lane and wave: 42 k clocks of a launch)
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(red) + (bb * 4 + q4) * 64 + lane;
+                    const f32x4 v = {a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
+                    *dst = w == 0 ? v : *dst + v;
                 }
             });
         }
         __syncthreads();
     }
+#ifdef PAG_FUSED_PROF
+    if (threadIdx.x == 0) {
+        const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_fused_prof[0], pt1 - pt0);
+        atomicAdd(&g_fused_prof[1], pt2 - pt1);
+        atomicAdd(&g_fused_prof[2], pt3 - pt2);
+        atomicAdd(&g_fused_prof[4], 1ull);
+    }
+#endif
     static_for<NBLK>([&](auto bi) {
         constexpr int bb = decltype(bi)::value;
         if ((bb & 3) != wave) return;
-        const float *src = red + bb * 16 * 64 + lane;
+        f32x4 sv[4];      // this lane's 16 values of block bb
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) sv[q4] = (reinterpret_cast<const f32x4 *>(red) + (bb * 4 + q4) * 64 + lane)[0];
+        auto srcv = [&](int q) __attribute__((always_inline)) { return sv[q >> 2][q & 3]; };
         if constexpr (bb < BM) {
             float *sl = p.slabs[NL - 1] + (int64_t)blockIdx.x * (OBL * 32) * WG_SLAB_COLS_F;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sl[(32 * (bb >> 1) + rho(q, h)) * WG_SLAB_COLS_F + 32 * (bb & 1) + r] = src[q * 64];
+            for (int q = 0; q < 16; ++q) sl[(32 * (bb >> 1) + rho(q, h)) * WG_SLAB_COLS_F + 32 * (bb & 1) + r] = srcv(q);
         } else if constexpr (bb < B0) {
             float *sl = p.slabs[1] + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sl[(32 * ((bb - BM) >> 1) + rho(q, h)) * WG_SLAB_COLS_F + 32 * ((bb - BM) & 1) + r] = src[q * 64];
+            for (int q = 0; q < 16; ++q) sl[(32 * ((bb - BM) >> 1) + rho(q, h)) * WG_SLAB_COLS_F + 32 * ((bb - BM) & 1) + r] = srcv(q);
         } else if constexpr (bb < NBLK - 1) {
             constexpr int ob = (bb - B0) >> 1, ib = (bb - B0) & 1;
             float *sl = p.slabs[0] + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float v = src[q * 64];
+                const float v = srcv(q);
                 sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = v;
                 if (ib == 1 && r == 31) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;      // input column 63 (the ones column) = db of layer 0
             }
         } else {      // dbacc: column ob -> last layer's block ob; column OBL + ob -> middle layer's block ob
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float v = src[q * 64];
+                const float v = srcv(q);
                 if (r < OBL) p.slabs[NL - 1][((int64_t)blockIdx.x * (OBL * 32) + 32 * r + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
                 if (NL == 3 && r >= OBL && r < OBL + 2) p.slabs[1][((int64_t)blockIdx.x * 64 + 32 * (r - OBL) + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
             }
@@ -2148,7 +2205,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
         else return dbacc;
     };
     __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);                      // [NBLK][16 q][64 lanes]
+    float *red = reinterpret_cast<float *>(smem);                      // [NBLK][4][64 lanes] x 4 floats
 #pragma unroll 1
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -2156,9 +2213,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
                 constexpr int bb = decltype(bi)::value;
                 const f32x16 &a = blk(bi);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    float *dst = red + (bb * 16 + q) * 64 + lane;
-                    *dst = w == 0 ? a[q] : *dst + a[q];
+                for (int q4 = 0; q4 < 4; ++q4) {      // four values per LDS access (the sum was 2 x 176 four-byte accesses per lane and wave: 42 k clocks of a launch)
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(red) + (bb * 4 + q4) * 64 + lane;
+                    const f32x4 v = {a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
+                    *dst = w == 0 ? v : *dst + v;
                 }
             });
         }
@@ -2167,27 +2225,30 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
     static_for<NBLK>([&](auto bi) {
         constexpr int bb = decltype(bi)::value;
         if ((bb & 3) != wave) return;
-        const float *src = red + bb * 16 * 64 + lane;
+        f32x4 sv[4];      // this lane's 16 values of block bb
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) sv[q4] = (reinterpret_cast<const f32x4 *>(red) + (bb * 4 + q4) * 64 + lane)[0];
+        auto srcv = [&](int q) __attribute__((always_inline)) { return sv[q >> 2][q & 3]; };
         if constexpr (bb < 4 || (bb >= 8 && bb < 10)) {               // output-layer blocks: rows = output channels
             constexpr bool S = bb >= 8;
             constexpr int ob = S ? 0 : (bb >> 1), ib = S ? (bb - 8) : (bb & 1);
             float *sl = (S ? ps.slabs[1] + (int64_t)blockIdx.x * 32 * WG_SLAB_COLS_F : pi.slabs[1] + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = src[q * 64];
+            for (int q = 0; q < 16; ++q) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = srcv(q);
         } else if constexpr (bb < 14) {                               // layer-0 blocks; input column 63 (the ones column) = db of layer 0
             constexpr bool S = bb >= 10;
             constexpr int k = S ? bb - 10 : bb - 4, ob = k >> 1, ib = k & 1;
             float *sl = (S ? ps.slabs[0] : pi.slabs[0]) + (int64_t)blockIdx.x * 64 * WG_SLAB_COLS_F;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float v = src[q * 64];
+                const float v = srcv(q);
                 sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 32 * ib + r] = v;
                 if (ib == 1 && r == 31) sl[(32 * ob + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
             }
         } else {      // dbacc: columns 0, 1 -> .i upper layer's blocks; column 2 -> .s output layer
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float v = src[q * 64];
+                const float v = srcv(q);
                 if (r < 2) pi.slabs[1][((int64_t)blockIdx.x * 64 + 32 * r + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
                 if (r == 2) ps.slabs[1][((int64_t)blockIdx.x * 32 + rho(q, h)) * WG_SLAB_COLS_F + 64] = v;
             }
@@ -3939,6 +4000,18 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
         }
 #undef MLP_BWD_FUSED
         PAG_CHECK_LAUNCH("pag_mlp_bwd (fused)");
+#ifdef PAG_FUSED_PROF
+        {
+            unsigned long long hp[8];
+            hipStreamSynchronize(st);
+            hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_fused_prof), sizeof(hp));
+            const double n = hp[4] ? (double)hp[4] : 1.0;
+            fprintf(stderr, "[fused_prof] kind %d M %lld grid %u: staging %.0f  tiles %.0f  cross-wave sum %.0f  (shader clocks per workgroup)\n", kind, (long long)M,
+                    grid, hp[0] / n, hp[1] / n, hp[2] / n);
+            for (auto &v : hp) v = 0;
+            hipMemcpyToSymbol(HIP_SYMBOL(g_fused_prof), hp, sizeof(hp));
+        }
+#endif
         FinishBatch fb{};
         int max_out = 0;
         for (int l = 0; l < a->n_layers; ++l) {
