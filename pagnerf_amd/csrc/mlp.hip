@@ -107,7 +107,7 @@ struct BwdParams {
 // prologue ran at one L2 round trip per element - 80 dependent round trips per thread, 23 - 27 k clocks = 10 us per launch whatever the batch
 // (-DPAG_FUSED_PROF).  Here eight loads are issued back to back - unconditionally, from clamped addresses, so that no branch separates them -
 // and the padding is applied to the values afterwards.
-constexpr int STAGE_BATCH = 8;
+constexpr int STAGE_BATCH = 8;      // 16: slower (registers / code size)
 __device__ void stage_weight(bf16_t *dst, int stride, int rows_pad, int cols_pad, const float *W, int n_out, int n_in,
                              bool permute, int grp_L = 0, int grp_F = 0) {
     const int total = rows_pad * cols_pad, step = (int)blockDim.x, last = n_out * n_in - 1;
@@ -139,7 +139,8 @@ __device__ void stage_weight_t(bf16_t *dst, int stride, int rows_pad, int cols_p
 #pragma unroll
         for (int k = 0; k < STAGE_BATCH; ++k) {
             const int e = e0 + k * step;
-            const int a = udiv_uniform(e, cols_pad), o = e - a * cols_pad;
+            const int o = udiv_uniform(e, rows_pad), a = e - o * rows_pad;      // W's own row-major order (input index fastest): whole cache lines per
+                                                                                // wave load, the transposition happens in the 2-byte LDS stores
             const int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
             const bool ok = e < total && o < n_out && col >= 0 && col < n_in;
             at[k] = e < total ? a * stride + swap23(o) : -1;
