@@ -1872,12 +1872,21 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
             static_for<NBLK>([&](auto bi) {
                 constexpr int bb = decltype(bi)::value;
                 const f32x16 &a = blk(bi);
+                // four values per LDS access (the sum was 2 x 176 four-byte accesses per lane and wave: 42 k clocks of a launch); a block's four
+                // reads are issued together, then its four writes (one select per access made each a dependent round trip)
+                f32x4 *dst = reinterpret_cast<f32x4 *>(red) + (bb * 4) * 64 + lane;
+                f32x4 v[4];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {      // four values per LDS access (the sum was 2 x 176 four-byte accesses per lane and wave: 42 k clocks of a launch)
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(red) + (bb * 4 + q4) * 64 + lane;
-                    const f32x4 v = {a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
-                    *dst = w == 0 ? v : *dst + v;
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = f32x4{a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
+                if (w != 0) {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) t[q4] = dst[q4 * 64];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) v[q4] = t[q4] + v[q4];
                 }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) dst[q4 * 64] = v[q4];
             });
         }
         __syncthreads();
@@ -1939,6 +1948,9 @@ struct PairParams {
     BwdParams i, s;
 };
 __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
+#ifdef PAG_FUSED_PROF
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
     const BwdParams &pi = pp.i, &ps = pp.s;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RSLI = 72, RSLS = 40;
@@ -1963,6 +1975,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
     bf16_t *Tx = reinterpret_cast<bf16_t *>(b0S + 64) + (threadIdx.x >> 6) * (4 * TW_ELEMS);      // wave-private swizzled tiles
     bf16_t *ThI = Tx + TW_ELEMS, *ThS = ThI + TW_ELEMS, *Tz = ThS + TW_ELEMS;
     __syncthreads();
+#ifdef PAG_FUSED_PROF
+    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -2206,23 +2221,48 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
         else return dbacc;
     };
     __syncthreads();
+#ifdef PAG_FUSED_PROF
+    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+#endif
     float *red = reinterpret_cast<float *>(smem);                      // [NBLK][4][64 lanes] x 4 floats
+    // wave 0 stores, waves 1 - 3 add in turn (same order of summation as a read-modify-write by all four); a block's four 16-byte reads are issued
+    // together.  (Written as two code paths: the single loop with `w == 0 ? v : *dst + v` ran one dependent LDS round trip per access, and the form
+    // mlp_bwd_fused uses crashes hipcc 7.2's 'AMDGPU Rewrite AGPR-Copy-MFMA' pass on this kernel.)
+    if (wave == 0) {
+        static_for<NBLK>([&](auto bi) {
+            constexpr int bb = decltype(bi)::value;
+            const f32x16 &a = blk(bi);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(red) + (bb * 4) * 64 + lane;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) dst[q4 * 64] = f32x4{a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
+        });
+    }
+    __syncthreads();
 #pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 1; w < 4; ++w) {
         if (wave == w) {
             static_for<NBLK>([&](auto bi) {
                 constexpr int bb = decltype(bi)::value;
                 const f32x16 &a = blk(bi);
+                f32x4 *dst = reinterpret_cast<f32x4 *>(red) + (bb * 4) * 64 + lane;
+                f32x4 t[4];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {      // four values per LDS access (the sum was 2 x 176 four-byte accesses per lane and wave: 42 k clocks of a launch)
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(red) + (bb * 4 + q4) * 64 + lane;
-                    const f32x4 v = {a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
-                    *dst = w == 0 ? v : *dst + v;
-                }
+                for (int q4 = 0; q4 < 4; ++q4) t[q4] = dst[q4 * 64];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) dst[q4 * 64] = t[q4] + f32x4{a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
             });
         }
         __syncthreads();
     }
+#ifdef PAG_FUSED_PROF
+    if (threadIdx.x == 0) {
+        const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_fused_prof[0], pt1 - pt0);
+        atomicAdd(&g_fused_prof[1], pt2 - pt1);
+        atomicAdd(&g_fused_prof[2], pt3 - pt2);
+        atomicAdd(&g_fused_prof[4], 1ull);
+    }
+#endif
     static_for<NBLK>([&](auto bi) {
         constexpr int bb = decltype(bi)::value;
         if ((bb & 3) != wave) return;
@@ -3944,6 +3984,18 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
             PairParams pp{pb, ps};
             hipLaunchKernelGGL(mlp_bwd_pair, dim3(grid), dim3(256), ldsP, st, pp);
             PAG_CHECK_LAUNCH("pag_mlp_bwd (fused, layers below the wide head + companion head)");
+#ifdef PAG_FUSED_PROF
+            {
+                unsigned long long hp[8];
+                hipStreamSynchronize(st);
+                hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_fused_prof), sizeof(hp));
+                const double n = hp[4] ? (double)hp[4] : 1.0;
+                fprintf(stderr, "[fused_prof] pair M %lld grid %u: staging %.0f  tiles %.0f  cross-wave sum %.0f  (shader clocks per workgroup)\n", (long long)M, grid,
+                        hp[0] / n, hp[1] / n, hp[2] / n);
+                for (auto &v : hp) v = 0;
+                hipMemcpyToSymbol(HIP_SYMBOL(g_fused_prof), hp, sizeof(hp));
+            }
+#endif
             fb.p[3] = FinishParams{slabS0, (int)grid, HID, 64, b->in_dim, p.grp_L, p.grp_F, b->dW[0], b->db[0]};
             fb.p[4] = FinishParams{slabS1, (int)grid, b->out_dim, 32, HID, 0, 0, b->dW[1], b->db[1]};
             n_fin = 5;
