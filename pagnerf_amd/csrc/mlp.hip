@@ -153,6 +153,34 @@ __device__ void stage_weight_t(bf16_t *dst, int stride, int rows_pad, int cols_p
     }
 }
 
+// Both images of one matrix from ONE pass over it: the natural image (as stage_weight: dst_s[o][a], optionally with the bit-2/3 swap) and the
+// transposed one (as stage_weight_t: dst_t[a][o permuted]).  The backward kernels need W_0 (and W_1) both ways - recomputed forward and W^T chain.
+__device__ void stage_weight_both(bf16_t *dst_s, int stride_s, bool permute_s, bf16_t *dst_t, int stride_t, int out_pad, int in_pad, const float *W,
+                                  int n_out, int n_in, int grp_L = 0, int grp_F = 0) {
+    const int total = out_pad * in_pad, step = (int)blockDim.x, last = n_out * n_in - 1;
+    for (int e0 = threadIdx.x; e0 < total; e0 += STAGE_BATCH * step) {
+        float v[STAGE_BATCH];
+        int as[STAGE_BATCH], at[STAGE_BATCH];
+#pragma unroll
+        for (int k = 0; k < STAGE_BATCH; ++k) {
+            const int e = e0 + k * step;
+            const int o = udiv_uniform(e, in_pad), a = e - o * in_pad;
+            const int col = grp_L ? grp_col(a, grp_L, grp_F) : a;
+            const bool ok = e < total && o < n_out && col >= 0 && col < n_in;
+            as[k] = e < total ? o * stride_s + (permute_s ? swap23(a) : a) : -1;
+            at[k] = a * stride_t + swap23(o);
+            v[k] = W[min(max(o * n_in + col, 0), last)];
+            v[k] = ok ? v[k] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < STAGE_BATCH; ++k)
+            if (as[k] >= 0) {
+                dst_s[as[k]] = (bf16_t)v[k];
+                dst_t[at[k]] = (bf16_t)v[k];
+            }
+    }
+}
+
 __device__ __forceinline__ bf16x8 load8(const float *p) {
     f32x4 a = *reinterpret_cast<const f32x4 *>(p);
     f32x4 b = *reinterpret_cast<const f32x4 *>(p + 4);
@@ -1530,8 +1558,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     bf16_t *W1t = WLt + 64 * RSL;                                // [64][RS]      (NL == 3)
     bf16_t *W0t = W1t + (NL == 3 ? 64 * RS : 0);                 // [64 in-feature rows][RS]
     stage_weight_t(WLt, RSL, 64, OBL * 32, p.W[NL - 1], p.out_dim, HID);
-    if (NL == 3) stage_weight_t(W1t, RS, 64, 64, p.W[1], HID, HID);
-    stage_weight_t(W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
+    // (W_1 and W_0 are staged below, both images from one pass each)
     // the forward's own images of the hidden layers: their activations are RECOMPUTED here (8 - 16 MFMAs per tile on idle matrix
     // cores, same fragments and instruction sequence as mlp_fwd_mfma: bit-identical) instead of being written by the forward and
     // read back - 268 MB each way per hidden layer at M = 2.1 M, in kernels that run at the HBM rate
@@ -1539,8 +1566,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     bf16_t *W1s = W0s + 64 * RS;                                 // [64][RS] permuted k (NL == 3)
     float *b0s = reinterpret_cast<float *>(W1s + (NL == 3 ? 64 * RS : 0));
     float *b1s = b0s + 64;
-    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
-    if (NL == 3) stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
+    stage_weight_both(W0s, RS, false, W0t, RS, 64, 64, p.W[0], HID, p.in_dim, p.grp_L, p.grp_F);
+    if (NL == 3) stage_weight_both(W1s, RS, true, W1t, RS, 64, 64, p.W[1], HID, HID);
     for (int e = threadIdx.x; e < 64; e += blockDim.x) {
         b0s[e] = p.b[0][e];
         b1s[e] = NL == 3 ? p.b[1][e] : 0.0f;
@@ -1963,11 +1990,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
     float *b0I = reinterpret_cast<float *>(W0sS + 64 * RS);
     float *b0S = b0I + 64;
     stage_weight_t(WLtI, RSLI, 64, 64, pi.W[1], pi.out_dim, HID);
-    stage_weight_t(W0tI, RS, 64, 64, pi.W[0], HID, pi.in_dim, pi.grp_L, pi.grp_F);
-    stage_weight(W0sI, RS, 64, 64, pi.W[0], HID, pi.in_dim, false, pi.grp_L, pi.grp_F);
+    stage_weight_both(W0sI, RS, false, W0tI, RS, 64, 64, pi.W[0], HID, pi.in_dim, pi.grp_L, pi.grp_F);
     stage_weight_t(WLtS, RSLS, 64, 32, ps.W[1], ps.out_dim, HID);
-    stage_weight_t(W0tS, RS, 64, 64, ps.W[0], HID, ps.in_dim, ps.grp_L, ps.grp_F);
-    stage_weight(W0sS, RS, 64, 64, ps.W[0], HID, ps.in_dim, false, ps.grp_L, ps.grp_F);
+    stage_weight_both(W0sS, RS, false, W0tS, RS, 64, 64, ps.W[0], HID, ps.in_dim, ps.grp_L, ps.grp_F);
     for (int e = threadIdx.x; e < 64; e += blockDim.x) {
         b0I[e] = pi.b[0][e];
         b0S[e] = ps.b[0][e];
@@ -2343,8 +2368,7 @@ __global__ __launch_bounds__((OB + 1) * 64) void mlp_bwd_wide_blocks(BwdParams p
     float *grow = reinterpret_cast<float *>(TzAll + OB * TW_ELEMS);      // [2][WB_RMAX][WR_RS]
     float *dotbuf = grow + 2 * WB_RMAX * WR_RS;                  // [2][OB][64]
     bf16x8 *zbuf = reinterpret_cast<bf16x8 *>(dotbuf + 2 * OB * 64);     // [2][OB][2][64]
-    stage_weight_t(WLt, RSL, 64, OB * 32, p.W[0], p.out_dim, HID);
-    stage_weight(WLs, RS, OB * 32, 64, p.W[0], p.out_dim, HID, true);
+    stage_weight_both(WLs, RS, true, WLt, RSL, OB * 32, 64, p.W[0], p.out_dim, HID);
     for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b_last[e] : -1e30f;      // padding channels: p = exp2(-huge) = 0
     for (int e = threadIdx.x; e < 2 * OB * 64; e += blockDim.x) dotbuf[e] = 0.0f;
     for (int e = threadIdx.x; e < 2 * OB * 2 * 64 * 4; e += blockDim.x) reinterpret_cast<float *>(zbuf)[e] = 0.0f;
