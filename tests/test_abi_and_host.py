@@ -61,6 +61,11 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pag_render_loss_fwd(one, None, 4, 1.0, *t, *t, 1e-27, one, one, None) == -1 and b"rgb_gt" in lib.pag_last_error_string()
     assert lib.pag_render_loss_fwd(None, None, 4, 1.0, one, 0, None, None, 1.0, 1.0, 0, *t, 1e-27, one, one, None) == -1
     assert lib.pag_render_loss_bwd(None, None, None, None, 4, 1.0, *t, *t, 1e-27, None, None, None, None) == -1
+    # round-3 entry points
+    assert lib.pag_ray_sample_grad(None, None, 0, None, None, None, None) == 0                        # no packs: no-op
+    assert lib.pag_ray_sample_grad(None, None, -1, None, None, None, None) == -1
+    assert lib.pag_ray_sample_grad(None, None, 4, None, None, None, None) == -1 and b"NULL" in lib.pag_last_error_string()
+    assert lib.pag_pad_packed(None, -1, 0, 1, None, None, None, None, None, None, None, None, None) == -1
 
 
 def test_product_path_refuses_cpu_tensors():
