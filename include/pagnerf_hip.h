@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 7
+#define PAG_ABI_VERSION 8
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -356,11 +356,14 @@ int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_start, int6
  * ignored; with the per-sample gradient tensors of the compositing backward zero-filled past M they carry zero gradient.  The step
  * after the march then has shapes that do not depend on device data and can be replayed as a HIP graph (pagnerf_amd/graphs.py - the
  * reference's boolean-mask indexing, wisp OctreeAS.raymarch, forces a host read-back instead).
- * M > capacity: nothing is written (the caller learns M from pag_pack_offsets' total_host and falls back to exact shapes).
+ * M > capacity: no filler is written (the caller learns M from pag_pack_offsets' total_host, discards the step and falls back to
+ * exact shapes).  pack_start_clamped i64 [N + 1] (optional, ABI 8) receives min(pack_start[r], capacity): the pack table to hand to
+ * every launch that is queued on capacity-sized views BEFORE the host knows M - equal to pack_start when the batch fits, a
+ * truncated batch otherwise, so that no per-ray kernel ever indexes a per-sample tensor past `capacity`.
  * ridx_sample i32 [capacity] / ridx_entry i32 [capacity / k] / ridx64 i64 [capacity / k] may be NULL; pidx i32 [capacity / k]. */
 int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capacity, int samples_per_entry, float *samples, float *depths,
                    float *deltas, int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx,
-                   uint8_t *boundary, void *stream);
+                   uint8_t *boundary, int64_t *pack_start_clamped, void *stream);
 
 /* View-direction embedding of the colour decoder (wisp PositionalEmbedder on -ray_d, pc_nerf/panoptic_delta_nef.py:196-200):
  * out f32 [R, width] = (-d, sin(-d 2^k) for k < n_freq, cos(-d 2^k) for k < n_freq), frequency-major, zero padded;

@@ -16,7 +16,7 @@ MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
 LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
 ENC_HALF_COORDS = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 MLP_FUSED_WIDE_MAX_M = 1 << 24      # PAG_MLP_FUSED_WIDE_MAX_M
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -98,7 +98,7 @@ _SIGS = {
     "pag_mlp_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
     "pag_raymarch_count": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp]),
     "pag_pack_offsets": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
-    "pag_pad_packed": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_pad_packed": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_view_embed": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "pag_raymarch_pack": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_raymarch_voxel_count": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp]),

@@ -39,9 +39,26 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+_COMPILER_ID = None
+
+
+def _compiler_id():
+    """The HIP / clang version lines of `hipcc --version`: part of the digest, so that a library built by another toolchain is not
+    taken for up to date (the paths hipcc also prints are left out - they differ between boxes of one image)."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        try:
+            out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=120).stdout
+        except Exception as e:              # no compiler: the digest then cannot match a stamp written where one was present
+            out = "unavailable: %r" % (e,)
+        _COMPILER_ID = "\n".join(l.strip() for l in out.splitlines() if l.startswith(("HIP version", "AMD clang version"))) or out.strip()
+    return _COMPILER_ID
+
+
 def _digest():
     h = hashlib.sha256()
     h.update(repr((COMMON, sorted(SOURCES.items()))).encode())
+    h.update(_compiler_id().encode())
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for f in sorted(os.listdir(root)):
             if not os.path.isfile(os.path.join(root, f)):

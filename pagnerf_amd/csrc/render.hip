@@ -736,14 +736,22 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__res
 // M = pack_start[N] real samples are followed by capacity - M filler samples that belong to NO pack (pack_start is left alone): the
 // per-ray kernels never see them, the per-sample kernels (encoders, decoders) compute on them and their results are ignored; the caller
 // zero-fills the per-sample gradient tensors the compositing backward produces, so the fillers carry exactly zero gradient.
-// Coordinates (0,0,0) are inside the volume, ray index = the last ray.  One workgroup.  M > capacity: nothing is touched (the caller
-// sees the true count in its mailbox and falls back to exact shapes).  k = samples per nugget (voxel mode: the per-nugget arrays are
-// padded up to capacity / k).
+// Coordinates (0,0,0) are inside the volume, ray index = the last ray.  One workgroup.  M > capacity: no filler is written (the caller
+// sees the true count in its mailbox and falls back to exact shapes) - but the launches that were queued on the capacity-sized views
+// before the host learnt M must stay inside them: pack_start_clamped[r] = min(pack_start[r], capacity) is the pack table THEY walk
+// (identical to pack_start when the batch fits; a truncated batch, whose results the caller discards, when it does not).
+// k = samples per nugget (voxel mode: the per-nugget arrays are padded up to capacity / k).
 __global__ __launch_bounds__(1024) void pad_packed_kernel(const int64_t *__restrict__ pack_start, int64_t N, int64_t capacity, int k, float *__restrict__ samples,
                                                           float *__restrict__ depths, float *__restrict__ deltas, int32_t *__restrict__ ridx_sample,
                                                           int32_t *__restrict__ ridx_nugget, int64_t *__restrict__ ridx64, int32_t *__restrict__ pidx,
-                                                          uint8_t *__restrict__ boundary) {
+                                                          uint8_t *__restrict__ boundary, int64_t *__restrict__ pack_start_clamped) {
     const int64_t M = pack_start[N];
+    // the pack table the capacity-sized launches may walk: no pack reaches past `capacity`, whatever the march produced
+    if (pack_start_clamped)
+        for (int64_t r = threadIdx.x; r <= N; r += blockDim.x) {
+            const int64_t p = pack_start[r];
+            pack_start_clamped[r] = p < capacity ? p : capacity;
+        }
     if (M > capacity) return;
     const int32_t last = (int32_t)(N - 1);
     for (int64_t i = M + threadIdx.x; i < capacity; i += blockDim.x) {
@@ -790,12 +798,13 @@ extern "C" int pag_pack_offsets(const int32_t *counts, int64_t N, int64_t *pack_
 }
 
 extern "C" int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capacity, int samples_per_entry, float *samples, float *depths, float *deltas,
-                              int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx, uint8_t *boundary, void *stream) {
+                              int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx, uint8_t *boundary, int64_t *pack_start_clamped,
+                              void *stream) {
     PAG_CHECK_ARG(N >= 1 && capacity >= 0 && samples_per_entry >= 1 && capacity % samples_per_entry == 0,
                   "pag_pad_packed: N %lld, capacity %lld must be a multiple of samples_per_entry %d", (long long)N, (long long)capacity, samples_per_entry);
     PAG_CHECK_ARG(pack_start && samples && depths && deltas && pidx && boundary, "pag_pad_packed: NULL buffer");
     hipLaunchKernelGGL(pad_packed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack_start, N, capacity, samples_per_entry, samples, depths, deltas,
-                       ridx_sample, ridx_entry, ridx64, pidx, boundary);
+                       ridx_sample, ridx_entry, ridx64, pidx, boundary, pack_start_clamped);
     PAG_CHECK_LAUNCH("pag_pad_packed");
     return PAG_OK;
 }

@@ -23,6 +23,7 @@ require a gradient (pose optimisation), foreign grids, N > 1 ranks (the early al
 the backward graph ends).
 """
 import collections
+import os
 
 import torch
 import torch.nn as nn
@@ -32,7 +33,18 @@ from .core import RenderBuffer
 
 GRANULE = 8192          # capacities are multiples of GRANULE * k samples
 HEADROOM = 1.02         # capacity >= the recent maximum count * HEADROOM
-HISTORY = 8             # steps whose counts decide the capacity
+HISTORY = 8             # steps whose counts decide whether the capacity must GROW
+CAP_STEPS = 32          # capacities are multiples of 1/CAP_STEPS of the power of two below them: <= 3.1 % of filler samples, and a batch
+                        # size that drifts by a per cent or two (ordinary batch-to-batch noise, the slow drift after a prune) stays in one bucket
+SHRINK_WINDOW = 64      # the capacity only shrinks when every count of this many steps would fit the smaller one (hysteresis)
+MAX_BUCKETS = 2         # captured capacities kept per configuration (each owns a private memory pool: every activation of `cap` samples)
+
+
+def _round_capacity(want, k):
+    """The smallest multiple of (2^floor(log2 want) / CAP_STEPS, itself rounded to whole granules) that holds `want` samples."""
+    gran = GRANULE * k
+    step = max(gran, (1 << (max(int(want), 1).bit_length() - 1)) // CAP_STEPS // gran * gran)
+    return (int(want) + step - 1) // step * step
 
 
 class _PostMarch(nn.Module):
@@ -51,47 +63,87 @@ class _PostMarch(nn.Module):
         ne = cap // k
         smp = samples.reshape(ne, k, 3)
         dep = depths.reshape(ne, k)
+        # pack_start_c = min(pack_start, capacity): these launches are queued before the host has seen the sample count, and a batch that
+        # overflows the capacity (its result is discarded afterwards) must not send a per-ray kernel past the capacity-sized tensors
         out = tracer.shade(self.nef, set(self.channels), set(), ray_dirs, N, buf.ridx_entry[:ne], buf.ridx_sample[:cap], buf.pidx[:ne], smp, dep,
-                           deltas, buf.pack_start, ops._ray_iota(N, samples.device), self.lod_idx, self.bg_color, self.stage)
+                           deltas, buf.pack_start_c, ops._ray_iota(N, samples.device), self.lod_idx, self.bg_color, self.stage)
         if self.names is None:
             self.names = sorted(out)
         return tuple(out[n] for n in self.names)
 
 
+def _fresh(statics):
+    """Copies of the capture's static tensors in ordinary (caching-allocator) memory: ONE multi-tensor copy."""
+    outs = [torch.empty_like(o) for o in statics]
+    if outs:
+        torch._foreach_copy_(outs, list(statics))
+    return outs
+
+
 class _GraphedFn(torch.autograd.Function):
+    """One autograd node per backward GROUP of a captured configuration (one group = the whole backward by default; two when the
+    capture is split, see _Graphed).  The node of group 0 replays the forward graph.
+
+    Ownership (every output freshly allocated per call; trainer.py:426 `zero_grad(set_to_none=True)` is the reference's own
+    usage but not a contract): the outputs handed to the caller are COPIES of the static outputs (a RenderBuffer of step k is untouched
+    by step k + 1).  The gradients returned to autograd are the static buffers themselves - AccumulateGrad adopts such a tensor as
+    `p.grad` when the parameter has none, which saves a 100 MB copy per step - and therefore, before the backward graph overwrites them,
+    any `p.grad` that still shares their storage (gradient accumulation over several traces, `zero_grad(set_to_none=False)`, a GradScaler
+    that unscaled in place) is first detached from the capture: it becomes a private copy.  A caller that follows the reference's loop
+    (`set_to_none=True`, one trace per step) never pays for that copy."""
+
     @staticmethod
-    def forward(ctx, runner, *params):
-        ctx.runner = runner
+    def forward(ctx, runner, gi, *params):
+        ctx.runner, ctx.gi = runner, gi
         ctx.set_materialize_grads(False)      # outputs the loss does not use arrive as None in backward(), not as zero tensors filled per step
-        runner.fwd.replay()
-        outs = tuple(o.detach() for o in runner.outs)
-        ctx.mark_non_differentiable(*[o for o, s in zip(outs, runner.outs) if not s.requires_grad])
-        return outs
+        grp = runner.groups[gi]
+        if gi == 0:
+            runner.fwd.replay()
+            runner.generation += 1
+        ctx.generation = runner.generation
+        idx = grp.out_idx + (runner.nondiff_idx if gi == 0 else [])
+        outs = _fresh([runner.outs[i] for i in idx])
+        ctx.mark_non_differentiable(*outs[len(grp.out_idx):])
+        return tuple(outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         r = ctx.runner
+        grp = r.groups[ctx.gi]
+        if ctx.generation != r.generation:
+            raise RuntimeError("pagnerf_amd.graphs: the forward graph of this configuration was replayed again before this backward ran - the "
+                               "activations it saved are gone.  Call backward() on a trace before tracing the same configuration again "
+                               "(or construct the tracer with use_graphs=False / 'static').")
+        # a p.grad that still aliases this group's static gradients must not be overwritten by the replay (see the class docstring)
+        for p, g in zip(grp.params, grp.gins):
+            pg = p.grad
+            if pg is not None and g is not None and pg.untyped_storage().data_ptr() == g.untyped_storage().data_ptr():
+                p.grad = pg.clone()
+                r.unaliased += 1
         # upstream gradients -> the backward graph's static inputs: ONE multi-tensor copy (they were five ~3 us launches in a 1.4 ms step);
         # an output the loss does not use arrives as None: its static gradient is zeroed once and stays zero (the graph only reads it)
         dst, src, zero = [], [], []
-        for i, (static, g) in enumerate(zip(r.gouts, grads)):
-            if static is None:
-                continue
+        for i, (static, g) in enumerate(zip(grp.gouts, grads)):
             if g is None:
-                if i not in r.zeroed:
+                if i not in grp.zeroed:
                     zero.append(static)
-                    r.zeroed.add(i)
-            elif static.data_ptr() != g.data_ptr():
+                    grp.zeroed.add(i)
+            else:
                 dst.append(static)
                 src.append(g if (g.dtype == static.dtype and g.shape == static.shape) else g.to(static.dtype).reshape(static.shape))
-                r.zeroed.discard(i)
+                grp.zeroed.discard(i)
         if zero:
             torch._foreach_zero_(zero)
         if dst:
             torch._foreach_copy_(dst, src)
-        r.bwd.replay()
-        return (None,) + tuple(g.detach() if g is not None else None for g in r.gins)
+        grp.bwd.replay()
+        return (None, None) + tuple(g.detach() if g is not None else None for g in grp.gins)
+
+
+class _Group:
+    """One backward graph: the differentiable outputs `out_idx` (indices into _Graphed.outs) -> gradients of `params`."""
+    __slots__ = ("out_idx", "gouts", "bwd", "gins", "params", "zeroed")
 
 
 class _Graphed:
@@ -103,12 +155,18 @@ class _Graphed:
     the capture stream with the default stream in the middle of the backward capture: hipStreamEndCapture crashed (ROCm 7.2).  Here
     the captured function runs on ALIASES of the parameters (fresh leaves sharing their storage: torch.func.functional_call), so the
     captured backward never touches a pre-existing autograd node; the real parameters are inputs of _GraphedFn and receive the static
-    gradients through ordinary autograd outside any capture."""
+    gradients through ordinary autograd outside any capture.
 
-    def __init__(self, mod, args):
+    split (names of outputs, e.g. the panoptic channels): the backward is captured as TWO graphs - the gradients that flow from the
+    `split` outputs, then those of the remaining outputs - and each graph sits behind its own autograd node, the split one created
+    last so that the engine runs it first.  Whatever a caller hangs on the parameters between the two (shard.GradSync's post-accumulate
+    hook: the delta grid's table gradient is complete after the panoptic heads' backward and starts its all-reduce while the colour /
+    density decoders and the main grid are still running) fires as in an eager backward.  Same kernels, same values."""
+
+    def __init__(self, mod, args, split=()):
         self.mod, self.args = mod, args
         named = [(n, p) for n, p in mod.named_parameters() if p.requires_grad]
-        self.params = [p for _, p in named]
+        params = [p for _, p in named]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -117,35 +175,100 @@ class _Graphed:
         leaves = list(self.alias.values())
 
         def run():
-            outs = torch.func.functional_call(mod, self.alias, args)
-            return outs, [o for o in outs if o.requires_grad]
+            return torch.func.functional_call(mod, self.alias, args)
+
+        def groups_of(outs):
+            diff = [i for i, o in enumerate(outs) if o.requires_grad]
+            late = [i for i in diff if mod.names[i] in split]
+            early = [i for i in diff if mod.names[i] not in split]
+            return [g for g in (early, late) if g] or [[]]
         with torch.cuda.stream(side):
             for _ in range(2):          # warm-up: lazy initialisations (cached index tensors, workspaces) happen outside the capture
-                outs, req = run()
-                torch.autograd.grad(req, leaves, [torch.zeros_like(o) for o in req], allow_unused=True)
-                del outs, req
+                outs = run()
+                gs = groups_of(outs)
+                for j, idx in enumerate(gs):
+                    if idx:
+                        torch.autograd.grad([outs[i] for i in idx], leaves, [torch.zeros_like(outs[i]) for i in idx], allow_unused=True,
+                                            retain_graph=j + 1 < len(gs))
+                del outs
         cur.wait_stream(side)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
-        self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.fwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.fwd, pool=pool):
-            self.outs, req = run()
-        self.gouts = [torch.zeros_like(o) if o.requires_grad else None for o in self.outs]
-        self.zeroed = set()             # indices of gouts known to hold zeros (set by _GraphedFn.backward)
-        with torch.cuda.graph(self.bwd, pool=pool):
-            self.gins = torch.autograd.grad(req, leaves, [g for g in self.gouts if g is not None], allow_unused=True)
+            self.outs = run()
+        self.nondiff_idx = [i for i, o in enumerate(self.outs) if not o.requires_grad]
+        self.groups = []
+        gs = groups_of(self.outs)
+        for j, idx in enumerate(gs):
+            grp = _Group()
+            grp.out_idx = idx
+            grp.gouts = [torch.zeros_like(self.outs[i]) for i in idx]
+            grp.zeroed = set()             # indices of gouts known to hold zeros (set by _GraphedFn.backward)
+            grp.bwd = torch.cuda.CUDAGraph()
+            if idx:
+                with torch.cuda.graph(grp.bwd, pool=pool):
+                    gins = torch.autograd.grad([self.outs[i] for i in idx], leaves, grp.gouts, allow_unused=True, retain_graph=j + 1 < len(gs))
+            else:
+                gins = [None] * len(leaves)
+            used = [i for i, g in enumerate(gins) if g is not None]
+            grp.params = [params[i] for i in used]     # a parameter this group's outputs do not depend on is not an input of its node
+            grp.gins = [gins[i] for i in used]
+            self.groups.append(grp)
+        self.generation = 0
+        self.unaliased = 0                 # p.grad tensors that had to be detached from the capture's static gradients (diagnostics / tests)
         torch.cuda.synchronize()
 
     def __call__(self):
-        return _GraphedFn.apply(self, *self.params)
+        res = [None] * len(self.outs)
+        for gi, grp in enumerate(self.groups):
+            outs = _GraphedFn.apply(self, gi, *grp.params)
+            for i, o in zip(grp.out_idx + (self.nondiff_idx if gi == 0 else []), outs):
+                res[i] = o
+        return tuple(res)
 
 
 class _State:
     def __init__(self):
         self.counts = collections.deque(maxlen=HISTORY)
+        self.long = collections.deque(maxlen=SHRINK_WINDOW)
+        self.cap = None
         self.buf = None
         self.dirs = None
-        self.buckets = {}
+        self.buckets = collections.OrderedDict()
+
+    def see(self, count):
+        self.counts.append(int(count))
+        self.long.append(int(count))
+
+    def capacity(self, buf):
+        """Capacity for the next step: grows at once when the recent counts (+ head-room) no longer fit, shrinks only after SHRINK_WINDOW
+        steps all of which would fit a smaller bucket; geometric buckets (_round_capacity) - every NEW capacity costs a capture (two
+        warm-up steps, two synchronisations) and a private memory pool, so ordinary batch-to-batch noise must not move it."""
+        want = _round_capacity(int(max(self.counts) * HEADROOM) + 1, buf.k)
+        if self.cap is None or want > self.cap:
+            self.cap = want
+            self.long.clear()
+        elif len(self.long) == self.long.maxlen:
+            small = _round_capacity(int(max(self.long) * HEADROOM) + 1, buf.k)
+            if small < self.cap:
+                self.cap = small
+                self.long.clear()
+        self.cap = min(buf.cap, self.cap)
+        return self.cap
+
+    def bucket(self, key, make=None):
+        """Least-recently-used cache of at most MAX_BUCKETS captured capacities (the evicted graphs release their memory pool)."""
+        b = self.buckets.get(key)
+        if b is not None:
+            self.buckets.move_to_end(key)
+            return b
+        if make is None:
+            return None
+        while len(self.buckets) >= MAX_BUCKETS:
+            self.buckets.popitem(last=False)
+        b = self.buckets[key] = make()
+        return b
 
 
 class GraphRunner:
@@ -170,6 +293,16 @@ class GraphRunner:
         return st
 
     @staticmethod
+    def _split(tracer):
+        """Names of the outputs whose backward is captured as a graph of its own (see _Graphed): the panoptic channels when more than one
+        rank trains (shard.GradSync's early all-reduce), or when PAG_GRAPH_SPLIT=1 / tracer.graph_split forces it (tests)."""
+        force = getattr(tracer, "graph_split", None)
+        if force is None:
+            force = os.environ.get("PAG_GRAPH_SPLIT", "") not in ("", "0")
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        return tuple(sorted(tracer.panoptic_channels)) if (force or multi) else ()
+
+    @staticmethod
     def eligible(tracer, nef, channels, extra_channels, rays, stage):
         if not torch.is_grad_enabled() or stage != "train" or extra_channels or tracer.ray_sparcity_reg > 0.0:
             return False
@@ -177,9 +310,6 @@ class GraphRunner:
             return False
         if not getattr(nef, "accepts_ray_index", False) or not getattr(nef.grid, "accepts_max_travel", False):
             return False
-        if tracer.use_graphs != "static" and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            return False            # captured backward: the gradient hooks of shard.GradSync would all fire after the whole graph (no overlap)
         return True
 
     def _key(self, tracer, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage):
@@ -188,11 +318,11 @@ class GraphRunner:
         return (id(nef), raymarch_type, int(rays.origins.shape[0]), int(num_steps), frozenset(channels), lod_idx, bg_color, stage, nef.precision,
                 nef.training, id(lw), lw._version, tuple((id(g.tables), g.tables.dtype, g.rounds_coords(), g.blas_level) for g in grids),
                 float(rays.dist_min), float(rays.dist_max), float(tracer.ray_max_travel), str(rays.origins.device),
-                tuple(p.data_ptr() for p in nef.parameters()))
+                tuple((p.data_ptr(), p.requires_grad) for p in nef.parameters()), self._split(tracer))
 
     def observe(self, key, count):
         """An eager step of this configuration saw `count` samples: the first capacities are chosen from it."""
-        self._state(key).counts.append(int(count))
+        self._state(key).see(count)
 
     def run(self, tracer, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage, jitter):
         """-> (RenderBuffer | None, key, jitter used).  None: take the eager path (and call observe(key, M) afterwards)."""
@@ -210,9 +340,7 @@ class GraphRunner:
                 st.buf = ops.MarchBuffers("voxel", N, int(ops.L.load().pag_raymarch_voxel_nugget_capacity(g.blas_level)), int(num_steps), dev)
             st.dirs = torch.empty(N, 3, device=dev)
         buf = st.buf
-        gran = GRANULE * buf.k
-        want = int(max(st.counts) * HEADROOM) + 1
-        cap = min(buf.cap, max(gran, (want + gran - 1) // gran * gran))
+        cap = st.capacity(buf)
         bits = None if g._all_occupied else g.blas_bits
         if bits is not None and bits.device != dev:
             g.blas_bits = bits = bits.to(dev)
@@ -227,10 +355,9 @@ class GraphRunner:
         if tracer.use_graphs == "static":
             # same static, padded buffers and optimistic count check - but the post-march part runs as ordinary eager launches: what the graph
             # path gains by never waiting for the sample count (the host runs ahead of the device) without a capture, for callers whose
-            # backward must stay an ordinary autograd pass (gradient hooks: the early all-reduce of shard.GradSync at N > 1)
-            mod = st.buckets.get(("static", cap))
-            if mod is None:
-                mod = st.buckets[("static", cap)] = _PostMarch(nef, tracer, buf, cap, channels, lod_idx, bg_color, stage)
+            # backward must stay an ordinary autograd pass.  A batch that overflows `cap` runs TRUNCATED (pack_start_c, see _PostMarch) and is
+            # discarded below: the launches stay inside the capacity-sized tensors.
+            mod = st.bucket(("static", cap), lambda: _PostMarch(nef, tracer, buf, cap, channels, lod_idx, bg_color, stage))
             ops.SAMPLES_HINT, ops.TAIL_ZERO = max(st.counts), True
             try:
                 outs = mod(*args)
@@ -238,17 +365,17 @@ class GraphRunner:
                 ops.SAMPLES_HINT, ops.TAIL_ZERO = None, False
             self.replays += 1
             M = self._count(mailbox, buf)
-            st.counts.append(M)
+            st.see(M)
             if M > cap:
                 self.overflows += 1
                 return None, key, jitter
             return RenderBuffer(**dict(zip(mod.names, outs))), key, jitter
-        graphed = st.buckets.get(cap)
+        graphed = st.bucket(cap)
         if graphed is None:
             # the count must be known to be <= cap before the capture's warm-up runs shade() on these buffers for real
             M = self._count(mailbox, buf)
             mailbox = None
-            st.counts.append(M)
+            st.see(M)
             if M > cap:
                 return None, key, jitter
             # tensors an earlier EAGER step left cached on the nef / grids (feature cache, density features, pack tables) would be
@@ -259,6 +386,8 @@ class GraphRunner:
                     setattr(nef, attr, None)
             for grid in [nef.grid] + ([nef.delta_grid] if hasattr(nef, "delta_grid") else []):
                 grid._pack_cache = None
+            while len(st.buckets) >= MAX_BUCKETS:       # release the evicted capture's pool BEFORE the new one allocates its own
+                st.buckets.popitem(last=False)
             gc.collect()
             torch.cuda.synchronize()
             mod = _PostMarch(nef, tracer, buf, cap, channels, lod_idx, bg_color, stage)
@@ -266,17 +395,16 @@ class GraphRunner:
             ops.SAMPLES_HINT = M            # launch heuristics see the real count, not the padded capacity (same split as the eager path)
             ops.TAIL_ZERO = True            # per-sample tensors that the per-pack kernels fill start as zeros: the fillers carry no gradient
             try:
-                graphed = _Graphed(mod, args)
+                graphed = st.bucket(cap, lambda: _Graphed(mod, args, split=self._split(tracer)))
             finally:
                 ops.SAMPLES_HINT, ops.TAIL_ZERO = None, False
-            st.buckets[cap] = graphed
             self.captures += 1
         outs = graphed()
         self.replays += 1
         if mailbox is not None:
             M = self._count(mailbox, buf)
-            st.counts.append(M)
-            if M > cap:                     # the batch did not fit: the replay ran on a truncated batch - discard it
+            st.see(M)
+            if M > cap:                     # the batch did not fit: the replay ran on a batch truncated at `cap` samples - discard it
                 self.overflows += 1
                 return None, key, jitter
         return RenderBuffer(**dict(zip(graphed.mod.names, outs))), key, jitter

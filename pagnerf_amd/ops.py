@@ -991,16 +991,20 @@ class MarchBuffers:
         self.pidx = torch.zeros(ne, device=dev, dtype=torch.int32)
         self.counts = torch.zeros(self.N, device=dev, dtype=torch.int32)
         self.pack_start = torch.zeros(self.N + 1, device=dev, dtype=torch.int64)
+        # min(pack_start, capacity), written by pad_to(): the pack table of every launch that is queued on the capacity-sized views before
+        # the host knows the sample count - no per-ray kernel can walk past the capacity when a batch overflows it
+        self.pack_start_c = torch.zeros(self.N + 1, device=dev, dtype=torch.int64)
         if mode == "voxel":
             self.nug_t = torch.empty(int(per_ray), self.N, 2, device=dev)
             self.nug_cell = torch.empty(int(per_ray), self.N, device=dev, dtype=torch.int32)
 
     def pad_to(self, capacity):
-        """Queue pag_pad_packed: samples [M, capacity) become filler samples outside every pack (pack_start is left alone)."""
+        """Queue pag_pad_packed: samples [M, capacity) become filler samples outside every pack (pack_start is left alone) and
+        pack_start_c = min(pack_start, capacity)."""
         assert 0 < capacity <= self.cap and capacity % self.k == 0
         _call("pag_pad_packed", L.ptr(self.pack_start), self.N, int(capacity), self.k, L.ptr(self.samples), L.ptr(self.depths), L.ptr(self.deltas),
               L.ptr(self.ridx_sample) if self.k > 1 else None, L.ptr(self.ridx_entry), L.ptr(self.ridx64), L.ptr(self.pidx), L.ptr(self.boundary),
-              L.stream())
+              L.ptr(self.pack_start_c), L.stream())
 
 
 def march_into(buf, origins, dirs, dist_min, dist_max, num_samples, jitter=None, occupancy_bits=None, blas_level=7, max_travel=None,

@@ -22,7 +22,7 @@ _TRACE_PARAMS = {}      # per tracer class: trace()'s parameters (inspect.signat
 
 class PanopticPackedRFTracer(nn.Module):
     def __init__(self, ray_sparcity_reg=0.0, ray_max_travel=6.0, raymarch_type="voxel", num_steps=64, step_size=1.0,
-                 bg_color="white", use_graphs=None, **kwargs):
+                 bg_color="white", use_graphs=None, graph_split=None, **kwargs):
         """use_graphs (this build's addition, default: the PAG_GRAPHS environment variable, else off): training-time traces replay the
         post-march part of the step - forward and backward - as HIP graphs over static, padded sample buffers (pagnerf_amd/graphs.py).
         Same channels, same values; what changes is that the host neither waits for the sample count nor issues ~35 launches per step."""
@@ -33,6 +33,9 @@ class PanopticPackedRFTracer(nn.Module):
             use_graphs = "static" if use_graphs == "static" else bool(int(use_graphs))
         # True: HIP graphs; "static": the graph path's static padded buffers and optimistic sample-count check with eager launches (no capture)
         self.use_graphs = "static" if use_graphs == "static" else bool(use_graphs)
+        # graph_split: capture the backward as two graphs (panoptic heads | the rest) so that gradient hooks fire between them; None = only
+        # when more than one rank trains (pagnerf_amd/graphs.py::_Graphed)
+        self.graph_split = graph_split
         self._graphs = None
         self.raymarch_type, self.num_steps, self.step_size, self.bg_color = raymarch_type, num_steps, step_size, bg_color
         self.render_channels = {"depth", "alpha", "hit"}

@@ -1,4 +1,5 @@
 // Microbenchmark: LDS atomic throughput on gfx950 (float add vs int add vs 64-bit int add vs plain RMW).
+//   hipcc --offload-arch=gfx950 -O3 scripts/ubench/lds_atomic.hip -o scripts/ubench/lds_atomic && scripts/ubench/lds_atomic
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

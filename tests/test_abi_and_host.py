@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_argument_validation_without_gpu(lib):
@@ -65,7 +65,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pag_ray_sample_grad(None, None, 0, None, None, None, None) == 0                        # no packs: no-op
     assert lib.pag_ray_sample_grad(None, None, -1, None, None, None, None) == -1
     assert lib.pag_ray_sample_grad(None, None, 4, None, None, None, None) == -1 and b"NULL" in lib.pag_last_error_string()
-    assert lib.pag_pad_packed(None, -1, 0, 1, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.pag_pad_packed(None, -1, 0, 1, None, None, None, None, None, None, None, None, None, None) == -1
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -369,3 +369,50 @@ def test_xcd8_layout_is_the_snake_permutation():
     # the cheap / expensive pairing the order exists for: every group of the 24-level grid sums to the same level total
     sums = {sum(ops.xcd8_level(g, j) for j in range(2)) for g in range(8)}
     assert sums == {15}
+
+
+def test_graph_capacity_buckets_are_geometric_with_hysteresis():
+    """pagnerf_amd/graphs.py::_State.capacity: every new capacity is a capture (two warm-up steps, a private memory pool), so batch-to-batch
+    noise must not move it: geometric buckets (<= 1/32 of a power of two of filler), immediate growth, shrink only after SHRINK_WINDOW
+    steps that would all fit the smaller bucket; at most MAX_BUCKETS captures stay alive per configuration."""
+    from pagnerf_amd import graphs
+
+    class Buf:
+        k, cap = 1, 4096 * 512
+    st = graphs._State()
+    rng = np.random.default_rng(0)
+    caps = set()
+    base = 1_600_000
+    for it in range(400):                       # +-0.3 % noise and a slow 3 % drift (what follows a prune): a handful of capacities (the 8192-sample
+                                                # granule alone gave ~ 20 here), not one every few steps
+        st.see(int(base * (1 + 0.03 * it / 400) * (1 + 0.003 * rng.standard_normal())))
+        caps.add(st.capacity(Buf))
+    assert len(caps) <= 3, sorted(caps)
+    cap = st.cap
+    assert cap % graphs.GRANULE == 0 and cap <= Buf.cap
+    assert cap >= max(st.counts) * graphs.HEADROOM and cap <= max(st.long) * graphs.HEADROOM * (1 + 1 / graphs.CAP_STEPS) + graphs.GRANULE
+    # growth is immediate
+    st.see(1_900_000)
+    assert st.capacity(Buf) >= 1_900_000 * graphs.HEADROOM
+    grown = st.cap
+    # a smaller batch does not shrink it until a whole window has passed
+    for it in range(graphs.SHRINK_WINDOW - 1):
+        st.see(400_000)
+        assert st.capacity(Buf) == grown
+    st.see(400_000)
+    small = st.capacity(Buf)
+    assert small < grown and small >= 400_000 * graphs.HEADROOM and small <= 400_000 * 1.02 * (1 + 1 / graphs.CAP_STEPS) + graphs.GRANULE
+    # never above the march buffers' upper bound (dense occupancy: M = N * S exactly)
+    st.see(Buf.cap)
+    assert st.capacity(Buf) == Buf.cap
+    # voxel mode: multiples of GRANULE * k
+    class Buf2:
+        k, cap = 2, 10 ** 9
+    st2 = graphs._State()
+    st2.see(325_001)
+    assert st2.capacity(Buf2) % (graphs.GRANULE * 2) == 0
+    # LRU of captured capacities
+    made = []
+    for c in (1, 2, 3, 2, 4):
+        st.bucket(c, lambda c=c: made.append(c) or ("graph", c))
+    assert list(st.buckets) == [2, 4] and made == [1, 2, 3, 4]

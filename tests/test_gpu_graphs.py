@@ -1,6 +1,8 @@
 """PanopticPackedRFTracer(use_graphs=True): the post-march part of a training trace replayed as HIP graphs over padded static buffers
 (pagnerf_amd/graphs.py) against the eager path on the same rays and jitter - forward values bit for bit, every gradient up to the
-fp32 summation order of the weight-gradient slabs; capacity overflow falls back to the eager path; no_grad traces never use graphs."""
+fp32 summation order of the weight-gradient slabs; a batch that overflows the capacity runs truncated inside the capacity-sized tensors
+and the eager path answers; the gradients / outputs handed to the caller obey ordinary ownership rules (accumulation, zero_grad(set_to_none=
+False), buffers kept across steps); the split backward (two graphs, N > 1 ranks) equals the single one; no_grad traces never use graphs."""
 import collections
 
 import numpy as np
@@ -66,12 +68,6 @@ def test_graph_replay_equals_eager(gpu_device, mode, use):
     rb_g2, loss_g2, g_g2 = _step(nef, gt, rays_p, jit[perm], tp)
     assert torch.equal(rb_g2.rgb, rb_e2.rgb) and torch.equal(rb_g2.inst_embedding, rb_e2.inst_embedding) and torch.equal(loss_g2, loss_e2)
     assert T._rel_l2(g_g2["delta_grid.tables"].float(), g_e2["delta_grid.tables"].float()) < 1e-5
-    # a capacity that the batch overflows: the replay is discarded, the eager path answers (same values)
-    st = next(iter(gt._graphs.states.values()))
-    st.counts = collections.deque([64], maxlen=8)
-    st.buckets = {k: v for k, v in st.buckets.items()}
-    rb_o, loss_o, _ = _step(nef, gt, rays, jit, targets)
-    assert torch.equal(rb_o.rgb, rb_e.rgb) and torch.equal(loss_o, loss_e)
     # no_grad / validation traces never take the graph path
     before = (gt._graphs.captures, gt._graphs.replays)
     with torch.no_grad():
@@ -138,3 +134,225 @@ def test_graph_states_are_bounded(gpu_device):
     a = tr(nef, channels=sets[0], rays=rays, stage="train", jitter=j).rgb
     b = eager(nef, channels=sets[0], rays=rays, stage="train", jitter=j).rgb
     assert torch.equal(a, b)
+
+
+def _half_outside(rays, dev):
+    """The same rays with every second one moved out of the volume (no samples): a batch about half the size under the SAME graph key."""
+    import pagnerf_amd
+    o, d = rays.origins.clone(), rays.dirs.clone()
+    o[::2] = torch.tensor([3.0, 3.0, 3.0], device=dev)
+    d[::2] = torch.nn.functional.normalize(torch.tensor([1.0, 1.0, 1.0], device=dev), dim=0)
+    return pagnerf_amd.Rays(o, d, rays.dist_min, rays.dist_max)
+
+
+@pytest.mark.parametrize("use", [True, "static"])
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_overflowing_batch_stays_inside_the_capacity(gpu_device, mode, use, monkeypatch):
+    """A capacity captured on small batches, then a batch twice as large through the same configuration: the launches queued before
+    the host learns the count walk the CLAMPED pack table (no pack reaches past the capacity), `overflows` counts it, the eager path
+    answers with the eager values, and the next steps (capacity grown) replay again."""
+    import pagnerf_amd
+    from pagnerf_amd import graphs
+    monkeypatch.setattr(graphs, "GRANULE", 64)
+    dev = gpu_device
+    N, S = 96, 32
+    nef, tracer, rays, occ, jitter = ragged_scene(dev, "bf16", N=N, S=S)
+    if mode == "voxel":
+        tracer.raymarch_type, tracer.num_steps, tracer.ray_max_travel = "voxel", 2, 0.8
+        rays.dist_max = 3.0
+    jit = jitter.to(dev)
+    targets = _targets(N, dev)
+    small = _half_outside(rays, dev)
+    gt = pagnerf_amd.PanopticPackedRFTracer(raymarch_type=tracer.raymarch_type, num_steps=tracer.num_steps, bg_color="white",
+                                            ray_max_travel=tracer.ray_max_travel, use_graphs=use)
+    for _ in range(3):                      # eager, capture (or first static step), replay - all on the small batch
+        _step(nef, gt, small, jit, targets)
+    g = gt._graphs
+    st = next(iter(g.states.values()))
+    cap = st.cap
+    rb_e, loss_e, g_e = _step(nef, tracer, rays, jit, targets)
+    M = int(st.buf.pack_start[N])           # still the small batch's table
+    assert M <= cap and g.overflows == 0
+    rb_o, loss_o, g_o = _step(nef, gt, rays, jit, targets)
+    M_big = int(st.buf.pack_start[N])
+    assert M_big > cap, (M_big, cap)        # the batch really overflowed the capacity the launches ran with
+    assert g.overflows == 1
+    ps, pc = st.buf.pack_start, st.buf.pack_start_c
+    assert int(pc.max()) == cap and torch.equal(pc, ps.clamp(max=cap))
+    for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding"):
+        assert torch.equal(getattr(rb_o, ch), getattr(rb_e, ch)), ch
+    assert torch.equal(loss_o, loss_e)
+    for name, want in g_e.items():
+        if want is not None:
+            assert T._rel_l2(g_o[name].float(), want.float()) < 1e-5, name
+    # the capacity has grown with the observed count: the same batch now fits and is replayed
+    before = g.replays
+    rb_2, loss_2, _ = _step(nef, gt, rays, jit, targets)
+    assert st.cap >= M_big and g.overflows == 1 and g.replays == before + 1
+    assert torch.equal(rb_2.rgb, rb_e.rgb) and torch.equal(loss_2, loss_e)
+    rb_3, loss_3, _ = _step(nef, gt, rays, jit, targets)
+    assert torch.equal(rb_3.inst_embedding, rb_e.inst_embedding) and torch.equal(loss_3, loss_e)
+    assert len(st.buckets) <= graphs.MAX_BUCKETS
+
+
+def _fresh_tracers(tracer, **kw):
+    import pagnerf_amd
+    mk = lambda use: pagnerf_amd.PanopticPackedRFTracer(raymarch_type=tracer.raymarch_type, num_steps=tracer.num_steps, bg_color="white",
+                                                        ray_max_travel=tracer.ray_max_travel, use_graphs=use, **kw)
+    return mk(False), mk(True)
+
+
+def _warm(nef, gt, rays, jit, targets):
+    for _ in range(3):                      # eager (learns the count), capture, replay
+        _step(nef, gt, rays, jit, targets)
+
+
+def test_graph_gradients_accumulate_like_eager(gpu_device):
+    """Two traces (different rays) of one captured configuration, each followed by backward(), then ONE optimiser step: p.grad = g1 + g2
+    as the eager path gives it - the first backward's p.grad (which autograd adopted from the capture's static buffer) must survive
+    the second replay."""
+    dev = gpu_device
+    N, S = 96, 32
+    nef, tracer, rays, occ, jitter = ragged_scene(dev, "bf16", N=N, S=S)
+    jit = jitter.to(dev)
+    targets = _targets(N, dev)
+    et, gt = _fresh_tracers(tracer)
+    _warm(nef, gt, rays, jit, targets)
+    perm = torch.randperm(N, device=dev)
+    import pagnerf_amd
+    rays2 = pagnerf_amd.Rays(rays.origins[perm], rays.dirs[perm], rays.dist_min, rays.dist_max)
+    t2 = tuple(t.flip(0) for t in targets)
+
+    def two_traces(tr):
+        for p in nef.parameters():
+            p.grad = None
+        for r, j, t in ((rays, jit, targets), (rays2, jit[perm], t2)):
+            rb = tr(nef, channels=CH, rays=r, jitter=j, stage="train")
+            train_loss(rb.rgb, rb.semantics.float(), rb.inst_embedding.float(), *t).backward()
+        torch.cuda.synchronize()
+        return {k: v.grad.clone() for k, v in hip_leaves(nef).items() if v.grad is not None}
+    want = two_traces(et)
+    got = two_traces(gt)
+    assert gt._graphs.overflows == 0 and gt._graphs.captures == 1
+    assert set(got) == set(want)
+    for name in want:
+        assert T._rel_l2(got[name].float(), want[name].float()) < 1e-5, (name, T._rel_l2(got[name].float(), want[name].float()))
+    # and it is NOT 2 x g2 (what an aliased p.grad would hold): g1 != g2 here
+    _, _, g2 = _step(nef, et, rays2, jit[perm], t2)
+    assert T._rel_l2(got["delta_grid.tables"].float(), 2 * g2["delta_grid.tables"].float()) > 1e-2
+
+
+def test_graph_zero_grad_in_place_tracks_eager(gpu_device):
+    """Five Adam steps with zero_grad(set_to_none=False) - p.grad keeps the tensor autograd adopted from the capture - and a
+    GradScaler-style in-place unscale of p.grad between backward and step: parameters follow the eager path."""
+    dev = gpu_device
+    N, S = 96, 32
+    finals = {}
+    for use in (False, True):
+        nef, tracer, rays, occ, jitter = ragged_scene(dev, "fp32", N=N, S=S)       # seeded: the same initial state both times
+        jit = jitter.to(dev)
+        targets = _targets(N, dev)
+        tr = _fresh_tracers(tracer)[1 if use else 0]
+        opt = torch.optim.Adam(nef.parameters(), lr=1e-3, eps=1e-15)
+        if use:
+            _warm(nef, tr, rays, jit, targets)          # no optimiser step in there: the parameters are still the initial ones
+        losses = []
+        for it in range(5):
+            opt.zero_grad(set_to_none=False)
+            rb = tr(nef, channels=CH, rays=rays, jitter=jit, stage="train")
+            loss = train_loss(rb.rgb, rb.semantics.float(), rb.inst_embedding.float(), *targets) * 4.0
+            loss.backward()
+            for p in nef.parameters():      # what GradScaler.unscale_ does: in place on p.grad
+                if p.grad is not None:
+                    p.grad.mul_(0.25)
+            opt.step()
+            losses.append(float(loss))
+        finals[use] = (losses, {k: v.detach().clone() for k, v in hip_leaves(nef).items()})
+        if use:
+            assert tr._graphs.replays >= 5 and tr._graphs.overflows == 0
+    np.testing.assert_allclose(finals[True][0], finals[False][0], rtol=1e-5)
+    for name, want in finals[False][1].items():
+        assert T._rel_l2(finals[True][1][name].float(), want.float()) < 1e-5, name
+
+
+def test_graph_outputs_are_owned_by_the_caller(gpu_device):
+    """The RenderBuffer of step k is bit-unchanged after step k + 1 (different rays), and so is a gradient tensor the caller kept."""
+    import pagnerf_amd
+    dev = gpu_device
+    N, S = 96, 32
+    nef, tracer, rays, occ, jitter = ragged_scene(dev, "bf16", N=N, S=S)
+    jit = jitter.to(dev)
+    targets = _targets(N, dev)
+    _, gt = _fresh_tracers(tracer)
+    _warm(nef, gt, rays, jit, targets)
+    rb1, _, g1 = _step(nef, gt, rays, jit, targets)
+    kept = {ch: getattr(rb1, ch).clone() for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding", "hit")}
+    perm = torch.randperm(N, device=dev)
+    rays2 = pagnerf_amd.Rays(rays.origins[perm], rays.dirs[perm], rays.dist_min, rays.dist_max)
+    rb2, _, _ = _step(nef, gt, rays2, jit[perm], tuple(t[perm] for t in targets))
+    assert not torch.equal(rb2.rgb, kept["rgb"])
+    for ch, want in kept.items():
+        assert torch.equal(getattr(rb1, ch), want), ch
+    # a second backward over a trace whose forward graph has been replayed since must fail loudly, not return stale gradients
+    rb_a = gt(nef, channels=CH, rays=rays, jitter=jit, stage="train")
+    rb_b = gt(nef, channels=CH, rays=rays2, jitter=jit[perm], stage="train")
+    with pytest.raises(RuntimeError, match="replayed again"):
+        rb_a.rgb.sum().backward()
+    rb_b.rgb.sum().backward()
+
+
+def test_split_backward_graphs_equal_the_single_graph(gpu_device):
+    """graph_split=True (what N > 1 ranks run): the panoptic heads' backward - which completes the delta table's gradient - is one graph,
+    the rest another, each behind its own autograd node; a post-accumulate hook on the delta table fires BEFORE the main table's
+    gradient exists.  Values are bit-equal to the single backward graph."""
+    dev = gpu_device
+    N, S = 96, 32
+    nef, tracer, rays, occ, jitter = ragged_scene(dev, "bf16", N=N, S=S)
+    jit = jitter.to(dev)
+    targets = _targets(N, dev)
+    _, single = _fresh_tracers(tracer)
+    _, split = _fresh_tracers(tracer, graph_split=True)
+    _warm(nef, single, rays, jit, targets)
+    _warm(nef, split, rays, jit, targets)
+    order = []
+    leaves = hip_leaves(nef)
+    hooks = [leaves[n].register_post_accumulate_grad_hook(lambda p, n=n: order.append(n)) for n in ("delta_grid.tables", "grid.tables")]
+    try:
+        rb_s, loss_s, g_s = _step(nef, single, rays, jit, targets)
+        order.clear()
+        rb_p, loss_p, g_p = _step(nef, split, rays, jit, targets)
+    finally:
+        for h in hooks:
+            h.remove()
+    gr = next(iter(split._graphs.states.values()))
+    graphed = next(iter(gr.buckets.values()))
+    assert len(graphed.groups) == 2
+    assert order == ["delta_grid.tables", "grid.tables"], order
+    assert torch.equal(loss_p, loss_s)
+    for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding"):
+        assert torch.equal(getattr(rb_p, ch), getattr(rb_s, ch)), ch
+    for name, want in g_s.items():
+        got = g_p[name]
+        assert (got is None) == (want is None), name
+        if want is not None:
+            assert torch.equal(got, want), name
+
+
+def test_graph_key_follows_requires_grad(gpu_device):
+    """A parameter frozen / unfrozen after a capture is a different configuration: the unfrozen parameter receives its gradient."""
+    dev = gpu_device
+    N, S = 96, 32
+    nef, tracer, rays, occ, jitter = ragged_scene(dev, "bf16", N=N, S=S)
+    jit = jitter.to(dev)
+    targets = _targets(N, dev)
+    _, gt = _fresh_tracers(tracer)
+    nef.delta_grid.tables.requires_grad_(False)
+    _warm(nef, gt, rays, jit, targets)
+    assert nef.delta_grid.tables.grad is None and gt._graphs.captures == 1
+    nef.delta_grid.tables.requires_grad_(True)
+    _warm(nef, gt, rays, jit, targets)
+    assert gt._graphs.captures == 2
+    _, _, g = _step(nef, gt, rays, jit, targets)
+    et, _ = _fresh_tracers(tracer)
+    _, _, ge = _step(nef, et, rays, jit, targets)
+    assert g["delta_grid.tables"] is not None and T._rel_l2(g["delta_grid.tables"].float(), ge["delta_grid.tables"].float()) < 1e-5
