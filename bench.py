@@ -463,6 +463,55 @@ def pmc_bytes_per_step(blob, entry, calls_per_step):
     return int(total)
 
 
+# ------------------------------------------------------------------------------------------- forward-only render (validation path)
+def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=8000, images=2):
+    """The reference's OTHER caller of the path: pc_nerf/trainer.py:943-999 validate -> :637-649 batch_render - one H x W image
+    (BUP20: 720 x 1280) through pagnerf_amd.batch_render under torch.no_grad(), render_batch = 8000 rays x 512 samples
+    (best.yaml:143,146), dense occupancy (every sample survives: the worst case for the renderer).  Reported for all channels and for
+    rgb + depth: ms per image, rays/s, per C-ABI entry point ms per image (HIP events around every call in a separate pass), and the
+    encode kernel's fraction of the HBM roof (876 B per sample and grid) over its launches in that pass."""
+    import numpy as np
+    import torch
+    import pagnerf_amd
+    from pagnerf_amd import ops
+    nef = make_model(args, dev, seed=0).eval()
+    tracer = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=512, bg_color="white", use_graphs=False)
+    pipe = pagnerf_amd.Pipeline(nef, tracer)
+    n = H * W
+    rays, _ = make_rays(n, dev, seed=77)
+    out = dict(image="%d x %d = %d rays x 512 samples, render_batch %d (%d traces per image), dense occupancy, torch.no_grad()"
+                     % (H, W, n, render_batch, (n + render_batch - 1) // render_batch))
+    bps = 12 + 24 * 4 * 2 * (2 if args.table_dtype == "fp16" else 4) + 24 * 2 * out_bytes
+    with torch.no_grad():
+        for tag, chans in (("all_channels", sorted(all_ch)), ("rgb_depth", ["depth", "rgb"])):
+            warm = pagnerf_amd.Rays(rays.origins[:4 * render_batch], rays.dirs[:4 * render_batch], rays.dist_min, rays.dist_max)
+            pagnerf_amd.batch_render(pipe, warm, channels=chans, render_batch=render_batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(images):
+                rb = pagnerf_amd.batch_render(pipe, rays, channels=chans, render_batch=render_batch)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / images
+            assert rb.rgb.shape[0] == n
+            ops.profile_start()
+            pagnerf_amd.batch_render(pipe, rays, channels=chans, render_batch=render_batch)
+            prof = ops.profile_stop()
+            per = {k.replace("pag_", ""): round(float(np.sum(v)), 3) for k, v in sorted(prof.items()) if float(np.sum(v)) > 0.05}
+            enc = prof.get("pag_%s_encode_fwd" % args.grid, [])
+            ent = dict(channels=chans, ms_per_image=round(dt * 1e3, 2), rays_s=round(n / dt, 1), samples_s=round(n * 512 / dt, 1),
+                       entry_points_ms_per_image=per, device_ms_per_image=round(float(sum(np.sum(v) for v in prof.values())), 2))
+            if enc:
+                m_launch = render_batch * 512
+                full = [e for e in enc][:n // render_batch]          # the full-size launches (the last chunk of an image is shorter)
+                ent["encode_fwd"] = dict(launches=len(enc), avg_launch_ms=round(float(np.mean(full)), 4),
+                                         hbm_frac=round(bps * m_launch / (float(np.mean(full)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         bytes_per_sample=bps)
+            out[tag] = ent
+    del nef, pipe, rays
+    torch.cuda.empty_cache()
+    return out
+
+
 # -------------------------------------------------------------------------------------------------- dry run (CPU, gloo)
 def dry_run_rank(args, world, rank):
     """No kernels: the process group, shard.GradSync / all_gather_render on CPU tensors, the timing protocol and the JSON line."""
@@ -847,6 +896,8 @@ def run_rank(args):
             cfgs.append(short_run("post-prune regime (f3): voxel march, %.0f %% occupancy, 2 samples per voxel, permuto, all channels"
                                   % (100 * args.occupancy), 20, 5, rays_n=4096, samples=2, grid="permuto", channels=all_ch, raymarch="voxel"))
             line["configs"] = cfgs
+        if world == 1 and default_cfg:
+            line["render"] = render_image_line(args, dev, all_ch, out_bytes)
         if world > 1 and default_cfg:
             # ---- strong scaling, BASELINE configs[3]: one 24 576-ray step (6 images, pose-opt) split over the ranks
             total = 6 * 4096

@@ -82,24 +82,23 @@ def _fresh(statics):
 
 class _GraphedFn(torch.autograd.Function):
     """One autograd node per backward GROUP of a captured configuration (one group = the whole backward by default; two when the
-    capture is split, see _Graphed).  The node of group 0 replays the forward graph.
+    capture is split, see _Graphed).  _Graphed.__call__ replays the forward graph, then creates the nodes.
 
     Ownership (every output freshly allocated per call; trainer.py:426 `zero_grad(set_to_none=True)` is the reference's own
     usage but not a contract): the outputs handed to the caller are COPIES of the static outputs (a RenderBuffer of step k is untouched
     by step k + 1).  The gradients returned to autograd are the static buffers themselves - AccumulateGrad adopts such a tensor as
-    `p.grad` when the parameter has none, which saves a 100 MB copy per step - and therefore, before the backward graph overwrites them,
-    any `p.grad` that still shares their storage (gradient accumulation over several traces, `zero_grad(set_to_none=False)`, a GradScaler
-    that unscaled in place) is first detached from the capture: it becomes a private copy.  A caller that follows the reference's loop
-    (`set_to_none=True`, one trace per step) never pays for that copy."""
+    `p.grad` when the parameter has none, which saves a 100 MB copy per step - and therefore, before the NEXT trace replays the forward
+    graph (whose temporaries may share pool blocks with them), any `p.grad` that still shares their storage (gradient accumulation
+    over several traces, `zero_grad(set_to_none=False)`, a GradScaler that unscaled in place) is first detached from the capture: it
+    becomes a private copy (_Graphed.detach_param_grads).  A caller that follows the reference's loop (`set_to_none=True`, one trace per
+    step) never pays for that copy.  What is NOT protected: a gradient tensor the caller took out of `p.grad` and kept beyond the next
+    trace of the same configuration without cloning it."""
 
     @staticmethod
     def forward(ctx, runner, gi, *params):
         ctx.runner, ctx.gi = runner, gi
         ctx.set_materialize_grads(False)      # outputs the loss does not use arrive as None in backward(), not as zero tensors filled per step
         grp = runner.groups[gi]
-        if gi == 0:
-            runner.fwd.replay()
-            runner.generation += 1
         ctx.generation = runner.generation
         idx = grp.out_idx + (runner.nondiff_idx if gi == 0 else [])
         outs = _fresh([runner.outs[i] for i in idx])
@@ -115,12 +114,7 @@ class _GraphedFn(torch.autograd.Function):
             raise RuntimeError("pagnerf_amd.graphs: the forward graph of this configuration was replayed again before this backward ran - the "
                                "activations it saved are gone.  Call backward() on a trace before tracing the same configuration again "
                                "(or construct the tracer with use_graphs=False / 'static').")
-        # a p.grad that still aliases this group's static gradients must not be overwritten by the replay (see the class docstring)
-        for p, g in zip(grp.params, grp.gins):
-            pg = p.grad
-            if pg is not None and g is not None and pg.untyped_storage().data_ptr() == g.untyped_storage().data_ptr():
-                p.grad = pg.clone()
-                r.unaliased += 1
+        r.detach_param_grads(grp)         # (already done before the forward replay; a p.grad assigned since then is caught here)
         # upstream gradients -> the backward graph's static inputs: ONE multi-tensor copy (they were five ~3 us launches in a 1.4 ms step);
         # an output the loss does not use arrives as None: its static gradient is zeroed once and stays zero (the graph only reads it)
         dst, src, zero = [], [], []
@@ -159,7 +153,7 @@ class _Graphed:
 
     split (names of outputs, e.g. the panoptic channels): the backward is captured as TWO graphs - the gradients that flow from the
     `split` outputs, then those of the remaining outputs - and each graph sits behind its own autograd node, the split one created
-    last so that the engine runs it first.  Whatever a caller hangs on the parameters between the two (shard.GradSync's post-accumulate
+    last so that the engine runs it first (each with a memory pool of its own: correct in either order).  Whatever a caller hangs on the parameters between the two (shard.GradSync's post-accumulate
     hook: the delta grid's table gradient is complete after the panoptic heads' backward and starts its all-reduce while the colour /
     density decoders and the main grid are still running) fires as in an eager backward.  Same kernels, same values."""
 
@@ -178,10 +172,11 @@ class _Graphed:
             return torch.func.functional_call(mod, self.alias, args)
 
         def groups_of(outs):
+            """Output indices per backward graph, in the order the graphs are captured AND replayed: the split outputs' graph first."""
             diff = [i for i, o in enumerate(outs) if o.requires_grad]
             late = [i for i in diff if mod.names[i] in split]
-            early = [i for i in diff if mod.names[i] not in split]
-            return [g for g in (early, late) if g] or [[]]
+            rest = [i for i in diff if mod.names[i] not in split]
+            return [g for g in (late, rest) if g] or [[]]
         with torch.cuda.stream(side):
             for _ in range(2):          # warm-up: lazy initialisations (cached index tensors, workspaces) happen outside the capture
                 outs = run()
@@ -207,7 +202,11 @@ class _Graphed:
             grp.zeroed = set()             # indices of gouts known to hold zeros (set by _GraphedFn.backward)
             grp.bwd = torch.cuda.CUDAGraph()
             if idx:
-                with torch.cuda.graph(grp.bwd, pool=pool):
+                # ONE backward graph shares the forward's pool (its temporaries reuse the activations autograd releases on the way: replayed
+                # strictly after the forward, as captured).  TWO backward graphs get a pool each: a pool hands memory freed by an earlier
+                # capture to a later one, which is only sound when replays follow the capture order - and which of the two autograd nodes
+                # runs first (or at all: a loss without the panoptic terms) is the engine's / the caller's choice, not ours.
+                with torch.cuda.graph(grp.bwd, pool=pool if len(gs) == 1 else torch.cuda.graph_pool_handle()):
                     gins = torch.autograd.grad([self.outs[i] for i in idx], leaves, grp.gouts, allow_unused=True, retain_graph=j + 1 < len(gs))
             else:
                 gins = [None] * len(leaves)
@@ -219,9 +218,25 @@ class _Graphed:
         self.unaliased = 0                 # p.grad tensors that had to be detached from the capture's static gradients (diagnostics / tests)
         torch.cuda.synchronize()
 
+    def detach_param_grads(self, grp=None):
+        """A p.grad that still shares storage with the capture's static gradients becomes a private copy.  Called BEFORE the forward
+        replay: the static gradients live in the capture's memory pool, where the forward graph's temporaries may occupy the same
+        blocks - a replay of the FORWARD already scribbles over them, not just the next backward."""
+        for g_ in ([grp] if grp is not None else self.groups):
+            for p, g in zip(g_.params, g_.gins):
+                pg = p.grad
+                if pg is not None and pg.untyped_storage().data_ptr() == g.untyped_storage().data_ptr():
+                    p.grad = pg.clone()
+                    self.unaliased += 1
+
     def __call__(self):
+        self.detach_param_grads()
+        self.fwd.replay()
+        self.generation += 1
         res = [None] * len(self.outs)
-        for gi, grp in enumerate(self.groups):
+        # autograd runs the node created LAST first: the groups are listed in the order their backward graphs should run
+        for gi in reversed(range(len(self.groups))):
+            grp = self.groups[gi]
             outs = _GraphedFn.apply(self, gi, *grp.params)
             for i, o in zip(grp.out_idx + (self.nondiff_idx if gi == 0 else []), outs):
                 res[i] = o

@@ -346,6 +346,19 @@ def _recompute_hidden(x1, x2, x2_index, Wc, bc, in_dim, k1, grouped, mode, hidde
 
 
 _NO_FAST_FWD = os.environ.get("PAG_NO_FAST_FWD") is not None
+_OUTER_GRAD = True          # grad mode of the code that called the decoder op (see _apply_decoder)
+
+
+def _apply_decoder(fn, *args):
+    """fn.apply(*args) with the caller's grad mode visible to the forward: under torch.no_grad() (validation renders, prune) the decoder
+    launches keep nothing for a backward - no hidden activations, no softmax statistics beyond what the statistics-only wide head hands to
+    its own compositing launch."""
+    global _OUTER_GRAD
+    prev, _OUTER_GRAD = _OUTER_GRAD, torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _OUTER_GRAD = prev
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -364,7 +377,12 @@ class _FusedMLP(torch.autograd.Function):
         if x1.dtype not in (torch.float32, torch.bfloat16):
             x1 = x1.float()
         out_dim = Ws[-1].shape[0]
-        need_grad = any(t.requires_grad for t in wb) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        # under torch.no_grad() (validation renders, prune) nothing is kept for a backward: no hidden activations, no softmax statistics
+        # beyond what the statistics-only wide head hands to its compositing launch
+        # (_OUTER_GRAD: the grad mode of the CALLER, recorded by _apply_decoder - inside an autograd.Function's forward grad mode is always
+        # off, and ctx.needs_input_grad / tensor.requires_grad still say True for a parameter inside a no_grad region)
+        any_grad = getattr(ctx, "any_grad", None)
+        need_grad = _OUTER_GRAD and bool(any(ctx.needs_input_grad) if any_grad is None else any_grad)
         wide_softmax = mode == L.MLP_MFMA_BF16 and out_act == L.ACT_SOFTMAX and out_dim > 64 and out_dtype == torch.bfloat16
         stats_only = bool(getattr(ctx, "stats_only", False)) and wide_softmax       # _HeadComposite: no [M,out] tensor at all
         out = None if stats_only else torch.empty(M, out_dim, device=x1.device, dtype=out_dtype)
@@ -379,7 +397,7 @@ class _FusedMLP(torch.autograd.Function):
         hidden = []
         if need_grad or stats_only:
             for i in range(n_layers - 1):
-                keep = not recompute or (stats_only and i == n_layers - 2)
+                keep = (need_grad and not recompute) or (stats_only and i == n_layers - 2)
                 hidden.append(torch.empty(M, 64, device=x1.device, dtype=hdt) if keep else None)
         a = L.MlpFwdArgs()
         a.x1, a.x1_dtype, a.k1 = L.ptr(x1), L.dtype_code(x1), k1
@@ -694,7 +712,7 @@ class _ColourDensity(_FusedMLP):
 def colour_and_density(x1, weights, biases, x2, x2_index, in_dim, out_act=L.ACT_SIGMOID, mode=L.MLP_MFMA_BF16,
                        out_dtype=torch.float32, x2_packs=None):
     """-> (rgb [M,3], sigma f32 [M] = relu(x1[:,0])); x1 = the density decoder's [M,16] output (see _ColourDensity)."""
-    rgb, sigma = _ColourDensity.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
+    rgb, sigma = _apply_decoder(_ColourDensity, x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
     if x2_packs is not None and x2 is not None and x2.requires_grad and rgb.grad_fn is not None:
         rgb.grad_fn.x2_packs = x2_packs
     return rgb, sigma
@@ -707,7 +725,7 @@ def fused_mlp(x1, weights, biases, x2=None, x2_index=None, in_dim=None, out_act=
     x1_grouped=(levels, feats): x1 is the encoders' bf16 [8, M, 8] XCD-grouped tensor."""
     if in_dim is None:
         in_dim = weights[0].shape[1]
-    out = _FusedMLP.apply(x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, x1_grouped, *weights, *biases)
+    out = _apply_decoder(_FusedMLP, x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, x1_grouped, *weights, *biases)
     if x2_packs is not None and x2 is not None and x2.requires_grad and out.grad_fn is not None:
         out.grad_fn.x2_packs = x2_packs      # (pack_start, ray_of_pack): x2_index is constant inside each pack (d/d x2 only)
     return out
@@ -1291,8 +1309,9 @@ class _HeadComposite(_FusedMLP):
 class _SubCtx:
     """Per-head stand-in for the autograd ctx inside _HeadCompositePair."""
 
-    def __init__(self, needs_x1):
+    def __init__(self, needs_x1, any_grad):
         self.needs_input_grad = (needs_x1, False)
+        self.any_grad = any_grad          # does ANY input of the enclosing node (features, weights, biases) need a gradient?
         self.saved_tensors = ()
 
     def save_for_backward(self, *tensors):
@@ -1306,7 +1325,8 @@ class _HeadCompositePair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dims, out_dtype, grouped, n_a, *wb):
-        sub_a, sub_b = _SubCtx(ctx.needs_input_grad[0]), _SubCtx(ctx.needs_input_grad[0])
+        any_grad = any(ctx.needs_input_grad)
+        sub_a, sub_b = _SubCtx(ctx.needs_input_grad[0], any_grad), _SubCtx(ctx.needs_input_grad[0], any_grad)
         part_a, part_b = wb[:n_a], wb[n_a:]
         # the second (narrow) decoder is prepared first and parked: where the library can, it is evaluated inside the first one's launch
         # (pag_mlp_fwd_args.pair: the features are read once); its compositing pass follows either way
@@ -1344,7 +1364,7 @@ class _HeadCompositePair(torch.autograd.Function):
 def head_composite_pair(x1, heads, w, alpha, ridx, pack_start, ray_of_pack, N, out_dtype=torch.bfloat16, x1_grouped=None):
     """heads = ((weights, biases, in_dim), (weights, biases, in_dim)) -> (out_a, out_b), each as head_composite()."""
     (wa, ba, ia), (wb_, bb, ib) = heads
-    return _HeadCompositePair.apply(x1, w, alpha, ridx, pack_start, ray_of_pack, N, (int(ia), int(ib)), out_dtype, x1_grouped,
+    return _apply_decoder(_HeadCompositePair, x1, w, alpha, ridx, pack_start, ray_of_pack, N, (int(ia), int(ib)), out_dtype, x1_grouped,
                                     len(wa) + len(ba), *wa, *ba, *wb_, *bb)
 
 
@@ -1353,7 +1373,7 @@ def head_composite(x1, weights, biases, w, alpha, ridx, pack_start, ray_of_pack,
     """alpha[ray] * sum_i w_i * act(decoder(x1))[i]  ->  f32 [N, out_dim]; ridx i32 [M] = ray of each sample."""
     if in_dim is None:
         in_dim = weights[0].shape[1]
-    return _HeadComposite.apply(x1, w, alpha, ridx, pack_start, ray_of_pack, N, int(in_dim), out_act, out_dtype, x1_grouped,
+    return _apply_decoder(_HeadComposite, x1, w, alpha, ridx, pack_start, ray_of_pack, N, int(in_dim), out_act, out_dtype, x1_grouped,
                                 *weights, *biases)
 
 
