@@ -147,3 +147,36 @@ def nef_forward_dd(feats, delta_feats, ray_d, params, channels, view_multires=4,
             e = F.softmax(e, dim=-1) if inst_softmax else e
             out["inst_embedding"] = e
     return out
+
+
+def nef_forward_base(feats, ray_d, params, channels, view_multires=4, lod_weights=None, sem_detach=True, inst_detach=True,
+                     inst_direct_pos=False, coords=None, sem_softmax=True, inst_softmax=True, sem_sigmoid=False, inst_sigmoid=False,
+                     sem_normalize=False, inst_normalize=False):
+    """The base field, pc_nerf/panoptic_nef.py:253-363 (PanopticNeF.rgb_semantics): one grid; the semantic head reads
+    `feats.detach() if sem_detach else feats` (:338), the instance head `coords` when inst_direct_pos (:350-351) else
+    `feats.detach() if inst_detach else feats` (:353); with inst_softmax the instance output is softmax(decoder(x)) - :358 re-evaluates
+    the decoder, so the sigmoid / normalize results of :355-356 are discarded."""
+    out = {}
+    if lod_weights is not None:
+        feats = feats * lod_weights
+    dfe = mlp(feats, *params["density"])
+    out["density_feats"] = dfe
+    out["density"] = torch.relu(dfe[..., 0:1])
+    if "rgb" in channels:
+        pe = positional_embed(-ray_d, view_multires)
+        out["rgb"] = torch.sigmoid(mlp(torch.cat([dfe, pe], dim=-1), *params["color"]))
+    if "semantics" in channels:
+        s = mlp(feats.detach() if sem_detach else feats, *params["semantics"])
+        s = torch.sigmoid(s) if sem_sigmoid else s
+        s = F.normalize(s, dim=-1) if sem_normalize else s
+        out["semantics"] = F.softmax(s, dim=-1) if sem_softmax else s
+    if "inst_embedding" in channels:
+        x = coords if inst_direct_pos else (feats.detach() if inst_detach else feats)
+        e = mlp(x, *params["inst"])
+        if inst_softmax:
+            e = F.softmax(e, dim=-1)
+        else:
+            e = torch.sigmoid(e) if inst_sigmoid else e
+            e = F.normalize(e, dim=-1) if inst_normalize else e
+        out["inst_embedding"] = e
+    return out

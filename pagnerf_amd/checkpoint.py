@@ -1,5 +1,5 @@
-"""Importing a checkpoint written by the reference (config_parser.py:753-776: `torch.save(pipeline)` /
-`pipeline.state_dict()`) into the HIP pipeline.
+"""Checkpoints shared with the reference (config_parser.py:753-776: `torch.save(pipeline)` / `pipeline.state_dict()`): importing one
+it wrote into the HIP pipeline (load_reference_state_dict) and writing one it can load (save_reference_state_dict).
 
 What maps one to one (same module / parameter names): the four (five) decoders `nef.decoder_*.layers.N.{weight,bias}`,
 `nef.decoder_*.lout.{weight,bias}`, BAPipeline's `camera_extrinsics`.  What needs a conversion:
@@ -119,3 +119,65 @@ def load_reference_state_dict(pipeline, state_dict, strict_decoders=True):
                 grid.blas_init_bits(octree_to_bits(parts["blas_octree"], grid.blas_level).to(grid.blas_bits.device))
                 used.update(prefix + k for k in parts if k.startswith("blas_"))
     return sorted(set(sd) - used)
+
+
+def spc_buffers(bits, level):
+    """The four buffers wisp's OctreeAS keeps beside a grid (grids/permuto_grid.py:33-38, grids/occtree.py:69-74) for the occupancy
+    bitfield `bits`: blas_octree (bits_to_octree), blas_points int16 [n_points, 3] (integer coordinates of every node of every level,
+    root first, each level in the octree's own breadth-first = Morton order), blas_pyramid int32 [2, level + 2] (row 0: points per level
+    followed by 0, row 1: their exclusive prefix sum followed by the total) and blas_prefix int32 [n_bytes] (exclusive prefix sum of the
+    child counts of the octree bytes).  Layouts recalled from kaolin's public SPC documentation (kaolin.ops.spc.scan_octrees /
+    generate_points): third party, PARITY UNPINNED - load_reference_state_dict() itself needs blas_octree only."""
+    octree = bits_to_octree(bits, level)
+    counts = torch.tensor([bin(int(b)).count("1") for b in octree.tolist()], dtype=torch.int32)
+    prefix = torch.cumsum(counts, 0, dtype=torch.int32) - counts
+    pts = [torch.zeros(1, 3, dtype=torch.int16)]
+    per_level = [1]
+    pos = 0
+    bit = torch.arange(8)
+    cur = torch.zeros(1, 3, dtype=torch.long)
+    for _ in range(level):
+        n = cur.shape[0]
+        present = ((octree[pos:pos + n].long()[:, None] >> bit[None, :]) & 1).bool()
+        pos += n
+        child = torch.stack([(bit >> 2) & 1, (bit >> 1) & 1, bit & 1], -1)                       # child i = 4x + 2y + z
+        cur = (cur[:, None, :] * 2 + child[None, :, :])[present]
+        pts.append(cur.to(torch.int16))
+        per_level.append(cur.shape[0])
+    n_lv = torch.tensor(per_level + [0], dtype=torch.int32)
+    start = torch.cumsum(n_lv, 0, dtype=torch.int32) - n_lv
+    start[-1] = int(sum(per_level))
+    return dict(blas_octree=octree, blas_points=torch.cat(pts), blas_prefix=prefix, blas_pyramid=torch.stack([n_lv, start]))
+
+
+def save_reference_state_dict(pipeline, permuto_names=("lattice_values", "random_shift_per_level")):
+    """The inverse of load_reference_state_dict(): a state dict with the key names a reference pipeline's own `state_dict()` has, so
+    that `config_parser.py:757-776` (`model_format` params_only / params_only_ignore_missmatch / state_dict, all `strict=False`)
+    can load a model trained here.  Decoders and `camera_extrinsics` keep their names; a hash grid's table goes out as
+    `nef.<grid>.embedder.embeddings.<level>.weight` [2^log2T, F] per level (grids/hash_grid_torch.py:61-62); a permutohedral grid's as
+    `nef.<grid>.embedder.<permuto_names[0]>` [L, capacity, F] and its shift as `...<permuto_names[1]>` [L, 3] - the parameter names of
+    the third-party `permutohedral_encoding.PermutoEncoding` module (recalled; pass the names of the installed
+    version if they differ); the occupancy as wisp's four SPC buffers (spc_buffers)."""
+    from .grids import PermutoGridHIP
+    nef = pipeline.nef
+    out = {}
+    for k, v in nef.state_dict().items():
+        if "decoder" in k:
+            out["nef." + k] = v.detach().float().cpu().clone()
+    if hasattr(pipeline, "camera_extrinsics"):
+        out["camera_extrinsics"] = pipeline.camera_extrinsics.detach().cpu().clone()
+    for name in ("grid", "delta_grid"):
+        grid = getattr(nef, name, None)
+        if grid is None:
+            continue
+        prefix = "nef.%s." % name
+        tab = grid.tables.detach().float().cpu()
+        if isinstance(grid, PermutoGridHIP):
+            out[prefix + "embedder." + permuto_names[0]] = tab.clone()
+            out[prefix + "embedder." + permuto_names[1]] = grid.random_shift_per_level.detach().float().cpu().clone()
+        else:
+            for lv in range(tab.shape[0]):
+                out[prefix + "embedder.embeddings.%d.weight" % lv] = tab[lv].clone()
+        for k, v in spc_buffers(grid.blas_bits, grid.blas_level).items():
+            out[prefix + k] = v
+    return out

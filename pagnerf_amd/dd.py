@@ -73,7 +73,7 @@ class PanopticDDensityNeF(PanopticDeltaNeF):
                                     ray_dirs=ray_dirs, ray_packs=ray_packs) if base else {}
         if extra:
             batch, num_samples, _ = coords.shape
-            feats = self._feat_cache[1]
+            feats = self._feat_cache[1].detach()
             delta = self._interp(self.delta_grid, coords.detach())
             pan = delta if self.separate_sem_grid else feats + delta                         # :231-234
             dd = self.decoder_delta_density(pan, self._grouped()).reshape(batch, num_samples, 1)   # :238

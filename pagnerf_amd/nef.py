@@ -260,7 +260,7 @@ class PanopticDeltaNeF(nn.Module):
             feats = pre[1]                                    # launched by the tracer right after the ray march
         else:
             feats = self._interp(self.grid, coords)                                   # :170-171
-        self._feat_cache = (coords, feats.detach())           # reused by panoptic_composited() for the same samples
+        self._feat_cache = (coords, feats)                    # reused by panoptic_composited() for the same samples
         grp = self._grouped()
         density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
         self._density_feats = density_feats                      # the delta-density variant adds to its column 0 (pre-ReLU)
@@ -279,28 +279,38 @@ class PanopticDeltaNeF(nn.Module):
         if "density" in compute_channels:
             out["density"] = density
         if "semantics" in compute_channels or "inst_embedding" in compute_channels:    # :210-236
-            pan = self._panoptic_feats(feats.detach(), coords)
-            grp = self._pan_grouped()
+            (sem_in, sem_grp), (inst_in, inst_grp) = self._head_inputs(feats, coords, compute_channels)
             if "semantics" in compute_channels:                                        # :238-244
                 plain = not (self.sem_sigmoid or self.sem_normalize)
                 act = L.ACT_SOFTMAX if (self.sem_softmax and plain) else L.ACT_NONE
-                s = self.decoder_semantics(pan, out_act=act, mode=mode, x1_grouped=grp, out_dtype=self.feat_dtype)
+                s = self.decoder_semantics(sem_in, out_act=act, mode=mode, x1_grouped=sem_grp, out_dtype=self.feat_dtype)
                 if not plain:
                     s = torch.sigmoid(s) if self.sem_sigmoid else s
                     s = F.normalize(s, dim=-1) if self.sem_normalize else s
                     s = F.softmax(s, dim=-1) if self.sem_softmax else s
                 out["semantics"] = s
             if "inst_embedding" in compute_channels:                                   # :246-257
-                plain = not (self.inst_sigmoid or self.inst_normalize or self.inst_soft_temperature > 0.0)
-                act = L.ACT_SOFTMAX if (self.inst_softmax and plain) else L.ACT_NONE
-                e = self.decoder_inst(pan, out_act=act, mode=mode, x1_grouped=grp, out_dtype=self.feat_dtype)
-                if not plain:
-                    e = torch.sigmoid(e) if self.inst_sigmoid else e
-                    e = F.normalize(e, dim=-1) if self.inst_normalize else e
-                    e = e / self.inst_soft_temperature if self.inst_soft_temperature > 0.0 else e
-                    e = F.softmax(e, dim=-1) if self.inst_softmax else e
-                out["inst_embedding"] = e
+                out["inst_embedding"] = self._inst_head(inst_in, inst_grp, mode)
         return out
+
+    def _inst_head(self, inst_in, inst_grp, mode):
+        """panoptic_delta_nef.py:246-257: decoder -> [sigmoid] -> [normalize] -> [/T] -> [softmax]."""
+        plain = not (self.inst_sigmoid or self.inst_normalize or self.inst_soft_temperature > 0.0)
+        act = L.ACT_SOFTMAX if (self.inst_softmax and plain) else L.ACT_NONE
+        e = self.decoder_inst(inst_in, out_act=act, mode=mode, x1_grouped=inst_grp, out_dtype=self.feat_dtype)
+        if not plain:
+            e = torch.sigmoid(e) if self.inst_sigmoid else e
+            e = F.normalize(e, dim=-1) if self.inst_normalize else e
+            e = e / self.inst_soft_temperature if self.inst_soft_temperature > 0.0 else e
+            e = F.softmax(e, dim=-1) if self.inst_softmax else e
+        return e
+
+    def _head_inputs(self, feats, coords, channels):
+        """((semantic head's input, its grouped layout or None), (instance head's ...)) from the LIVE main features `feats`
+        (panoptic_delta_nef.py:210-236: both heads read one tensor built from feats.detach())."""
+        pan = self._panoptic_feats(feats.detach(), coords)
+        grp = self._pan_grouped()
+        return (pan, grp), (pan, grp)
 
     def can_fuse_panoptic(self, channels):
         """True when the semantic / instance heads can run as decoder + compositing in one autograd node."""
@@ -318,20 +328,19 @@ class PanopticDeltaNeF(nn.Module):
         rgb_semantics() :210-255 followed by tracer :197-205, but each head + its per-ray weighted sum is one autograd
         node whose backward feeds the decoder a rank-1 gradient (ops.head_composite)."""
         cache = getattr(self, "_feat_cache", None)
-        feats = cache[1] if cache is not None and cache[0] is coords else self._interp(self.grid, coords).detach()
-        pan = self._panoptic_feats(feats, coords)
-        grp = self._grouped()
+        feats = cache[1] if cache is not None and cache[0] is coords else self._interp(self.grid, coords)
+        (sem_in, sem_grp), (inst_in, inst_grp) = self._head_inputs(feats, coords, channels)
         out = {}
-        if "semantics" in channels and "inst_embedding" in channels and grp is not None:
+        if "semantics" in channels and "inst_embedding" in channels and sem_in is inst_in and sem_grp is not None:
             # both heads read the same features: one autograd node, the input gradient is summed inside the kernels
             heads = tuple((*dec.weights(), dec.input_dim) for dec in (self.decoder_inst, self.decoder_semantics))
-            out["inst_embedding"], out["semantics"] = ops.head_composite_pair(pan, heads, w, alpha, ridx, pack_start, ray_of_pack, N,
-                                                                              out_dtype=self.feat_dtype, x1_grouped=grp)
+            out["inst_embedding"], out["semantics"] = ops.head_composite_pair(sem_in, heads, w, alpha, ridx, pack_start, ray_of_pack, N,
+                                                                              out_dtype=self.feat_dtype, x1_grouped=sem_grp)
             return out
-        for ch, dec in (("semantics", self.decoder_semantics), ("inst_embedding", self.decoder_inst)):
+        for ch, dec, x, grp in (("semantics", self.decoder_semantics, sem_in, sem_grp), ("inst_embedding", self.decoder_inst, inst_in, inst_grp)):
             if ch in channels:
                 W, b = dec.weights()
-                out[ch] = ops.head_composite(pan, W, b, w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=dec.input_dim,
+                out[ch] = ops.head_composite(x, W, b, w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=dec.input_dim,
                                              out_act=L.ACT_SOFTMAX, out_dtype=self.feat_dtype, x1_grouped=grp)
         return out
 
@@ -360,3 +369,76 @@ class PanopticDeltaNeF(nn.Module):
         ops.occupancy_update(density.reshape(-1), g.occupancy, bits, density_decay, min_density)   # EMA-max + threshold + pack
         for grid in [self.grid] + ([self.delta_grid] if hasattr(self, "delta_grid") else []):
             grid.blas_init_bits(bits)
+
+
+class PanopticNeF(PanopticDeltaNeF):
+    """pc_nerf/panoptic_nef.py::PanopticNeF - the base field the delta class derives from in the reference, registrable under the same
+    name (configs/bup20/lin_assign_app.yaml:71, lin_assign_direct_app.yaml:115, contrastive_delta_app.yaml:115): ONE grid; the semantic
+    and the instance head read the main features (:338, :353), detached only when `sem_detach` / `inst_detach` say so - with a flag off
+    the panoptic losses train the main grid as well; `inst_direct_pos` feeds the instance head the raw coordinates (:350-351).  Same
+    kernels as the delta class: each head (+ its per-ray compositing in training) is one fused node whose input gradient flows back
+    into the main grid's encode backward when its features are live.
+
+    Quirks of the reference kept: `inst_direct_pos` is read by rgb_semantics (:350) but set by no constructor - a reference run has to
+    assign the attribute (the YAML key reaches BaseNeuralField's **kwargs only); here it is also a constructor keyword (default False).
+    With `inst_softmax` the instance head is `softmax(decoder(x))` whatever `inst_sigmoid` / `inst_normalize` say (:358 re-evaluates the
+    decoder).  `panoptic_features_type` only sizes the heads' inputs (:99-107: 'position' -> 3): the semantic head is always fed the grid
+    features (:338), so 'position' fails on the first semantic evaluation there (shape mismatch) and raises here; 'pos_encoding' reads an
+    attribute the base class never defines (:103) and raises at construction, as there."""
+
+    def __init__(self, *args, sem_detach=True, inst_detach=True, inst_direct_pos=False, panoptic_features_type=None, **kwargs):
+        if panoptic_features_type == "pos_encoding":
+            raise AttributeError("'PanopticNeF' object has no attribute 'pos_embed_dim'")         # panoptic_nef.py:103
+        # the parent with 'appearance' / 'position' builds exactly this class' modules: one grid, heads sized for features / positions
+        super().__init__(*args, sem_detach=sem_detach, inst_detach=inst_detach,
+                         panoptic_features_type="position" if panoptic_features_type == "position" else "appearance", **kwargs)
+        self.panoptic_features_type = panoptic_features_type
+        self.sem_detach, self.inst_detach, self.inst_direct_pos = bool(sem_detach), bool(inst_detach), bool(inst_direct_pos)
+        if self.inst_soft_temperature > 0.0:
+            raise NotImplementedError("inst_soft_temperature is an option of PanopticDeltaNeF only")
+
+    def get_nef_type(self):
+        return "panoptic_nef"                                                                       # panoptic_nef.py:204-210
+
+    def _pan_grouped(self):
+        return self._grouped()
+
+    def _head_inputs(self, feats, coords, channels):
+        grp = self._grouped()
+        if "semantics" in channels and self.panoptic_features_type == "position":
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied: PanopticNeF feeds its semantic head the grid features "
+                               "(panoptic_nef.py:338) but panoptic_features_type='position' sized it for 3 inputs (:99-101)")
+        det = feats.detach()
+        sem = det if self.sem_detach else feats                                                    # :338
+        if self.inst_direct_pos:                                                                    # :350-351 (coordinates stay live)
+            inst, inst_grp = self._pad8(coords.reshape(-1, 3).float(), self.feat_dtype), None
+        else:
+            inst = sem if self.inst_detach == self.sem_detach else (det if self.inst_detach else feats)   # :353
+            inst_grp = grp
+        return (sem, grp), (inst, inst_grp)
+
+    def _inst_head(self, inst_in, inst_grp, mode):
+        """:355-359 - with inst_softmax the output is softmax(decoder(x)): the sigmoid / normalize results are discarded."""
+        if self.inst_softmax:
+            return self.decoder_inst(inst_in, out_act=L.ACT_SOFTMAX, mode=mode, x1_grouped=inst_grp, out_dtype=self.feat_dtype)
+        e = self.decoder_inst(inst_in, out_act=L.ACT_NONE, mode=mode, x1_grouped=inst_grp, out_dtype=self.feat_dtype)
+        e = torch.sigmoid(e) if self.inst_sigmoid else e
+        return F.normalize(e, dim=-1) if self.inst_normalize else e
+
+    def rgb_semantics(self, coords, ray_d=None, compute_channels=None, pidx=None, lod_idx=None, ridx=None, ray_dirs=None,
+                      ray_packs=None):
+        out = super().rgb_semantics(coords, ray_d=ray_d, compute_channels=compute_channels, pidx=pidx, lod_idx=lod_idx, ridx=ridx,
+                                    ray_dirs=ray_dirs, ray_packs=ray_packs)
+        if self.inst_direct_pos and "inst_embedding" in out:                                        # decoder_inst(coords): [batch, num_samples, I]
+            out["inst_embedding"] = out["inst_embedding"].reshape(coords.shape[0], coords.shape[1], -1)
+        return out
+
+    def can_fuse_panoptic(self, channels):
+        if self.precision != "bf16" or self._grouped() is None:
+            return False
+        ok = True
+        if "semantics" in channels:
+            ok &= self.sem_softmax and not (self.sem_sigmoid or self.sem_normalize) and self.panoptic_features_type != "position"
+        if "inst_embedding" in channels:
+            ok &= self.inst_softmax and not self.inst_direct_pos
+        return bool(ok)

@@ -546,6 +546,63 @@ def g8(dd_nef_mod, dd_tracer_mod):
     np.savez_compressed(os.path.join(HERE, "g8_dd.npz"), **save)
 
 
+def g9(nef_mod):
+    """The BASE field pc_nerf/panoptic_nef.py::PanopticNeF on a HashGridTorch grid: channels, and reference autograd of a fixed linear
+    functional of them with sem_detach / inst_detach on and off (does the panoptic term reach the grid?), plus inst_direct_pos."""
+    L, log2T, C, I = 8, 10, 6, 200
+    res = [16] * (L - 1) + [256]
+    rs = np.random.RandomState(19)
+    M = 192
+    coords = torch.from_numpy(rs.uniform(-1, 1, size=(M, 1, 3)).astype(np.float32))
+    d = rs.standard_normal(size=(M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ray_d = torch.from_numpy(d)
+    G = {"rgb": torch.from_numpy(rs.standard_normal(size=(M, 1, 3)).astype(np.float32)),
+         "density": torch.from_numpy(rs.standard_normal(size=(M, 1, 1)).astype(np.float32)),
+         "semantics": torch.from_numpy(rs.standard_normal(size=(M, C)).astype(np.float32)),
+         "inst_embedding": torch.from_numpy(rs.standard_normal(size=(M, I)).astype(np.float32) * 30)}
+    tab = table_from_seed(900, (L, 2 ** log2T, 2), "normal") * np.float32(0.5)
+    save = dict(coords=coords.numpy(), ray_d=ray_d.numpy(), res=np.array(res, np.float32), log2T=log2T, L=L, seed_main=900,
+                **{"G_" + k: v.numpy() for k, v in G.items()})
+    for tag, sd, idt, direct in (("dd", True, True, False), ("ll", False, False, False), ("ld", False, True, False), ("pos", True, True, True)):
+        torch.manual_seed(9)
+        nef = nef_mod.PanopticNeF(
+            grid_type='HashGridTorch', interpolation_type='linear', multiscale_type='cat', feature_dim=2, num_lods=L,
+            base_lod=2, hidden_dim=64, num_layers=1, activation_type='relu', layer_type='none', embedder_type='positional',
+            view_multires=4, pos_multires=4, position_input=False, num_classes=C, num_instances=I, sem_num_layers=2,
+            sem_hidden_dim=64, sem_softmax=True, inst_num_layers=1, inst_hidden_dim=64, inst_softmax=True, sem_detach=sd, inst_detach=idt,
+            panoptic_features_type='position' if direct else None, codebook_bitwidth=log2T)
+        nef.inst_direct_pos = direct           # read at panoptic_nef.py:350, set by no constructor
+        nef.grid.init_from_resolutions(res)
+        with torch.no_grad():
+            for i in range(L):
+                nef.grid.embedder.embeddings[i].weight.copy_(torch.from_numpy(tab[i]))
+        chans = {'density', 'rgb', 'inst_embedding'} if direct else {'density', 'rgb', 'semantics', 'inst_embedding'}
+        out = nef(coords=coords, ray_d=ray_d, pidx=None, lod_idx=None, channels=chans)
+        loss = sum((out[c] * G[c].reshape(out[c].shape)).sum() for c in chans)
+        loss.backward()
+        for c in chans:
+            save[f"{tag}_{c}"] = out[c].detach().numpy()
+        save[f"{tag}_dtables"] = np.stack([nef.grid.embedder.embeddings[i].weight.grad.numpy() for i in range(L)])
+        for name in ("decoder_density", "decoder_color", "decoder_semantics", "decoder_inst"):
+            dec = getattr(nef, name)
+            lins = list(dec.layers) + [dec.lout]
+            for li, lin in enumerate(lins):
+                wtag = tag if tag in ("dd", "pos") else "dd"       # same seed, same shapes: ll / ld carry dd's weights (checked, stored once)
+                if wtag == tag:
+                    save[f"{tag}_{name}_w{li}"] = lin.weight.detach().numpy()
+                    save[f"{tag}_{name}_b{li}"] = lin.bias.detach().numpy()
+                else:
+                    assert np.array_equal(save[f"dd_{name}_w{li}"], lin.weight.detach().numpy())
+                    assert np.array_equal(save[f"dd_{name}_b{li}"], lin.bias.detach().numpy())
+                if lin.weight.grad is not None:
+                    save[f"{tag}_{name}_dw{li}"] = lin.weight.grad.numpy()
+                    save[f"{tag}_{name}_db{li}"] = lin.bias.grad.numpy()
+            save[f"{tag}_{name}_n"] = len(lins)
+        save[f"{tag}_nef_type"] = nef.get_nef_type()
+    np.savez_compressed(os.path.join(HERE, "g9_base_nef.npz"), **save)
+
+
 def main():
     install_stubs()
     torch.set_num_threads(1)
@@ -554,6 +611,10 @@ def main():
         hgt = importlib.import_module("grids.hash_grid_torch")
     if "--only-g7" in sys.argv:
         g7(hgt)
+        return
+    if "--only-g9" in sys.argv:
+        with _CudaToCpu():
+            g9(importlib.import_module("pc_nerf.panoptic_nef"))
         return
     if "--only-g8" in sys.argv:
         with _CudaToCpu():
@@ -574,6 +635,8 @@ def main():
     with _CudaToCpu():
         dd_nef = importlib.import_module("pc_nerf.panoptic_dd_nef")
     g8(dd_nef, importlib.import_module("tracers.panoptic_dd_packed_rf_tracer"))
+    with _CudaToCpu():
+        g9(importlib.import_module("pc_nerf.panoptic_nef"))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,6 +1,7 @@
 """The CPU oracle against the golden vectors captured from the reference's own modules
 (tests/golden/make_golden.py).  Runs without a GPU."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden, table_from_seed
@@ -303,3 +304,54 @@ def test_permuto_points_on_simplex_faces_edges_and_vertices():
         ulp = float(np.spacing(np.float32(np.abs(Ef).max())))
         assert np.abs(f32 - f64).max() <= (8 * ulp + 1e-5) * np.abs(tab[l]).max(), l
         assert (b32 >= -4 * ulp - 1e-6).all() and np.abs(b32.sum(-1) - 1).max() < 1e-5
+
+
+def _g9_params(g, tag, requires_grad=False):
+    wt = tag if tag in ("dd", "pos") else "dd"
+    p = {}
+    for short, name in (("density", "decoder_density"), ("color", "decoder_color"), ("semantics", "decoder_semantics"), ("inst", "decoder_inst")):
+        n = int(g[f"{wt}_{name}_n"])
+        p[short] = ([torch.from_numpy(g[f"{wt}_{name}_w{i}"]).clone().requires_grad_(requires_grad) for i in range(n)],
+                    [torch.from_numpy(g[f"{wt}_{name}_b{i}"]).clone().requires_grad_(requires_grad) for i in range(n)])
+    return p
+
+
+def g9_oracle(g, tag):
+    """-> (channels dict, table gradient, params) of oracle.decoders.nef_forward_base + oracle.hash_encode under torch autograd for one
+    configuration of golden g9 (the reference's BASE field pc_nerf/panoptic_nef.py::PanopticNeF)."""
+    L, log2T = int(g["L"]), int(g["log2T"])
+    res = [float(r) for r in oh.level_resolutions(int(g["res"][0]), int(g["res"][-1]), L)]
+    coords = torch.from_numpy(g["coords"]).reshape(-1, 3)
+    tab = torch.from_numpy(table_from_seed(int(g["seed_main"]), (L, 2 ** log2T, 2), "normal") * np.float32(0.5)).requires_grad_(True)
+    feats, _ = oh.hash_encode(coords, tab, res, log2T)
+    params = _g9_params(g, tag, requires_grad=True)
+    sd, idt, direct = dict(dd=(True, True, False), ll=(False, False, False), ld=(False, True, False), pos=(True, True, True))[tag]
+    chans = {"density", "rgb", "inst_embedding"} | (set() if direct else {"semantics"})
+    out = od.nef_forward_base(feats, torch.from_numpy(g["ray_d"]), params, chans, sem_detach=sd, inst_detach=idt, inst_direct_pos=direct,
+                              coords=coords)
+    loss = sum((out[c] * torch.from_numpy(g["G_" + c]).reshape(out[c].shape)).sum() for c in chans)
+    loss.backward()
+    return {c: out[c] for c in chans}, tab.grad, params
+
+
+@pytest.mark.parametrize("tag", ["dd", "ll", "ld", "pos"])
+def test_g9_base_nef_channels_and_gradients(tag):
+    """oracle.decoders.nef_forward_base against the reference's PanopticNeF (golden g9): channels, and the gradients of a fixed linear
+    functional of them - with sem_detach / inst_detach off the panoptic term reaches the grid tables (the table gradient changes), with
+    both on it does not."""
+    g = golden("g9_base_nef.npz")
+    assert str(g[f"{tag}_nef_type"]) == "panoptic_nef"
+    out, dtab, params = g9_oracle(g, tag)
+    for c, v in out.items():
+        np.testing.assert_allclose(v.detach().numpy().reshape(g[f"{tag}_{c}"].shape), g[f"{tag}_{c}"], rtol=1e-5, atol=1e-7)
+    want = g[f"{tag}_dtables"]
+    np.testing.assert_allclose(dtab.numpy(), want, rtol=1e-4, atol=1e-5 * float(np.abs(want).max()))
+    for short, name in (("density", "decoder_density"), ("color", "decoder_color"), ("semantics", "decoder_semantics"), ("inst", "decoder_inst")):
+        for i, (W, b) in enumerate(zip(*params[short])):
+            if f"{tag}_{name}_dw{i}" in g.files:
+                wg = g[f"{tag}_{name}_dw{i}"]
+                np.testing.assert_allclose(W.grad.numpy(), wg, rtol=1e-4, atol=1e-5 * float(np.abs(wg).max()))
+                np.testing.assert_allclose(b.grad.numpy(), g[f"{tag}_{name}_db{i}"], rtol=1e-4, atol=1e-5 * float(np.abs(wg).max()))
+    if tag != "dd":
+        rel = np.abs(want - g["dd_dtables"]).max() / np.abs(g["dd_dtables"]).max()
+        assert (rel > 1e-2) == (tag in ("ll", "ld")), rel          # 'pos': the instance head never touches the grid
