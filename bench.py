@@ -69,8 +69,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the rgb-only / sustained / configs / strong measurements")
     ap.add_argument("--graphs", default="on", choices=["on", "off", "static"],
-                    help="PanopticPackedRFTracer(use_graphs=...): on = replay the post-march part of the step as HIP graphs (N = 1, no pose-opt; at N > 1 "
-                         "the tracer takes the 'static' form); static = static padded buffers + optimistic count check with eager launches; off = eager")
+                    help="PanopticPackedRFTracer(use_graphs=...): on = replay the post-march part of the step as HIP graphs (no pose-opt; at N > 1 the "
+                         "backward is captured as two graphs so the delta table's all-reduce starts between them); static = static padded buffers + "
+                         "optimistic count check with eager launches; off = eager")
     ap.add_argument("--grad-sync", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1: table gradients as RCCL fp32 all-reduce (default) or bf16 messages with fp32 accumulation (shard._DirectReduce)")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: process group, shard collectives, timing and JSON plumbing only")
@@ -144,9 +145,10 @@ def make_tracer(args, raymarch=None, samples=None):
     import pagnerf_amd
     rm = raymarch or args.raymarch
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # at N > 1 the backward stays an ordinary autograd pass (shard.GradSync's early all-reduce hangs on gradient hooks): the static-buffer
-    # eager form keeps the graph path's other gain - the host never waits for the sample count
-    g = {"on": (True if world == 1 else "static"), "static": "static", "off": False}[args.graphs]
+    # at N > 1 the tracer captures the backward as TWO graphs (panoptic heads | the rest, pagnerf_amd/graphs.py) behind two autograd nodes, so
+    # shard.GradSync's post-accumulate hook on the delta table - its early all-reduce - fires between them as in an eager backward;
+    # --graphs static keeps the uncaptured static-buffer form (ordinary autograd pass, host never waits for the sample count)
+    g = {"on": True, "static": "static", "off": False}[args.graphs]
     if rm == "voxel":            # after trainer.py:362-366: 2 samples per intersected occupied voxel (best.yaml:31), ray_max_travel 6 x scale
         return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="voxel", num_steps=2, bg_color="white", ray_max_travel=6.0, use_graphs=g)
     return pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=samples or args.samples, bg_color="white", use_graphs=g)
@@ -379,6 +381,11 @@ def cpu_baseline(n_rays, n_samples, budget_s=9.0, points=((256, 64), (4096, 64))
                                                                "train": "train step (forward + backward + Adam)"}[mode],
                             s_per_step=round(d, 4), rays_s=round(nr / d, 1), samples_s=round(nr * ns / d, 1), steps=k, first_call_only=cold))
     return dict(value=n_rays / dt, unit="rays/s", cores=torch.get_num_threads(), cores_available=cores_available, kind="port", sample=note,
+                threads_rationale=("torch-CPU on this workload's tensor shapes stops scaling at a few dozen threads: the per-level gather / index_add "
+                                   "ops of grids/hash_grid_torch.py are launched as hundreds of small parallel regions per step, and with all 256 "
+                                   "hardware threads of the GPU box's host the same step ran ~400x slower than with 8 (oversubscribed OpenMP barriers); "
+                                   "min(32, cores_available) is the fastest setting measured there, so BASELINE.md section 3's 'all cores' is reported as "
+                                   "cores_available next to the cores actually used"),
                 torch=torch.__version__, points=pts)
 
 
@@ -461,6 +468,54 @@ def pmc_bytes_per_step(blob, entry, calls_per_step):
     if entry.endswith("encode_bwd_set") or entry.endswith("encode_fwd") or entry.endswith("encode_fwd_add"):
         total *= calls_per_step           # one bin + one reduce launch (or one encode launch) per call
     return int(total)
+
+
+# ------------------------------------------------------------------------------- the roof that binds the encode launch: row requests
+def request_rate(nef, rays, tracer, enc_ms, table_dtype):
+    """What limits the grid-interpolate launch is not bytes but the RATE OF ROW REQUESTS THAT MISS THE L1 (profiles/README.md
+    round 3: ~0.4 lane-requests per clock and CU; a request costs the same whether it returns 4, 8 or 16 bytes - which is why a byte
+    fraction reads low for fp16 tables).  Measured live: the same launch on the same samples with EVERY level at the finest scale /
+    resolution, where no two lanes share a row and every one of the L x V gathers per sample misses: `all_miss_rows_per_s` is the
+    request ceiling of this chip for this sample set.  `rows_per_s` is the launch as benched; `frac_of_all_miss_time` = its time over
+    the all-miss time: how much of the request-bound worst case the locality of the coarse levels (L1 hits between neighbouring samples
+    of a ray) and the per-XCD level tables (L2 hits) take off - the part that is left is the fine levels' requests, at the ceiling."""
+    import numpy as np
+    import torch
+    from pagnerf_amd import ops
+    g = nef.grid
+    with torch.no_grad():
+        out = g.raymarch(rays() if callable(rays) else rays, level=None, num_samples=tracer.num_steps, raymarch_type=tracer.raymarch_type)
+        xyz = out[2].reshape(-1, 3).contiguous()
+        M = xyz.shape[0]
+        Lv, Fd = g.tables.shape[0], g.tables.shape[2]
+        if hasattr(g, "random_shift_per_level"):
+            verts = 4
+            finest = float(np.min(np.asarray(g.resolutions)))
+            spec = ops.permuto_spec(type(g).scale_factors(np.asarray([finest] * Lv)), g.random_shift_per_level, g.tables.shape[1], Fd,
+                                    half_coords=bool(g.half_coords))
+        else:
+            verts = 8
+            finest = float(np.max(np.asarray(g.resolutions)))
+            spec = ops.hash_spec([finest] * Lv, g.codebook_bitwidth, Fd, half_coords=bool(g.half_coords))
+        lay = "xcd8" if nef._grouped() else None
+        fn = lambda: ops.encode(xyz, g.tables.detach(), spec, None, nef.feat_dtype, layout=lay)
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(5):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        miss_ms = a.elapsed_time(b) / 5
+    rows = M * Lv * verts
+    ent = dict(rows_per_launch=rows, rows_per_sample=Lv * verts, all_miss_launch_ms=round(miss_ms, 4),
+               all_miss_rows_per_s=round(rows / (miss_ms * 1e-3), 1), table_dtype=table_dtype,
+               note="every level at the finest scale on the same samples: every gather misses the L1 - the request ceiling, measured in this run")
+    if enc_ms:
+        ent.update(rows_per_s=round(rows / (enc_ms * 1e-3), 1), frac_of_all_miss_time=round(enc_ms / miss_ms, 4))
+    return ent
 
 
 # ------------------------------------------------------------------------------------------- forward-only render (validation path)
@@ -701,8 +756,6 @@ def run_rank(args):
     # call exists to bracket with events: the roofline kernel's duration is then measured over K further EAGER steps right after the
     # timed region (same process, same inputs, HIP events on the launch stream around its C-ABI call).  With --graphs off the events
     # sit inside the timed region itself, as in rounds 1 - 2.
-    # (N > 1 runs the static-buffer form, use_graphs = "static": its launches are eager, but a profiled region switches the tracer to the plain
-    # eager path - so there, too, the events are taken after the timed region.)
     graphs_on = job.tracer.use_graphs and not args.pose_opt
     if graphs_on:
         dt, _ = job.timed(args.steps)
@@ -741,6 +794,8 @@ def run_rank(args):
                                 "replay HIP graphs: no per-launch host call to bracket)" % args.steps) if graphs_on else
                                "HIP events around the kernel's C-ABI call inside the timed steps")
 
+    if roofline is not None and not args.no_aux:
+        roofline["request_rate"] = request_rate(job.nef, job.rays, job.tracer, roofline["avg_launch_ms"], args.table_dtype)
     line = dict(
         metric="rays/sec (train step) on BUP20-shape scene", value=round(world * args.rays * args.steps / dt, 1), unit="rays/s",
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
@@ -872,6 +927,8 @@ def run_rank(args):
                        encode_frac=round(bps * m / (float(np.mean(e)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if e else None)
             if kw.get("raymarch") == "voxel":
                 ent["occupied_fraction"] = round(j.occupied, 4)
+            if e:
+                ent["request_rate"] = request_rate(j.nef, j.rays, j.tracer, float(np.mean(e)), kw.get("table_dtype") or args.table_dtype)
             ent["hip_graphs"] = j.graph_stats()
             j.close()
             del j
@@ -921,6 +978,9 @@ def run_rank(args):
                 barrier()
                 d = max_over_ranks(time.perf_counter() - t0) / 5
                 lo, hi = shard.shard_bounds(n_val, rank, world)
+                torch.manual_seed(4242 + rank)          # the march draws its jitter from the device generator: same seed, same samples
+                rb = shard.render_sharded(pipe, rays_all, channels=sorted(all_ch))
+                torch.manual_seed(4242 + rank)
                 local = pipe(rays=rays_all[lo:hi], channels=sorted(all_ch))
                 same = bool(torch.equal(rb.rgb[lo:hi], local.rgb))
             line["render_sharded"] = dict(rays=n_val, ms=round(d * 1e3, 3), rays_s=round(n_val / d, 1), gathered_bytes_per_rank=n_val * 211 * 4,

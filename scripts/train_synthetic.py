@@ -55,7 +55,22 @@ def run(precision, a, dev):
         import pagnerf_amd
         rb = pagnerf_amd.batch_render(pagnerf_amd.Pipeline(nef, tracer), rays, channels=chans, render_batch=a.rays)
     mse = float(((rb.rgb - gt["rgb"]) ** 2).mean())
-    return dict(precision=precision, final_loss=float(loss.detach()), psnr_db=round(-10 * math.log10(mse), 2),
+    vs_oracle = None
+    if a.oracle_psnr:
+        # "PSNR vs ref" anchored on the CPU oracle: the TRAINED parameters rendered by the HIP path and by the oracle chain (same samples,
+        # same jitter) on a subset of the held-out rays; the helper lives under tests/ (nothing outside tests/ imports oracle/)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from test_gpu_trajectory import hip_vs_oracle_render
+        import pagnerf_amd
+        n = a.oracle_psnr
+        sub = pagnerf_amd.Rays(rays.origins[:n], rays.dirs[:n], rays.dist_min, rays.dist_max)
+        r = hip_vs_oracle_render(nef, tracer, sub, a.samples)
+        g = gt["rgb"][:n].float().cpu()
+        vs_oracle = dict(rays=n, samples=r["samples"], psnr_hip_vs_oracle_db=r["psnr_hip_vs_oracle_db"],
+                         psnr_hip_vs_gt_db=round(-10 * math.log10(float(((r["rgb_hip"] - g) ** 2).mean())), 2),
+                         psnr_oracle_vs_gt_db=round(-10 * math.log10(float(((r["rgb_oracle"] - g) ** 2).mean())), 2),
+                         sem_max_abs_diff=round(r["sem_max_abs_diff"], 5), inst_max_abs_diff=round(r["inst_max_abs_diff"], 5))
+    return dict(precision=precision, vs_oracle=vs_oracle, final_loss=float(loss.detach()), psnr_db=round(-10 * math.log10(mse), 2),
                 sem_acc=round(float((rb.semantics.argmax(-1) == gt["sem"])[gt["sem"] >= 0].float().mean()), 4),
                 inst_acc=round(float((rb.inst_embedding.argmax(-1) == gt["inst"])[gt["inst"] >= 0].float().mean()), 4))
 
@@ -66,6 +81,9 @@ if __name__ == "__main__":
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--grid", default="permuto")
+    ap.add_argument("--oracle-psnr", type=int, default=0, metavar="RAYS",
+                    help="also render RAYS held-out rays of the trained model with the CPU oracle (tests/test_gpu_trajectory.py) and report the "
+                         "PSNR of the HIP render against it, next to both renders' PSNR against the ground truth")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import __graft_entry__ as ge

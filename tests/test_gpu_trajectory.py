@@ -64,6 +64,22 @@ class OracleChain:
                 v.copy_(hip[k].detach().float().cpu())
 
 
+def hip_vs_oracle_render(nef, tracer, rays, S, seed=5):
+    """PSNR (dB) of the HIP render of `rays` against the oracle chain's render of the SAME parameters, samples and jitter, + both rgb
+    buffers.  Used by the trajectory test below and by scripts/train_synthetic.py --oracle-psnr (the oracle stays under tests/)."""
+    dev = rays.origins.device
+    N = rays.origins.shape[0]
+    jitter = torch.rand(N, S, generator=torch.Generator().manual_seed(seed))
+    occ = None if nef.grid._all_occupied else nef.grid.occupancy_mask().reshape(3 * [2 ** nef.grid.blas_level])
+    chain = OracleChain(nef, rays, occ, jitter, S)
+    with torch.no_grad():
+        rgb_o, sem_o, inst_o = chain.render()
+        rb = tracer(nef, channels={"rgb", "depth", "semantics", "inst_embedding"}, rays=rays, jitter=jitter.to(dev), stage="val")
+    return dict(psnr_hip_vs_oracle_db=round(_psnr(rb.rgb.float().cpu(), rgb_o), 2), rgb_hip=rb.rgb.float().cpu(), rgb_oracle=rgb_o,
+                sem_max_abs_diff=float((rb.semantics.float().cpu() - sem_o).abs().max()),
+                inst_max_abs_diff=float((rb.inst_embedding.float().cpu() - inst_o).abs().max()), samples=int(chain.march[0].shape[0]))
+
+
 def _adam(leaves):
     grid = [v for k, v in leaves.items() if "grid" in k]
     rest = [v for k, v in leaves.items() if "grid" not in k]
