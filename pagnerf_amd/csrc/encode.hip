@@ -418,9 +418,12 @@ struct BinLayout {
     int NS, shift;
 };
 
-// bf16 gradients with F = 2 (the production path): one 8-byte entry = 12-bit row | 2 x 26-bit floats (fp32 with the low
-// 6 mantissa bits rounded away - 2^-18 relative, far below the bf16 inputs' 2^-9) instead of a 4-byte key + 8-byte
-// value: a third less pass-1 -> pass-2 traffic and one store / load per entry instead of two.
+// bf16 gradients with F = 2 (the production path): one 8-byte entry = two 32-bit words, each a 26-bit float (fp32 with the low
+// 6 mantissa bits rounded away - 2^-18 relative, far below the bf16 inputs' 2^-9) with half of the 12-bit row in the freed bits,
+// instead of a 4-byte key + 8-byte value: a third less pass-1 -> pass-2 traffic and one store / load per entry instead of two.
+// Word form (round 4; before: row | a << 12 | b << 38 in one 64-bit integer - the 64-bit shifts and ors were ~10 VALU instructions per
+// entry in the bin pass and ~8 in the reduce pass): pack = 2 adds + 1 shift + 2 v_bfi_b32, unpack = 3 ands + 1 v_lshl_or_b32.  Same values.
+#ifdef PAG_PACK_U64
 __device__ __forceinline__ uint64_t pack_entry(uint32_t key12, float v0, float v1) {
     const uint64_t a = (uint64_t)((__float_as_uint(v0) + 0x20u) >> 6), b = (uint64_t)((__float_as_uint(v1) + 0x20u) >> 6);
     return (uint64_t)key12 | (a << 12) | (b << 38);
@@ -430,6 +433,19 @@ __device__ __forceinline__ void unpack_entry(uint64_t e, uint32_t &key12, float 
     v0 = __uint_as_float(((uint32_t)(e >> 12) & 0x3FFFFFFu) << 6);
     v1 = __uint_as_float((uint32_t)(e >> 38) << 6);
 }
+#else
+__device__ __forceinline__ uint64_t pack_entry(uint32_t key12, float v0, float v1) {
+    const uint32_t a = __float_as_uint(v0) + 0x20u, b = __float_as_uint(v1) + 0x20u;
+    const uint32_t lo = (a & ~63u) | (key12 & 63u), hi = (b & ~63u) | (key12 >> 6);       // key12 < 4096: v_bfi_b32
+    return (uint64_t)lo | ((uint64_t)hi << 32);                                          // a register pair: no instruction
+}
+__device__ __forceinline__ void unpack_entry(uint64_t e, uint32_t &key12, float &v0, float &v1) {
+    const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+    key12 = (lo & 63u) | ((hi & 63u) << 6);
+    v0 = __uint_as_float(lo & ~63u);
+    v1 = __uint_as_float(hi & ~63u);
+}
+#endif
 
 // merge runs of equal keys in adjacent lanes: on return `emit` is set on the last lane of every run
 // and that lane's v[] holds the run's sum.  Skipped (wave-uniformly) when the wave has few repeats.
