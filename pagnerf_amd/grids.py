@@ -19,24 +19,6 @@ import torch.nn as nn
 from . import ops
 
 
-class _VoxelSamples(torch.autograd.Function):
-    """Voxel-mode counterpart of ops.ray_samples: samples [M',k,3] of nugget i belong to ray ridx[i]."""
-
-    @staticmethod
-    def forward(ctx, origins, dirs, samples, depths, ridx):
-        ctx.save_for_backward(depths, ridx)
-        ctx.N = origins.shape[0]
-        return samples.view_as(samples)
-
-    @staticmethod
-    def backward(ctx, g):
-        depths, ridx = ctx.saved_tensors
-        g = g.float()
-        per = torch.cat([g.sum(1), (g * depths[..., None]).sum(1)], dim=1)             # [M',6] per nugget
-        seg = torch.zeros(ctx.N, 6, device=g.device).index_add_(0, ridx.long(), per)
-        return seg[:, :3], seg[:, 3:], None, None, None
-
-
 class OccupancyBLAS(nn.Module):
     """Dense occupancy bitfield standing in for wisp's OctreeAS (grids/occtree.py:54-67 is the
     in-tree description of that contract).  Bit (x*R + y)*R + z of `blas_bits`."""
@@ -122,7 +104,9 @@ class OccupancyBLAS(nn.Module):
                 occupancy_coarse_bits=coarse, want_packs=True)
             self._pack_cache = (ridx64, ridx_sample, pack_start, ray_of_pack)
             if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
-                samples = _VoxelSamples.apply(rays.origins, rays.dirs, samples, depths, ridx)   # pose gradient
+                # pose gradient: the k samples of a ray's nuggets are its pack (pack_start counts samples) - the same per-ray segmented
+                # sums as in 'ray' mode (pag_ray_sample_grad: one launch, fixed order)
+                samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack)
             return ridx64, pidx, samples, depths[..., None], deltas[:, None], boundary
         if raymarch_type != "ray":
             raise NotImplementedError("raymarch_type '%s'" % raymarch_type)
