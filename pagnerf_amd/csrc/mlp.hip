@@ -1545,8 +1545,14 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
 #ifdef PAG_FUSED_PROF      // debug build: where a workgroup of mlp_bwd_fused spends its clocks outside the tile loop (printed per launch by pag_mlp_bwd)
 __device__ unsigned long long g_fused_prof[8];      // shader clocks summed over workgroups: [0] staging, [1] tile loop, [2] cross-wave sum, [4] workgroups
 #endif
+// Experiment switches (scripts/build_variant.sh; never set in the shipped build): PAG_EXP_NO_WGRAD drops the weight-gradient MFMAs (wrong
+// results, timing only: what the backward-data chain alone costs), PAG_EXP_FUSED_WAVES = minimum waves per SIMD asked of the compiler and
+// workgroups per CU launched - together they measure the producer half of a producer / consumer split at two waves per SIMD.
+#ifndef PAG_EXP_FUSED_WAVES
+#define PAG_EXP_FUSED_WAVES 1
+#endif
 template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */, bool DZ0 = false>
-__global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
+__global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdParams p) {
 #ifdef PAG_FUSED_PROF
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1688,6 +1694,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused(BwdParams p) {
     // dW[ob][ib] += dz(Tz block ob)^T . input(Tin block ib) over this tile's 32 samples; dbcol >= 0: bias gradients into dbacc
     auto wgrad_tile = [&](const bf16_t *Tin, auto &aw, int dbcol) __attribute__((always_inline)) {      // aw: f32x16 [out blocks][2]
         constexpr int NOB = (int)(sizeof(aw) / sizeof(aw[0]));
+#ifdef PAG_EXP_NO_WGRAD
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 bfr[2], afr[NOB];
@@ -2058,6 +2067,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
     };
     auto wgrad_tile = [&](const bf16_t *Tin, auto &aw, int dbcol) __attribute__((always_inline)) {      // aw: f32x16 [out blocks][2]
         constexpr int NOB = (int)(sizeof(aw) / sizeof(aw[0]));
+#ifdef PAG_EXP_NO_WGRAD
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 bfr[2], afr[NOB];
@@ -3772,7 +3784,7 @@ __global__ __launch_bounds__(WF_SPLITS * WG_SLAB_COLS) void wgrad_finish_kernel(
 
 static unsigned fused_grid(int64_t M) {
     const int64_t tiles = (M + 31) / 32;
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, 256));      // one 4-wave workgroup per CU, tiles grid-strided
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, 256 * PAG_EXP_FUSED_WAVES));      // one 4-wave workgroup per CU, tiles grid-strided
 }
 
 // which mlp_bwd_fused instantiation serves these arguments: 0 density-like, 1 colour-like, 2 semantic-like, -1 none
