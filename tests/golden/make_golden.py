@@ -495,7 +495,7 @@ def g8(dd_nef_mod, dd_tracer_mod):
             save[f"{name}_b{li}"] = lin.bias.detach().numpy()
         save[f"{name}_n"] = len(lins)
     save.update(coords=coords.numpy(), ray_d=ray_d.numpy(), res=np.array(res, np.float32), log2T=log2T, L=L,
-                seed_main=800, seed_delta=801, **{"nef_" + k: v.numpy() for k, v in out.items()})
+                seed_main=800, seed_delta=801, **{"nef_" + k: out[k].numpy() for k in sorted(out)})      # sorted: the archive's member order must not follow set hashing
     # ---- tracer on a fixed packed scene
     N, S = 40, 20
     origins = torch.from_numpy(rs.uniform(-0.3, 0.3, size=(N, 3)).astype(np.float32))
@@ -579,9 +579,9 @@ def g9(nef_mod):
                 nef.grid.embedder.embeddings[i].weight.copy_(torch.from_numpy(tab[i]))
         chans = {'density', 'rgb', 'inst_embedding'} if direct else {'density', 'rgb', 'semantics', 'inst_embedding'}
         out = nef(coords=coords, ray_d=ray_d, pidx=None, lod_idx=None, channels=chans)
-        loss = sum((out[c] * G[c].reshape(out[c].shape)).sum() for c in chans)
+        loss = sum((out[c] * G[c].reshape(out[c].shape)).sum() for c in sorted(chans))       # sorted: fixed summation and archive order
         loss.backward()
-        for c in chans:
+        for c in sorted(chans):
             save[f"{tag}_{c}"] = out[c].detach().numpy()
         save[f"{tag}_dtables"] = np.stack([nef.grid.embedder.embeddings[i].weight.grad.numpy() for i in range(L)])
         for name in ("decoder_density", "decoder_color", "decoder_semantics", "decoder_inst"):
