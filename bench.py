@@ -230,10 +230,16 @@ def make_optimizer(nef, extra=()):
         groups[0]["eps"] = 1e-4       # fp16 tables keep fp16 Adam state: the reference's eps = 1e-15 underflows to 0 there (0 / 0 on untouched rows)
     if extra:
         groups.append(dict(params=list(extra), lr=1e-4))
-    try:
-        return torch.optim.Adam(groups, eps=1e-15, fused=True)                         # config_parser.py:672
-    except Exception:
-        return torch.optim.Adam(groups, eps=1e-15)
+    if os.environ.get("PAG_BENCH_TORCH_ADAM") or any(p.dtype != torch.float32 for p in grid_params):
+        # A/B switch, or fp16 tables (BASELINE configs[4]): pag_adam_step covers fp32 tensors - torch's own fused multi-tensor kernel
+        try:
+            return torch.optim.Adam(groups, eps=1e-15, fused=True)
+        except Exception:
+            return torch.optim.Adam(groups, eps=1e-15)
+    # config_parser.py:667-673 `optim_cls(params, eps=1e-15)` with optim_cls = torch.optim.Adam: pagnerf_amd.optim.Adam is that class with its
+    # step() on pag_adam_step (same arithmetic, same state); groups it does not cover (fp16 tables) take torch's implementation inside it
+    import pagnerf_amd
+    return pagnerf_amd.optim.Adam(groups, eps=1e-15)
 
 
 class ReferenceFormulationThingsLoss:
@@ -433,6 +439,10 @@ def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16):
     rows = (1 << 18) if grid == "permuto" else (1 << 19)
     out["pag_%s_encode_bwd_set" % grid] = dict(bytes=(12 + C * s + 2 * gather) * M * (2 if pan else 1), flops=0,
                                                bytes_min=((12 + C * s) * M + L_ * rows * F_ * 4) * (2 if pan else 1))
+    # the optimiser: p, g, m, v read and p, m, v written per fp32 parameter - the two tables (rows x F per level) and the 35 k decoder weights;
+    # independent of the batch
+    n_par = 2 * L_ * rows * F_ + 35169
+    out["pag_adam_step"] = dict(bytes=28 * n_par, flops=0)
     if pan:
         out["pag_head_composite_fwd"] = dict(bytes=M * (64 * s + 8 + 4) + N * 200 * 4, flops=0, rebuild_flops=2 * M * 64 * 200)
         out["pag_composite_feats_fwd"] = dict(bytes=M * (6 * s + 4) + N * 6 * 4, flops=0)
@@ -447,6 +457,7 @@ PMC_KERNELS = {
     "pag_mlp_bwd": ["mlp_bwd_fused<2, 0", "mlp_bwd_fused<3, 1", "mlp_bwd_wide_blocks", "mlp_bwd_pair", "wgrad_finish_kernel"],
     "pag_head_composite_fwd": ["head_composite_fwd_kernel"], "pag_composite_fwd": ["composite_fwd_kernel"],
     "pag_composite_bwd": ["composite_bwd_kernel"], "pag_composite_feats_fwd": ["composite_feats_small_fwd_kernel"],
+    "pag_adam_step": ["adam_kernel"],
 }
 
 
@@ -467,6 +478,8 @@ def pmc_bytes_per_step(blob, entry, calls_per_step):
         return None
     if entry.endswith("encode_bwd_set") or entry.endswith("encode_fwd") or entry.endswith("encode_fwd_add"):
         total *= calls_per_step           # one bin + one reduce launch (or one encode launch) per call
+    if entry == "pag_adam_step":
+        total *= 2                        # one streaming launch per table (the decoders' small launch is not counted)
     return int(total)
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 8
+#define PAG_ABI_VERSION 9
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -528,6 +528,17 @@ int pag_render_loss_bwd(const float *g, const float *fwd_out, const float *rgb, 
                         const float *prob_b, int C_b, const int64_t *target_b, const float *conf_b, float weight_b,
                         float inv_temp_b, int all_b,
                         float eps, float *d_rgb, float *d_a, float *d_b, void *stream);
+
+/* ---- optimiser step of the train step's caller (round 4, ABI 9) ------------------------------------------------------------------
+ * torch.optim.Adam(params, lr, betas, eps, weight_decay) as the reference builds it (config_parser.py:667-673: eps = 1e-15;
+ * pc_nerf/trainer.py:268-286 parameter groups; :583 scaler.step(optimizer)) for fp32 tensors, op for op the single-tensor formula
+ * of torch/optim/adam.py (maximize / amsgrad off):  g += weight_decay p ; m += (g - m)(1 - beta1) ; v = v beta2 + (1 - beta2) g g ;
+ * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).   `step` = the step count AFTER this update (>= 1).
+ * n_tensors host arrays of device pointers (f32, contiguous, numel[i] elements each); tensors of >= 65536 elements get a streaming
+ * launch each (704 MB per step for the two 50.3 MB tables: the update is a pure stream), the small ones share one launch. */
+int pag_adam_step(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                  const int64_t *numel, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                  void *stream);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
     pose  : BAPipeline (learnable extrinsics)     (ba_pipeline.py) <- pc_nerf/ba_pipeline.py
     dd    : PanopticDDensityNeF / ...PackedRFTracer (dd.py)     <- pc_nerf/panoptic_dd_nef.py, tracers/panoptic_dd_packed_rf_tracer.py
     shard : ray sharding + RCCL gather/all-reduce (shard.py)
+    optim : Adam (torch.optim.Adam's interface on pag_adam_step) (optim.py) <- config_parser.py:667-673, trainer.py:583
 
 All compute goes through libpagnerf_hip.so (include/pagnerf_hip.h); there is no CPU fallback.
 """
@@ -16,5 +17,6 @@ from .nef import PanopticDeltaNeF, PanopticNeF, BasicDecoder                    
 from .tracer import PanopticPackedRFTracer                         # noqa: F401
 from .ba_pipeline import BAPipeline                                # noqa: F401
 from .dd import PanopticDDensityNeF, PanopticDDensityPackedRFTracer    # noqa: F401
+from . import optim                                                # noqa: F401
 
 __version__ = "0.1.0"

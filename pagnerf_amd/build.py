@@ -29,6 +29,7 @@ SOURCES = {
     "mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "assign.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=off"],
+    "optim.hip": ["-ffp-contract=off"],      # Adam: torch's op order, no contraction beyond the explicit fmaf
 }
 
 

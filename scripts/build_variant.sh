@@ -8,10 +8,10 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 lib=$root/pagnerf_amd/lib
 base=$(basename $src .hip)
 extra=""
-case $base in encode|render|assign|loss) extra="-ffp-contract=off";; mlp) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+case $base in encode|render|assign|loss|optim) extra="-ffp-contract=off";; mlp) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-value $extra $flags -c $root/pagnerf_amd/csrc/$base.hip -o $lib/obj/${base}_$tag.o
 objs=""
-for o in api encode render mlp assign loss; do
+for o in api encode render mlp assign loss optim; do
   if [ $o == $base ]; then objs="$objs $lib/obj/${base}_$tag.o"; else objs="$objs $lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/libpagnerf_hip_$tag.so $objs

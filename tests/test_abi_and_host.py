@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_argument_validation_without_gpu(lib):
@@ -66,6 +66,10 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pag_ray_sample_grad(None, None, -1, None, None, None, None) == -1
     assert lib.pag_ray_sample_grad(None, None, 4, None, None, None, None) == -1 and b"NULL" in lib.pag_last_error_string()
     assert lib.pag_pad_packed(None, -1, 0, 1, None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.pag_adam_step(2, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-15, 0.0, 1, None) == -1                 # NULL lists
+    assert lib.pag_adam_step(0, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-15, 0.0, 0, None) == -1                 # step counts from 1
+    assert lib.pag_adam_step(0, None, None, None, None, None, 1e-3, 1.0, 0.999, 1e-15, 0.0, 1, None) == -1                 # beta1 < 1
+    assert lib.pag_adam_step(0, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-15, 0.0, 1, None) == 0                  # nothing to do
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -336,6 +340,7 @@ def test_bench_byte_model_matches_design_table():
     assert m["pag_mlp_bwd"]["parts"] == {"density": 288, "colour": 88, "inst_stage_A": 264, "inst_stage_B+sem": 396} and per["pag_mlp_bwd"] == 1036
     assert per["pag_permuto_encode_fwd"] == 876 and per["pag_permuto_encode_fwd_add"] == 972 and per["pag_permuto_encode_bwd_set"] == 2 * 1644
     assert m["pag_mlp_fwd"]["flops"] == 2 * M * 34560 and m["pag_mlp_bwd"]["flops"] == 2 * M * (34560 + 32832)
+    assert m["pag_adam_step"]["bytes"] == 28 * (2 * 24 * 262144 * 2 + 35169)          # 16 B read + 12 B written per fp32 parameter: 705.6 MB per step
     rgb = bench.algorithmic_model("permuto", M, N, {"rgb"}, 24, 2, 4, True)
     assert rgb["pag_mlp_fwd"]["bytes"] / M == 212 and rgb["pag_permuto_encode_bwd_set"]["bytes"] / M == 1644 and "pag_head_composite_fwd" not in rgb
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -416,3 +421,25 @@ def test_graph_capacity_buckets_are_geometric_with_hysteresis():
     for c in (1, 2, 3, 2, 4):
         st.bucket(c, lambda c=c: made.append(c) or ("graph", c))
     assert list(st.buckets) == [2, 4] and made == [1, 2, 3, 4]
+
+
+def test_adam_is_a_torch_adam_with_the_same_interface():
+    """pagnerf_amd.optim.Adam: constructor / param_groups / state_dict of torch.optim.Adam (config_parser.py:667-673 builds `optim_cls(params,
+    **optim_params)`); CPU parameters take torch's own step (the kernel needs GPU tensors)."""
+    import pagnerf_amd
+    p = torch.nn.Parameter(torch.ones(5))
+    q = torch.nn.Parameter(torch.ones(5))
+    oa = pagnerf_amd.optim.Adam([dict(params=[p], lr=0.1)], lr=1e-3, eps=1e-15, fused=True)
+    ob = torch.optim.Adam([dict(params=[q], lr=0.1)], lr=1e-3, eps=1e-15)
+    assert isinstance(oa, torch.optim.Adam) and oa.defaults["eps"] == 1e-15 and oa.param_groups[0]["lr"] == 0.1
+    for _ in range(3):
+        p.grad, q.grad = torch.full((5,), 0.5), torch.full((5,), 0.5)
+        oa.step()
+        ob.step()
+    assert torch.equal(p.detach(), q.detach())
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+    ob.load_state_dict(sd)
+    sched = torch.optim.lr_scheduler.StepLR(oa, step_size=1, gamma=0.1)
+    sched.step()
+    assert abs(oa.param_groups[0]["lr"] - 0.01) < 1e-12
