@@ -112,6 +112,7 @@ extern "C" int pag_adam_step(int n_tensors, float *const *params, const float *c
                   "pag_adam_step: lr %g, betas (%g, %g), eps %g, weight_decay %g out of range", lr, beta1, beta2, eps, weight_decay);
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     AdamScalars s{(float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)weight_decay};
+    if (n_tensors == 0) return PAG_OK;
     hipStream_t st = (hipStream_t)stream;
     AdamBatch small{};
     small.count = 0;
