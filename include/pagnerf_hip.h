@@ -365,6 +365,11 @@ int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capacity, int s
                    float *deltas, int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx,
                    uint8_t *boundary, int64_t *pack_start_clamped, void *stream);
 
+/* Up to 16 device-to-device copies in ONE launch (pagnerf_amd/graphs.py: the caller-owned copies of a graph replay's static
+ * outputs, the upstream gradients into the backward graph's static inputs).  dst / src: host arrays of device pointers, nbytes[i]
+ * bytes each (0 = skipped); 16-byte pieces where both pointers are 16-byte aligned.  (ABI 9) */
+int pag_copy_batch(int n, void *const *dst, const void *const *src, const int64_t *nbytes, void *stream);
+
 /* View-direction embedding of the colour decoder (wisp PositionalEmbedder on -ray_d, pc_nerf/panoptic_delta_nef.py:196-200):
  * out f32 [R, width] = (-d, sin(-d 2^k) for k < n_freq, cos(-d 2^k) for k < n_freq), frequency-major, zero padded;
  * dirs f32 [R,3], width >= 3 + 6 n_freq. */
@@ -447,20 +452,24 @@ int pag_occupancy_update(const float *density, int64_t density_stride, float *oc
  *   rgb f32 [M,3] or NULL
  *   weights f32 [M] (out): w_i = exp(-sum_{j<i} tau_j) (1 - exp(-tau_i)), tau = sigma*delta
  *   out_alpha f32 [N], out_rgb f32 [N,3], out_depth f32 [N], out_hit u8 [N]: rows of rays that
- *   have a pack are overwritten; the caller pre-fills the rest with the background. */
+ *   have a pack are overwritten; the caller pre-fills the rest with the background.
+ *   n_samples (ABI 9): 0, or the length of `weights` when the batch carries filler samples past pack_start[P]
+ *   (pag_pad_packed): weights[pack_start[P] .. n_samples) is zeroed by the same launch. */
 int pag_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
                       const float *sigma, const float *deltas, const float *depths,
                       const float *rgb, int bg_color, float *weights, float *out_alpha,
-                      float *out_rgb, float *out_depth, uint8_t *out_hit, void *stream);
+                      float *out_rgb, float *out_depth, uint8_t *out_hit, int64_t n_samples, void *stream);
 
 /* Gradients of pag_composite_fwd w.r.t. sigma and rgb.
  *   g_rgb f32 [N,3] / g_depth f32 [N] / g_alpha f32 [N]: upstream gradients (any may be NULL)
- *   d_sigma f32 [M], d_rgb f32 [M,3] (NULL allowed when rgb is NULL) */
+ *   d_sigma f32 [M], d_rgb f32 [M,3] (NULL allowed when rgb is NULL)
+ *   n_samples (ABI 9): 0, or the length of d_sigma / d_rgb of a padded batch: the rows of the filler samples
+ *   [pack_start[P], n_samples) are zeroed by the same launch (they carry no gradient). */
 int pag_composite_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P,
                       const float *sigma, const float *deltas, const float *depths,
                       const float *rgb, int bg_color, const float *weights,
                       const float *out_alpha, const float *g_rgb, const float *g_depth,
-                      const float *g_alpha, float *d_sigma, float *d_rgb, void *stream);
+                      const float *g_alpha, float *d_sigma, float *d_rgb, int64_t n_samples, void *stream);
 
 /* Pose optimisation (pc_nerf/ba_pipeline.py:85-92): gradients of samples[m] = origins[ray] + dirs[ray] * depths[m] with respect to the rays -
  * out f32 [N,6], row r = (sum of grad_samples over ray r's pack | sum of grad_samples * depth); rows of rays without a pack are NOT written

@@ -117,10 +117,11 @@ _SIGS = {
     "pag_render_loss_workspace_bytes": (c_i64, []),
     "pag_render_loss_fwd": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "pag_render_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
-    "pag_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "pag_composite_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_composite_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "pag_composite_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pag_composite_feats_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "pag_composite_feats_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "pag_copy_batch": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "pag_adam_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, c_i64, c_vp]),
 }

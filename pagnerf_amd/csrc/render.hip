@@ -416,11 +416,27 @@ struct CompArgs {
     int64_t P;
     const float *sigma, *deltas, *depths, *rgb;
     int bg;
+    int64_t n_samples;      // > 0: the per-sample outputs hold n_samples elements and [pack_start[P], n_samples) - filler samples of a padded
+                            // batch (pag_pad_packed) that belong to no pack - is zeroed by the extra workgroups of the launch
 };
+constexpr int COMP_TAIL_BLOCKS = 8;
+// workgroups past the packs' zero the tail of the per-sample outputs (instead of a full-size fill launch per tensor before the call)
+__device__ __forceinline__ void comp_zero_tail(const CompArgs &a, int64_t block, float *w0, float *w1_3) {
+    const int64_t beg = a.pack_start[a.P];
+    for (int64_t i = beg + block * 256 + threadIdx.x; i < a.n_samples; i += (int64_t)COMP_TAIL_BLOCKS * 256) {
+        if (w0) w0[i] = 0.0f;
+        if (w1_3) w1_3[3 * i] = 0.0f, w1_3[3 * i + 1] = 0.0f, w1_3[3 * i + 2] = 0.0f;
+    }
+}
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a, float *weights, float *out_alpha, float *out_rgb,
                                                             float *out_depth, uint8_t *out_hit) {
     const int lane = threadIdx.x & 63;
+    const int64_t pack_blocks = (a.P + 3) / 4;
+    if ((int64_t)blockIdx.x >= pack_blocks) {
+        comp_zero_tail(a, (int64_t)blockIdx.x - pack_blocks, weights, nullptr);
+        return;
+    }
     const int64_t pk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pk >= a.P) return;
     const int64_t beg = a.pack_start[pk], end = a.pack_start[pk + 1];
@@ -471,6 +487,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const fl
                                                             const float *g_rgb, const float *g_depth, const float *g_alpha,
                                                             float *d_sigma, float *d_rgb) {
     const int lane = threadIdx.x & 63;
+    const int64_t pack_blocks = (a.P + 3) / 4;
+    if ((int64_t)blockIdx.x >= pack_blocks) {
+        comp_zero_tail(a, (int64_t)blockIdx.x - pack_blocks, d_sigma, d_rgb);
+        return;
+    }
     const int64_t pk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pk >= a.P) return;
     const int64_t beg = a.pack_start[pk], end = a.pack_start[pk + 1];
@@ -768,6 +789,31 @@ __global__ __launch_bounds__(1024) void pad_packed_kernel(const int64_t *__restr
     }
 }
 
+// Several small device-to-device copies as ONE launch (pagnerf_amd/graphs.py: the copies of a replay's static outputs handed to the
+// caller, and of the upstream gradients into the backward graph's static inputs - ten `hipMemcpyAsync`-style copies of 4 KB - 3 MB
+// per step cost 4.7 us each as separate runtime copies).  blockIdx.y = copy, 16-byte pieces where both pointers allow, bytes otherwise.
+constexpr int COPY_MAX = 16;
+struct CopyBatch {
+    void *dst[COPY_MAX];
+    const void *src[COPY_MAX];
+    int64_t nbytes[COPY_MAX];
+};
+__global__ __launch_bounds__(256) void copy_batch_kernel(CopyBatch b) {
+    const int c = blockIdx.y;
+    const int64_t n = b.nbytes[c];
+    unsigned char *d = reinterpret_cast<unsigned char *>(b.dst[c]);
+    const unsigned char *s = reinterpret_cast<const unsigned char *>(b.src[c]);
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const int64_t n16 = n >> 4;
+        for (int64_t i = i0; i < n16; i += stride) reinterpret_cast<u32x4 *>(d)[i] = reinterpret_cast<const u32x4 *>(s)[i];
+        for (int64_t i = (n16 << 4) + i0; i < n; i += stride) d[i] = s[i];
+    } else {
+        for (int64_t i = i0; i < n; i += stride) d[i] = s[i];
+    }
+}
+
 // wisp PositionalEmbedder on the NEGATED ray directions (pc_nerf/panoptic_delta_nef.py:196-200): out[r] = (-d, sin(-d 2^k) k<F,
 // cos(-d 2^k) k<F), frequency-major, zero padded to `width` columns.  One launch instead of the ten of the tensor-op form.
 __global__ __launch_bounds__(256) void view_embed_kernel(const float *__restrict__ dirs, int64_t R, int n_freq, int width,
@@ -809,6 +855,31 @@ extern "C" int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capa
     return PAG_OK;
 }
 
+extern "C" int pag_copy_batch(int n, void *const *dst, const void *const *src, const int64_t *nbytes, void *stream) {
+    PAG_CHECK_ARG(n >= 0 && n <= COPY_MAX, "pag_copy_batch: %d copies (at most %d per call)", n, COPY_MAX);
+    if (n == 0) return PAG_OK;
+    PAG_CHECK_ARG(dst && src && nbytes, "pag_copy_batch: NULL list");
+    CopyBatch b{};
+    int64_t longest = 0;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        PAG_CHECK_ARG(nbytes[i] >= 0, "pag_copy_batch: copy %d has a negative size", i);
+        if (nbytes[i] == 0) continue;
+        PAG_CHECK_ARG(dst[i] && src[i], "pag_copy_batch: copy %d: NULL pointer", i);
+        b.dst[m] = dst[i];
+        b.src[m] = src[i];
+        b.nbytes[m] = nbytes[i];
+        longest = nbytes[i] > longest ? nbytes[i] : longest;
+        ++m;
+    }
+    if (m == 0) return PAG_OK;
+    const int64_t want = (longest / 16 + 255) / 256;
+    const unsigned gx = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    hipLaunchKernelGGL(copy_batch_kernel, dim3(gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, b);
+    PAG_CHECK_LAUNCH("pag_copy_batch");
+    return PAG_OK;
+}
+
 extern "C" int pag_view_embed(const float *dirs, int64_t R, int n_freq, int width, float *out, void *stream) {
     PAG_CHECK_ARG(R >= 0 && n_freq >= 0 && n_freq <= 16 && width >= 3 + 6 * n_freq, "pag_view_embed: n_freq %d / width %d out of range", n_freq, width);
     if (R == 0) return PAG_OK;
@@ -836,15 +907,15 @@ extern "C" int pag_raymarch_pack(const float *origins, const float *dirs, int64_
 
 extern "C" int pag_composite_fwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *sigma,
                                  const float *deltas, const float *depths, const float *rgb, int bg_color, float *weights,
-                                 float *out_alpha, float *out_rgb, float *out_depth, uint8_t *out_hit, void *stream) {
-    PAG_CHECK_ARG(P >= 0, "pag_composite_fwd: P < 0");
+                                 float *out_alpha, float *out_rgb, float *out_depth, uint8_t *out_hit, int64_t n_samples, void *stream) {
+    PAG_CHECK_ARG(P >= 0 && n_samples >= 0, "pag_composite_fwd: P < 0 or n_samples < 0");
     if (P == 0) return PAG_OK;
     PAG_CHECK_ARG(pack_start && ray_of_pack && sigma && deltas && weights && out_alpha, "pag_composite_fwd: NULL input");
     PAG_CHECK_ARG(!rgb || out_rgb, "pag_composite_fwd: rgb given but out_rgb is NULL");
     PAG_CHECK_ARG(!depths || out_depth, "pag_composite_fwd: depths given but out_depth is NULL");
     PAG_CHECK_ARG(bg_color == PAG_BG_BLACK || bg_color == PAG_BG_WHITE, "pag_composite_fwd: bad bg_color %d", bg_color);
-    CompArgs a{pack_start, ray_of_pack, P, sigma, deltas, depths, rgb, bg_color};
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, weights,
+    CompArgs a{pack_start, ray_of_pack, P, sigma, deltas, depths, rgb, bg_color, n_samples};
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((P + 3) / 4 + (n_samples > 0 ? COMP_TAIL_BLOCKS : 0))), dim3(256), 0, (hipStream_t)stream, a, weights,
                        out_alpha, out_rgb, out_depth, out_hit);
     PAG_CHECK_LAUNCH("pag_composite_fwd");
     return PAG_OK;
@@ -853,13 +924,13 @@ extern "C" int pag_composite_fwd(const int64_t *pack_start, const int32_t *ray_o
 extern "C" int pag_composite_bwd(const int64_t *pack_start, const int32_t *ray_of_pack, int64_t P, const float *sigma,
                                  const float *deltas, const float *depths, const float *rgb, int bg_color, const float *weights,
                                  const float *out_alpha, const float *g_rgb, const float *g_depth, const float *g_alpha,
-                                 float *d_sigma, float *d_rgb, void *stream) {
-    PAG_CHECK_ARG(P >= 0, "pag_composite_bwd: P < 0");
+                                 float *d_sigma, float *d_rgb, int64_t n_samples, void *stream) {
+    PAG_CHECK_ARG(P >= 0 && n_samples >= 0, "pag_composite_bwd: P < 0 or n_samples < 0");
     if (P == 0) return PAG_OK;
     PAG_CHECK_ARG(pack_start && ray_of_pack && sigma && deltas && weights && out_alpha && d_sigma, "pag_composite_bwd: NULL input");
     PAG_CHECK_ARG(bg_color == PAG_BG_BLACK || bg_color == PAG_BG_WHITE, "pag_composite_bwd: bad bg_color %d", bg_color);
-    CompArgs a{pack_start, ray_of_pack, P, sigma, deltas, depths, rgb, bg_color};
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, weights,
+    CompArgs a{pack_start, ray_of_pack, P, sigma, deltas, depths, rgb, bg_color, n_samples};
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((P + 3) / 4 + (n_samples > 0 ? COMP_TAIL_BLOCKS : 0))), dim3(256), 0, (hipStream_t)stream, a, weights,
                        out_alpha, g_rgb, g_depth, g_alpha, d_sigma, d_rgb);
     PAG_CHECK_LAUNCH("pag_composite_bwd");
     return PAG_OK;

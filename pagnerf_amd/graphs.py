@@ -73,10 +73,10 @@ class _PostMarch(nn.Module):
 
 
 def _fresh(statics):
-    """Copies of the capture's static tensors in ordinary (caching-allocator) memory: ONE multi-tensor copy."""
-    outs = [torch.empty_like(o) for o in statics]
+    """Copies of the capture's static tensors in ordinary (caching-allocator) memory: ONE launch."""
+    outs = [torch.empty_like(o, memory_format=torch.contiguous_format) for o in statics]
     if outs:
-        torch._foreach_copy_(outs, list(statics))
+        ops.copy_batch(outs, list(statics))       # one launch (six runtime copies of 4 KB - 3 MB cost 4.7 us each)
     return outs
 
 
@@ -130,7 +130,7 @@ class _GraphedFn(torch.autograd.Function):
         if zero:
             torch._foreach_zero_(zero)
         if dst:
-            torch._foreach_copy_(dst, src)
+            ops.copy_batch(dst, src)
         grp.bwd.replay()
         return (None, None) + tuple(g.detach() if g is not None else None for g in grp.gins)
 

@@ -1067,6 +1067,22 @@ def march_into(buf, origins, dirs, dist_min, dist_max, num_samples, jitter=None,
     return mailbox, jitter
 
 
+def copy_batch(dsts, srcs):
+    """dst[i].copy_(src[i]) for lists of same-shape, same-dtype contiguous GPU tensors as ONE launch per 16 tensors (pag_copy_batch);
+    pairs that need a conversion or are not contiguous take torch's copy_."""
+    easy, hard = [], []
+    for d, s_ in zip(dsts, srcs):
+        (easy if (d.dtype == s_.dtype and d.shape == s_.shape and d.is_contiguous() and s_.is_contiguous() and d.is_cuda and s_.is_cuda)
+         else hard).append((d, s_))
+    for c0 in range(0, len(easy), 16):
+        part = easy[c0:c0 + 16]
+        n = len(part)
+        _call("pag_copy_batch", n, (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in part]), (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in part]),
+              (ctypes.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in part]), L.stream())
+    for d, s_ in hard:
+        d.copy_(s_)
+
+
 def packs_from_boundary(ridx, boundary):
     """(pack_start i64[P+1], ray_of_pack i32[P]) from kaolin-style (ridx, boundary) arrays."""
     starts = torch.nonzero(boundary).reshape(-1)
@@ -1099,7 +1115,8 @@ class _Composite(torch.autograd.Function):
         deltas = deltas.detach().contiguous().float()
         rgbc = rgb.detach().contiguous().float() if rgb is not None else None
         depc = depths.detach().contiguous().float() if depths is not None else None
-        w = (torch.zeros if TAIL_ZERO else torch.empty)(M, device=dev)
+        # padded batches (graphs.py): the weights of the filler samples past pack_start[P] are zeroed by the launch itself (n_samples)
+        w = torch.empty(M, device=dev) if (P and M) else torch.zeros(M, device=dev)
         ctx.tail_zero = TAIL_ZERO
         if M and _one_pack_per_ray(ray_of_pack, N):      # the kernel writes every ray (background for empty packs): no fills
             alpha = torch.empty(N, device=dev)
@@ -1114,7 +1131,7 @@ class _Composite(torch.autograd.Function):
         if P and M:                     # M == 0: every pack is empty, the outputs already hold the background
             _call("pag_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
                                           L.ptr(rgbc), L.BG_WHITE if bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
-                                          L.ptr(out_rgb), L.ptr(out_depth), L.ptr(hit), L.stream())
+                                          L.ptr(out_rgb), L.ptr(out_depth), L.ptr(hit), M if TAIL_ZERO else 0, L.stream())
         ctx.save_for_backward(sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha)
         ctx.bg_white = bg_white
         ctx.mark_non_differentiable(hit, w)
@@ -1125,7 +1142,7 @@ class _Composite(torch.autograd.Function):
     def backward(ctx, g_alpha, _g_hit, g_rgb, g_depth, _g_w):
         sigma, rgbc, deltas, depc, pack_start, ray_of_pack, w, alpha = ctx.saved_tensors
         M, P = sigma.shape[0], ray_of_pack.shape[0]
-        mk = torch.empty if (P and M and not ctx.tail_zero) else torch.zeros          # all samples are covered by packs: kernels write every element
+        mk = torch.empty if (P and M) else torch.zeros          # samples covered by packs: the kernel writes every element; fillers: zeroed by the launch (n_samples)
         d_sigma = mk(M, device=sigma.device)
         d_rgb = mk(M, 3, device=sigma.device) if rgbc is not None else None
         gc = lambda t: t.contiguous().float() if t is not None else None
@@ -1134,7 +1151,7 @@ class _Composite(torch.autograd.Function):
             _call("pag_composite_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), L.ptr(depc),
                                           L.ptr(rgbc), L.BG_WHITE if ctx.bg_white else L.BG_BLACK, L.ptr(w), L.ptr(alpha),
                                           L.ptr(g_rgb), L.ptr(g_depth), L.ptr(g_alpha), L.ptr(d_sigma), L.ptr(d_rgb),
-                                          L.stream())
+                                          M if ctx.tail_zero else 0, L.stream())
         return d_sigma, d_rgb, None, None, None, None, None, None
 
 
@@ -1206,7 +1223,7 @@ class _CompositeFeatsWeights(torch.autograd.Function):
         out = torch.zeros(N, C, device=dev)
         if P and M:
             _call("pag_composite_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), None, None, L.BG_BLACK,
-                  L.ptr(w), L.ptr(alpha), None, None, L.ptr(hit), L.stream())
+                  L.ptr(w), L.ptr(alpha), None, None, L.ptr(hit), 0, L.stream())
             _call("pag_composite_feats_fwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(w), L.ptr(alpha), L.ptr(feats),
                   L.dtype_code(feats), C, L.ptr(out), L.stream())
         ctx.save_for_backward(sigma, deltas, feats, ridx, pack_start, ray_of_pack, w, alpha)
@@ -1237,7 +1254,7 @@ class _CompositeFeatsWeights(torch.autograd.Function):
                 ones[:, 0] = 1.0
                 d_rgb = torch.empty(M, 3, device=dev)
                 _call("pag_composite_bwd", L.ptr(pack_start), L.ptr(ray_of_pack), P, L.ptr(sigma), L.ptr(deltas), None, L.ptr(s3),
-                      L.BG_BLACK, L.ptr(w), L.ptr(alpha), L.ptr(ones), None, None, L.ptr(d_sigma), L.ptr(d_rgb), L.stream())
+                      L.BG_BLACK, L.ptr(w), L.ptr(alpha), L.ptr(ones), None, None, L.ptr(d_sigma), L.ptr(d_rgb), 0, L.stream())
         return d_sigma, None, (d_feats if ctx.needs_input_grad[2] else None), None, None, None, None
 
 

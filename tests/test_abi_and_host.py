@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu(lib):
     f = (ctypes.c_float * 4)(16, 32, 64, 128)
     # M == 0 is a no-op for every entry point (empty packs / empty batches, permuto_grid.py:68-69)
     assert lib.pag_hash_encode_fwd(None, 0, None, L.F32, 4, 2, 10, f, None, None, L.F32, 8, 1, 0, 0, None) == 0
-    assert lib.pag_composite_fwd(None, None, 0, None, None, None, None, 1, None, None, None, None, None, None) == 0
+    assert lib.pag_composite_fwd(None, None, 0, None, None, None, None, 1, None, None, None, None, None, 0, None) == 0
     assert lib.pag_raymarch_count(None, None, 0, 8, None, None, 0.0, 2.0, None, 7, None, None) == 0
     # bad arguments are rejected before any launch
     assert lib.pag_hash_encode_fwd(None, 5, None, L.F32, 4, 2, 10, f, None, None, L.F32, 8, 1, 0, 0, None) == -1
