@@ -965,6 +965,8 @@ def run_rank(args):
                                   rays_n=131072, samples=64, grid="hash", channels={"rgb"}, finest=1024, table_dtype="fp16"))
             cfgs.append(short_run("post-prune regime (f3): voxel march, %.0f %% occupancy, 2 samples per voxel, permuto, all channels"
                                   % (100 * args.occupancy), 20, 5, rays_n=4096, samples=2, grid="permuto", channels=all_ch, raymarch="voxel"))
+            cfgs.append(short_run("post-prune regime, rgb only (epochs 201 - 600 of best.yaml: voxel march from 201, panoptic heads from 601): %.0f %% occupancy, permuto"
+                                  % (100 * args.occupancy), 20, 5, rays_n=4096, samples=2, grid="permuto", channels={"rgb"}, raymarch="voxel"))
             line["configs"] = cfgs
         if world == 1 and default_cfg:
             line["render"] = render_image_line(args, dev, all_ch, out_bytes)

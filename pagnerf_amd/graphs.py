@@ -327,13 +327,31 @@ class GraphRunner:
             return False
         return True
 
+    PARAM_RESCAN = 64       # steps between full walks of the module tree (a step in between looks the known parameter slots up directly)
+
+    def _param_sig(self, nef):
+        """((data_ptr, requires_grad), ...) of the nef's parameters - part of the key: a capture bakes the storages in.  `nef.parameters()`
+        walks the whole module tree (~90 us of Python per step, a sixth of a post-prune rgb-only step): the (module, name) slots are
+        remembered and read directly; a replaced Parameter object shows up at once (its slot is read every step), a module that was added
+        or removed at the next full walk."""
+        cache = getattr(self, "_slots", None)
+        if cache is None or cache[0] != id(nef) or cache[2] <= 0:
+            slots = [(m, n) for m in nef.modules() for n, p in m._parameters.items() if p is not None]
+            cache = self._slots = [id(nef), slots, self.PARAM_RESCAN]
+        cache[2] -= 1
+        try:
+            return tuple((m._parameters[n].data_ptr(), m._parameters[n].requires_grad) for m, n in cache[1])
+        except (KeyError, AttributeError):          # a slot vanished: walk again
+            self._slots = None
+            return self._param_sig(nef)
+
     def _key(self, tracer, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage):
         lw = nef.lod_weights
         grids = [nef.grid] + ([nef.delta_grid] if hasattr(nef, "delta_grid") else [])
         return (id(nef), raymarch_type, int(rays.origins.shape[0]), int(num_steps), frozenset(channels), lod_idx, bg_color, stage, nef.precision,
                 nef.training, id(lw), lw._version, tuple((id(g.tables), g.tables.dtype, g.rounds_coords(), g.blas_level) for g in grids),
                 float(rays.dist_min), float(rays.dist_max), float(tracer.ray_max_travel), str(rays.origins.device),
-                tuple((p.data_ptr(), p.requires_grad) for p in nef.parameters()), self._split(tracer))
+                self._param_sig(nef), self._split(tracer))
 
     def observe(self, key, count):
         """An eager step of this configuration saw `count` samples: the first capacities are chosen from it."""

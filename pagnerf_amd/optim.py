@@ -10,7 +10,12 @@ formula (csrc/optim.hip).  Why: the update is 704 MB of pure streaming per step 
 kernel moves it at 3.6 TB/s on MI355X - 0.196 ms per step, 5 % of the full step and 16 % of the post-prune step.
 
 Anything this kernel does not cover takes torch's own implementation for that group, silently and correctly: amsgrad, maximize,
-capturable / differentiable, sparse gradients, CPU tensors, non-fp32 parameters (fp16 tables), non-contiguous tensors."""
+capturable / differentiable, sparse gradients, CPU tensors, non-fp32 parameters (fp16 tables), non-contiguous tensors.
+
+Host cost matters as much as the kernel in the post-prune regime (a 0.6 ms step): per group the parameter list, the moment pointers and
+the step counters are prepared ONCE (`_Plan`) and a step is one pass over the gradients (pointer + dtype / layout check), one
+`_foreach_add_` on the step counters and one ctypes call; the plan is rebuilt when the set of parameters that carry a gradient, or any
+state tensor, changes (load_state_dict, a parameter frozen / unfrozen)."""
 import ctypes
 
 import torch
@@ -19,24 +24,77 @@ from . import _lib as L
 from . import ops
 
 
+class _Plan:
+    """Everything of a parameter group's step that does not change from step to step."""
+
+    def __init__(self, opt, params):
+        self.params = params
+        self.ids = tuple(id(p) for p in params)
+        for p in params:
+            st = opt.state[p]
+            if len(st) == 0:          # torch's own lazy initialisation (Adam._init_group): step as a CPU scalar tensor, zero moments
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        states = [opt.state[p] for p in params]
+        self.steps = [st["step"] for st in states]
+        self.state_ids = tuple((id(st["step"]), id(st["exp_avg"]), id(st["exp_avg_sq"])) for st in states)
+        self.ok = all(isinstance(t, torch.Tensor) and not t.is_cuda for t in self.steps) and \
+            all(st["exp_avg"].is_cuda and st["exp_avg"].dtype == torch.float32 and st["exp_avg"].is_contiguous() and
+                st["exp_avg_sq"].dtype == torch.float32 and st["exp_avg_sq"].is_contiguous() for st in states)
+        counts = {float(t) for t in self.steps} if self.ok else set()
+        self.uniform = len(counts) == 1          # every parameter has taken the same number of steps (the normal case)
+        self.count = int(counts.pop()) if self.uniform else None
+        n = len(params)
+        self.n = n
+        arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+        self.pp = arr([p.data_ptr() for p in params])
+        self.mm = arr([st["exp_avg"].data_ptr() for st in states])
+        self.vv = arr([st["exp_avg_sq"].data_ptr() for st in states])
+        self.ptrs = tuple(p.data_ptr() for p in params)
+        self.nn = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+        self.gg = (ctypes.c_void_p * n)()
+        self.device = params[0].device
+
+
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kwargs):
         kwargs.pop("fused", None)         # our launches replace torch's fused / foreach kernels for the groups they cover
         kwargs.pop("foreach", None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kwargs)
+        self._plans = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}
 
     @staticmethod
-    def _eligible(group, params):
-        if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
+    def _group_ok(group):
+        return not (group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable")
+                    or isinstance(group["lr"], torch.Tensor))
+
+    def _plan(self, gi, group):
+        """The group's plan, or None when a parameter / gradient is outside what the kernel covers (-> torch's step for the group)."""
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
             return False
-        if isinstance(group["lr"], torch.Tensor):
-            return False
-        for p in params:
+        plan = self._plans.get(gi)
+        ids = tuple(id(p) for p in params)
+        if plan is None or plan.ids != ids or any(p.data_ptr() != q for p, q in zip(params, plan.ptrs)) or \
+                any(id(self.state[p].get("exp_avg")) != s[1] for p, s in zip(params, plan.state_ids)):
+            if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+                return None
+            plan = self._plans[gi] = _Plan(self, params)
+        if not plan.ok:
+            return None
+        gg = plan.gg
+        f32 = torch.float32
+        for i, p in enumerate(params):
             g = p.grad
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g is not None and not g.is_sparse
-                    and g.dtype == torch.float32 and g.is_contiguous() and g.device == p.device):
-                return False
-        return True
+            if g.dtype is not f32 or g.is_sparse or not g.is_contiguous() or g.device != plan.device:
+                return None
+            gg[i] = g.data_ptr()
+        return plan
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -46,39 +104,39 @@ class Adam(torch.optim.Adam):
                 loss = closure()
         fallback = []
         for gi, group in enumerate(self.param_groups):
-            params = [p for p in group["params"] if p.grad is not None]
-            if not params:
+            plan = self._plan(gi, group) if self._group_ok(group) else None
+            if plan is False:
                 continue
-            if not self._eligible(group, params):
-                fallback.append(gi)
+            if plan is None:
+                if any(p.grad is not None for p in group["params"]):
+                    fallback.append(gi)
                 continue
-            steps = set()
-            for p in params:
-                st = self.state[p]
-                if len(st) == 0:          # torch's own lazy initialisation (_init_group): step as a CPU scalar tensor, zero moments
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                steps.add(float(st["step"]))
             beta1, beta2 = group["betas"]
-            # parameters that joined the optimiser at different times carry different step counts: one call per count
-            for step in sorted(steps):
-                part = [p for p in params if float(self.state[p]["step"]) == step]
-                self._launch(gi, part, float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), int(step))
+            hyper = (float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]))
+            torch._foreach_add_(plan.steps, 1)
+            if plan.uniform:
+                plan.count += 1
+                self._launch(plan, plan.pp, plan.gg, plan.mm, plan.vv, plan.nn, plan.n, hyper, plan.count)
+            else:       # parameters that joined the optimiser at different times carry different step counts: one call per count
+                by = {}
+                for i, t in enumerate(plan.steps):
+                    by.setdefault(int(float(t)), []).append(i)
+                for count, idx in sorted(by.items()):
+                    n = len(idx)
+                    sel = lambda a, ct: (ct * n)(*[a[i] for i in idx])
+                    self._launch(plan, sel(plan.pp, ctypes.c_void_p), sel(plan.gg, ctypes.c_void_p), sel(plan.mm, ctypes.c_void_p),
+                                 sel(plan.vv, ctypes.c_void_p), sel(plan.nn, ctypes.c_int64), n, hyper, count)
         if fallback:
             self._torch_step(fallback)
         return loss
 
-    def _launch(self, gi, params, lr, beta1, beta2, eps, weight_decay, step):
-        n = len(params)
-        arr = lambda vals: (ctypes.c_void_p * n)(*vals)
-        pp, gg = arr([p.data_ptr() for p in params]), arr([p.grad.data_ptr() for p in params])
-        mm = arr([self.state[p]["exp_avg"].data_ptr() for p in params])
-        vv = arr([self.state[p]["exp_avg_sq"].data_ptr() for p in params])
-        nn = (ctypes.c_int64 * n)(*[p.numel() for p in params])
-        with torch.cuda.device(params[0].device):
-            ops._call("pag_adam_step", n, pp, gg, mm, vv, nn, lr, beta1, beta2, eps, weight_decay, step, L.stream())
+    @staticmethod
+    def _launch(plan, pp, gg, mm, vv, nn, n, hyper, count):
+        if plan.device.index is not None and plan.device.index != torch.cuda.current_device():
+            with torch.cuda.device(plan.device):
+                ops._call("pag_adam_step", n, pp, gg, mm, vv, nn, *hyper, count, L.stream())
+        else:
+            ops._call("pag_adam_step", n, pp, gg, mm, vv, nn, *hyper, count, L.stream())
 
     def _torch_step(self, group_ids):
         """torch.optim.Adam.step on the groups our kernel does not cover (the others are hidden from it for the call)."""
@@ -88,3 +146,4 @@ class Adam(torch.optim.Adam):
             super().step()
         finally:
             self.param_groups = keep
+        self._plans = {k: v for k, v in self._plans.items() if k not in group_ids}

@@ -1,4 +1,4 @@
-"""Host-side profile of the launch-bound regimes: python3 scripts/host_profile_small.py voxel|cfg0 [steps]
+"""Host-side profile of the launch-bound regimes: python3 scripts/host_profile_small.py voxel|voxelrgb|cfg0 [steps]
 voxel: post-prune step (voxel march, 10 % occupancy, all channels); cfg0: 256 rays x 64 samples, hash grid, rgb."""
 import cProfile
 import os
@@ -14,11 +14,11 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "voxel"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 dev = torch.device("cuda:0")
 gflag = ["--graphs", os.environ.get("BENCH_GRAPHS", "on")]
-if mode == "voxel":
+if mode in ("voxel", "voxelrgb"):
     args = bench.parse(["--rays", "4096", "--raymarch", "voxel"] + gflag)
     nef, tracer = bench.make_model(args, dev, 0), bench.make_tracer(args, "voxel")
     bench.synthetic_prune(nef, 0.1)
-    chans = {"rgb", "depth", "semantics", "inst_embedding"}
+    chans = {"rgb", "depth", "semantics", "inst_embedding"} if mode == "voxel" else {"rgb"}
     n = 4096
 else:
     args = bench.parse(["--rays", "256", "--samples", "64", "--grid", "hash"] + gflag)
