@@ -16,10 +16,19 @@ import torch.distributed as dist
 from .core import Rays, RenderBuffer
 
 
+FORCE_COLLECTIVES = False      # tests: issue the collectives on a ONE-rank process group too (tests/test_gpu_rccl_single_rank.py: the only way to
+                               # put RCCL itself under this module's calls on a one-GPU box)
+
+
 def world_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def _single():
+    """True when there is nothing to exchange: one rank (unless a test forces the collectives onto the one-rank group)."""
+    return world_info()[1] == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 _AVG_OK = {}        # backend -> bool: ReduceOp.AVG verified on this process group (first use)
@@ -108,7 +117,7 @@ def all_gather_render(rb, n_total, channels=None):
     """Gather per-rank RenderBuffers (rows = this rank's ray block) into the full [n_total, .] buffers
     on every rank with one all_gather.  Bool channels travel as floats."""
     rank, world = world_info()
-    if world == 1:
+    if _single():
         return rb
     names = sorted(channels or [c for c in rb.channels if isinstance(getattr(rb, c), torch.Tensor) and getattr(rb, c).dim() > 0])
     cols = [getattr(rb, c).reshape(getattr(rb, c).shape[0], -1).float() for c in names]
@@ -137,7 +146,7 @@ def allreduce_grads(params, average=True, big=1 << 20, comm_dtype=None):
     smaller (decoders, poses: ~0.14 MB) travels as ONE flat all_reduce.  No staging copy of the large tensors.
     comm_dtype (e.g. torch.bfloat16): the large gradients go through _DirectReduce (reduced-precision messages, fp32 accumulation)."""
     rank, world = world_info()
-    if world == 1:
+    if _single():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
@@ -187,8 +196,7 @@ class GradSync:
         self._early_ids = {id(p) for p in self.early}
         self._handles = []
         self._hooks = []
-        _, world = world_info()
-        if world > 1:
+        if not _single():
             for p in self.early:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._launch))
 
@@ -203,7 +211,7 @@ class GradSync:
 
     def finish(self):
         _, world = world_info()
-        if world == 1:
+        if _single():
             return
         rest = [p for p in self.params if id(p) not in self._early_ids or not any(q is p for q, _, _ in self._handles)]
         allreduce_grads(rest, average=self.average, big=self.big, comm_dtype=self.comm_dtype)
