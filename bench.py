@@ -457,7 +457,6 @@ PMC_KERNELS = {
     "pag_mlp_bwd": ["mlp_bwd_fused<2, 0", "mlp_bwd_fused<3, 1", "mlp_bwd_wide_blocks", "mlp_bwd_pair", "wgrad_finish_kernel"],
     "pag_head_composite_fwd": ["head_composite_fwd_kernel"], "pag_composite_fwd": ["composite_fwd_kernel"],
     "pag_composite_bwd": ["composite_bwd_kernel"], "pag_composite_feats_fwd": ["composite_feats_small_fwd_kernel"],
-    "pag_adam_step": ["adam_kernel"],
 }
 
 
@@ -478,8 +477,8 @@ def pmc_bytes_per_step(blob, entry, calls_per_step):
         return None
     if entry.endswith("encode_bwd_set") or entry.endswith("encode_fwd") or entry.endswith("encode_fwd_add"):
         total *= calls_per_step           # one bin + one reduce launch (or one encode launch) per call
-    if entry == "pag_adam_step":
-        total *= 2                        # one streaming launch per table (the decoders' small launch is not counted)
+    # pag_adam_step: one launch per parameter group (both tables in the first; the decoders' launch is the same kernel name, 5 us: the mean of the
+    # committed per-launch figure mixes the two - read the optimiser's traffic from its algorithmic bytes instead)
     return int(total)
 
 

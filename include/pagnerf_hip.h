@@ -365,6 +365,14 @@ int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capacity, int s
                    float *deltas, int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx,
                    uint8_t *boundary, int64_t *pack_start_clamped, void *stream);
 
+/* pag_pack_offsets + pag_pad_packed + the copy of the ray directions (dirs_src f32 [N,3] -> dirs_dst, both may be NULL) as ONE
+ * one-workgroup launch: the head of a graph-replayed step (pagnerf_amd/graphs.py).  Arguments as the two entry points';
+ * pack_start_clamped is required.  The fillers lie behind the samples the pack pass writes, so it may be queued before that pass. (ABI 9) */
+int pag_pack_offsets_pad(const int32_t *counts, int64_t N, int64_t *pack_start, int64_t *total_host, int64_t capacity,
+                         int samples_per_entry, float *samples, float *depths, float *deltas, int32_t *ridx_sample,
+                         int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx, uint8_t *boundary, int64_t *pack_start_clamped,
+                         const float *dirs_src, float *dirs_dst, void *stream);
+
 /* Up to 16 device-to-device copies in ONE launch (pagnerf_amd/graphs.py: the caller-owned copies of a graph replay's static
  * outputs, the upstream gradients into the backward graph's static inputs).  dst / src: host arrays of device pointers, nbytes[i]
  * bytes each (0 = skipped); 16-byte pieces where both pointers are 16-byte aligned.  (ABI 9) */
@@ -543,8 +551,8 @@ int pag_render_loss_bwd(const float *g, const float *fwd_out, const float *rgb, 
  * pc_nerf/trainer.py:268-286 parameter groups; :583 scaler.step(optimizer)) for fp32 tensors, op for op the single-tensor formula
  * of torch/optim/adam.py (maximize / amsgrad off):  g += weight_decay p ; m += (g - m)(1 - beta1) ; v = v beta2 + (1 - beta2) g g ;
  * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).   `step` = the step count AFTER this update (>= 1).
- * n_tensors host arrays of device pointers (f32, contiguous, numel[i] elements each); tensors of >= 65536 elements get a streaming
- * launch each (704 MB per step for the two 50.3 MB tables: the update is a pure stream), the small ones share one launch. */
+ * n_tensors host arrays of device pointers (f32, contiguous, numel[i] elements each); ONE launch per 48 tensors (704 MB per step
+ * for the two 50.3 MB tables: the update is a pure stream; a tensor gets one block per 4096 elements, at most 4096). */
 int pag_adam_step(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                   const int64_t *numel, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                   void *stream);

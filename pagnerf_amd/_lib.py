@@ -121,6 +121,7 @@ _SIGS = {
     "pag_composite_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pag_composite_feats_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "pag_composite_feats_bwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "pag_pack_offsets_pad": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_copy_batch": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "pag_adam_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, c_i64, c_vp]),

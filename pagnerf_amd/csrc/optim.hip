@@ -25,11 +25,7 @@ struct AdamTensor {
     float *m, *v;
     int64_t n;
 };
-constexpr int ADAM_MAX_TENSORS = 48;       // small tensors of one launch (the decoders: 22)
-struct AdamBatch {
-    AdamTensor t[ADAM_MAX_TENSORS];
-    int count;
-};
+constexpr int ADAM_MAX_TENSORS = 48;       // tensors of one launch (the two tables + the decoders: 24)
 struct AdamScalars {
     float step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bc2_sqrt, eps, weight_decay;
 };
@@ -42,11 +38,34 @@ __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v,
     p = p - s.step_size * (m / denom);
 }
 
-// ONE large tensor (n % 4 handled by the tail lanes): float4 groups, four per lane, a grid-stride apart
-__global__ __launch_bounds__(256) void adam_kernel(AdamTensor t, AdamScalars s) {
+// ONE launch for every tensor of the call: block b works on the tensor whose block range [first[t], first[t + 1]) holds it (a scan over at
+// most 48 scalars); the range is sized by the host - a streaming tensor gets thousands of blocks, a decoder matrix one or two.  Within a
+// tensor: float4 groups, four per lane a stride apart (four independent 16-byte loads per array in flight), the n % 4 tail by block 0;
+// tensors that are not 16-byte aligned take the element loop.
+struct AdamAll {
+    AdamTensor t[ADAM_MAX_TENSORS];
+    int first[ADAM_MAX_TENSORS + 1];
+    unsigned char vec[ADAM_MAX_TENSORS];
+    int count;
+};
+__global__ __launch_bounds__(256) void adam_kernel(AdamAll b, AdamScalars s) {
+    int ti = 0;
+    for (int k = 1; k < b.count; ++k) ti = (int)blockIdx.x >= b.first[k] ? k : ti;
+    const AdamTensor t = b.t[ti];
+    const int64_t nblk = b.first[ti + 1] - b.first[ti], blk = (int)blockIdx.x - b.first[ti];
+    const int64_t stride = nblk * 256;
+    const int64_t i0 = blk * 256 + threadIdx.x;
+    if (!b.vec[ti]) {
+        for (int64_t i = i0; i < t.n; i += stride) {
+            float p = t.p[i], m = t.m[i], v = t.v[i];
+            adam_elem(p, t.g[i], m, v, s);
+            t.p[i] = p;
+            t.m[i] = m;
+            t.v[i] = v;
+        }
+        return;
+    }
     const int64_t n4 = t.n >> 2;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     f32x4 *p4 = reinterpret_cast<f32x4 *>(t.p), *m4 = reinterpret_cast<f32x4 *>(t.m), *v4 = reinterpret_cast<f32x4 *>(t.v);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(t.g);
     for (int64_t base = i0; base < n4; base += 4 * stride) {
@@ -87,20 +106,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensor t, AdamScalars s) 
         }
     }
     const int64_t tail = n4 << 2;
-    if (blockIdx.x == 0 && threadIdx.x < (t.n - tail)) {
+    if (blk == 0 && threadIdx.x < (t.n - tail)) {
         const int64_t i = tail + threadIdx.x;
-        float p = t.p[i], m = t.m[i], v = t.v[i];
-        adam_elem(p, t.g[i], m, v, s);
-        t.p[i] = p;
-        t.m[i] = m;
-        t.v[i] = v;
-    }
-}
-
-// many SMALL tensors in one launch: blockIdx.y = tensor, blockIdx.x strides over its elements
-__global__ __launch_bounds__(256) void adam_batch_kernel(AdamBatch b, AdamScalars s) {
-    const AdamTensor t = b.t[blockIdx.y];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (int64_t)gridDim.x * 256) {
         float p = t.p[i], m = t.m[i], v = t.v[i];
         adam_elem(p, t.g[i], m, v, s);
         t.p[i] = p;
@@ -121,33 +128,33 @@ extern "C" int pag_adam_step(int n_tensors, float *const *params, const float *c
     AdamScalars s{(float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)weight_decay};
     if (n_tensors == 0) return PAG_OK;
     hipStream_t st = (hipStream_t)stream;
-    AdamBatch small{};
-    small.count = 0;
-    int64_t small_max = 0;
+    AdamAll all{};
+    all.count = 0;
+    all.first[0] = 0;
+    bool launched = false;
     auto flush = [&]() {
-        if (small.count == 0) return;
-        const unsigned gx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (small_max + 255) / 256));
-        hipLaunchKernelGGL(adam_batch_kernel, dim3(gx, (unsigned)small.count), dim3(256), 0, st, small, s);
-        small.count = 0;
-        small_max = 0;
+        if (all.count == 0) return;
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)all.first[all.count]), dim3(256), 0, st, all, s);
+        launched = true;
+        all.count = 0;
+        all.first[0] = 0;
     };
     for (int i = 0; i < n_tensors; ++i) {
         if (numel[i] == 0) continue;
         PAG_CHECK_ARG(numel[i] > 0 && params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i], "pag_adam_step: tensor %d: NULL pointer or negative size", i);
         AdamTensor t{params[i], grads[i], exp_avg[i], exp_avg_sq[i], numel[i]};
         const bool aligned = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0;
-        if (numel[i] >= (1 << 16) && aligned) {
-            // enough workgroups to fill the chip several times over, few enough that every lane walks >= 1 batch of four groups
-            const int64_t n4 = numel[i] >> 2;
-            const unsigned grid = (unsigned)std::min<int64_t>(256 * 16, std::max<int64_t>(1, (n4 + 1023) / 1024));
-            hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, t, s);
-        } else {
-            small.t[small.count++] = t;
-            small_max = std::max(small_max, numel[i]);
-            if (small.count == ADAM_MAX_TENSORS) flush();
-        }
+        // blocks of this tensor: one per 4096 elements (a lane's four float4 groups), at most 4096 - enough to fill the chip several times
+        // over, few enough that every lane of a streaming tensor walks several batches
+        const int64_t want = aligned ? (numel[i] + 4095) / 4096 : (numel[i] + 1023) / 1024;
+        const int nb = (int)std::min<int64_t>(4096, std::max<int64_t>(1, want));
+        all.t[all.count] = t;
+        all.vec[all.count] = aligned ? 1 : 0;
+        all.first[all.count + 1] = all.first[all.count] + nb;
+        if (++all.count == ADAM_MAX_TENSORS) flush();
     }
     flush();
+    if (!launched) return PAG_OK;
     PAG_CHECK_LAUNCH("pag_adam_step");
     return PAG_OK;
 }

@@ -762,31 +762,83 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__res
 // before the host learnt M must stay inside them: pack_start_clamped[r] = min(pack_start[r], capacity) is the pack table THEY walk
 // (identical to pack_start when the batch fits; a truncated batch, whose results the caller discards, when it does not).
 // k = samples per nugget (voxel mode: the per-nugget arrays are padded up to capacity / k).
-__global__ __launch_bounds__(1024) void pad_packed_kernel(const int64_t *__restrict__ pack_start, int64_t N, int64_t capacity, int k, float *__restrict__ samples,
-                                                          float *__restrict__ depths, float *__restrict__ deltas, int32_t *__restrict__ ridx_sample,
-                                                          int32_t *__restrict__ ridx_nugget, int64_t *__restrict__ ridx64, int32_t *__restrict__ pidx,
-                                                          uint8_t *__restrict__ boundary, int64_t *__restrict__ pack_start_clamped) {
+struct PadArgs {
+    int64_t capacity;
+    int k;
+    float *samples, *depths, *deltas;
+    int32_t *ridx_sample, *ridx_nugget;
+    int64_t *ridx64;
+    int32_t *pidx;
+    uint8_t *boundary;
+};
+// filler samples [M, capacity) of a padded batch (one workgroup; M > capacity: nothing to write)
+__device__ __forceinline__ void pad_tail(const PadArgs &a, int64_t M, int64_t N) {
+    if (M > a.capacity) return;
+    const int32_t last = (int32_t)(N - 1);
+    for (int64_t i = M + threadIdx.x; i < a.capacity; i += blockDim.x) {
+        a.samples[i * 3] = 0.0f, a.samples[i * 3 + 1] = 0.0f, a.samples[i * 3 + 2] = 0.0f;
+        a.depths[i] = 0.0f;
+        a.deltas[i] = 0.0f;
+        a.boundary[i] = 0;
+        if (a.ridx_sample) a.ridx_sample[i] = last;
+    }
+    for (int64_t g = M / a.k + threadIdx.x; g < a.capacity / a.k; g += blockDim.x) {
+        if (a.ridx_nugget) a.ridx_nugget[g] = last;
+        if (a.ridx64) a.ridx64[g] = last;
+        a.pidx[g] = 0;
+    }
+}
+__global__ __launch_bounds__(1024) void pad_packed_kernel(const int64_t *__restrict__ pack_start, int64_t N, PadArgs a, int64_t *__restrict__ pack_start_clamped) {
     const int64_t M = pack_start[N];
     // the pack table the capacity-sized launches may walk: no pack reaches past `capacity`, whatever the march produced
     if (pack_start_clamped)
         for (int64_t r = threadIdx.x; r <= N; r += blockDim.x) {
             const int64_t p = pack_start[r];
-            pack_start_clamped[r] = p < capacity ? p : capacity;
+            pack_start_clamped[r] = p < a.capacity ? p : a.capacity;
         }
-    if (M > capacity) return;
-    const int32_t last = (int32_t)(N - 1);
-    for (int64_t i = M + threadIdx.x; i < capacity; i += blockDim.x) {
-        samples[i * 3] = 0.0f, samples[i * 3 + 1] = 0.0f, samples[i * 3 + 2] = 0.0f;
-        depths[i] = 0.0f;
-        deltas[i] = 0.0f;
-        boundary[i] = 0;
-        if (ridx_sample) ridx_sample[i] = last;
+    pad_tail(a, M, N);
+}
+
+// pack_offsets_kernel + pad_packed_kernel + the copy of the ray directions into the graph's static buffer as ONE one-workgroup launch
+// (pagnerf_amd/graphs.py: three 5 - 10 us launches at the head of every graph-replayed step; the fillers lie behind the samples the pack
+// pass - queued after this kernel - writes, so the order does not matter)
+__global__ __launch_bounds__(1024) void pack_offsets_pad_kernel(const int32_t *__restrict__ counts, int64_t N, int64_t *__restrict__ pack_start, int64_t *total_host,
+                                                                PadArgs a, int64_t *__restrict__ pack_start_clamped, const float *__restrict__ dirs_src,
+                                                                float *__restrict__ dirs_dst) {
+    __shared__ int64_t wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t chunk = (N + 1023) / 1024;
+    const int64_t lo = tid * chunk, hi = lo + chunk < N ? lo + chunk : N;
+    int64_t sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += counts[i];
+    int64_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
     }
-    for (int64_t g = M / k + threadIdx.x; g < capacity / k; g += blockDim.x) {
-        if (ridx_nugget) ridx_nugget[g] = last;
-        if (ridx64) ridx64[g] = last;
-        pidx[g] = 0;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int64_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += w < wave ? wave_tot[w] : 0;
+        total += wave_tot[w];
     }
+    int64_t run = base + incl - sum;
+    for (int64_t i = lo; i < hi; ++i) {
+        pack_start[i] = run;
+        pack_start_clamped[i] = run < a.capacity ? run : a.capacity;
+        run += counts[i];
+    }
+    if (tid == 0) {
+        pack_start[N] = total;
+        pack_start_clamped[N] = total < a.capacity ? total : a.capacity;
+        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    pad_tail(a, total, N);
+    if (dirs_dst)
+        for (int64_t i = tid; i < N * 3; i += 1024) dirs_dst[i] = dirs_src[i];
 }
 
 // Several small device-to-device copies as ONE launch (pagnerf_amd/graphs.py: the copies of a replay's static outputs handed to the
@@ -849,9 +901,23 @@ extern "C" int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capa
     PAG_CHECK_ARG(N >= 1 && capacity >= 0 && samples_per_entry >= 1 && capacity % samples_per_entry == 0,
                   "pag_pad_packed: N %lld, capacity %lld must be a multiple of samples_per_entry %d", (long long)N, (long long)capacity, samples_per_entry);
     PAG_CHECK_ARG(pack_start && samples && depths && deltas && pidx && boundary, "pag_pad_packed: NULL buffer");
-    hipLaunchKernelGGL(pad_packed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack_start, N, capacity, samples_per_entry, samples, depths, deltas,
-                       ridx_sample, ridx_entry, ridx64, pidx, boundary, pack_start_clamped);
+    PadArgs a{capacity, samples_per_entry, samples, depths, deltas, ridx_sample, ridx_entry, ridx64, pidx, boundary};
+    hipLaunchKernelGGL(pad_packed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack_start, N, a, pack_start_clamped);
     PAG_CHECK_LAUNCH("pag_pad_packed");
+    return PAG_OK;
+}
+
+extern "C" int pag_pack_offsets_pad(const int32_t *counts, int64_t N, int64_t *pack_start, int64_t *total_host, int64_t capacity, int samples_per_entry,
+                                    float *samples, float *depths, float *deltas, int32_t *ridx_sample, int32_t *ridx_entry, int64_t *ridx64, int32_t *pidx,
+                                    uint8_t *boundary, int64_t *pack_start_clamped, const float *dirs_src, float *dirs_dst, void *stream) {
+    PAG_CHECK_ARG(N >= 1 && counts && pack_start && pack_start_clamped, "pag_pack_offsets_pad: bad arguments");
+    PAG_CHECK_ARG(capacity >= 0 && samples_per_entry >= 1 && capacity % samples_per_entry == 0,
+                  "pag_pack_offsets_pad: capacity %lld must be a multiple of samples_per_entry %d", (long long)capacity, samples_per_entry);
+    PAG_CHECK_ARG(samples && depths && deltas && pidx && boundary, "pag_pack_offsets_pad: NULL buffer");
+    PAG_CHECK_ARG(!dirs_dst || dirs_src, "pag_pack_offsets_pad: dirs_dst without dirs_src");
+    PadArgs a{capacity, samples_per_entry, samples, depths, deltas, ridx_sample, ridx_entry, ridx64, pidx, boundary};
+    hipLaunchKernelGGL(pack_offsets_pad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, pack_start, total_host, a, pack_start_clamped, dirs_src, dirs_dst);
+    PAG_CHECK_LAUNCH("pag_pack_offsets_pad");
     return PAG_OK;
 }
 

@@ -378,12 +378,11 @@ class GraphRunner:
         if bits is not None and bits.device != dev:
             g.blas_bits = bits = bits.to(dev)
         coarse = g._coarse_bits(bits) if (bits is not None and raymarch_type == "voxel") else None
+        # count -> offsets + padding to `cap` + the directions into the static tensor (one launch) -> pack
         mailbox, jitter = ops.march_into(buf, rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_steps, jitter=jitter,
                                          occupancy_bits=bits, blas_level=g.blas_level,
-                                         max_travel=tracer.ray_max_travel if raymarch_type == "voxel" else None, occupancy_coarse_bits=coarse)
-        buf.pad_to(cap)
-        if st.dirs.data_ptr() != rays.dirs.data_ptr():
-            st.dirs.copy_(rays.dirs)
+                                         max_travel=tracer.ray_max_travel if raymarch_type == "voxel" else None, occupancy_coarse_bits=coarse,
+                                         pad_capacity=cap, dirs_out=st.dirs)
         args = (buf.samples[:cap], buf.depths[:cap], buf.deltas[:cap], st.dirs)
         if tracer.use_graphs == "static":
             # same static, padded buffers and optimistic count check - but the post-march part runs as ordinary eager launches: what the graph

@@ -1025,11 +1025,25 @@ class MarchBuffers:
               L.ptr(self.pack_start_c), L.stream())
 
 
+def _offsets(buf, N, mb_ptr, st, pad_capacity, dirs, dirs_out):
+    """The scan of the per-ray counts into the pack table, alone or fused with the padding / direction copy of the graph path."""
+    if pad_capacity is None:
+        _call("pag_pack_offsets", L.ptr(buf.counts), N, L.ptr(buf.pack_start), mb_ptr, st)
+        return
+    assert 0 < pad_capacity <= buf.cap and pad_capacity % buf.k == 0
+    copy = dirs_out is not None and dirs_out.data_ptr() != dirs.data_ptr()
+    _call("pag_pack_offsets_pad", L.ptr(buf.counts), N, L.ptr(buf.pack_start), mb_ptr, int(pad_capacity), buf.k, L.ptr(buf.samples), L.ptr(buf.depths),
+          L.ptr(buf.deltas), L.ptr(buf.ridx_sample) if buf.k > 1 else None, L.ptr(buf.ridx_entry), L.ptr(buf.ridx64), L.ptr(buf.pidx),
+          L.ptr(buf.boundary), L.ptr(buf.pack_start_c), L.ptr(dirs) if copy else None, L.ptr(dirs_out) if copy else None, st)
+
+
 def march_into(buf, origins, dirs, dist_min, dist_max, num_samples, jitter=None, occupancy_bits=None, blas_level=7, max_travel=None,
-               occupancy_coarse_bits=None):
+               occupancy_coarse_bits=None, pad_capacity=None, dirs_out=None):
     """The ray march of raymarch_ray() / raymarch_voxel() written into `buf` (MarchBuffers) WITHOUT waiting for the sample count:
     count -> offsets (+ pinned mailbox) -> pack are queued back to back.  -> the mailbox (poll it with _poll_count() when convenient;
-    give it back with _release_mailbox()) or None when polling is disabled (the caller then reads buf.pack_start[N] itself)."""
+    give it back with _release_mailbox()) or None when polling is disabled (the caller then reads buf.pack_start[N] itself).
+    pad_capacity: the offsets launch also pads the batch to that capacity (MarchBuffers.pad_to) and, with dirs_out, copies the ray
+    directions into that static tensor - one launch instead of three (pag_pack_offsets_pad)."""
     _check_gpu(origins, dirs)
     dev = origins.device
     N = origins.shape[0]
@@ -1050,7 +1064,7 @@ def march_into(buf, origins, dirs, dist_min, dist_max, num_samples, jitter=None,
         tvals = _tvals(S, dev)
         _call("pag_raymarch_count", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min), float(dist_max), occ,
               blas_level, L.ptr(buf.counts), st)
-        _call("pag_pack_offsets", L.ptr(buf.counts), N, L.ptr(buf.pack_start), mb_ptr, st)
+        _offsets(buf, N, mb_ptr, st, pad_capacity, dirs, dirs_out)
         _call("pag_raymarch_pack", L.ptr(origins), L.ptr(dirs), N, S, L.ptr(tvals), L.ptr(jitter), float(dist_min), float(dist_max), occ,
               blas_level, L.ptr(buf.pack_start), L.ptr(buf.ridx_entry), L.ptr(buf.pidx), L.ptr(buf.samples), L.ptr(buf.depths),
               L.ptr(buf.deltas), L.ptr(buf.boundary), L.ptr(buf.ridx64), st)
@@ -1060,7 +1074,7 @@ def march_into(buf, origins, dirs, dist_min, dist_max, num_samples, jitter=None,
         travel = float("inf") if max_travel is None else float(max_travel)
         _call("pag_raymarch_voxel_count_nuggets", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse,
               blas_level, travel, L.ptr(buf.counts), L.ptr(buf.nug_t), L.ptr(buf.nug_cell), st)
-        _call("pag_pack_offsets", L.ptr(buf.counts), N, L.ptr(buf.pack_start), mb_ptr, st)
+        _offsets(buf, N, mb_ptr, st, pad_capacity, dirs, dirs_out)
         _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(buf.pack_start), L.ptr(buf.nug_t), L.ptr(buf.nug_cell),
               L.ptr(buf.ridx_entry), L.ptr(buf.pidx), L.ptr(buf.samples), L.ptr(buf.depths), L.ptr(buf.deltas), L.ptr(buf.boundary),
               L.ptr(buf.ridx_sample), L.ptr(buf.ridx64), st)

@@ -1,11 +1,11 @@
 """Print the kernel sequence of the LAST training step of a rocprofv3 --kernel-trace csv (start-ordered, with the idle gap before
-each launch).  usage: python3 scripts/step_timeline.py <kernel_trace.csv> [marker-substring] [steps-back]   (default marker: the optimiser's last launch, adam_batch_kernel;
+each launch).  usage: python3 scripts/step_timeline.py <kernel_trace.csv> [marker-substring] [steps-back]   (default marker: the optimiser's last launch, adam_kernel;
 steps-back k: the step k before the last one - bench.py ends with K eager steps for the roofline kernel, the graph-replayed ones come before them)"""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-marker = sys.argv[2] if len(sys.argv) > 2 else "adam_batch_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else "adam_kernel"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ends = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 # a step ends with the last optimizer launch of a burst

@@ -5,6 +5,6 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/tl_tmp; rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-aux "$@" > $out/bench.json 2> $out/err
 f=$(find $out -name "*kernel_trace.csv" | head -1)
-python3 scripts/step_timeline.py $f adam_batch_kernel $back > gpurun_out/timeline.txt
+python3 scripts/step_timeline.py $f adam_kernel $back > gpurun_out/timeline.txt
 rm -rf $out
 cat gpurun_out/timeline.txt
