@@ -24,6 +24,7 @@ the backward graph ends).
 """
 import collections
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -335,9 +336,9 @@ class GraphRunner:
         remembered and read directly; a replaced Parameter object shows up at once (its slot is read every step), a module that was added
         or removed at the next full walk."""
         cache = getattr(self, "_slots", None)
-        if cache is None or cache[0] != id(nef) or cache[2] <= 0:
+        if cache is None or cache[0]() is not nef or cache[2] <= 0:           # weak reference: a new nef at a recycled address is a different nef
             slots = [(m, n) for m in nef.modules() for n, p in m._parameters.items() if p is not None]
-            cache = self._slots = [id(nef), slots, self.PARAM_RESCAN]
+            cache = self._slots = [weakref.ref(nef), slots, self.PARAM_RESCAN]
         cache[2] -= 1
         try:
             return tuple((m._parameters[n].data_ptr(), m._parameters[n].requires_grad) for m, n in cache[1])

@@ -443,3 +443,33 @@ def test_adam_is_a_torch_adam_with_the_same_interface():
     sched = torch.optim.lr_scheduler.StepLR(oa, step_size=1, gamma=0.1)
     sched.step()
     assert abs(oa.param_groups[0]["lr"] - 0.01) < 1e-12
+
+
+def test_graph_key_parameter_signature_without_a_module_walk():
+    """GraphRunner._param_sig: the (data_ptr, requires_grad) signature of the nef's parameters read from remembered (module, name) slots - a
+    frozen parameter, a replaced Parameter object and a different nef all change it; the same nef gives the same signature."""
+    import gc
+    import pagnerf_amd
+    from pagnerf_amd.graphs import GraphRunner
+
+    def make():
+        nef = pagnerf_amd.PanopticDeltaNeF(grid_type="PermutoGrid", num_lods=4, feature_dim=2, num_classes=3, num_instances=5, capacity_log_2=6,
+                                           delta_capacity_log_2=6, blas_level=2)
+        nef.grid.init_from_scales()
+        nef.delta_grid.init_from_scales()
+        return nef
+    r = GraphRunner()
+    nef = make()
+    a = r._param_sig(nef)
+    assert a == r._param_sig(nef) and len(a) == len(list(nef.parameters()))
+    nef.decoder_density.lout.weight.requires_grad_(False)
+    b = r._param_sig(nef)
+    assert b != a
+    nef.grid.init_from_scales()                      # replaces nef.grid.tables by a new Parameter: seen without a rescan
+    c = r._param_sig(nef)
+    assert c != b
+    other = make()
+    assert r._param_sig(other) != c and r._param_sig(nef) == c
+    del other
+    gc.collect()
+    assert r._param_sig(nef) == c
