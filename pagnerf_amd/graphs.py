@@ -9,18 +9,21 @@ How: the march kernels write into upper-bound buffers without the host learning 
 filler samples that belong to no ray's pack up to a fixed CAPACITY chosen from the counts of the previous steps, so every tensor after
 the march has a shape that does not depend on device data (the per-ray kernels never see the fillers; the per-sample gradient tensors
 of the compositing backward are zero past the real samples, so the fillers carry no gradient); tracer.shade() - the nef on the packed samples,
-compositing, the panoptic heads - is captured ONCE per capacity with torch.cuda.make_graphed_callables (forward graph + backward
-graph; our C-ABI launches go to torch's current stream, which is the capture stream) and replayed from then on: one graph launch
-forward, one backward when the caller's `loss.backward()` reaches it.  The count is read from the pinned mailbox AFTER the forward
-graph has been queued; only if it exceeds the capacity (rare: the capacity follows the recent maximum with 2 % head-room) is the
-result discarded and the eager path run with the same jitter.
+compositing, the panoptic heads - is captured ONCE per capacity (_Graphed: forward graph + backward graph(s); our C-ABI launches go
+to torch's current stream, which is the capture stream) and replayed from then on: one graph launch forward, one backward when the
+caller's `loss.backward()` reaches it.  The count is read from the pinned mailbox AFTER the forward graph has been queued; only if it
+exceeds the capacity (rare: the capacity follows the recent maximum with 2 % head-room, in geometric buckets with hysteresis) is the
+result discarded and the eager path run with the same jitter - the replay itself ran truncated at the capacity (clamped pack table).
 
 Forward values are bit-identical to the eager path (the fillers take part in no per-ray sum); gradients agree up to the fp32
 summation order of the per-wave weight-gradient slabs (the tile -> wave assignment depends on the padded sample count).
 
+Ownership: the outputs handed out are copies; p.grad may alias the capture's static gradients until the next trace of the
+configuration, which first turns such a p.grad into a private copy (_GraphedFn).  With more than one rank
+the backward is captured as two graphs so that gradient hooks fire between them (_Graphed, `split`).
+
 Not taken (the tracer falls back to eager): torch.no_grad() / stage != 'train', extra channels, ray_sparcity_reg > 0, rays that
-require a gradient (pose optimisation), foreign grids, N > 1 ranks (the early all-reduce of the delta table needs its gradient before
-the backward graph ends).
+require a gradient (pose optimisation), foreign grids.
 """
 import collections
 import os
