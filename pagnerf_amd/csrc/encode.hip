@@ -765,14 +765,69 @@ __device__ __forceinline__ long long to_fixed(float v, int S) {
     else return __float2ll_rn(ldexpf(v, S));
 }
 
+#ifdef PAG_REDUCE_TIMING      // experiment builds only (scripts/reduce_phases.py): lane 0 of wave 0 / wave 15 of every block stamps the phases.
+// The stamps (shader clock; slots 13 / 14 the 100 MHz clock all CUs share) wait in LDS until the end of the kernel: kept in registers
+// they push the kernel past 64 VGPRs and halve its occupancy, stored to memory as they are taken they join the vmcnt waits.
+__device__ unsigned long long pag_dbg_times[8192 * 32];
+#define PAG_STAMP(k) do { if (lane == 0 && (wave == 0 || wave == 15)) pag_stamps[wave ? 1 : 0][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PAG_STAMP_RT(k) do { if (lane == 0 && (wave == 0 || wave == 15)) pag_stamps[wave ? 1 : 0][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int pag_debug_reduce_times(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pag_dbg_times), bytes); }
+#else
+#define PAG_STAMP(k)
+#define PAG_STAMP_RT(k)
+#endif
+// Experiment switches (scripts/build_variant.sh; profiles/README.md round 4 has the A/B numbers):
+//   PAG_RED_SGPRS  SGPR budget.  With 81 SGPRs (what the compiler takes when left alone: next_free_sgpr 75 + 6) a gfx950 SIMD holds 7 waves of this
+//                  kernel, not 8 - the runtime's occupancy query still answers "2 workgroups per CU", the hardware runs ONE 1024-thread workgroup per
+//                  CU (scripts/exp/lds_occupancy.hip: the step is between next_free_sgpr 74 and 75).  80 costs no spill and no VGPR.
+//   PAG_RED_ORDER  0 = blocks in (level, slice) order, 1 = finest level first, 2 = + each XCD takes 8 neighbouring slices, 3 = + the coarsest
+//                  PAG_RED_HEAD levels stay in front.
+#ifndef PAG_RED_SGPRS
+#define PAG_RED_SGPRS 80
+#endif
+#ifndef PAG_RED_ORDER
+#define PAG_RED_ORDER 3
+#endif
+#ifndef PAG_RED_HEAD
+#define PAG_RED_HEAD 8
+#endif
+
 template <int F, int NV, bool PACK>
-__global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab, int overwrite) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(PAG_RED_SGPRS))) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab, int overwrite) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [2^shift][F] fixed point
     constexpr int TS = tile_samples(NV);
-    const int level = blockIdx.x / lay.NS, slice = blockIdx.x % lay.NS;
+    // Block -> (level, slice).  Blocks are handed out in blockIdx order and run for very different times: the fine levels hold most of the
+    // entries (a block of level 20 streams 1 MB and runs ~100 us next to its neighbours, one of level 8 ~20 us), and a few slices of the
+    // COARSEST levels - the ones that hold the rows every ray touches - run 60 - 100 us although their level's average is 12 us.  In
+    // (level, slice) order the launch ended on a tail of the longest blocks (the last 60 us ran half empty).  Now: the coarsest levels
+    // first (their long blocks start at t = 0, in the shadow of everything else), then the remaining levels from the finest down, so that
+    // the launch ends on the short blocks of the middle levels: 179 -> 153 us per launch on the bench workload.
+    // Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8): each XCD takes 1/8 of a level's slices as ONE contiguous
+    // run, because neighbouring slices' segments are neighbours in every tile region (~450 B each, unaligned) and a 128-byte line they
+    // share is then fetched into one L2 once instead of into two.
+    int level, slice;
+    {
+        const int nl = (int)(gridDim.x / lay.NS);
+        int q;                                                  // position in the launch order -> q-th (level, slice) pair, slices fastest
+        if (PAG_RED_ORDER >= 2 && lay.NS % 8 == 0) {
+            const int per = lay.NS / 8, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+            q = (j / per) * lay.NS + x * per + j % per;
+        } else {
+            q = blockIdx.x;
+        }
+        const int k = q / lay.NS;
+        slice = q % lay.NS;
+        const int head = PAG_RED_ORDER == 3 ? min(PAG_RED_HEAD, nl / 3) : 0;      // the coarsest levels keep their place at the front
+        level = PAG_RED_ORDER == 0 ? k : k < head ? k : nl - 1 - (k - head);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int slice_rows = 1 << lay.shift;
     __shared__ uint32_t lvl_max;
+#ifdef PAG_REDUCE_TIMING
+    __shared__ unsigned long long pag_stamps[2][16];
+#endif
+    PAG_STAMP_RT(13);
+    PAG_STAMP(0);
     if (tid == 0) lvl_max = 0;
     __syncthreads();
     {
@@ -797,8 +852,10 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
     int ex;
     frexpf(poisoned ? 1.0f : maxabs, &ex);            // maxabs < 2^ex
     const int S = 38 - ex;                            // |val| * 2^S < 2^38 ; 2^23 addends stay below 2^61
+    PAG_STAMP(1);
     for (int j = tid; j < slice_rows * F; j += blockDim.x) acc[j] = 0ull;
     __syncthreads();
+    PAG_STAMP(2);
     const uint32_t *hb = lay.header + ((int64_t)level * (lay.NS + 1) + slice) * lay.ntiles;
     const uint32_t *he = hb + lay.ntiles;
     // A (tile, slice) segment holds ~20 entries on average (the fine levels fill all 64 slices evenly), so walking one
@@ -819,6 +876,11 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         const bool has = lane < G && tl < lay.ntiles;
         const uint32_t mb = has ? hb[tl] : 0u, me = has ? he[tl] : 0u;
         uint32_t incl = me - mb;
+#ifdef PAG_REDUCE_TIMING
+        const bool first_group = t0 == (int64_t)wave * G;      // the in-loop stamps describe a wave's first group of tiles
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(incl) : : "memory");
+        if (first_group) PAG_STAMP(7);
+#endif
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
@@ -873,6 +935,9 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         RawEntry<F, PACK> raw_a, raw_b;
         bool ok_a = fetch(0, raw_a);
         bool ok_b = fetch(64, raw_b);
+#ifdef PAG_REDUCE_TIMING
+        if (first_group) PAG_STAMP(3);
+#endif
         auto stage = [&](RawEntry<F, PACK> &raw, bool &ok_r, uint32_t c_next) __attribute__((always_inline)) {
             uint32_t key;
             float fv[F];
@@ -893,8 +958,16 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
             stage(raw_a, ok_a, c0 + 128);
             stage(raw_b, ok_b, c0 + 192);          // past the end: ok_b is false, nothing is added
         }
+#ifdef PAG_REDUCE_TIMING
+        if (first_group) {
+            PAG_STAMP(9);
+            if (lane == 0 && (wave == 0 || wave == 15)) pag_stamps[wave ? 1 : 0][10] = total;
+        }
+#endif
     }
+    PAG_STAMP(4);
     __syncthreads();
+    PAG_STAMP(5);
     const int64_t row0 = (int64_t)slice * slice_rows;
     float *dst = gtab + ((int64_t)level * rows_per_level + row0) * F;
     const int64_t valid = min((int64_t)slice_rows, rows_per_level - row0) * F;
@@ -902,7 +975,26 @@ __global__ __launch_bounds__(1024) void reduce_kernel(BinLayout lay, int64_t row
         const float v = poisoned ? __uint_as_float(0x7FC00000u) : (float)ldexp((double)(long long)acc[j], -S);
         dst[j] = overwrite ? v : dst[j] + v;
     }
+#ifdef PAG_REDUCE_TIMING
+    PAG_STAMP(6);
+    PAG_STAMP_RT(14);
+    if (lane == 0 && (wave == 0 || wave == 15) && blockIdx.x < 8192) {
+        pag_stamps[wave ? 1 : 0][11] = (unsigned long long)level;
+        pag_stamps[wave ? 1 : 0][12] = (unsigned long long)slice;
+        pag_stamps[wave ? 1 : 0][15] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);      // HW_ID, XCC_ID
+        for (int k = 0; k < 16; ++k) pag_dbg_times[blockIdx.x * 32 + (wave ? 16 : 0) + k] = pag_stamps[wave ? 1 : 0][k];
+    }
+#endif
 }
+
+#ifdef PAG_REDUCE_TIMING
+extern "C" int pag_debug_reduce_occupancy(int threads, int dyn_bytes) {
+    int occ = -1;
+    hipFuncSetAttribute((const void *)reduce_kernel<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_bytes);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reduce_kernel<2, 4, true>, threads, dyn_bytes);
+    return occ;
+}
+#endif
 
 struct BinPlan {
     int64_t ntiles, keys_bytes, vals_bytes, header_bytes, total;
