@@ -14,6 +14,7 @@
 // order of the oracle (oracle/hash_encode.py, oracle/permuto_encode.py); the file is compiled with
 // -ffp-contract=off.  With fp32 tables and fp32 output the result is bit-identical to the oracle.
 #include "encode_common.h"
+#include "blocktime.h"
 
 using namespace pag_enc;
 
@@ -48,13 +49,21 @@ __device__ __forceinline__ void store_grouped(bf16_t *out, int64_t M, int g, int
 }
 __device__ __forceinline__ void store_grouped(float *, int64_t, int, int64_t, ...) {}
 
+// Workgroup size of the per-sample, XCD-pinned kernels (forward gathers, position gradients).  A workgroup of the permutohedral forward lives ~5 us (12 gathers per thread, combine, store) and the launch has
+// 8 * M / threads of them: at 256 threads the dispatcher handed a CU a new workgroup only every ~0.5 us and the CUs held 3.3 workgroups
+// on average where their registers allow 6 (scripts/block_timeline.py) - half of the gathers that could be in flight were not.  512
+// threads halve the number of workgroups: 399 -> 328 us on the bench workload (two 256-sample tiles per workgroup in a loop measure the
+// same but cost 10 VGPRs; 1024 threads lose a little again: 344).
+#ifndef PAG_ENC_FWD_THREADS
+#define PAG_ENC_FWD_THREADS 512
+#endif
 template <typename TableT, typename OutT, int F, int LPX>
-__global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__ xyz, int64_t M,
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void hash_fwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                        const TableT *__restrict__ tables, HashParams p,
                                                        OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped,
                                                        const bf16_t *__restrict__ addend) {
     const int g = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
     if (i >= M) return;
     float x[3];
     load_xyz(xyz, i, p.half_coords, x);
@@ -121,11 +130,11 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(const float *__restrict__
 }
 
 template <typename GradT, int F, int LPX>
-__global__ __launch_bounds__(256) void hash_bwd_kernel(const float *__restrict__ xyz, int64_t M,
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void hash_bwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                        const GradT *__restrict__ go, int64_t sm, int64_t sc,
                                                        HashParams p, float *__restrict__ gtab) {
     const int g = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
     if (i >= M) return;
     float x[3];
     load_xyz(xyz, i, p.half_coords, x);
@@ -157,7 +166,7 @@ template <typename TableT, typename OutT, int F, int LPX>
 __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, const PermutoParams &p,
                                                  OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped, const bf16_t *__restrict__ addend) {
     const int g = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
     if (i >= M) return;
     float x[3];
     load_xyz(xyz, i, p.half_coords, x);
@@ -196,7 +205,9 @@ __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, 
         for (int r = 0; r < 4; ++r) bary[j][r] = 0.25f;
 #endif
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gather<F>(tab + (int64_t)idx[r] * F, e[j][r]);
+        for (int r = 0; r < 4; ++r) {
+            gather_row<F>(tab, idx[r], e[j][r]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
@@ -222,23 +233,25 @@ __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, 
 #define PAG_ENC_FWD_WAVES 1      // minimum waves per SIMD asked of the compiler for the permutohedral forward (experiments: 8 = 64 VGPRs)
 #endif
 template <typename TableT, typename OutT, int F, int LPX>
-__global__ __launch_bounds__(256, PAG_ENC_FWD_WAVES) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS, PAG_ENC_FWD_WAVES) void permuto_fwd_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
                                                           OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped) {
+    PAG_BLOCK_TIMER(1);
     permuto_fwd_body<TableT, OutT, F, LPX>(xyz, M, tables, p, out, sm, sc, grouped, nullptr);
 }
 template <typename TableT, typename OutT, int F, int LPX>
-__global__ __launch_bounds__(256, PAG_ENC_FWD_WAVES) void permuto_fwd_add_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS, PAG_ENC_FWD_WAVES) void permuto_fwd_add_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, PermutoParams p,
                                                               OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped,
                                                               const bf16_t *__restrict__ addend) {
+    PAG_BLOCK_TIMER(2);
     permuto_fwd_body<TableT, OutT, F, LPX>(xyz, M, tables, p, out, sm, sc, grouped, addend);
 }
 
 template <typename GradT, int F, int LPX>
-__global__ __launch_bounds__(256) void permuto_bwd_kernel(const float *__restrict__ xyz, int64_t M,
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void permuto_bwd_kernel(const float *__restrict__ xyz, int64_t M,
                                                           const GradT *__restrict__ go, int64_t sm, int64_t sc,
                                                           PermutoParams p, float *__restrict__ gtab) {
     const int g = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
     if (i >= M) return;
     float x[3];
     load_xyz(xyz, i, p.half_coords, x);
@@ -272,12 +285,12 @@ __global__ __launch_bounds__(256) void permuto_bwd_kernel(const float *__restric
 // derivatives.  Same XCD-pinned launch as the forward; group g writes its partial sum to part[g][m][3] and a tiny
 // second kernel adds the 8 groups (deterministic, no atomics).
 template <int KIND /*0 hash, 1 permuto*/, typename TableT, typename GradT, int F, int LPX>
-__global__ __launch_bounds__(256) void xyz_grad_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables,
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables,
                                                        const GradT *__restrict__ go, int64_t sm, int64_t sc, int grouped,
                                                        HashParams hp, PermutoParams pp, float *__restrict__ part) {
     constexpr int NV = KIND == 0 ? 8 : 4;
     const int g = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
     if (i >= M) return;
     const int L = KIND == 0 ? hp.L : pp.L;
     const float *scale = KIND == 0 ? hp.scale : pp.scale;
@@ -542,6 +555,7 @@ template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool P
 #endif
 __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_BIN_WAVES : PAG_BIN_WAVES_HASH)) void bin_kernel(const float *__restrict__ xyz, int64_t M, const GradT *__restrict__ go,
                                                  int64_t sm, int64_t sc, int grouped, HashParams hp, PermutoParams pp, BinLayout lay) {
+    PAG_BLOCK_TIMER(0);
     constexpr int NV = KIND == 0 ? 8 : 4;
     constexpr int TS = tile_samples(NV);
 #ifndef PAG_BIN_NO_STAGE
@@ -794,6 +808,7 @@ extern "C" int pag_debug_reduce_times(void *dst, size_t bytes) { return (int)hip
 
 template <int F, int NV, bool PACK>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(PAG_RED_SGPRS))) void reduce_kernel(BinLayout lay, int64_t rows_per_level, float *__restrict__ gtab, int overwrite) {
+    PAG_BLOCK_TIMER(3);
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];      // [2^shift][F] fixed point
     constexpr int TS = tile_samples(NV);
     // Block -> (level, slice).  Blocks are handed out in blockIdx order and run for very different times: the fine levels hold most of the
@@ -1060,7 +1075,7 @@ int launch_binned(const float *xyz, int64_t M, const void *grad_out, int grad_dt
     return PAG_OK;
 }
 
-inline unsigned encode_grid(int64_t M) { return (unsigned)(((M + 255) / 256) * 8); }
+inline unsigned encode_grid(int64_t M) { return (unsigned)(((M + PAG_ENC_FWD_THREADS - 1) / PAG_ENC_FWD_THREADS) * 8); }
 
 // ---- dispatch helpers: (table dtype, out dtype, F, LPX) -> kernel instantiation
 #define PAG_DISPATCH_F_LPX(F_, LPX_, CALL)                 \
@@ -1122,7 +1137,7 @@ static int hash_encode_fwd_impl(const float *xyz, int64_t M, const void *tables,
     for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
     const int lpx = (n_levels + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(encode_grid(M)), block(256);
+    dim3 grid(encode_grid(M)), block(PAG_ENC_FWD_THREADS);
     bool launched = false;
     if (table_dtype == PAG_F32 && out_dtype == PAG_F32) {
         PAG_DISPATCH_ALL((hash_fwd_kernel<float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, p, (float *)out, out_stride_m, out_stride_c, grouped, addend)))
@@ -1184,7 +1199,7 @@ static int hash_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, con
         PAG_CHECK_LAUNCH("pag_hash_encode_bwd");
         return PAG_OK;
     }
-    dim3 grid(encode_grid(M)), block(256);
+    dim3 grid(encode_grid(M)), block(PAG_ENC_FWD_THREADS);
     bool launched = false;
     if (grad_dtype == PAG_F32) {
         PAG_DISPATCH_ALL((hash_bwd_kernel<float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)grad_out, g_stride_m, g_stride_c, p, grad_tables)))
@@ -1234,7 +1249,7 @@ static int permuto_encode_fwd_impl(const float *xyz, int64_t M, const void *tabl
     fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host, flags);
     const int lpx = (n_levels + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(encode_grid(M)), block(256);
+    dim3 grid(encode_grid(M)), block(PAG_ENC_FWD_THREADS);
     bool launched = false;
 #define PFWD(TT, OT)                                                                                                                 \
     PAG_DISPATCH_ALL((permuto_fwd_kernel<TT, OT, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const TT *)tables, p, (OT *)out, out_stride_m, \
@@ -1300,7 +1315,7 @@ static int permuto_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, 
         PAG_CHECK_LAUNCH("pag_permuto_encode_bwd");
         return PAG_OK;
     }
-    dim3 grid(encode_grid(M)), block(256);
+    dim3 grid(encode_grid(M)), block(PAG_ENC_FWD_THREADS);
     bool launched = false;
     if (grad_dtype == PAG_F32) {
         PAG_DISPATCH_ALL((permuto_bwd_kernel<float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)grad_out, g_stride_m, g_stride_c, p, grad_tables)))
@@ -1327,7 +1342,7 @@ static int launch_xyz_grad(const char *name, const float *xyz, int64_t M, const 
     PAG_CHECK_ARG(workspace_bytes >= (int64_t)8 * M * 3 * (int64_t)sizeof(float), "%s: workspace smaller than 8*M*3 floats", name);
     float *part = (float *)workspace;
     const int lpx = (n_levels + 7) / 8;
-    dim3 grid(encode_grid(M)), block(256);
+    dim3 grid(encode_grid(M)), block(PAG_ENC_FWD_THREADS);
     bool launched = false;
     if (table_dtype == PAG_F32 && grad_dtype == PAG_F32) {
         PAG_DISPATCH_ALL((xyz_grad_kernel<KIND, float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, (const float *)grad_out, sm, sc, grouped, hp, pp, part)))
@@ -1414,3 +1429,5 @@ extern "C" int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const voi
     return permuto_encode_bwd_impl(true, xyz, M, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat, capacity, scale_factor_host,
                                    shift_host, feat_scale_host, grad_tables, workspace, workspace_bytes, flags, stream);
 }
+
+PAG_BLOCK_TIMING_EXPORT(encode)

@@ -55,6 +55,12 @@ template <int F> __device__ __forceinline__ void gather(const __half *row, float
     for (int f = 0; f < F; ++f) v[f] = __half2float(p[f]);
 }
 
+// Row `row` of a table whose base is wave-uniform: the byte offset stays in 32 bits (a level's table is far below 4 GiB), so the load takes
+// the scalar-base + 32-bit-vector-offset form and its address costs one VGPR instead of two and no 64-bit add.
+template <int F, typename T> __device__ __forceinline__ void gather_row(const T *base, uint32_t row, float (&v)[F]) {
+    gather<F>(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + row * (uint32_t)(F * sizeof(T))), v);
+}
+
 // ------------------------------------------------------------------------------------ hash grid
 // grids/hash_grid_torch.py:26-46 (cell lookup) and :69-77 (weights), one level.
 // dwdx[a] = d w[a] / d x[a] = 1 / (vmax - vmin)  (the clamp of :34-36 is local to the cell lookup, :100,105)

@@ -22,6 +22,7 @@
 // FP32 path (PAG_MLP_FP32): one lane per sample, fp32 FMA chains in k order with the weights
 // broadcast from LDS - the parity path (tolerance 1e-5 against the fp32 oracle).
 #include "common.h"
+#include "blocktime.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -895,6 +896,7 @@ __device__ __forceinline__ void tile64_store_buf(bf16_t *stg, RS_T rs, unsigned 
 // SAVE: write the hidden activations (hsave[0], and hsave[1] with three layers) - the backward that recomputes them passes none.
 template <int NL, int KIND, bool SAVE>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_fast(FwdParams p) {
+    PAG_BLOCK_TIMER(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool GRP = KIND != 1;
     constexpr int NKS0 = GRP ? 4 : 3;
@@ -1037,6 +1039,7 @@ template <bool SAVE0, bool PAIR>
 #define PAG_WIDE_FWD_PAIR_THREADS 1024
 #endif
 __global__ __launch_bounds__(PAIR ? PAG_WIDE_FWD_PAIR_THREADS : 256, PAIR ? 1 : 2) void mlp_fwd_wide_stats(FwdParams p) {
+    PAG_BLOCK_TIMER(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OB = 7;
     constexpr float LOG2E = 1.4426950408889634f;
@@ -1553,6 +1556,7 @@ __device__ unsigned long long g_fused_prof[8];      // shader clocks summed over
 #endif
 template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */, bool DZ0 = false>
 __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdParams p) {
+    PAG_BLOCK_TIMER(2);
 #ifdef PAG_FUSED_PROF
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1984,6 +1988,7 @@ struct PairParams {
     BwdParams i, s;
 };
 __global__ __launch_bounds__(256, 1) void mlp_bwd_pair(PairParams pp) {
+    PAG_BLOCK_TIMER(3);
 #ifdef PAG_FUSED_PROF
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2368,6 +2373,7 @@ __device__ unsigned long long g_wb_prof[2][8];      // [0] cycles at the barrier
 constexpr int WB_RMAX = 4;         // rays whose gradient rows are staged per tile; tiles spanning more read their rows from global
 template <int OB>
 __global__ __launch_bounds__((OB + 1) * 64) void mlp_bwd_wide_blocks(BwdParams p) {
+    PAG_BLOCK_TIMER(4);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RSL = OB * 32 + 8;
     constexpr float LOG2E = 1.4426950408889634f;
@@ -3008,6 +3014,7 @@ __device__ __forceinline__ float dpp_add(float v) {
 // and every block ran as reads -> 4 chained MFMAs -> 16 exponentials, nothing overlapping at two waves per SIMD).
 template <int OBT>
 __global__ __launch_bounds__(256, 2) void head_composite_fwd_kernel(HeadCompParams p) {      // two waves per SIMD: 256 registers
+    PAG_BLOCK_TIMER(5);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = OBT ? OBT : (p.out_dim + 31) / 32;
     bf16_t *WLs = reinterpret_cast<bf16_t *>(smem);                  // [OB*32][RS] permuted k (forward layout)
@@ -3401,6 +3408,7 @@ template <typename A1T, int APW /* accumulator blocks per wave */, int NWV = 4 /
 // registers.  Wide layers (up to 224 outputs = 21 block pairs): 8 waves x 3 pairs instead of 4 x 6 - 48 accumulator
 // registers per wave leave room for the prefetch and for 4 waves per SIMD (the 4 x 6 form ran 2 waves per SIMD, no prefetch).
 __global__ __launch_bounds__(NWV * 64, (APW == 2 ? 5 : (APW == 3 ? 4 : 1))) void mlp_wgrad_kernel(WgradBatch batch) {
+    PAG_BLOCK_TIMER(6);
     const WgradParams &p = batch.p[blockIdx.y];       // blockIdx.y = layer: the layers of one decoder share a launch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int OB = (p.n_out + 31) / 32;
@@ -3670,7 +3678,12 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
                 p.out2_dim = b->out_dim;
                 constexpr int NWP = PAG_WIDE_FWD_PAIR_THREADS / 64;      // waves per workgroup (one workgroup per CU shares the 66 KiB of weights)
                 const size_t lds = (size_t)(128 + 224 + 96) * RS * sizeof(bf16_t) + (128 + 224 + 96) * sizeof(float) + NWP * ST_BYTES;
-                const unsigned grid = (mlp_grid(M) * 4 + NWP - 1) / NWP;
+                // one workgroup per CU is all that fits (LDS): a grid of 1.5 x 256 ran a full round and a half-empty one (220 us, of which
+                // the second round's 110 us kept 128 CUs idle: scripts/block_timeline.py) - at most ONE round, tiles grid-strided
+#ifndef PAG_WIDE_FWD_PAIR_GRID
+#define PAG_WIDE_FWD_PAIR_GRID 256
+#endif
+                const unsigned grid = std::min<unsigned>((mlp_grid(M) * 4 + NWP - 1) / NWP, PAG_WIDE_FWD_PAIR_GRID);
                 hipLaunchKernelGGL((mlp_fwd_wide_stats<false, true>), dim3(grid), dim3(PAG_WIDE_FWD_PAIR_THREADS), lds, st, p);
             } else {
                 const size_t lds = (size_t)(128 + 224) * RS * sizeof(bf16_t) + (128 + 224) * sizeof(float) + 4 * ST_BYTES;
@@ -4324,3 +4337,5 @@ extern "C" int pag_head_composite_fwd(const int64_t *pack_start, const int32_t *
     PAG_CHECK_LAUNCH("pag_head_composite_fwd");
     return PAG_OK;
 }
+
+PAG_BLOCK_TIMING_EXPORT(mlp)
