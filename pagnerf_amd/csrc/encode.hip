@@ -543,6 +543,14 @@ __device__ __forceinline__ void run_combine(uint32_t key, bool pair, unsigned lo
     emit = live && (lane == 63 || !next_same);
 }
 
+#ifdef PAG_BIN_TIMING      // experiment builds only (scripts/bin_phases.py): wave 0 / wave 15 of every workgroup stamp the phases into LDS, flushed at the end
+__device__ unsigned long long pag_bin_times[32768 * 32];
+#define PAG_BSTAMP(k) do { if (lane == 0 && (wave == 0 || wave == 15)) pag_bstamps[wave ? 1 : 0][k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int pag_debug_bin_times(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pag_bin_times), bytes); }
+#else
+#define PAG_BSTAMP(k)
+#endif
+
 template <int KIND /*0 hash, 1 permuto*/, typename GradT, int F, int LPX, bool PACK>
 // TWO 1024-thread workgroups per CU (8 waves per SIMD, <= 64 VGPRs): with one, every block barrier of the counting sort / staging
 // stalls the whole CU - nothing else is resident to run.  The permutohedral variant fits 64 VGPRs with 48 B of scratch and the encode
@@ -569,6 +577,11 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
     const int L = KIND == 0 ? hp.L : pp.L;
     const int64_t tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PAG_BIN_TIMING
+    __shared__ unsigned long long pag_bstamps[2][16];
+    if (lane == 0 && (wave == 0 || wave == 15)) pag_bstamps[wave ? 1 : 0][13] = __builtin_amdgcn_s_memrealtime();
+#endif
+    PAG_BSTAMP(0);
     const int64_t i = tile * TS + tid;
     const bool live = i < M;
     const int64_t ic = live ? i : M - 1;
@@ -587,6 +600,10 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
     const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
     for (int s = tid; s < LPX * (NS_MAX + 2); s += TS) (&cnt[0][0])[s] = 0;
     __syncthreads();
+#ifdef PAG_BIN_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(gpiece[0]) : : "memory");
+#endif
+    PAG_BSTAMP(1);
     uint32_t idx[LPX][NV];
     float ev[LPX][NV][F];
     bool emit[LPX][NV];
@@ -654,8 +671,10 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
 #endif
             if (emit[j][k]) rank[j][k] = atomicAdd(&cnt[j][idx[j][k] >> lay.shift], 1u);      // read only where emit is set
         }
+        PAG_BSTAMP(2 + j);
     }
     __syncthreads();
+    PAG_BSTAMP(6);
     if (wave < LPX) {   // wave j: exclusive prefix over level j's NS slice counters
         uint32_t carry = 0;
         for (int s0 = 0; s0 < lay.NS; s0 += 64) {
@@ -673,6 +692,7 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
         if (lane == 0) offs[wave][lay.NS] = carry;
     }
     __syncthreads();
+    PAG_BSTAMP(7);
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
         const int level = grouped ? xcd8_level((int)blockIdx.y, j) : (int)blockIdx.y;
@@ -688,10 +708,13 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
                     stage[offs[j][idx[j][k] >> lay.shift] + rank[j][k]] =
                         pack_entry(idx[j][k] & ((1u << lay.shift) - 1u), ev[j][k][0], ev[j][k][F - 1]);
             __syncthreads();
+            if (j == 0) PAG_BSTAMP(8);
             const uint32_t total = offs[j][lay.NS];
             uint64_t *dst = reinterpret_cast<uint64_t *>(lay.vals) + region;
             for (uint32_t q = tid; q < total; q += TS) dst[q] = stage[q];
+            if (j == 0) PAG_BSTAMP(9);
             __syncthreads();      // the next level reuses the staging tile
+            if (j == 0) PAG_BSTAMP(10);
         }
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -710,6 +733,14 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
         for (int s = tid; s <= lay.NS; s += TS) lay.header[((int64_t)level * (lay.NS + 1) + s) * lay.ntiles + tile] = offs[j][s];
         if (tid == 0) lay.tile_max[(int64_t)level * lay.ntiles + tile] = cnt[j][NS_MAX + 1];
     }
+#ifdef PAG_BIN_TIMING
+    PAG_BSTAMP(11);
+    if (lane == 0 && (wave == 0 || wave == 15)) {
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.y;
+        pag_bstamps[wave ? 1 : 0][14] = __builtin_amdgcn_s_memrealtime();
+        if (b < 32768) for (int k = 0; k < 16; ++k) pag_bin_times[b * 32 + (wave ? 16 : 0) + k] = pag_bstamps[wave ? 1 : 0][k];
+    }
+#endif
 }
 
 // Add one wave's 64 (key, value) entries into the LDS slice.  LDS float atomics (ds_add_f32) serialise

@@ -3695,7 +3695,10 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
         }
         if (kind >= 0 && (save_all || save_none)) {
             const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + 32) * RS * sizeof(bf16_t) + (128 + 32) * sizeof(float) + 4 * ST_BYTES;
-#define FWD_FAST(NL_, K_, S_) hipLaunchKernelGGL((mlp_fwd_fast<NL_, K_, S_>), dim3(mlp_grid(M)), dim3(256), lds, st, p)
+#ifndef PAG_FAST_FWD_GRID_CAP
+#define PAG_FAST_FWD_GRID_CAP 768      // three workgroups per CU are resident: one round, tiles grid-strided (1536 ran two rounds with a ragged second: colour forward 63 -> 57 us)
+#endif
+#define FWD_FAST(NL_, K_, S_) hipLaunchKernelGGL((mlp_fwd_fast<NL_, K_, S_>), dim3(std::min<unsigned>(mlp_grid(M), PAG_FAST_FWD_GRID_CAP)), dim3(256), lds, st, p)
 #define FWD_FAST_K(K_)                                                        \
     do {                                                                      \
         if (a->n_layers == 2) { if (save_all) FWD_FAST(2, K_, true); else FWD_FAST(2, K_, false); } \
