@@ -762,6 +762,7 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__res
 // before the host learnt M must stay inside them: pack_start_clamped[r] = min(pack_start[r], capacity) is the pack table THEY walk
 // (identical to pack_start when the batch fits; a truncated batch, whose results the caller discards, when it does not).
 // k = samples per nugget (voxel mode: the per-nugget arrays are padded up to capacity / k).
+constexpr int PAD_WGS = 16;
 struct PadArgs {
     int64_t capacity;
     int k;
@@ -775,14 +776,15 @@ struct PadArgs {
 __device__ __forceinline__ void pad_tail(const PadArgs &a, int64_t M, int64_t N) {
     if (M > a.capacity) return;
     const int32_t last = (int32_t)(N - 1);
-    for (int64_t i = M + threadIdx.x; i < a.capacity; i += blockDim.x) {
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;      // every workgroup of the launch takes its share
+    for (int64_t i = M + first; i < a.capacity; i += stride) {
         a.samples[i * 3] = 0.0f, a.samples[i * 3 + 1] = 0.0f, a.samples[i * 3 + 2] = 0.0f;
         a.depths[i] = 0.0f;
         a.deltas[i] = 0.0f;
         a.boundary[i] = 0;
         if (a.ridx_sample) a.ridx_sample[i] = last;
     }
-    for (int64_t g = M / a.k + threadIdx.x; g < a.capacity / a.k; g += blockDim.x) {
+    for (int64_t g = M / a.k + first; g < a.capacity / a.k; g += stride) {
         if (a.ridx_nugget) a.ridx_nugget[g] = last;
         if (a.ridx64) a.ridx64[g] = last;
         a.pidx[g] = 0;
@@ -791,7 +793,7 @@ __device__ __forceinline__ void pad_tail(const PadArgs &a, int64_t M, int64_t N)
 __global__ __launch_bounds__(1024) void pad_packed_kernel(const int64_t *__restrict__ pack_start, int64_t N, PadArgs a, int64_t *__restrict__ pack_start_clamped) {
     const int64_t M = pack_start[N];
     // the pack table the capacity-sized launches may walk: no pack reaches past `capacity`, whatever the march produced
-    if (pack_start_clamped)
+    if (pack_start_clamped && blockIdx.x == 0)
         for (int64_t r = threadIdx.x; r <= N; r += blockDim.x) {
             const int64_t p = pack_start[r];
             pack_start_clamped[r] = p < a.capacity ? p : a.capacity;
@@ -799,9 +801,11 @@ __global__ __launch_bounds__(1024) void pad_packed_kernel(const int64_t *__restr
     pad_tail(a, M, N);
 }
 
-// pack_offsets_kernel + pad_packed_kernel + the copy of the ray directions into the graph's static buffer as ONE one-workgroup launch
+// pack_offsets_kernel + pad_packed_kernel + the copy of the ray directions into the graph's static buffer as ONE launch
 // (pagnerf_amd/graphs.py: three 5 - 10 us launches at the head of every graph-replayed step; the fillers lie behind the samples the pack
-// pass - queued after this kernel - writes, so the order does not matter)
+// pass - queued after this kernel - writes, so the order does not matter).  PAD_WGS workgroups: every one repeats the (tiny) scan to learn
+// the total, workgroup 0 writes the tables, and the filler stores - up to capacity - M ~ 10^4 samples x 25 B, which one workgroup took
+// 10 us to write - and the direction copy are shared by all of them.
 __global__ __launch_bounds__(1024) void pack_offsets_pad_kernel(const int32_t *__restrict__ counts, int64_t N, int64_t *__restrict__ pack_start, int64_t *total_host,
                                                                 PadArgs a, int64_t *__restrict__ pack_start_clamped, const float *__restrict__ dirs_src,
                                                                 float *__restrict__ dirs_dst) {
@@ -825,20 +829,22 @@ __global__ __launch_bounds__(1024) void pack_offsets_pad_kernel(const int32_t *_
         base += w < wave ? wave_tot[w] : 0;
         total += wave_tot[w];
     }
-    int64_t run = base + incl - sum;
-    for (int64_t i = lo; i < hi; ++i) {
-        pack_start[i] = run;
-        pack_start_clamped[i] = run < a.capacity ? run : a.capacity;
-        run += counts[i];
-    }
-    if (tid == 0) {
-        pack_start[N] = total;
-        pack_start_clamped[N] = total < a.capacity ? total : a.capacity;
-        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 0) {
+        int64_t run = base + incl - sum;
+        for (int64_t i = lo; i < hi; ++i) {
+            pack_start[i] = run;
+            pack_start_clamped[i] = run < a.capacity ? run : a.capacity;
+            run += counts[i];
+        }
+        if (tid == 0) {
+            pack_start[N] = total;
+            pack_start_clamped[N] = total < a.capacity ? total : a.capacity;
+            if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     pad_tail(a, total, N);
     if (dirs_dst)
-        for (int64_t i = tid; i < N * 3; i += 1024) dirs_dst[i] = dirs_src[i];
+        for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < N * 3; i += (int64_t)gridDim.x * 1024) dirs_dst[i] = dirs_src[i];
 }
 
 // Several small device-to-device copies as ONE launch (pagnerf_amd/graphs.py: the copies of a replay's static outputs handed to the
@@ -902,7 +908,7 @@ extern "C" int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capa
                   "pag_pad_packed: N %lld, capacity %lld must be a multiple of samples_per_entry %d", (long long)N, (long long)capacity, samples_per_entry);
     PAG_CHECK_ARG(pack_start && samples && depths && deltas && pidx && boundary, "pag_pad_packed: NULL buffer");
     PadArgs a{capacity, samples_per_entry, samples, depths, deltas, ridx_sample, ridx_entry, ridx64, pidx, boundary};
-    hipLaunchKernelGGL(pad_packed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack_start, N, a, pack_start_clamped);
+    hipLaunchKernelGGL(pad_packed_kernel, dim3(PAD_WGS), dim3(1024), 0, (hipStream_t)stream, pack_start, N, a, pack_start_clamped);
     PAG_CHECK_LAUNCH("pag_pad_packed");
     return PAG_OK;
 }
@@ -916,7 +922,7 @@ extern "C" int pag_pack_offsets_pad(const int32_t *counts, int64_t N, int64_t *p
     PAG_CHECK_ARG(samples && depths && deltas && pidx && boundary, "pag_pack_offsets_pad: NULL buffer");
     PAG_CHECK_ARG(!dirs_dst || dirs_src, "pag_pack_offsets_pad: dirs_dst without dirs_src");
     PadArgs a{capacity, samples_per_entry, samples, depths, deltas, ridx_sample, ridx_entry, ridx64, pidx, boundary};
-    hipLaunchKernelGGL(pack_offsets_pad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, pack_start, total_host, a, pack_start_clamped, dirs_src, dirs_dst);
+    hipLaunchKernelGGL(pack_offsets_pad_kernel, dim3(PAD_WGS), dim3(1024), 0, (hipStream_t)stream, counts, N, pack_start, total_host, a, pack_start_clamped, dirs_src, dirs_dst);
     PAG_CHECK_LAUNCH("pag_pack_offsets_pad");
     return PAG_OK;
 }
