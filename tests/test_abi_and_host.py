@@ -30,6 +30,14 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.pag_abi_version() == _lib.ABI_VERSION == 9
 
 
+def test_regular_library_carries_no_instrumentation(lib):
+    """The timing builds (-DPAG_REDUCE_TIMING / PAG_BIN_TIMING / PAG_BLOCK_TIMING: scripts/reduce_phases.py, bin_phases.py, block_timeline.py)
+    export pag_debug_* readers; the library the product loads must not - nothing in it stamps clocks or writes debug tables."""
+    for name in ("pag_debug_reduce_times", "pag_debug_reduce_occupancy", "pag_debug_bin_times", "pag_debug_block_times_encode", "pag_debug_block_times_mlp"):
+        assert not hasattr(lib, name), name
+    assert not os.environ.get("PAG_LIB_VARIANT"), "tests must run against the regular library"
+
+
 def test_argument_validation_without_gpu(lib):
     from pagnerf_amd import _lib as L
     f = (ctypes.c_float * 4)(16, 32, 64, 128)
