@@ -939,10 +939,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(PAG_RED_SGPRS)
         s_excl[wave][lane] = excl;
         s_adj[wave][lane] = (uint32_t)lane * (uint32_t)(TS * NV) + mb - excl;      // modulo 2^32: only position + s_adj is used
         if (lane < 8) s_excl[wave][64 + lane] = 0xFFFFFFFFu;                        // "no further boundary"
-        // segments that still hold (nearly) every entry a tile can have for one slice - TS * NV / NS: 64 permutohedral, 32 hash - come from a level without repeats:
-        // the wave-wide pre-summation of shared rows (lds_accumulate's leader loop) has nothing to find there
+        // The wave-wide pre-summation of shared rows (lds_accumulate's leader loop) pays where MANY lanes of a 64-entry chunk carry one row: the
+        // coarse levels, whose (tile, slice) segments hold a few entries each, so that a chunk gathers the same hot rows from dozens of tiles.
+        // Where the segments average >= 12 entries a chunk spans ~5 tiles and - adjacent repeats having been merged inside each tile by the bin
+        // pass - a row appears a handful of times at most: the loop's test (a leader key through the LDS crossbar, a ballot, a count per chunk)
+        // can only fail there, and is skipped.  (Before: only levels still holding >= 15/16 of a tile's entries took this path - level 23 alone
+        // on the bench rays; 155 -> 152 us.)  The sums are integers: identical either way.
+#ifndef PAG_RED_DISTINCT_SEG
+#define PAG_RED_DISTINCT_SEG 12
+#endif
         const int tiles_here = (int)min((int64_t)G, lay.ntiles - t0);
-        const bool distinct = total * 16u >= 15u * (uint32_t)((TS * NV) / lay.NS) * (uint32_t)tiles_here;      // >= 15/16 of a tile's entries per slice
+        const bool distinct = total >= (uint32_t)(PAG_RED_DISTINCT_SEG) * (uint32_t)tiles_here;
         int ts = 0;
         auto fetch = [&](uint32_t c0, RawEntry<F, PACK> &raw) __attribute__((always_inline)) {
             const uint32_t i = c0 + lane;
