@@ -874,11 +874,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(PAG_RED_SGPRS)
 #endif
     PAG_STAMP_RT(13);
     PAG_STAMP(0);
+    // The level's largest |gradient| (the fixed-point scale) from the bin pass's per-tile maxima.  The accumulators are cleared while those loads
+    // are in flight and under the same barrier that publishes lvl_max = 0: one barrier and one exposed load round trip less per workgroup than
+    // max-then-clear (the fixed part of a workgroup is what the small batches of the post-prune regime pay: 1536 workgroups whatever M is).
     if (tid == 0) lvl_max = 0;
-    __syncthreads();
     {
         uint32_t mb = 0;
         for (int64_t t = tid; t < lay.ntiles; t += blockDim.x) mb = max(mb, lay.tile_max[(int64_t)level * lay.ntiles + t]);
+        for (int j = tid; j < slice_rows * F; j += blockDim.x) acc[j] = 0ull;
+        __syncthreads();
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, d));
         if (lane == 0 && mb) atomicMax(&lvl_max, mb);
@@ -899,8 +903,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(PAG_RED_SGPRS)
     frexpf(poisoned ? 1.0f : maxabs, &ex);            // maxabs < 2^ex
     const int S = 38 - ex;                            // |val| * 2^S < 2^38 ; 2^23 addends stay below 2^61
     PAG_STAMP(1);
-    for (int j = tid; j < slice_rows * F; j += blockDim.x) acc[j] = 0ull;
-    __syncthreads();
     PAG_STAMP(2);
     const uint32_t *hb = lay.header + ((int64_t)level * (lay.NS + 1) + slice) * lay.ntiles;
     const uint32_t *he = hb + lay.ntiles;

@@ -16,11 +16,13 @@ import bench
 from pagnerf_amd import _lib
 
 dev = torch.device("cuda:0")
-args = bench.parse(["--graphs", "off"])
-nef, tracer = bench.make_model(args, dev, 0), bench.make_tracer(args, "ray")
+args = bench.parse(["--graphs", "off"] + sys.argv[1:])          # e.g. --raymarch voxel --channels rgb : the post-prune regime
+nef, tracer = bench.make_model(args, dev, 0), bench.make_tracer(args, args.raymarch)
+if args.raymarch == "voxel":
+    bench.synthetic_prune(nef, args.occupancy)
 rays, gt = bench.make_rays(args.rays, dev, 1)
 opt = bench.make_optimizer(nef)
-chans = {"rgb", "depth", "semantics", "inst_embedding"}
+chans = {"rgb", "depth", "semantics", "inst_embedding"} if args.channels == "all" else {"rgb"}
 for _ in range(5):
     bench.train_step(nef, tracer, opt, rays, gt, chans, 1)
 torch.cuda.synchronize()
