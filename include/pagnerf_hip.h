@@ -366,7 +366,8 @@ int pag_pad_packed(const int64_t *pack_start, int64_t N, int64_t capacity, int s
                    uint8_t *boundary, int64_t *pack_start_clamped, void *stream);
 
 /* pag_pack_offsets + pag_pad_packed + the copy of the ray directions (dirs_src f32 [N,3] -> dirs_dst, both may be NULL) as ONE
- * one-workgroup launch: the head of a graph-replayed step (pagnerf_amd/graphs.py).  Arguments as the two entry points';
+ * launch (16 workgroups: each repeats the scan for the total, the first writes the tables, all share the filler stores and the
+ * copy): the head of a graph-replayed step (pagnerf_amd/graphs.py).  Arguments as the two entry points';
  * pack_start_clamped is required.  The fillers lie behind the samples the pack pass writes, so it may be queued before that pass. (ABI 9) */
 int pag_pack_offsets_pad(const int32_t *counts, int64_t N, int64_t *pack_start, int64_t *total_host, int64_t capacity,
                          int samples_per_entry, float *samples, float *depths, float *deltas, int32_t *ridx_sample,
