@@ -20,4 +20,5 @@ for o in api encode render mlp assign loss optim; do
   if [ -n "${rebuilt[$o]}" ]; then objs="$objs $lib/obj/${o}_$tag.o"; else objs="$objs $lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/libpagnerf_hip_$tag.so $objs
+rm -f $lib/obj/*_$tag.o      # the snapshot that travels to the GPU box carries lib/: keep it small
 echo built $lib/libpagnerf_hip_$tag.so
