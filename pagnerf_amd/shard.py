@@ -113,14 +113,29 @@ def shard_rays(rays, rank=None, world=None):
     return rays[lo:hi]
 
 
-def all_gather_render(rb, n_total, channels=None):
+def _as_labels(rb, label_channels):
+    """rb with the channels named in label_channels replaced by their arg-max over the last dimension (int64 [rows])."""
+    if not label_channels:
+        return rb
+    vals = {c: getattr(rb, c) for c in rb.channels if isinstance(getattr(rb, c), torch.Tensor)}
+    for c in label_channels:
+        if c in vals and vals[c].dim() > 1:
+            vals[c] = vals[c].argmax(-1)
+    return RenderBuffer(**vals)
+
+
+def all_gather_render(rb, n_total, channels=None, label_channels=()):
     """Gather per-rank RenderBuffers (rows = this rank's ray block) into the full [n_total, .] buffers
-    on every rank with one all_gather.  Bool channels travel as floats."""
+    on every rank with one all_gather.  Bool channels travel as floats.
+    label_channels: channels of which only the arg-max is needed (the semantic / instance images of validate(): trainer.py:706-710 takes
+    `argmax` of both) travel as ONE column instead of C - with the 6 + 200 probability columns of the panoptic heads a ray's message
+    shrinks from 844 to 28 bytes.  They come back as int64 [n_total] labels; a single rank gets the same type."""
     rank, world = world_info()
+    rb = _as_labels(rb, label_channels)
     if _single():
         return rb
     names = sorted(channels or [c for c in rb.channels if isinstance(getattr(rb, c), torch.Tensor) and getattr(rb, c).dim() > 0])
-    cols = [getattr(rb, c).reshape(getattr(rb, c).shape[0], -1).float() for c in names]
+    cols = [getattr(rb, c).reshape(getattr(rb, c).shape[0], -1).float() for c in names]      # labels < 2^24: exact as floats
     widths = [c.shape[1] for c in cols]
     n_max = (n_total + world - 1) // world
     lo, hi = shard_bounds(n_total, rank, world)
@@ -136,6 +151,8 @@ def all_gather_render(rb, n_total, channels=None):
         src = getattr(rb, name)
         if src.dtype == torch.bool:
             t = t > 0.5
+        elif not src.dtype.is_floating_point:
+            t = t.round().to(src.dtype)
         res[name] = t.reshape(n_total, *src.shape[1:])
         off += w
     return RenderBuffer(**res)
@@ -230,9 +247,9 @@ class GradSync:
         self._hooks = []
 
 
-def render_sharded(pipeline, rays, channels, **kwargs):
-    """Every rank renders its block of `rays` and receives the full image buffers."""
+def render_sharded(pipeline, rays, channels, label_channels=(), **kwargs):
+    """Every rank renders its block of `rays` and receives the full image buffers (label_channels: see all_gather_render)."""
     n = rays.origins.shape[0]
     local = shard_rays(rays)
     rb = pipeline(rays=local, channels=channels, **kwargs)
-    return all_gather_render(rb, n, channels=None)
+    return all_gather_render(rb, n, channels=None, label_channels=label_channels)

@@ -43,6 +43,10 @@ def _worker(rank, world, port, n, q):
         ref = _fake_render(rays)
         for ch in ("rgb", "alpha", "hit", "inst_embedding"):
             assert torch.equal(getattr(full, ch), getattr(ref, ch)), ch          # bitwise: gather moves data only
+        # labels only: the instance channel travels as its arg-max (one column), everything else unchanged
+        lab = shard.all_gather_render(_fake_render(local), n, label_channels=("inst_embedding", "not_there"))
+        assert lab.inst_embedding.dtype == torch.int64 and torch.equal(lab.inst_embedding, ref.inst_embedding.argmax(-1))
+        assert torch.equal(lab.rgb, ref.rgb) and torch.equal(lab.hit, ref.hit)
         # gradient all-reduce: mean over ranks of rank-dependent grads
         p1, p2 = torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))
         p1.grad = torch.full((5, 3), float(rank + 1))
