@@ -127,7 +127,7 @@ def _as_labels(rb, label_channels):
 def all_gather_render(rb, n_total, channels=None, label_channels=()):
     """Gather per-rank RenderBuffers (rows = this rank's ray block) into the full [n_total, .] buffers
     on every rank with one all_gather.  Bool channels travel as floats.
-    label_channels: channels of which only the arg-max is needed (the semantic / instance images of validate(): trainer.py:706-710 takes
+    label_channels: channels of which only the arg-max is needed (the semantic / instance images of validate(): trainer.py:717 and :740 take
     `argmax` of both) travel as ONE column instead of C - with the 6 + 200 probability columns of the panoptic heads a ray's message
     shrinks from 844 to 28 bytes.  They come back as int64 [n_total] labels; a single rank gets the same type."""
     rank, world = world_info()
