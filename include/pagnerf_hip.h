@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 9
+#define PAG_ABI_VERSION 10
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -511,6 +511,32 @@ int pag_composite_feats_bwd(const int64_t *pack_start, const int32_t *ray_of_pac
 int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_stride, int col0, int C,
                    const int64_t *labels_gt, const uint8_t *row_mask, const int64_t *label_list, int K,
                    float *sums, int32_t *counts, void *stream);
+
+/* The same loss with ONE host synchronisation per step (ABI 10; loss/lin_assignment_things.py:23-82).
+ *
+ * pag_assign_cost (three launches):
+ *   labels i64 [max_rows]          the distinct positive gt ids of the image, ascending: `sorted(torch.unique(things_gt))[:max_rows]`
+ *                                  (:29); entries past info[0] hold a sentinel no ray carries.  max_rows <= 1024.
+ *   cost   f32 [max_rows, n_cols - col0]   row r = -(sum of prob[p, col0:] over the rays with gt == labels[r]) / (count + 1e-4)
+ *                                  (:31-33: fp32 sums in ray order, int64 count + python float -> fp32, fp32 division); rows past info[0] untouched
+ *   info   i32 [2]                 info[0] = number of labels, info[1] = 1 if the image carries more than 1024 distinct ids (take the
+ *                                  general path: pag_label_sums with an explicit list)
+ * so that ONE fixed-size device-to-host copy carries everything SciPy needs.  sums_ws f32 [max_rows, n_cols - col0] and counts_ws i32
+ * [max_rows] are scratch.
+ *
+ * pag_assign_nll_fwd: per ray  valid = stuff_mask | gt > 0 (:60; stuff_mask u8 [P] or NULL),
+ *   virt = gt > 0 ? (gt == labels[r] for some r < info[0] ? targets[r] : default_label) : 0   - targets i64 [max_rows] holds the assignment
+ *   (:47-53: assigned column + 1; default_label = 1 for ids that got none), arg-max of the ray's n_cols probabilities,
+ *   loss[ray] = -log(prob[ray, virt] + 1e-27) (:80) for valid rays when ANY valid ray of the image has virt != arg-max (:79), else 0;
+ *   wrong i32 [1] (zeroed by the caller) receives that flag, virt / valid are kept for the backward.
+ * pag_assign_nll_bwd: d_prob f32 [P, n_cols] (contiguous, every element written) from grad f32 [P]. */
+int pag_assign_cost(const float *prob, int64_t P, int64_t row_stride, int n_cols, int col0, const int64_t *labels_gt,
+                    int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels, float *cost, void *stream);
+int pag_assign_nll_fwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *labels_gt,
+                       const uint8_t *stuff_mask, const int64_t *labels, const int64_t *targets, const int32_t *info,
+                       int64_t default_label, int64_t *virt, float *loss, uint8_t *valid, int32_t *wrong, void *stream);
+int pag_assign_nll_bwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *virt,
+                       const uint8_t *valid, const int32_t *wrong, const float *grad, float *d_prob, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-ray training loss of the rendered buffers (pc_nerf/trainer.py:443-446 rgb, :459-465 semantics,

@@ -16,7 +16,7 @@ MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
 LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
 ENC_HALF_COORDS = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 MLP_FUSED_WIDE_MAX_M = 1 << 24      # PAG_MLP_FUSED_WIDE_MAX_M
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -114,6 +114,9 @@ _SIGS = {
     "pag_occupancy_coarse": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "pag_occupancy_update": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
     "pag_label_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "pag_assign_cost": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_assign_nll_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_assign_nll_bwd": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_render_loss_workspace_bytes": (c_i64, []),
     "pag_render_loss_fwd": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "pag_render_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),

@@ -56,7 +56,177 @@ __global__ __launch_bounds__(256) void label_sums_kernel(const T *__restrict__ v
     if (tid == 0) counts[k] = total;
 }
 
+// ---- the instance term of the late-training step with ONE host synchronisation (pag_assign_cost / pag_assign_nll_*; pagnerf_amd/loss.py) ----------------
+// loss/lin_assignment_things.py:23-54 asks the device three times per image before SciPy can run (the sorted unique gt ids, one masked sum per id) and
+// the loss that follows is a dozen small tensor ops forward and as many backward: ~0.9 ms on a 3.5 ms step, nearly all of it host latency.
+//
+// assign_unique_kernel (one workgroup): the distinct positive gt ids of the image through an LDS hash set (1024 slots, 64-bit compare-and-swap), sorted
+// ascending by a bitonic network -> labels[0 .. n) = the reference's `sorted(torch.unique(things_gt))[:max_rows]` (:29), the rest of labels[] a sentinel no
+// ray carries.  info[0] = n, info[1] = 1 when the image has more distinct ids than the set holds (the caller then takes the general path).
+constexpr int ASSIGN_SET = 1024;
+constexpr long long ASSIGN_NONE = -(1ll << 62);
+__global__ __launch_bounds__(1024) void assign_unique_kernel(const int64_t *__restrict__ labels_gt, int64_t P, int max_rows, int32_t *__restrict__ info,
+                                                             int64_t *__restrict__ labels) {
+    __shared__ unsigned long long set[ASSIGN_SET];      // 0 = empty (only ids > 0 are inserted)
+    __shared__ int32_t over, count;
+    const int tid = threadIdx.x;
+    set[tid] = 0ull;
+    if (tid == 0) over = 0, count = 0;
+    __syncthreads();
+    for (int64_t p = tid; p < P; p += 1024) {
+        const int64_t id = labels_gt[p];
+        if (id <= 0) continue;
+        const unsigned long long key = (unsigned long long)id;
+        unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 54);      // 10 bits
+        bool done = false;
+        for (int probe = 0; probe < ASSIGN_SET && !done; ++probe) {
+            const unsigned long long prev = atomicCAS(&set[h], 0ull, key);
+            done = prev == 0ull || prev == key;
+            h = (h + 1) & (ASSIGN_SET - 1);
+        }
+        if (!done) over = 1;                                               // set full: more than 1024 distinct ids
+    }
+    __syncthreads();
+    // empty slots sort to the end: +inf
+    unsigned long long v = set[tid] ? set[tid] : ~0ull;
+    if (set[tid]) atomicAdd(&count, 1);
+    __syncthreads();
+    set[tid] = v;
+    __syncthreads();
+    for (int k = 2; k <= ASSIGN_SET; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int partner = tid ^ j;
+            if (partner > tid) {
+                const unsigned long long a = set[tid], b = set[partner];
+                const bool up = (tid & k) == 0;
+                if ((a > b) == up) { set[tid] = b; set[partner] = a; }
+            }
+            __syncthreads();
+        }
+    const int n = count < max_rows ? count : max_rows;
+    if (tid < max_rows) labels[tid] = tid < n ? (int64_t)set[tid] : (int64_t)ASSIGN_NONE;
+    if (tid == 0) {
+        info[0] = n;
+        info[1] = over;
+    }
+}
+// cost[r, :] = -(sum / (count + 1e-4)) of labels[r] (:31-33: int64 count + python float -> fp32, fp32 division); rows past info[0] are left alone
+__global__ __launch_bounds__(256) void assign_cost_kernel(const float *__restrict__ sums, const int32_t *__restrict__ counts, int C, const int32_t *__restrict__ info,
+                                                          float *__restrict__ cost) {
+    const int r = blockIdx.x;
+    if (r >= info[0]) return;
+    const float den = __fadd_rn((float)counts[r], 1e-4f);
+    for (int c = threadIdx.x; c < C; c += 256) cost[(int64_t)r * C + c] = -__fdiv_rn(sums[(int64_t)r * C + c], den);
+}
+
+// One wave per ray: valid = stuff | gt > 0 (:60), virtual label = targets[r] for gt == labels[r] (the assignment's relabelling, :47-53; ids without a row
+// take `deflt`), else 0; first arg-max of the ray's probabilities (torch.argmax: lowest index of the maximum); nll = -log(p[virtual] + 1e-27) (:80);
+// *wrong |= valid && virtual != arg-max (:79).  assign_nll_finish_kernel then keeps nll where the image has a wrong ray.
+__global__ __launch_bounds__(256) void assign_nll_fwd_kernel(const float *__restrict__ prob, int64_t P, int64_t row_stride, int n_cols,
+                                                             const int64_t *__restrict__ labels_gt, const uint8_t *__restrict__ stuff,
+                                                             const int64_t *__restrict__ labels, const int64_t *__restrict__ targets, const int32_t *__restrict__ info,
+                                                             int64_t deflt, int64_t *__restrict__ virt, float *__restrict__ nll, uint8_t *__restrict__ valid,
+                                                             int32_t *__restrict__ wrong) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= P) return;
+    const int64_t gt = labels_gt[ray];
+    const bool things = gt > 0;
+    const bool ok = things || (stuff && stuff[ray] != 0);
+    int64_t v = 0;
+    if (things) {                                      // the assignment's relabelling: labels[] is sorted, ids it does not hold keep `deflt`
+        int lo = 0, hi = info[0];
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (labels[mid] < gt) lo = mid + 1; else hi = mid;
+        }
+        v = (lo < info[0] && labels[lo] == gt) ? targets[lo] : deflt;
+    }
+    const float *row = prob + ray * row_stride;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    bool any_nan = false;
+    for (int c = lane; c < n_cols; c += 64) {
+        const float x = row[c];
+        if (x != x) { if (!any_nan) { any_nan = true; arg = c; } }           // torch.argmax: NaN is the maximum, the first one wins
+        else if (!any_nan && x > best) { best = x; arg = c; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oa = __shfl_xor(arg, d);
+        const int on = __shfl_xor((int)any_nan, d);
+        const bool take = (on && !any_nan) || (on == (int)any_nan && ((!any_nan && (ob > best || (ob == best && oa < arg))) || (any_nan && oa < arg)));
+        if (take) { best = ob; arg = oa; any_nan = on != 0; }
+    }
+    if (lane == 0) {
+        virt[ray] = v;
+        valid[ray] = ok ? 1 : 0;
+        const float pv = (v >= 0 && v < n_cols) ? row[v] : 0.0f;
+        nll[ray] = -logf(__fadd_rn(pv, 1e-27f));
+        if (ok && v != (int64_t)arg) atomicOr(wrong, 1);
+    }
+}
+__global__ __launch_bounds__(256) void assign_nll_finish_kernel(float *__restrict__ nll, const uint8_t *__restrict__ valid, const int32_t *__restrict__ wrong, int64_t P) {
+    const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ray >= P) return;
+    if (!(valid[ray] && *wrong)) nll[ray] = 0.0f;
+}
+// d loss_ray / d prob[ray, :] : -g / (p + 1e-27) in the virtual label's column of the rays the finish pass kept, zero everywhere else (rows written whole)
+__global__ __launch_bounds__(256) void assign_nll_bwd_kernel(const float *__restrict__ prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *__restrict__ virt,
+                                                             const uint8_t *__restrict__ valid, const int32_t *__restrict__ wrong, const float *__restrict__ grad,
+                                                             float *__restrict__ d_prob) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= P) return;
+    const bool on = valid[ray] && *wrong;
+    const int64_t v = virt[ray];
+    const float g = on && v >= 0 && v < n_cols ? -__fdiv_rn(grad[ray], __fadd_rn(prob[ray * row_stride + v], 1e-27f)) : 0.0f;
+    for (int c = lane; c < n_cols; c += 64) d_prob[ray * n_cols + c] = (on && c == v) ? g : 0.0f;
+}
+
 }  // namespace
+
+extern "C" int pag_assign_cost(const float *prob, int64_t P, int64_t row_stride, int n_cols, int col0, const int64_t *labels_gt, int max_rows,
+                               float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels, float *cost, void *stream) {
+    PAG_CHECK_ARG(P >= 0, "pag_assign_cost: P < 0");
+    PAG_CHECK_ARG(col0 >= 0 && n_cols - col0 >= 1 && n_cols - col0 <= 1024 && row_stride >= n_cols, "pag_assign_cost: columns");
+    PAG_CHECK_ARG(max_rows >= 1 && max_rows <= 1024, "pag_assign_cost: max_rows %d not in [1,1024]", max_rows);
+    PAG_CHECK_ARG(sums_ws && counts_ws && info && labels && cost && (P == 0 || (prob && labels_gt)), "pag_assign_cost: NULL input/output");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = n_cols - col0;
+    hipLaunchKernelGGL(assign_unique_kernel, dim3(1), dim3(1024), 0, st, labels_gt, P, max_rows, info, labels);
+    hipLaunchKernelGGL(label_sums_kernel<float>, dim3(max_rows), dim3(256), 0, st, prob, P, row_stride, col0, C, labels_gt, (const uint8_t *)nullptr,
+                       (const int64_t *)labels, sums_ws, counts_ws);
+    hipLaunchKernelGGL(assign_cost_kernel, dim3(max_rows), dim3(256), 0, st, (const float *)sums_ws, (const int32_t *)counts_ws, C, (const int32_t *)info, cost);
+    PAG_CHECK_LAUNCH("pag_assign_cost");
+    return PAG_OK;
+}
+
+extern "C" int pag_assign_nll_fwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *labels_gt, const uint8_t *stuff_mask,
+                                  const int64_t *labels, const int64_t *targets, const int32_t *info, int64_t default_label, int64_t *virt, float *nll,
+                                  uint8_t *valid, int32_t *wrong, void *stream) {
+    PAG_CHECK_ARG(P >= 0 && n_cols >= 1 && row_stride >= n_cols, "pag_assign_nll_fwd: sizes");
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(prob && labels_gt && labels && targets && info && virt && nll && valid && wrong, "pag_assign_nll_fwd: NULL input/output");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(assign_nll_fwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, prob, P, row_stride, n_cols, labels_gt, stuff_mask, labels, targets, info,
+                       default_label, virt, nll, valid, wrong);
+    hipLaunchKernelGGL(assign_nll_finish_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, nll, (const uint8_t *)valid, (const int32_t *)wrong, P);
+    PAG_CHECK_LAUNCH("pag_assign_nll_fwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_assign_nll_bwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *virt, const uint8_t *valid, const int32_t *wrong,
+                                  const float *grad, float *d_prob, void *stream) {
+    PAG_CHECK_ARG(P >= 0 && n_cols >= 1 && row_stride >= n_cols, "pag_assign_nll_bwd: sizes");
+    if (P == 0) return PAG_OK;
+    PAG_CHECK_ARG(prob && virt && valid && wrong && grad && d_prob, "pag_assign_nll_bwd: NULL input/output");
+    hipLaunchKernelGGL(assign_nll_bwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, prob, P, row_stride, n_cols, virt, valid, wrong, grad,
+                       d_prob);
+    PAG_CHECK_LAUNCH("pag_assign_nll_bwd");
+    return PAG_OK;
+}
 
 extern "C" int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_stride, int col0, int C,
                               const int64_t *labels_gt, const uint8_t *row_mask, const int64_t *label_list, int K, float *sums,

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_regular_library_carries_no_instrumentation(lib):

@@ -62,6 +62,61 @@ def test_g5_virtual_labels_and_losses(gpu_device):
         assert torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
 
 
+def test_one_sync_assignment_path_equals_general_path(gpu_device):
+    """LinAssignmentThingsLoss: the one-synchronisation path (pag_assign_cost + _AssignNLL, ABI 10) against the general path (explicit label list, tensor ops) -
+    loss values and gradients on the golden batch and on random batches with stuff-only rays, invalid rays, an image without things, an image whose
+    prediction is already right (loss 0), and large arbitrary ids."""
+    from pagnerf_amd import loss as pl
+    dev = gpu_device
+    g = golden("g5_linassign.npz")
+    cases = [(torch.from_numpy(g["prob"]).to(dev), torch.from_numpy(g["gt"]).to(dev), torch.from_numpy(g["stuff"]).to(dev))]
+    gen = torch.Generator().manual_seed(5)
+    B, P, I = 3, 777, 40
+    prob = torch.softmax(torch.randn(B, P, I, generator=gen) * 3, -1)
+    gt = torch.randint(-1, 9, (B, P), generator=gen) * 3            # ids -3, 0, 3 .. 24
+    gt[1] = 0                                                        # an image without things
+    stuff = torch.rand(B, P, generator=gen) > 0.5
+    # image 2: the prediction already matches what the assignment will pick (every things ray puts its mass on one column per id)
+    ids = gt[2].clamp(min=0)
+    onehot = torch.full((P, I), 1e-3)
+    onehot[torch.arange(P), torch.where(ids > 0, ids // 3 + 4, torch.zeros_like(ids))] = 1.0
+    prob[2] = onehot / onehot.sum(-1, keepdim=True)
+    cases.append((prob.to(dev), gt.to(dev), stuff.to(dev)))
+    big = gt.clone()
+    big[0, :5] = 5000000000                                          # ids are arbitrary int64 values
+    cases.append((prob.to(dev), big.to(dev), stuff.to(dev)))
+    for n, (p, t, m) in enumerate(cases):
+        fast, slow = pl.LinAssignmentThingsLoss(), pl.LinAssignmentThingsLoss()
+        slow.fast_path = False
+        pf, ps = p.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        lf, ls = fast(pf, t, m), slow(ps, t, m)
+        assert lf.shape == ls.shape == p.shape[:2]
+        np.testing.assert_allclose(lf.detach().cpu().numpy(), ls.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(n))
+        assert np.array_equal((lf != 0).cpu().numpy(), (ls != 0).cpu().numpy())
+        w = torch.rand(lf.shape, device=dev)
+        (lf * w).sum().backward()
+        (ls * w).sum().backward()
+        np.testing.assert_allclose(pf.grad.cpu().numpy(), ps.grad.cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(n))
+        if n == 1:      # image 1 has no things: its stuff rays are trained towards column 0; image 2's prediction is already the assignment: no loss
+            assert float(lf[1].detach().abs().sum()) > 0 and float(lf[2].detach().abs().sum()) == 0 and float(lf[0].detach().abs().sum()) > 0
+    # the kernels' own outputs: labels, counts-derived cost and virtual labels against the general path's pieces
+    p, t, m = cases[0]
+    lo = pl.LinAssignmentThingsLoss()
+    for b in range(p.shape[0]):
+        vm = m[b] | (t[b] > 0)
+        gt_v = torch.where(vm, t[b], torch.zeros_like(t[b]))
+        labels = sorted(torch.unique(gt_v[gt_v > 0]).cpu().tolist())[:p.shape[2] - 1]
+        ref_cost = pl.cost_matrix(p[b], gt_v, labels, col0=1)
+        w = lo._workspace(1, p.shape[1], p.shape[2], dev)
+        from pagnerf_amd import _lib as L, ops
+        ops._call("pag_assign_cost", p[b].data_ptr(), p.shape[1], p.stride(1), p.shape[2], 1, t[b].contiguous().data_ptr(), p.shape[2] - 1,
+                  w["sums"][0].data_ptr(), w["counts"][0].data_ptr(), w["info"][0].data_ptr(), w["labels"][0].data_ptr(), w["cost"][0].data_ptr(), L.stream())
+        torch.cuda.synchronize()
+        n = int(w["info"][0, 0])
+        assert n == len(labels) and int(w["info"][0, 1]) == 0 and w["labels"][0, :n].cpu().tolist() == labels
+        assert np.array_equal(w["cost"][0, :n].cpu().numpy().astype(np.float64), ref_cost)
+
+
 def test_render_loss_matches_trainer_formulas(gpu_device):
     """pag_render_loss_fwd / _bwd against the reference trainer's arithmetic written as plain tensor ops in float64
     (pc_nerf/trainer.py:443-446 rgb L1; :459-465 semantics: nll 'none' / temperature * conf, mean over all rays;
