@@ -915,7 +915,7 @@ def run_rank(args):
             job.lin_assign = None
             la["labels_per_image"] = int((torch.unique(job.gt["inst_ids"]) > 0).sum())
             la["note"] = ("same step with the instance term of trainer.py:483-520 (per-image Hungarian relabelling + NLL); device_cost_matrix = "
-                          "pag_label_sums + one [K,199] copy + SciPy; reference_formulation = one masked sum and one device-to-host copy per label")
+                          "pagnerf_amd.loss.LinAssignmentThingsLoss: pag_assign_cost (ids, sums, cost rows on the device), ONE copy + synchronisation, SciPy, pag_assign_nll; reference_formulation = one masked sum and one device-to-host copy per label")
             line["with_lin_assignment"] = la
         job.close()
         del job
