@@ -981,6 +981,14 @@ def run_rank(args):
                                                  epochs_and_ms=[dict(epochs=w, ms_per_step=t) for w, t in parts],
                                                  note="epoch-weighted mean step of a best.yaml run (4096 rays per step): 200 epochs dense rgb-only, 400 post-prune "
                                                       "rgb-only, 200 post-prune all channels; synthetic occupancy %.0f %% after the prune" % (100 * args.occupancy))
+                # the trainer's own instance term (per-image Hungarian relabelling, trainer.py:483-520) is not in the step measured above: what it adds to a
+                # step was measured on the dense workload (with_lin_assignment); it is host latency around one synchronisation, the same at any sample count
+                la = line.get("with_lin_assignment", {}).get("device_cost_matrix")
+                if la:
+                    extra = max(0.0, la["ms_per_step"] - line["ms_per_step"])
+                    ms2 = sum(w * (t + (extra if k == 2 else 0.0)) for k, (w, t) in enumerate(parts)) / sum(w for w, _ in parts)
+                    line["schedule_weighted"]["with_assignment_term"] = dict(ms_per_step=round(ms2, 3), rays_s=round(args.rays / ms2 * 1e3, 1),
+                                                                             added_ms_in_the_last_200_epochs=round(extra, 3))
             except (StopIteration, KeyError):
                 pass
         if world == 1 and default_cfg:
