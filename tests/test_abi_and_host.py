@@ -30,6 +30,20 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.pag_abi_version() == _lib.ABI_VERSION == 10
 
 
+def test_assignment_entry_points_validate_without_gpu(lib):
+    """pag_assign_cost / pag_assign_nll_fwd / _bwd (ABI 10): empty batches are no-ops, bad sizes and NULL buffers are rejected before any launch."""
+    assert lib.pag_assign_nll_fwd(None, 0, 200, 200, None, None, None, None, None, 1, None, None, None, None, None) == 0
+    assert lib.pag_assign_nll_bwd(None, 0, 200, 200, None, None, None, None, None, None) == 0
+    assert lib.pag_assign_cost(None, 5, 200, 200, 1, None, 199, None, None, None, None, None, None) == -1          # NULL buffers
+    assert b"NULL" in lib.pag_last_error_string()
+    buf = (ctypes.c_float * 8)()
+    assert lib.pag_assign_cost(buf, 5, 100, 200, 1, buf, 199, buf, buf, buf, buf, buf, None) == -1                 # row_stride < n_cols
+    assert lib.pag_assign_cost(buf, 5, 200, 200, 1, buf, 2000, buf, buf, buf, buf, buf, None) == -1                # max_rows > 1024
+    assert b"max_rows" in lib.pag_last_error_string()
+    assert lib.pag_assign_nll_fwd(buf, 5, 100, 200, buf, None, buf, buf, buf, 1, buf, buf, buf, buf, None) == -1
+    assert lib.pag_assign_nll_bwd(buf, 5, 200, 200, buf, buf, buf, None, buf, None) == -1                          # NULL grad
+
+
 def test_regular_library_carries_no_instrumentation(lib):
     """The timing builds (-DPAG_REDUCE_TIMING / PAG_BIN_TIMING / PAG_BLOCK_TIMING: scripts/reduce_phases.py, bin_phases.py, block_timeline.py)
     export pag_debug_* readers; the library the product loads must not - nothing in it stamps clocks or writes debug tables."""
