@@ -51,17 +51,21 @@ def cost_matrix(prob, labels_gt, labels, col0=0):
     return cost.cpu().numpy().astype(np.float64)
 
 
-def id_range_cost(cost, centers_x, frame_min_length=0.3, max_num_inst_at_x=30, id_margin=30):
-    """utils/outlier_rejection.py:8-51: ids outside [lo(x), lo(x)+margin] of an instance's x position cost 10000.
-    cost float64 [K,num_ids] (modified in place), centers_x f32 tensor [K]."""
-    num_ids = cost.shape[1]
+def _id_range_allowed(centers_x, num_ids, frame_min_length=0.3, max_num_inst_at_x=30, id_margin=30):
+    """bool [K, num_ids] on centers_x's device: the ids inside [lo(x), lo(x) + margin] of each instance's x position (utils/outlier_rejection.py:8-51)."""
     slope = (max_num_inst_at_x + id_margin) / frame_min_length
     x_limit = (num_ids - id_margin) / slope
     x = (-centers_x + 1) / 2
     lo = torch.clamp(slope * (x % x_limit), 0, num_ids - 1).long()
     hi = torch.clamp(lo + id_margin, 0, num_ids - 1)
     ids = torch.arange(num_ids, device=centers_x.device)[None, :]
-    allowed = (lo[:, None] <= ids) & (ids <= hi[:, None])
+    return (lo[:, None] <= ids) & (ids <= hi[:, None])
+
+
+def id_range_cost(cost, centers_x, frame_min_length=0.3, max_num_inst_at_x=30, id_margin=30):
+    """utils/outlier_rejection.py:8-51: ids outside [lo(x), lo(x)+margin] of an instance's x position cost 10000.
+    cost float64 [K,num_ids] (modified in place), centers_x f32 tensor [K]."""
+    allowed = _id_range_allowed(centers_x, cost.shape[1], frame_min_length, max_num_inst_at_x, id_margin)
     cost[~allowed.cpu().numpy()] = 10000
     return cost
 
@@ -150,13 +154,15 @@ class LinAssignmentThingsLoss(nn.Module):
             f = dict(key=key,
                      sums=torch.empty(B, R, C, device=dev), counts=torch.empty(B, R, device=dev, dtype=torch.int32),
                      info=torch.zeros(B, 2, device=dev, dtype=torch.int32), labels=torch.zeros(B, R, device=dev, dtype=torch.int64),
-                     cost=torch.zeros(B, R, C, device=dev), targets=torch.ones(B, R, device=dev, dtype=torch.int64))
-            for name in ("info", "cost", "targets"):
+                     cost=torch.zeros(B, R, C, device=dev), targets=torch.ones(B, R, device=dev, dtype=torch.int64),
+                     psums=torch.zeros(B, R, 3, device=dev), pcounts=torch.zeros(B, R, device=dev, dtype=torch.int32),
+                     allowed=torch.ones(B, R, C, device=dev, dtype=torch.bool))
+            for name in ("info", "cost", "targets", "allowed"):
                 f["h_" + name] = torch.empty(f[name].shape, dtype=f[name].dtype).pin_memory()
             self._ws = f
         return self._ws
 
-    def _fast(self, prob, labels_gt, stuff_mask):
+    def _fast(self, prob, labels_gt, stuff_mask, points_3d=None):
         B, P, I = prob.shape
         w = self._workspace(B, P, I, prob.device)
         st = L.stream()
@@ -164,7 +170,18 @@ class LinAssignmentThingsLoss(nn.Module):
         for b in range(B):
             ops._call("pag_assign_cost", pd[b].data_ptr(), P, pd.stride(1), I, 1, labels_gt[b].data_ptr(), I - 1, w["sums"][b].data_ptr(),
                       w["counts"][b].data_ptr(), w["info"][b].data_ptr(), w["labels"][b].data_ptr(), w["cost"][b].data_ptr(), st)
-        for name in ("info", "cost"):
+        names = ("info", "cost")
+        if points_3d is not None:
+            # outlier rejection (:38-43): per-id centres from the same device-side label list (rows past info[0] hold a sentinel id: count 0, centre NaN,
+            # never read on the host), the id-range test with the general path's own tensor ops, its mask in the same copy as the cost
+            pts = points_3d.detach().float().contiguous()
+            for b in range(B):
+                ops._call("pag_label_sums", pts[b].data_ptr(), L.F32, P, 3, 0, 3, labels_gt[b].data_ptr(), None, w["labels"][b].data_ptr(), I - 1,
+                          w["psums"][b].data_ptr(), w["pcounts"][b].data_ptr(), st)
+            centres_x = w["psums"][:, :, 0] / w["pcounts"].float()
+            w["allowed"].copy_(_id_range_allowed(centres_x.reshape(-1), I - 1).reshape(B, I - 1, I - 1))
+            names = ("info", "cost", "allowed")
+        for name in names:
             w["h_" + name].copy_(w[name], non_blocking=True)
         torch.cuda.current_stream().synchronize()                      # the step's one wait for the device
         info = w["h_info"].numpy()
@@ -177,6 +194,8 @@ class LinAssignmentThingsLoss(nn.Module):
             if n == 0:
                 continue
             cost = w["h_cost"].numpy()[b, :n].astype(np.float64)
+            if points_3d is not None:
+                cost[~w["h_allowed"].numpy()[b, :n]] = 10000                                    # utils/outlier_rejection.py:8-51
             rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))              # :45
             tg[b, rows] = cols + 1
         w["targets"].copy_(w["h_targets"], non_blocking=True)
@@ -184,13 +203,17 @@ class LinAssignmentThingsLoss(nn.Module):
 
     def forward(self, inst_probabilities, labels_gt, stuff_mask, points_3d=None, *args, **kwargs):
         p3 = inst_probabilities
-        if (self.fast_path and not self.outlier_rejection and torch.is_tensor(p3) and p3.is_cuda and p3.dim() == 3 and p3.dtype == torch.float32
+        assert (self.outlier_rejection and points_3d is not None) or not self.outlier_rejection, "Outlier rejection requires 3d points"      # :36-37
+        if (self.fast_path and torch.is_tensor(p3) and p3.is_cuda and p3.dim() == 3 and p3.dtype == torch.float32
                 and p3.stride(2) == 1 and 2 <= p3.shape[2] <= 1025 and torch.is_tensor(labels_gt) and labels_gt.dtype == torch.int64
                 and labels_gt.shape == p3.shape[:2] and torch.is_tensor(stuff_mask) and stuff_mask.shape == p3.shape[:2]):
             gt_c = labels_gt.contiguous()
             sm_c = stuff_mask.contiguous()
             sm_c = sm_c.view(torch.uint8) if sm_c.dtype == torch.bool else sm_c.to(torch.uint8)
-            out = self._fast(p3, gt_c, sm_c)
+            pts = None
+            if self.outlier_rejection:
+                pts = points_3d if torch.is_tensor(points_3d) else torch.stack(list(points_3d))
+            out = self._fast(p3, gt_c, sm_c, pts)
             if out is not None:
                 return out
         loss = []

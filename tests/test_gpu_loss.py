@@ -99,6 +99,20 @@ def test_one_sync_assignment_path_equals_general_path(gpu_device):
         np.testing.assert_allclose(pf.grad.cpu().numpy(), ps.grad.cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(n))
         if n == 1:      # image 1 has no things: its stuff rays are trained towards column 0; image 2's prediction is already the assignment: no loss
             assert float(lf[1].detach().abs().sum()) > 0 and float(lf[2].detach().abs().sum()) == 0 and float(lf[0].detach().abs().sum()) > 0
+    # with outlier rejection (best.yaml:106 `inst_outlier_rejection: true`): the id-range mask travels in the same copy as the cost
+    p, t, m = cases[0]
+    pts = torch.from_numpy(g["points_3d"]).to(dev)
+    fast, slow = pl.LinAssignmentThingsLoss(outlier_rejection=True), pl.LinAssignmentThingsLoss(outlier_rejection=True)
+    slow.fast_path = False
+    pf, ps = p.clone().requires_grad_(True), p.clone().requires_grad_(True)
+    lf, ls = fast(pf, t, m, pts), slow(ps, t, m, pts)
+    np.testing.assert_allclose(lf.detach().cpu().numpy(), ls.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(lf.detach().cpu().numpy(), g["loss_things_rej"], rtol=1e-5, atol=1e-6)
+    lf.sum().backward()
+    ls.sum().backward()
+    np.testing.assert_allclose(pf.grad.cpu().numpy(), ps.grad.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    with pytest.raises(AssertionError):
+        fast(p, t, m)                                                 # :36-37: outlier rejection requires the 3-D points
     # the kernels' own outputs: labels, counts-derived cost and virtual labels against the general path's pieces
     p, t, m = cases[0]
     lo = pl.LinAssignmentThingsLoss()
