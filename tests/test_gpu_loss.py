@@ -99,6 +99,15 @@ def test_one_sync_assignment_path_equals_general_path(gpu_device):
         np.testing.assert_allclose(pf.grad.cpu().numpy(), ps.grad.cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(n))
         if n == 1:      # image 1 has no things: its stuff rays are trained towards column 0; image 2's prediction is already the assignment: no loss
             assert float(lf[1].detach().abs().sum()) > 0 and float(lf[2].detach().abs().sum()) == 0 and float(lf[0].detach().abs().sum()) > 0
+    # more distinct ids than the device-side set holds (1024): pag_assign_cost reports it and the module takes the general path by itself
+    P2, I2 = 3000, 12
+    many = (torch.arange(P2) % 1500 + 1)[None].to(dev)
+    pm = torch.softmax(torch.randn(1, P2, I2, generator=gen), -1).to(dev)
+    sm = torch.zeros(1, P2, dtype=torch.bool, device=dev)
+    fast, slow = pl.LinAssignmentThingsLoss(), pl.LinAssignmentThingsLoss()
+    slow.fast_path = False
+    assert fast._fast(pm, many, sm.view(torch.uint8)) is None
+    assert torch.equal(fast(pm, many, sm), slow(pm, many, sm))
     # with outlier rejection (best.yaml:106 `inst_outlier_rejection: true`): the id-range mask travels in the same copy as the cost
     p, t, m = cases[0]
     pts = torch.from_numpy(g["points_3d"]).to(dev)
