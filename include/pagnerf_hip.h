@@ -514,6 +514,11 @@ int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_s
 
 /* The same loss with ONE host synchronisation per step (ABI 10; loss/lin_assignment_things.py:23-82).
  *
+ * All three take a BATCH of B images in one set of launches (the reference loops over the images of a step, :58): prob is
+ * [B][P] rows of n_cols floats with element strides image_stride / row_stride, every other array is contiguous with the image as its
+ * leading dimension (labels_gt [B,P], stuff_mask [B,P], info [B,2], labels / targets [B,max_rows], cost [B,max_rows,n_cols-col0],
+ * sums_ws [B,max_rows,n_cols-col0], counts_ws [B,max_rows], virt / loss / valid / grad [B,P], wrong [B], d_prob [B,P,n_cols]).
+ * Per image:
  * pag_assign_cost (three launches):
  *   labels i64 [max_rows]          the distinct positive gt ids of the image, ascending: `sorted(torch.unique(things_gt))[:max_rows]`
  *                                  (:29); entries past info[0] hold a sentinel no ray carries.  max_rows <= 1024.
@@ -530,13 +535,16 @@ int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_s
  *   loss[ray] = -log(prob[ray, virt] + 1e-27) (:80) for valid rays when ANY valid ray of the image has virt != arg-max (:79), else 0;
  *   wrong i32 [1] (zeroed by the caller) receives that flag, virt / valid are kept for the backward.
  * pag_assign_nll_bwd: d_prob f32 [P, n_cols] (contiguous, every element written) from grad f32 [P]. */
-int pag_assign_cost(const float *prob, int64_t P, int64_t row_stride, int n_cols, int col0, const int64_t *labels_gt,
-                    int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels, float *cost, void *stream);
-int pag_assign_nll_fwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *labels_gt,
-                       const uint8_t *stuff_mask, const int64_t *labels, const int64_t *targets, const int32_t *info,
-                       int64_t default_label, int64_t *virt, float *loss, uint8_t *valid, int32_t *wrong, void *stream);
-int pag_assign_nll_bwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *virt,
-                       const uint8_t *valid, const int32_t *wrong, const float *grad, float *d_prob, void *stream);
+int pag_assign_cost(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, int col0,
+                    const int64_t *labels_gt, int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels,
+                    float *cost, void *stream);
+int pag_assign_nll_fwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols,
+                       const int64_t *labels_gt, const uint8_t *stuff_mask, const int64_t *labels, const int64_t *targets,
+                       const int32_t *info, int max_rows, int64_t default_label, int64_t *virt, float *loss, uint8_t *valid,
+                       int32_t *wrong, void *stream);
+int pag_assign_nll_bwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols,
+                       const int64_t *virt, const uint8_t *valid, const int32_t *wrong, const float *grad, float *d_prob,
+                       void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-ray training loss of the rendered buffers (pc_nerf/trainer.py:443-446 rgb, :459-465 semantics,

@@ -15,10 +15,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void label_sums_kernel(const T *__restrict__ values, int64_t P, int64_t row_stride, int col0, int C,
                                                          const int64_t *__restrict__ labels_gt, const uint8_t *__restrict__ row_mask,
                                                          const int64_t *__restrict__ label_list, float *__restrict__ sums,
-                                                         int32_t *__restrict__ counts) {
+                                                         int32_t *__restrict__ counts, int64_t image_stride = 0) {
     __shared__ int32_t rows[256];
     __shared__ int32_t wave_n[4];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // blockIdx.y = image of a batch (pag_assign_cost): values advance by image_stride elements, every other array is [B, ...] contiguous
+        const int64_t b = blockIdx.y, K = gridDim.x;
+        values += b * image_stride;
+        labels_gt += b * P;
+        label_list += b * K;
+        sums += b * K * C;
+        counts += b * K;
+    }
     const int64_t mine = label_list[k];
     const int ncol = (C + 255) / 256;          // columns per lane (C <= 1024)
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -70,6 +78,9 @@ __global__ __launch_bounds__(1024) void assign_unique_kernel(const int64_t *__re
     __shared__ unsigned long long set[ASSIGN_SET];      // 0 = empty (only ids > 0 are inserted)
     __shared__ int32_t over, count;
     const int tid = threadIdx.x;
+    labels_gt += (int64_t)blockIdx.x * P;               // one workgroup per image
+    info += (int64_t)blockIdx.x * 2;
+    labels += (int64_t)blockIdx.x * max_rows;
     set[tid] = 0ull;
     if (tid == 0) over = 0, count = 0;
     __syncthreads();
@@ -114,9 +125,10 @@ __global__ __launch_bounds__(1024) void assign_unique_kernel(const int64_t *__re
 __global__ __launch_bounds__(256) void assign_cost_kernel(const float *__restrict__ sums, const int32_t *__restrict__ counts, int C, const int32_t *__restrict__ info,
                                                           float *__restrict__ cost) {
     const int r = blockIdx.x;
-    if (r >= info[0]) return;
-    const float den = __fadd_rn((float)counts[r], 1e-4f);
-    for (int c = threadIdx.x; c < C; c += 256) cost[(int64_t)r * C + c] = -__fdiv_rn(sums[(int64_t)r * C + c], den);
+    const int64_t b = blockIdx.y, R = gridDim.x;
+    if (r >= info[b * 2]) return;
+    const float den = __fadd_rn((float)counts[b * R + r], 1e-4f);
+    for (int c = threadIdx.x; c < C; c += 256) cost[(b * R + r) * C + c] = -__fdiv_rn(sums[(b * R + r) * C + c], den);
 }
 
 // One wave per ray: valid = stuff | gt > 0 (:60), virtual label = targets[r] for gt == labels[r] (the assignment's relabelling, :47-53; ids without a row
@@ -126,10 +138,23 @@ __global__ __launch_bounds__(256) void assign_nll_fwd_kernel(const float *__rest
                                                              const int64_t *__restrict__ labels_gt, const uint8_t *__restrict__ stuff,
                                                              const int64_t *__restrict__ labels, const int64_t *__restrict__ targets, const int32_t *__restrict__ info,
                                                              int64_t deflt, int64_t *__restrict__ virt, float *__restrict__ nll, uint8_t *__restrict__ valid,
-                                                             int32_t *__restrict__ wrong) {
+                                                             int32_t *__restrict__ wrong, int64_t image_stride, int max_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= P) return;
+    {   // blockIdx.y = image
+        const int64_t b = blockIdx.y;
+        prob += b * image_stride;
+        labels_gt += b * P;
+        if (stuff) stuff += b * P;
+        labels += b * max_rows;
+        targets += b * max_rows;
+        info += b * 2;
+        virt += b * P;
+        nll += b * P;
+        valid += b * P;
+        wrong += b;
+    }
     const int64_t gt = labels_gt[ray];
     const bool things = gt > 0;
     const bool ok = things || (stuff && stuff[ray] != 0);
@@ -170,15 +195,25 @@ __global__ __launch_bounds__(256) void assign_nll_fwd_kernel(const float *__rest
 __global__ __launch_bounds__(256) void assign_nll_finish_kernel(float *__restrict__ nll, const uint8_t *__restrict__ valid, const int32_t *__restrict__ wrong, int64_t P) {
     const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (ray >= P) return;
-    if (!(valid[ray] && *wrong)) nll[ray] = 0.0f;
+    const int64_t b = blockIdx.y;
+    if (!(valid[b * P + ray] && wrong[b])) nll[b * P + ray] = 0.0f;
 }
 // d loss_ray / d prob[ray, :] : -g / (p + 1e-27) in the virtual label's column of the rays the finish pass kept, zero everywhere else (rows written whole)
 __global__ __launch_bounds__(256) void assign_nll_bwd_kernel(const float *__restrict__ prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *__restrict__ virt,
                                                              const uint8_t *__restrict__ valid, const int32_t *__restrict__ wrong, const float *__restrict__ grad,
-                                                             float *__restrict__ d_prob) {
+                                                             float *__restrict__ d_prob, int64_t image_stride) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= P) return;
+    {   // blockIdx.y = image
+        const int64_t b = blockIdx.y;
+        prob += b * image_stride;
+        virt += b * P;
+        valid += b * P;
+        wrong += b;
+        grad += b * P;
+        d_prob += b * P * n_cols;
+    }
     const bool on = valid[ray] && *wrong;
     const int64_t v = virt[ray];
     const float g = on && v >= 0 && v < n_cols ? -__fdiv_rn(grad[ray], __fadd_rn(prob[ray * row_stride + v], 1e-27f)) : 0.0f;
@@ -187,43 +222,44 @@ __global__ __launch_bounds__(256) void assign_nll_bwd_kernel(const float *__rest
 
 }  // namespace
 
-extern "C" int pag_assign_cost(const float *prob, int64_t P, int64_t row_stride, int n_cols, int col0, const int64_t *labels_gt, int max_rows,
-                               float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels, float *cost, void *stream) {
-    PAG_CHECK_ARG(P >= 0, "pag_assign_cost: P < 0");
+extern "C" int pag_assign_cost(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, int col0, const int64_t *labels_gt,
+                               int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels, float *cost, void *stream) {
+    PAG_CHECK_ARG(P >= 0 && B >= 0 && B <= 65535, "pag_assign_cost: P < 0 or B not in [0,65535]");
     PAG_CHECK_ARG(col0 >= 0 && n_cols - col0 >= 1 && n_cols - col0 <= 1024 && row_stride >= n_cols, "pag_assign_cost: columns");
     PAG_CHECK_ARG(max_rows >= 1 && max_rows <= 1024, "pag_assign_cost: max_rows %d not in [1,1024]", max_rows);
+    if (B == 0) return PAG_OK;
     PAG_CHECK_ARG(sums_ws && counts_ws && info && labels && cost && (P == 0 || (prob && labels_gt)), "pag_assign_cost: NULL input/output");
     hipStream_t st = (hipStream_t)stream;
     const int C = n_cols - col0;
-    hipLaunchKernelGGL(assign_unique_kernel, dim3(1), dim3(1024), 0, st, labels_gt, P, max_rows, info, labels);
-    hipLaunchKernelGGL(label_sums_kernel<float>, dim3(max_rows), dim3(256), 0, st, prob, P, row_stride, col0, C, labels_gt, (const uint8_t *)nullptr,
-                       (const int64_t *)labels, sums_ws, counts_ws);
-    hipLaunchKernelGGL(assign_cost_kernel, dim3(max_rows), dim3(256), 0, st, (const float *)sums_ws, (const int32_t *)counts_ws, C, (const int32_t *)info, cost);
+    hipLaunchKernelGGL(assign_unique_kernel, dim3(B), dim3(1024), 0, st, labels_gt, P, max_rows, info, labels);
+    hipLaunchKernelGGL(label_sums_kernel<float>, dim3(max_rows, B), dim3(256), 0, st, prob, P, row_stride, col0, C, labels_gt, (const uint8_t *)nullptr,
+                       (const int64_t *)labels, sums_ws, counts_ws, image_stride);
+    hipLaunchKernelGGL(assign_cost_kernel, dim3(max_rows, B), dim3(256), 0, st, (const float *)sums_ws, (const int32_t *)counts_ws, C, (const int32_t *)info, cost);
     PAG_CHECK_LAUNCH("pag_assign_cost");
     return PAG_OK;
 }
 
-extern "C" int pag_assign_nll_fwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *labels_gt, const uint8_t *stuff_mask,
-                                  const int64_t *labels, const int64_t *targets, const int32_t *info, int64_t default_label, int64_t *virt, float *nll,
-                                  uint8_t *valid, int32_t *wrong, void *stream) {
-    PAG_CHECK_ARG(P >= 0 && n_cols >= 1 && row_stride >= n_cols, "pag_assign_nll_fwd: sizes");
-    if (P == 0) return PAG_OK;
+extern "C" int pag_assign_nll_fwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, const int64_t *labels_gt,
+                                  const uint8_t *stuff_mask, const int64_t *labels, const int64_t *targets, const int32_t *info, int max_rows, int64_t default_label,
+                                  int64_t *virt, float *nll, uint8_t *valid, int32_t *wrong, void *stream) {
+    PAG_CHECK_ARG(P >= 0 && B >= 0 && B <= 65535 && n_cols >= 1 && row_stride >= n_cols && max_rows >= 1, "pag_assign_nll_fwd: sizes");
+    if (P == 0 || B == 0) return PAG_OK;
     PAG_CHECK_ARG(prob && labels_gt && labels && targets && info && virt && nll && valid && wrong, "pag_assign_nll_fwd: NULL input/output");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(assign_nll_fwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, prob, P, row_stride, n_cols, labels_gt, stuff_mask, labels, targets, info,
-                       default_label, virt, nll, valid, wrong);
-    hipLaunchKernelGGL(assign_nll_finish_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, nll, (const uint8_t *)valid, (const int32_t *)wrong, P);
+    hipLaunchKernelGGL(assign_nll_fwd_kernel, dim3((unsigned)((P + 3) / 4), B), dim3(256), 0, st, prob, P, row_stride, n_cols, labels_gt, stuff_mask, labels, targets, info,
+                       default_label, virt, nll, valid, wrong, image_stride, max_rows);
+    hipLaunchKernelGGL(assign_nll_finish_kernel, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, st, nll, (const uint8_t *)valid, (const int32_t *)wrong, P);
     PAG_CHECK_LAUNCH("pag_assign_nll_fwd");
     return PAG_OK;
 }
 
-extern "C" int pag_assign_nll_bwd(const float *prob, int64_t P, int64_t row_stride, int n_cols, const int64_t *virt, const uint8_t *valid, const int32_t *wrong,
-                                  const float *grad, float *d_prob, void *stream) {
-    PAG_CHECK_ARG(P >= 0 && n_cols >= 1 && row_stride >= n_cols, "pag_assign_nll_bwd: sizes");
-    if (P == 0) return PAG_OK;
+extern "C" int pag_assign_nll_bwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, const int64_t *virt, const uint8_t *valid,
+                                  const int32_t *wrong, const float *grad, float *d_prob, void *stream) {
+    PAG_CHECK_ARG(P >= 0 && B >= 0 && B <= 65535 && n_cols >= 1 && row_stride >= n_cols, "pag_assign_nll_bwd: sizes");
+    if (P == 0 || B == 0) return PAG_OK;
     PAG_CHECK_ARG(prob && virt && valid && wrong && grad && d_prob, "pag_assign_nll_bwd: NULL input/output");
-    hipLaunchKernelGGL(assign_nll_bwd_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, prob, P, row_stride, n_cols, virt, valid, wrong, grad,
-                       d_prob);
+    hipLaunchKernelGGL(assign_nll_bwd_kernel, dim3((unsigned)((P + 3) / 4), B), dim3(256), 0, (hipStream_t)stream, prob, P, row_stride, n_cols, virt, valid, wrong, grad,
+                       d_prob, image_stride);
     PAG_CHECK_LAUNCH("pag_assign_nll_bwd");
     return PAG_OK;
 }

@@ -93,11 +93,9 @@ class _AssignNLL(torch.autograd.Function):
         valid = torch.empty(B, P, device=dev, dtype=torch.uint8)
         loss = torch.empty(B, P, device=dev)
         wrong = torch.zeros(B, device=dev, dtype=torch.int32)
-        st = L.stream()
-        for b in range(B):
-            ops._call("pag_assign_nll_fwd", prob[b].data_ptr(), P, prob.stride(1), I, labels_gt[b].data_ptr(),
-                      stuff_mask[b].data_ptr() if stuff_mask is not None else None, labels[b].data_ptr(), targets[b].data_ptr(), info[b].data_ptr(), 1,
-                      virt[b].data_ptr(), loss[b].data_ptr(), valid[b].data_ptr(), wrong[b:b + 1].data_ptr(), st)
+        ops._call("pag_assign_nll_fwd", prob.data_ptr(), B, P, prob.stride(0), prob.stride(1), I, labels_gt.data_ptr(),
+                  stuff_mask.data_ptr() if stuff_mask is not None else None, labels.data_ptr(), targets.data_ptr(), info.data_ptr(), labels.shape[1], 1,
+                  virt.data_ptr(), loss.data_ptr(), valid.data_ptr(), wrong.data_ptr(), L.stream())
         ctx.save_for_backward(prob, virt, valid, wrong)
         return loss
 
@@ -107,10 +105,8 @@ class _AssignNLL(torch.autograd.Function):
         B, P, I = prob.shape
         g = g.contiguous().float()
         d = torch.empty(B, P, I, device=prob.device)
-        st = L.stream()
-        for b in range(B):
-            ops._call("pag_assign_nll_bwd", prob[b].data_ptr(), P, prob.stride(1), I, virt[b].data_ptr(), valid[b].data_ptr(), wrong[b:b + 1].data_ptr(),
-                      g[b].data_ptr(), d[b].data_ptr(), st)
+        ops._call("pag_assign_nll_bwd", prob.data_ptr(), B, P, prob.stride(0), prob.stride(1), I, virt.data_ptr(), valid.data_ptr(), wrong.data_ptr(), g.data_ptr(),
+                  d.data_ptr(), L.stream())
         return d, None, None, None, None, None
 
 
@@ -167,9 +163,8 @@ class LinAssignmentThingsLoss(nn.Module):
         w = self._workspace(B, P, I, prob.device)
         st = L.stream()
         pd = prob.detach()
-        for b in range(B):
-            ops._call("pag_assign_cost", pd[b].data_ptr(), P, pd.stride(1), I, 1, labels_gt[b].data_ptr(), I - 1, w["sums"][b].data_ptr(),
-                      w["counts"][b].data_ptr(), w["info"][b].data_ptr(), w["labels"][b].data_ptr(), w["cost"][b].data_ptr(), st)
+        ops._call("pag_assign_cost", pd.data_ptr(), B, P, pd.stride(0), pd.stride(1), I, 1, labels_gt.data_ptr(), I - 1, w["sums"].data_ptr(), w["counts"].data_ptr(),
+                  w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), st)          # every image of the step in one set of launches
         names = ("info", "cost")
         if points_3d is not None:
             # outlier rejection (:38-43): per-id centres from the same device-side label list (rows past info[0] hold a sentinel id: count 0, centre NaN,

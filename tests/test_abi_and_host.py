@@ -32,16 +32,17 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_assignment_entry_points_validate_without_gpu(lib):
     """pag_assign_cost / pag_assign_nll_fwd / _bwd (ABI 10): empty batches are no-ops, bad sizes and NULL buffers are rejected before any launch."""
-    assert lib.pag_assign_nll_fwd(None, 0, 200, 200, None, None, None, None, None, 1, None, None, None, None, None) == 0
-    assert lib.pag_assign_nll_bwd(None, 0, 200, 200, None, None, None, None, None, None) == 0
-    assert lib.pag_assign_cost(None, 5, 200, 200, 1, None, 199, None, None, None, None, None, None) == -1          # NULL buffers
+    assert lib.pag_assign_nll_fwd(None, 1, 0, 0, 200, 200, None, None, None, None, None, 199, 1, None, None, None, None, None) == 0
+    assert lib.pag_assign_nll_bwd(None, 0, 5, 0, 200, 200, None, None, None, None, None, None) == 0
+    assert lib.pag_assign_cost(None, 0, 5, 0, 200, 200, 1, None, 199, None, None, None, None, None, None) == 0               # no image: nothing to do
+    assert lib.pag_assign_cost(None, 1, 5, 0, 200, 200, 1, None, 199, None, None, None, None, None, None) == -1              # NULL buffers
     assert b"NULL" in lib.pag_last_error_string()
     buf = (ctypes.c_float * 8)()
-    assert lib.pag_assign_cost(buf, 5, 100, 200, 1, buf, 199, buf, buf, buf, buf, buf, None) == -1                 # row_stride < n_cols
-    assert lib.pag_assign_cost(buf, 5, 200, 200, 1, buf, 2000, buf, buf, buf, buf, buf, None) == -1                # max_rows > 1024
+    assert lib.pag_assign_cost(buf, 1, 5, 0, 100, 200, 1, buf, 199, buf, buf, buf, buf, buf, None) == -1                     # row_stride < n_cols
+    assert lib.pag_assign_cost(buf, 1, 5, 0, 200, 200, 1, buf, 2000, buf, buf, buf, buf, buf, None) == -1                    # max_rows > 1024
     assert b"max_rows" in lib.pag_last_error_string()
-    assert lib.pag_assign_nll_fwd(buf, 5, 100, 200, buf, None, buf, buf, buf, 1, buf, buf, buf, buf, None) == -1
-    assert lib.pag_assign_nll_bwd(buf, 5, 200, 200, buf, buf, buf, None, buf, None) == -1                          # NULL grad
+    assert lib.pag_assign_nll_fwd(buf, 1, 5, 0, 100, 200, buf, None, buf, buf, buf, 199, 1, buf, buf, buf, buf, None) == -1
+    assert lib.pag_assign_nll_bwd(buf, 1, 5, 0, 200, 200, buf, buf, buf, None, buf, None) == -1                              # NULL grad
 
 
 def test_regular_library_carries_no_instrumentation(lib):
