@@ -529,6 +529,11 @@ int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_s
  * so that ONE fixed-size device-to-host copy carries everything SciPy needs.  sums_ws f32 [max_rows, n_cols - col0] and counts_ws i32
  * [max_rows] are scratch.
  *
+ *   points f32 [B,P,3] or NULL (outlier rejection, :38-43 + utils/outlier_rejection.py:8-51,56-71): the per-id centres of the same labels and
+ *                                  id_lo_hi i32 [B,max_rows,2] = the id range [lo, hi] each may take (id_slope = (max_num_inst_at_x + id_margin) /
+ *                                  frame_min_length and id_x_limit = (n_ids - id_margin) / id_slope as fp32, n_ids = n_cols - col0); every id outside
+ *                                  costs 10000 - applied by the caller on the host.  psums_ws f32 [B,max_rows,3], pcounts_ws i32 [B,max_rows]: scratch.
+ *
  * pag_assign_nll_fwd: per ray  valid = stuff_mask | gt > 0 (:60; stuff_mask u8 [P] or NULL),
  *   virt = gt > 0 ? (gt == labels[r] for some r < info[0] ? targets[r] : default_label) : 0   - targets i64 [max_rows] holds the assignment
  *   (:47-53: assigned column + 1; default_label = 1 for ids that got none), arg-max of the ray's n_cols probabilities,
@@ -537,7 +542,8 @@ int pag_label_sums(const void *values, int value_dtype, int64_t P, int64_t row_s
  * pag_assign_nll_bwd: d_prob f32 [P, n_cols] (contiguous, every element written) from grad f32 [P]. */
 int pag_assign_cost(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, int col0,
                     const int64_t *labels_gt, int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels,
-                    float *cost, void *stream);
+                    float *cost, const float *points, float id_slope, float id_x_limit, int id_margin, float *psums_ws,
+                    int32_t *pcounts_ws, int32_t *id_lo_hi, void *stream);
 int pag_assign_nll_fwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols,
                        const int64_t *labels_gt, const uint8_t *stuff_mask, const int64_t *labels, const int64_t *targets,
                        const int32_t *info, int max_rows, int64_t default_label, int64_t *virt, float *loss, uint8_t *valid,

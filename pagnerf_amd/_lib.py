@@ -114,7 +114,8 @@ _SIGS = {
     "pag_occupancy_coarse": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "pag_occupancy_update": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
     "pag_label_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
-    "pag_assign_cost": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_assign_cost": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_i32,
+                                c_vp, c_vp, c_vp, c_vp]),
     "pag_assign_nll_fwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_assign_nll_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_render_loss_workspace_bytes": (c_i64, []),

@@ -131,6 +131,26 @@ __global__ __launch_bounds__(256) void assign_cost_kernel(const float *__restric
     for (int c = threadIdx.x; c < C; c += 256) cost[(b * R + r) * C + c] = -__fdiv_rn(sums[(b * R + r) * C + c], den);
 }
 
+// Outlier rejection (utils/outlier_rejection.py:8-51 on the per-id centres of :56-71): the range [lo, hi] of ids an instance at centre x may take, with the
+// tensor ops' own fp32 arithmetic - centre = sum_x / count, x = (-centre + 1) / 2, lo = (int64) clamp(slope * remainder(x, x_limit), 0, n_ids - 1) (torch's
+// remainder: fmod, moved by the divisor when the signs differ), hi = clamp(lo + margin, 0, n_ids - 1).  One workgroup per image, a lane per label.
+__global__ __launch_bounds__(256) void assign_id_range_kernel(const float *__restrict__ psums, const int32_t *__restrict__ pcounts, int R, float slope, float x_limit,
+                                                              int id_margin, int n_ids, int32_t *__restrict__ lo_hi) {
+    const int64_t b = blockIdx.x;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float centre = __fdiv_rn(psums[(b * R + r) * 3], (float)pcounts[b * R + r]);
+        const float x = __fdiv_rn(__fadd_rn(-centre, 1.0f), 2.0f);
+        float m = fmodf(x, x_limit);
+        if (m != 0.0f && ((x_limit < 0.0f) != (m < 0.0f))) m = __fadd_rn(m, x_limit);
+        const float v = fminf(fmaxf(__fmul_rn(slope, m), 0.0f), (float)(n_ids - 1));
+        const long long lo = (long long)v;                                      // rows without rays: NaN centre, never read by the caller
+        long long hi = lo + id_margin;
+        hi = hi < 0 ? 0 : (hi > n_ids - 1 ? n_ids - 1 : hi);
+        lo_hi[(b * R + r) * 2] = (int32_t)lo;
+        lo_hi[(b * R + r) * 2 + 1] = (int32_t)hi;
+    }
+}
+
 // One wave per ray: valid = stuff | gt > 0 (:60), virtual label = targets[r] for gt == labels[r] (the assignment's relabelling, :47-53; ids without a row
 // take `deflt`), else 0; first arg-max of the ray's probabilities (torch.argmax: lowest index of the maximum); nll = -log(p[virtual] + 1e-27) (:80);
 // *wrong |= valid && virtual != arg-max (:79).  assign_nll_finish_kernel then keeps nll where the image has a wrong ray.
@@ -223,7 +243,8 @@ __global__ __launch_bounds__(256) void assign_nll_bwd_kernel(const float *__rest
 }  // namespace
 
 extern "C" int pag_assign_cost(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, int col0, const int64_t *labels_gt,
-                               int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels, float *cost, void *stream) {
+                               int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels, float *cost, const float *points, float id_slope,
+                               float id_x_limit, int id_margin, float *psums_ws, int32_t *pcounts_ws, int32_t *id_lo_hi, void *stream) {
     PAG_CHECK_ARG(P >= 0 && B >= 0 && B <= 65535, "pag_assign_cost: P < 0 or B not in [0,65535]");
     PAG_CHECK_ARG(col0 >= 0 && n_cols - col0 >= 1 && n_cols - col0 <= 1024 && row_stride >= n_cols, "pag_assign_cost: columns");
     PAG_CHECK_ARG(max_rows >= 1 && max_rows <= 1024, "pag_assign_cost: max_rows %d not in [1,1024]", max_rows);
@@ -235,6 +256,13 @@ extern "C" int pag_assign_cost(const float *prob, int B, int64_t P, int64_t imag
     hipLaunchKernelGGL(label_sums_kernel<float>, dim3(max_rows, B), dim3(256), 0, st, prob, P, row_stride, col0, C, labels_gt, (const uint8_t *)nullptr,
                        (const int64_t *)labels, sums_ws, counts_ws, image_stride);
     hipLaunchKernelGGL(assign_cost_kernel, dim3(max_rows, B), dim3(256), 0, st, (const float *)sums_ws, (const int32_t *)counts_ws, C, (const int32_t *)info, cost);
+    if (points) {
+        PAG_CHECK_ARG(psums_ws && pcounts_ws && id_lo_hi, "pag_assign_cost: points without psums_ws / pcounts_ws / id_lo_hi");
+        hipLaunchKernelGGL(label_sums_kernel<float>, dim3(max_rows, B), dim3(256), 0, st, points, P, (int64_t)3, 0, 3, labels_gt, (const uint8_t *)nullptr,
+                           (const int64_t *)labels, psums_ws, pcounts_ws, P * 3);
+        hipLaunchKernelGGL(assign_id_range_kernel, dim3(B), dim3(256), 0, st, (const float *)psums_ws, (const int32_t *)pcounts_ws, max_rows, id_slope, id_x_limit, id_margin,
+                           C, id_lo_hi);
+    }
     PAG_CHECK_LAUNCH("pag_assign_cost");
     return PAG_OK;
 }

@@ -152,8 +152,8 @@ class LinAssignmentThingsLoss(nn.Module):
                      info=torch.zeros(B, 2, device=dev, dtype=torch.int32), labels=torch.zeros(B, R, device=dev, dtype=torch.int64),
                      cost=torch.zeros(B, R, C, device=dev), targets=torch.ones(B, R, device=dev, dtype=torch.int64),
                      psums=torch.zeros(B, R, 3, device=dev), pcounts=torch.zeros(B, R, device=dev, dtype=torch.int32),
-                     allowed=torch.ones(B, R, C, device=dev, dtype=torch.bool))
-            for name in ("info", "cost", "targets", "allowed"):
+                     lo_hi=torch.zeros(B, R, 2, device=dev, dtype=torch.int32))
+            for name in ("info", "cost", "targets", "lo_hi"):
                 f["h_" + name] = torch.empty(f[name].shape, dtype=f[name].dtype).pin_memory()
             self._ws = f
         return self._ws
@@ -163,19 +163,19 @@ class LinAssignmentThingsLoss(nn.Module):
         w = self._workspace(B, P, I, prob.device)
         st = L.stream()
         pd = prob.detach()
-        ops._call("pag_assign_cost", pd.data_ptr(), B, P, pd.stride(0), pd.stride(1), I, 1, labels_gt.data_ptr(), I - 1, w["sums"].data_ptr(), w["counts"].data_ptr(),
-                  w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), st)          # every image of the step in one set of launches
+        pts, slope, x_limit, margin = None, 0.0, 0.0, 0
         names = ("info", "cost")
         if points_3d is not None:
-            # outlier rejection (:38-43): per-id centres from the same device-side label list (rows past info[0] hold a sentinel id: count 0, centre NaN,
-            # never read on the host), the id-range test with the general path's own tensor ops, its mask in the same copy as the cost
+            # outlier rejection (:38-43): the per-id centres and the id range each may take come out of the same launches (utils/outlier_rejection.py:8-51 with its
+            # default frame_min_length 0.3, max_num_inst_at_x 30, id_margin 30 - the python scalars the tensor ops would cast to fp32)
             pts = points_3d.detach().float().contiguous()
-            for b in range(B):
-                ops._call("pag_label_sums", pts[b].data_ptr(), L.F32, P, 3, 0, 3, labels_gt[b].data_ptr(), None, w["labels"][b].data_ptr(), I - 1,
-                          w["psums"][b].data_ptr(), w["pcounts"][b].data_ptr(), st)
-            centres_x = w["psums"][:, :, 0] / w["pcounts"].float()
-            w["allowed"].copy_(_id_range_allowed(centres_x.reshape(-1), I - 1).reshape(B, I - 1, I - 1))
-            names = ("info", "cost", "allowed")
+            margin = 30
+            slope = (30 + margin) / 0.3
+            x_limit = ((I - 1) - margin) / slope
+            names = ("info", "cost", "lo_hi")
+        ops._call("pag_assign_cost", pd.data_ptr(), B, P, pd.stride(0), pd.stride(1), I, 1, labels_gt.data_ptr(), I - 1, w["sums"].data_ptr(), w["counts"].data_ptr(),
+                  w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), pts.data_ptr() if pts is not None else None, slope, x_limit, margin,
+                  w["psums"].data_ptr(), w["pcounts"].data_ptr(), w["lo_hi"].data_ptr(), st)          # every image of the step in one set of launches
         for name in names:
             w["h_" + name].copy_(w[name], non_blocking=True)
         torch.cuda.current_stream().synchronize()                      # the step's one wait for the device
@@ -190,7 +190,9 @@ class LinAssignmentThingsLoss(nn.Module):
                 continue
             cost = w["h_cost"].numpy()[b, :n].astype(np.float64)
             if points_3d is not None:
-                cost[~w["h_allowed"].numpy()[b, :n]] = 10000                                    # utils/outlier_rejection.py:8-51
+                lh = w["h_lo_hi"].numpy()[b, :n]
+                ids = np.arange(I - 1)[None, :]
+                cost[~((lh[:, :1] <= ids) & (ids <= lh[:, 1:]))] = 10000                        # utils/outlier_rejection.py:8-51
             rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))              # :45
             tg[b, rows] = cols + 1
         w["targets"].copy_(w["h_targets"], non_blocking=True)

@@ -34,12 +34,13 @@ def test_assignment_entry_points_validate_without_gpu(lib):
     """pag_assign_cost / pag_assign_nll_fwd / _bwd (ABI 10): empty batches are no-ops, bad sizes and NULL buffers are rejected before any launch."""
     assert lib.pag_assign_nll_fwd(None, 1, 0, 0, 200, 200, None, None, None, None, None, 199, 1, None, None, None, None, None) == 0
     assert lib.pag_assign_nll_bwd(None, 0, 5, 0, 200, 200, None, None, None, None, None, None) == 0
-    assert lib.pag_assign_cost(None, 0, 5, 0, 200, 200, 1, None, 199, None, None, None, None, None, None) == 0               # no image: nothing to do
-    assert lib.pag_assign_cost(None, 1, 5, 0, 200, 200, 1, None, 199, None, None, None, None, None, None) == -1              # NULL buffers
+    tail = (None, 0.0, 0.0, 0, None, None, None, None)              # no outlier rejection: points, id_slope, id_x_limit, id_margin, psums_ws, pcounts_ws, id_lo_hi; stream
+    assert lib.pag_assign_cost(None, 0, 5, 0, 200, 200, 1, None, 199, None, None, None, None, None, *tail) == 0               # no image: nothing to do
+    assert lib.pag_assign_cost(None, 1, 5, 0, 200, 200, 1, None, 199, None, None, None, None, None, *tail) == -1              # NULL buffers
     assert b"NULL" in lib.pag_last_error_string()
     buf = (ctypes.c_float * 8)()
-    assert lib.pag_assign_cost(buf, 1, 5, 0, 100, 200, 1, buf, 199, buf, buf, buf, buf, buf, None) == -1                     # row_stride < n_cols
-    assert lib.pag_assign_cost(buf, 1, 5, 0, 200, 200, 1, buf, 2000, buf, buf, buf, buf, buf, None) == -1                    # max_rows > 1024
+    assert lib.pag_assign_cost(buf, 1, 5, 0, 100, 200, 1, buf, 199, buf, buf, buf, buf, buf, *tail) == -1                     # row_stride < n_cols
+    assert lib.pag_assign_cost(buf, 1, 5, 0, 200, 200, 1, buf, 2000, buf, buf, buf, buf, buf, *tail) == -1                    # max_rows > 1024
     assert b"max_rows" in lib.pag_last_error_string()
     assert lib.pag_assign_nll_fwd(buf, 1, 5, 0, 100, 200, buf, None, buf, buf, buf, 199, 1, buf, buf, buf, buf, None) == -1
     assert lib.pag_assign_nll_bwd(buf, 1, 5, 0, 200, 200, buf, buf, buf, None, buf, None) == -1                              # NULL grad

@@ -133,7 +133,8 @@ def test_one_sync_assignment_path_equals_general_path(gpu_device):
         w = lo._workspace(1, p.shape[1], p.shape[2], dev)
         from pagnerf_amd import _lib as L, ops
         ops._call("pag_assign_cost", p[b].data_ptr(), 1, p.shape[1], 0, p.stride(1), p.shape[2], 1, t[b].contiguous().data_ptr(), p.shape[2] - 1,
-                  w["sums"].data_ptr(), w["counts"].data_ptr(), w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), L.stream())
+                  w["sums"].data_ptr(), w["counts"].data_ptr(), w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), None, 0.0, 0.0, 0, None, None, None,
+                  L.stream())
         torch.cuda.synchronize()
         n = int(w["info"][0, 0])
         assert n == len(labels) and int(w["info"][0, 1]) == 0 and w["labels"][0, :n].cpu().tolist() == labels
