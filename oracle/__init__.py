@@ -18,6 +18,8 @@ Pinning status (see DESIGN.md "Oracle"):
                               tracers/panoptic_packed_rf_tracer.py (kaolin spc_render
                               ops are third-party and restated)
   lin_assign       pinned   - against g5_linassign.npz (reference loss/*.py + SciPy)
+  regularizers     pinned   - against g6_reg.npz (reference loss/regularizers.py: value and
+                              autograd gradient of segment_consistency_regularizer)
   permuto_encode   PARITY UNPINNED - permutohedral_encoding is an un-vendored,
                               un-versioned third-party CUDA package (README.md:45);
                               this file restates its published algorithm and is the

@@ -118,9 +118,12 @@ def batch_render(pipeline, rays, channels=("rgb",), render_batch=4000, cam_ids=N
     if len(parts) == 1:
         return parts[0]
     out = {}
-    for k, v in parts[0]._items():
-        if isinstance(v, torch.Tensor) and v.dim() > 0:
-            out[k] = torch.cat([p.__dict__[k] for p in parts if isinstance(p.__dict__.get(k), torch.Tensor)], 0)
-        else:
-            out[k] = v                     # scalars (e.g. a regularisation loss) keep the first chunk's value, as `+=` does
+    for part in parts:                     # channels in first-seen order over ALL chunks: one that is None in the first chunk and a tensor later is kept, as `+=` keeps it
+        for k, v in part._items():
+            if k in out and out[k] is not None:
+                continue
+            if isinstance(v, torch.Tensor) and v.dim() > 0:
+                out[k] = torch.cat([p.__dict__[k] for p in parts if isinstance(p.__dict__.get(k), torch.Tensor) and p.__dict__[k].dim() > 0], 0)
+            else:
+                out[k] = v                 # scalars (e.g. a regularisation loss) keep the first chunk's value, as `+=` does
     return RenderBuffer(**out)

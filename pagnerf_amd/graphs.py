@@ -332,21 +332,44 @@ class GraphRunner:
         return True
 
     PARAM_RESCAN = 64       # steps between full walks of the module tree (a step in between looks the known parameter slots up directly)
+    MAX_SLOT_CACHES = 4     # nefs whose parameter slots are remembered at once (two nefs alternating on one tracer do not thrash)
+
+    @staticmethod
+    def _structure(nef, mods):
+        """Cheap structural fingerprint of the nef and its remembered sub-modules: a sub-module or parameter that was added, removed or
+        swapped in changes the number of entries of some module's `_parameters` dict or the identity of a child (one pass over ~25 small
+        dicts, no recursion) - the slots are then walked again at once instead of at the next periodic rescan."""
+        out = [(len(m._parameters), *m._modules.values()) for m in mods]          # modules compare by identity
+        out.append((len(nef._parameters), *nef._modules.values()))
+        return out
 
     def _param_sig(self, nef):
         """((data_ptr, requires_grad), ...) of the nef's parameters - part of the key: a capture bakes the storages in.  `nef.parameters()`
         walks the whole module tree (~90 us of Python per step, a sixth of a post-prune rgb-only step): the (module, name) slots are
-        remembered and read directly; a replaced Parameter object shows up at once (its slot is read every step), a module that was added
-        or removed at the next full walk."""
-        cache = getattr(self, "_slots", None)
-        if cache is None or cache[0]() is not nef or cache[2] <= 0:           # weak reference: a new nef at a recycled address is a different nef
-            slots = [(m, n) for m in nef.modules() for n, p in m._parameters.items() if p is not None]
-            cache = self._slots = [weakref.ref(nef), slots, self.PARAM_RESCAN]
+        remembered per nef and read directly; a replaced Parameter object shows up at once (its slot is read every step), a module or
+        parameter that was added / removed through the structural fingerprint, anything else at the next full walk.  The cache holds the
+        nef itself only weakly (its sub-modules strongly: they die with the entry, which goes when the nef is gone or the cache is full)."""
+        caches = self.__dict__.setdefault("_slot_caches", collections.OrderedDict())
+        for k in [k for k, c in caches.items() if c[0]() is None]:
+            del caches[k]
+        cache = caches.get(id(nef))
+        if cache is not None and (cache[0]() is not nef or cache[2] <= 0 or self._structure(nef, cache[3]) != cache[4]):
+            cache = None                                                      # weak reference: a new nef at a recycled address is a different nef
+        if cache is None:
+            mods = [m for m in nef.modules() if m is not nef]
+            slots = [(m, n) for m in mods for n, p in m._parameters.items() if p is not None]
+            own = [n for n, p in nef._parameters.items() if p is not None]
+            cache = caches[id(nef)] = [weakref.ref(nef), slots, self.PARAM_RESCAN, mods, self._structure(nef, mods), own]
+            while len(caches) > self.MAX_SLOT_CACHES:
+                caches.popitem(last=False)
+        caches.move_to_end(id(nef))
         cache[2] -= 1
         try:
-            return tuple((m._parameters[n].data_ptr(), m._parameters[n].requires_grad) for m, n in cache[1])
+            sig = [(m._parameters[n].data_ptr(), m._parameters[n].requires_grad) for m, n in cache[1]]
+            sig += [(nef._parameters[n].data_ptr(), nef._parameters[n].requires_grad) for n in cache[5]]
+            return tuple(sig)
         except (KeyError, AttributeError):          # a slot vanished: walk again
-            self._slots = None
+            caches.pop(id(nef), None)
             return self._param_sig(nef)
 
     def _key(self, tracer, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage):

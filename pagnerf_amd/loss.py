@@ -97,10 +97,11 @@ class _AssignNLL(torch.autograd.Function):
                   stuff_mask.data_ptr() if stuff_mask is not None else None, labels.data_ptr(), targets.data_ptr(), info.data_ptr(), labels.shape[1], 1,
                   virt.data_ptr(), loss.data_ptr(), valid.data_ptr(), wrong.data_ptr(), L.stream())
         ctx.save_for_backward(prob, virt, valid, wrong)
-        return loss
+        ctx.mark_non_differentiable(virt)
+        return loss, virt
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_virt=None):
         prob, virt, valid, wrong = ctx.saved_tensors
         B, P, I = prob.shape
         g = g.contiguous().float()
@@ -117,6 +118,7 @@ class LinAssignmentThingsLoss(nn.Module):
         self.min_distance, self.max_distance = min_distance, max_distance
         self._ws = None          # device scratch + pinned host mirrors of the one-synchronisation path, keyed by (B, P, I, device)
         self.fast_path = True
+        self.last_virtual_labels = None
 
     @torch.no_grad()
     def create_virtual_gt_with_linear_assignment(self, inst_probabilities, labels_gt, points_3d=None):
@@ -178,7 +180,7 @@ class LinAssignmentThingsLoss(nn.Module):
                   w["psums"].data_ptr(), w["pcounts"].data_ptr(), w["lo_hi"].data_ptr(), st)          # every image of the step in one set of launches
         for name in names:
             w["h_" + name].copy_(w[name], non_blocking=True)
-        torch.cuda.current_stream().synchronize()                      # the step's one wait for the device
+        torch.cuda.current_stream(prob.device).synchronize()           # the step's one wait for the device (the stream the launches above went to)
         info = w["h_info"].numpy()
         if info[:, 1].any():
             return None                                                # more distinct ids than the device-side set holds: general path
@@ -196,23 +198,30 @@ class LinAssignmentThingsLoss(nn.Module):
             rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))              # :45
             tg[b, rows] = cols + 1
         w["targets"].copy_(w["h_targets"], non_blocking=True)
-        return _AssignNLL.apply(prob, labels_gt, stuff_mask, w["labels"], w["targets"], w["info"])
+        loss, virt = _AssignNLL.apply(prob, labels_gt, stuff_mask, w["labels"], w["targets"], w["info"])
+        self.last_virtual_labels = virt       # i64 [B, P]: the virtual ground truth of :23-54 this step trained against (defined on valid rays: stuff | id > 0)
+        return loss
 
     def forward(self, inst_probabilities, labels_gt, stuff_mask, points_3d=None, *args, **kwargs):
         p3 = inst_probabilities
         assert (self.outlier_rejection and points_3d is not None) or not self.outlier_rejection, "Outlier rejection requires 3d points"      # :36-37
         if (self.fast_path and torch.is_tensor(p3) and p3.is_cuda and p3.dim() == 3 and p3.dtype == torch.float32
                 and p3.stride(2) == 1 and 2 <= p3.shape[2] <= 1025 and torch.is_tensor(labels_gt) and labels_gt.dtype == torch.int64
-                and labels_gt.shape == p3.shape[:2] and torch.is_tensor(stuff_mask) and stuff_mask.shape == p3.shape[:2]):
-            gt_c = labels_gt.contiguous()
-            sm_c = stuff_mask.contiguous()
-            sm_c = sm_c.view(torch.uint8) if sm_c.dtype == torch.bool else sm_c.to(torch.uint8)
+                and labels_gt.shape == p3.shape[:2] and torch.is_tensor(stuff_mask) and stuff_mask.shape == p3.shape[:2]
+                and labels_gt.device == p3.device and stuff_mask.device == p3.device):
+            # (everything the launches read through raw pointers lives on the probabilities' device and has the shape the kernels index with;
+            # anything else - a CPU label tensor, a ragged list of points - takes the general path below, which raises Python errors)
             pts = None
             if self.outlier_rejection:
                 pts = points_3d if torch.is_tensor(points_3d) else torch.stack(list(points_3d))
-            out = self._fast(p3, gt_c, sm_c, pts)
-            if out is not None:
-                return out
+            if pts is None or (pts.device == p3.device and tuple(pts.shape) == (p3.shape[0], p3.shape[1], 3)):
+                gt_c = labels_gt.contiguous()
+                sm_c = stuff_mask.contiguous()
+                # any non-zero entry is True, as torch.logical_or (:60) reads it (a plain .to(uint8) would wrap 256 to 0 and truncate 0.5)
+                sm_c = sm_c.view(torch.uint8) if sm_c.dtype == torch.bool else (sm_c != 0).view(torch.uint8)
+                out = self._fast(p3, gt_c, sm_c, pts)
+                if out is not None:
+                    return out
         loss = []
         for i, (p, gt, m) in enumerate(zip(inst_probabilities, labels_gt, stuff_mask)):
             valid = torch.logical_or(m, gt > 0)                                             # :60

@@ -260,10 +260,13 @@ class PanopticDeltaNeF(nn.Module):
             feats = pre[1]                                    # launched by the tracer right after the ray march
         else:
             feats = self._interp(self.grid, coords)                                   # :170-171
-        self._feat_cache = (coords, feats)                    # reused by panoptic_composited() for the same samples
+        # reused by panoptic_composited() for the same samples.  Detached unless a head reads the LIVE features (PanopticNeF with a detach flag
+        # off): the cache must not pin the encode autograd node and its saved tensors beyond the trace - across the optimiser step, inside
+        # a captured step's memory pool
+        self._feat_cache = (coords, feats if self._heads_read_live_features() else feats.detach())
         grp = self._grouped()
         density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
-        self._density_feats = density_feats                      # the delta-density variant adds to its column 0 (pre-ReLU)
+        self._density_feats = density_feats.detach()             # the delta-density variant adds to its (detached) column 0 (pre-ReLU)
         if "rgb" in compute_channels:                                                 # :188, :196-204
             if num_samples != 1 and ridx is None:                                  # one direction per pack entry -> per sample
                 ray_d = ray_d[:, None].repeat(1, num_samples, 1).reshape(-1, 3)
@@ -305,6 +308,10 @@ class PanopticDeltaNeF(nn.Module):
             e = F.softmax(e, dim=-1) if self.inst_softmax else e
         return e
 
+    def _heads_read_live_features(self):
+        """Does a panoptic head's gradient flow into the main grid?  Never here (panoptic_delta_nef.py:214,226: feats.detach())."""
+        return False
+
     def _head_inputs(self, feats, coords, channels):
         """((semantic head's input, its grouped layout or None), (instance head's ...)) from the LIVE main features `feats`
         (panoptic_delta_nef.py:210-236: both heads read one tensor built from feats.detach())."""
@@ -328,7 +335,14 @@ class PanopticDeltaNeF(nn.Module):
         rgb_semantics() :210-255 followed by tracer :197-205, but each head + its per-ray weighted sum is one autograd
         node whose backward feeds the decoder a rank-1 gradient (ops.head_composite)."""
         cache = getattr(self, "_feat_cache", None)
-        feats = cache[1] if cache is not None and cache[0] is coords else self._interp(self.grid, coords)
+        self._feat_cache = None                               # one use: nothing of this trace stays referenced from the module
+        if cache is not None and cache[0] is coords:
+            feats = cache[1]
+        elif self._heads_read_live_features():
+            feats = self._interp(self.grid, coords)
+        else:
+            with torch.no_grad():                             # the heads detach it anyway: no autograd node, no saved tensors
+                feats = self._interp(self.grid, coords)
         (sem_in, sem_grp), (inst_in, inst_grp) = self._head_inputs(feats, coords, channels)
         out = {}
         if "semantics" in channels and "inst_embedding" in channels and sem_in is inst_in and sem_grp is not None:
@@ -402,6 +416,9 @@ class PanopticNeF(PanopticDeltaNeF):
 
     def _pan_grouped(self):
         return self._grouped()
+
+    def _heads_read_live_features(self):
+        return not (self.sem_detach and (self.inst_detach or self.inst_direct_pos))       # :338, :353
 
     def _head_inputs(self, feats, coords, channels):
         grp = self._grouped()

@@ -10,7 +10,8 @@ formula (csrc/optim.hip).  Why: the update is 704 MB of pure streaming per step 
 kernel moves it at 3.6 TB/s on MI355X - 0.196 ms per step, 5 % of the full step and 16 % of the post-prune step.
 
 Anything this kernel does not cover takes torch's own implementation for that group, silently and correctly: amsgrad, maximize,
-capturable / differentiable, sparse gradients, CPU tensors, non-fp32 parameters (fp16 tables), non-contiguous tensors.
+capturable / differentiable, decoupled weight decay (AdamW's `p *= 1 - lr * wd`; the kernel implements Adam's L2 form `g += wd * p`),
+tensor-valued lr / betas, sparse gradients, CPU tensors, non-fp32 parameters (fp16 tables), non-contiguous tensors.
 
 Host cost matters as much as the kernel in the post-prune regime (a 0.6 ms step): per group the parameter list, the moment pointers and
 the step counters are prepared ONCE (`_Plan`) and a step is one pass over the gradients (pointer + dtype / layout check), one
@@ -70,8 +71,11 @@ class Adam(torch.optim.Adam):
 
     @staticmethod
     def _group_ok(group):
-        return not (group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable")
-                    or isinstance(group["lr"], torch.Tensor))
+        if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
+            return False
+        if group.get("decoupled_weight_decay") and group.get("weight_decay", 0) != 0:       # torch >= 2.7 Adam(decoupled_weight_decay=True) = AdamW
+            return False
+        return not (isinstance(group["lr"], torch.Tensor) or any(isinstance(b, torch.Tensor) for b in group["betas"]))
 
     def _plan(self, gi, group):
         """The group's plan, or None when a parameter / gradient is outside what the kernel covers (-> torch's step for the group)."""
@@ -113,19 +117,21 @@ class Adam(torch.optim.Adam):
                 continue
             beta1, beta2 = group["betas"]
             hyper = (float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]))
-            torch._foreach_add_(plan.steps, 1)
+            # the step counters advance only once the launch has been accepted: a call that raises (bad hyper-parameter, launch failure)
+            # leaves counters, moments and parameters as they were
             if plan.uniform:
+                self._launch(plan, plan.pp, plan.gg, plan.mm, plan.vv, plan.nn, plan.n, hyper, plan.count + 1)
                 plan.count += 1
-                self._launch(plan, plan.pp, plan.gg, plan.mm, plan.vv, plan.nn, plan.n, hyper, plan.count)
             else:       # parameters that joined the optimiser at different times carry different step counts: one call per count
                 by = {}
                 for i, t in enumerate(plan.steps):
-                    by.setdefault(int(float(t)), []).append(i)
+                    by.setdefault(int(float(t)) + 1, []).append(i)
                 for count, idx in sorted(by.items()):
                     n = len(idx)
                     sel = lambda a, ct: (ct * n)(*[a[i] for i in idx])
                     self._launch(plan, sel(plan.pp, ctypes.c_void_p), sel(plan.gg, ctypes.c_void_p), sel(plan.mm, ctypes.c_void_p),
                                  sel(plan.vv, ctypes.c_void_p), sel(plan.nn, ctypes.c_int64), n, hyper, count)
+            torch._foreach_add_(plan.steps, 1)
         if fallback:
             self._torch_step(fallback)
         return loss
@@ -139,11 +145,17 @@ class Adam(torch.optim.Adam):
             ops._call("pag_adam_step", n, pp, gg, mm, vv, nn, *hyper, count, L.stream())
 
     def _torch_step(self, group_ids):
-        """torch.optim.Adam.step on the groups our kernel does not cover (the others are hidden from it for the call)."""
+        """torch.optim.Adam.step on the groups our kernel does not cover (the others are hidden from it for the call).  Called from inside
+        this class' own (hook-wrapped) step(): torch's step is entered BELOW its hook wrapper (Optimizer.profile_hook_step marks the class'
+        `step` as `hooked` once a plain torch.optim.Adam has been constructed), so step pre / post hooks and the profiler record fire once
+        per step() of this optimiser, not a second time for the fallback groups - and no hook sees the temporary group list."""
         keep = self.param_groups
+        inner = torch.optim.Adam.step
+        if getattr(inner, "hooked", False) and hasattr(inner, "__wrapped__"):
+            inner = inner.__wrapped__
         try:
             self.param_groups = [keep[i] for i in group_ids]
-            super().step()
+            inner(self)
         finally:
             self.param_groups = keep
         self._plans = {k: v for k, v in self._plans.items() if k not in group_ids}

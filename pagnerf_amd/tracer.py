@@ -181,4 +181,7 @@ class PanopticPackedRFTracer(nn.Module):
             f = nef(coords=samples, ray_d=ray_dirs.index_select(0, ridx), pidx=pidx, lod_idx=lod_idx, channels=ch)
             outputs[ch] = ops.composite_features(sigma, deltas.reshape(-1), f.reshape(-1, f.shape[-1]), ridx32, pack_start,
                                                  ray_of_pack, N)[0]
+        for attr in ("_feat_cache", "_density_feats"):                                     # per-trace caches of the nef: nothing of this trace stays referenced
+            if getattr(nef, attr, None) is not None:
+                setattr(nef, attr, None)
         return outputs

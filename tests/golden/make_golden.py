@@ -17,7 +17,7 @@ Fixtures are DATA: inputs, seeds and the reference's outputs.
   g3_nef.npz        pc_nerf/panoptic_delta_nef.py  PanopticDeltaNeF.rgb_semantics with HashGridTorch grids
   g4_tracer.npz     tracers/panoptic_packed_rf_tracer.py  trace() on a packed random scene, both bg colours
   g5_linassign.npz  loss/lin_assignment.py + loss/lin_assignment_things.py virtual labels (bit-exact)
-  g6_reg.npz        loss/regularizers.py sigma_sparsity_loss
+  g6_reg.npz        loss/regularizers.py sigma_sparsity_loss, segment_consistency_regularizer (value + autograd gradient)
 """
 import os
 import sys
@@ -433,8 +433,30 @@ def g5(la, lat):
 def g6(reg):
     rs = np.random.RandomState(13)
     s = rs.gamma(1.0, 5.0, size=(512,)).astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, "g6_reg.npz"), sigma=s,
-                        sparsity=reg.sigma_sparsity_loss(torch.from_numpy(s)).numpy())
+    save = dict(sigma=s, sparsity=reg.sigma_sparsity_loss(torch.from_numpy(s)).numpy())
+    # segment_consistency_regularizer (loss/regularizers.py:5-35) as pc_nerf/trainer.py:525-527 calls it: softmaxed instance probabilities
+    # + 1e-27, [B, P, I], and the per-ray ground-truth ids [B, P].  The batch exercises every branch: id 0 is a segment of its own, a
+    # segment whose rays all predict column 0 (skipped, :24-25), a segment where more than twice as many rays predict 0 as the best other
+    # column (label forced to 0, :29-30), segments of one ray, images with different segment counts (the running total is divided by each
+    # image's count in turn, :33), ids that are large and not contiguous.
+    B, P, I = 3, 600, 12
+    logits = (rs.standard_normal(size=(B, P, I)) * 2.0).astype(np.float32)
+    labels = np.zeros((B, P), dtype=np.int64)
+    labels[0] = rs.choice([0, 3, 4, 17, 1005], size=P, p=[0.4, 0.2, 0.2, 0.15, 0.05])
+    labels[1] = rs.choice([0, 2, 9], size=P, p=[0.5, 0.3, 0.2])
+    labels[2] = rs.choice([5, 6, 7, 8, 40, 41, 1000000007], size=P)
+    labels[2, 0] = 99                                                  # a one-ray segment
+    for b, lab, col, boost in ((0, 3, 5, 6.0), (0, 4, 0, 9.0), (1, 2, 7, 5.0), (2, 6, 2, 4.0)):
+        logits[b, labels[b] == lab, col] += boost                      # (0, 4): every ray of segment 4 predicts column 0 -> skipped
+    m = np.nonzero(labels[1] == 9)[0]                                  # segment 9 of image 1: ~75 % of the rays predict 0, the rest column 3
+    logits[1, m[: (3 * len(m)) // 4], 0] += 9.0
+    logits[1, m[(3 * len(m)) // 4:], 3] += 9.0
+    prob = torch.softmax(torch.from_numpy(logits), -1)
+    x = (prob + 1e-27).clone().requires_grad_(True)
+    val = reg.segment_consistency_regularizer(x, torch.from_numpy(labels))
+    val.backward()
+    save.update(seg_prob=prob.numpy(), seg_labels=labels, seg_reg=val.detach().numpy(), seg_reg_grad=x.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "g6_reg.npz"), **save)
 
 
 def g7(hgt):
@@ -611,6 +633,9 @@ def main():
         hgt = importlib.import_module("grids.hash_grid_torch")
     if "--only-g7" in sys.argv:
         g7(hgt)
+        return
+    if "--only-g6" in sys.argv:
+        g6(importlib.import_module("loss.regularizers"))
         return
     if "--only-g9" in sys.argv:
         with _CudaToCpu():

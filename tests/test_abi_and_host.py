@@ -469,6 +469,32 @@ def test_adam_is_a_torch_adam_with_the_same_interface():
     assert abs(oa.param_groups[0]["lr"] - 0.01) < 1e-12
 
 
+def test_adam_group_gate_and_hooks_fire_once():
+    """Groups the kernel's arithmetic does not cover are refused by the gate (amsgrad, maximize, decoupled weight decay with a non-zero decay,
+    tensor-valued lr / betas) and take torch's step - entered below its hook wrapper, so step hooks fire once per step()."""
+    import pagnerf_amd
+    ok = pagnerf_amd.optim.Adam._group_ok
+    base = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-15, weight_decay=0.0, amsgrad=False, maximize=False, capturable=False, differentiable=False,
+                decoupled_weight_decay=False)
+    assert ok(base) and ok(dict(base, weight_decay=0.1)) and ok(dict(base, decoupled_weight_decay=True))        # decoupled with wd = 0 is plain Adam
+    for bad in (dict(amsgrad=True), dict(maximize=True), dict(decoupled_weight_decay=True, weight_decay=0.1), dict(lr=torch.tensor(1e-3)),
+                dict(betas=(torch.tensor(0.9), 0.999)), dict(capturable=True)):
+        assert not ok(dict(base, **bad)), bad
+    torch.optim.Adam([torch.nn.Parameter(torch.ones(1))])          # a plain torch Adam exists: torch.optim.Adam.step is hook-wrapped from here on
+    p, q = torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(5))
+    oa = pagnerf_amd.optim.Adam([p], lr=0.1, weight_decay=0.1, decoupled_weight_decay=True)
+    ob = torch.optim.Adam([q], lr=0.1, weight_decay=0.1, decoupled_weight_decay=True)
+    fired = []
+    oa.register_step_pre_hook(lambda *a: fired.append("pre"))
+    oa.register_step_post_hook(lambda *a: fired.append("post"))
+    for _ in range(3):
+        p.grad, q.grad = torch.full((5,), 0.5), torch.full((5,), 0.5)
+        oa.step()
+        ob.step()
+    assert fired == ["pre", "post"] * 3 and torch.equal(p.detach(), q.detach())
+    assert oa.param_groups[0]["params"][0] is p          # the group list the caller sees is the original one again
+
+
 def test_graph_key_parameter_signature_without_a_module_walk():
     """GraphRunner._param_sig: the (data_ptr, requires_grad) signature of the nef's parameters read from remembered (module, name) slots - a
     frozen parameter, a replaced Parameter object and a different nef all change it; the same nef gives the same signature."""
@@ -497,3 +523,36 @@ def test_graph_key_parameter_signature_without_a_module_walk():
     del other
     gc.collect()
     assert r._param_sig(nef) == c
+    # a module attached between two periodic rescans is seen at the next step (structural fingerprint), as is one swapped in for another
+    nef.extra_head = torch.nn.Linear(3, 3)
+    d = r._param_sig(nef)
+    assert len(d) == len(c) + 2
+    nef.extra_head = torch.nn.Linear(3, 3)
+    e = r._param_sig(nef)
+    assert len(e) == len(d) and e != d
+    # two nefs alternating on one runner keep a slot cache each
+    other = make()
+    for _ in range(3):
+        r._param_sig(other)
+        r._param_sig(nef)
+    assert len(r._slot_caches) == 2 and r._slot_caches[id(nef)][2] < r.PARAM_RESCAN - 2
+
+
+def test_batch_render_keeps_channels_that_appear_in_later_chunks():
+    """pagnerf_amd.batch_render joins the per-chunk buffers channel by channel over ALL chunks (trainer.py:648 `rb += ...` keeps a channel
+    that is None in the first chunk and a tensor in a later one)."""
+    import pagnerf_amd
+
+    class P:
+        def __init__(self):
+            self.n = 0
+
+        def __call__(self, rays, lod_idx=None, channels=None):
+            self.n += 1
+            k = rays.origins.shape[0]
+            return pagnerf_amd.RenderBuffer(rgb=torch.full((k, 3), float(self.n)), depth=None if self.n == 1 else torch.full((k, 1), float(self.n)),
+                                            reg=torch.tensor(float(self.n)))
+    rays = pagnerf_amd.Rays(torch.zeros(10, 3), torch.zeros(10, 3))
+    rb = pagnerf_amd.batch_render(P(), rays, render_batch=4)
+    assert rb.rgb.shape == (10, 3) and rb.depth.shape == (6, 1) and float(rb.reg) == 1.0
+    assert torch.equal(rb.rgb[:, 0], torch.tensor([1.0] * 4 + [2.0] * 4 + [3.0] * 2))

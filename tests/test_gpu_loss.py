@@ -62,6 +62,29 @@ def test_g5_virtual_labels_and_losses(gpu_device):
         assert torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
 
 
+def test_one_sync_path_virtual_labels_bit_exact_vs_reference(gpu_device):
+    """north_star: instance-ID linear-assignment indices bit-exact.  The DEFAULT path (pag_assign_cost -> SciPy -> pag_assign_nll_fwd, both images of the
+    golden batch in one launch set) hands out the virtual labels it trained against; on the valid rays (stuff | id > 0, lin_assignment_things.py:60-62) they
+    equal the labels the reference's own create_virtual_gt_with_linear_assignment produced (g5 virt_things_{b} / virt_things_rej_{b}), bit for bit."""
+    from pagnerf_amd import loss as pl
+    dev = gpu_device
+    g = golden("g5_linassign.npz")
+    prob = torch.from_numpy(g["prob"]).to(dev)
+    gt = torch.from_numpy(g["gt"]).to(dev)
+    stuff = torch.from_numpy(g["stuff"]).to(dev)
+    pts = torch.from_numpy(g["points_3d"]).to(dev)
+    assert prob.shape[0] == 2
+    for tag, rej in (("things", False), ("things_rej", True)):
+        lo = pl.LinAssignmentThingsLoss(outlier_rejection=rej)
+        out = lo(prob.clone().requires_grad_(True), gt, stuff, pts if rej else None)
+        virt = lo.last_virtual_labels
+        assert virt is not None and virt.dtype == torch.int64 and virt.shape == gt.shape and not virt.requires_grad, "the fast path did not run"
+        for b in range(2):
+            vm = (stuff[b] | (gt[b] > 0))
+            assert np.array_equal(virt[b][vm].cpu().numpy(), g[f"virt_{tag}_{b}"]), (tag, b)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"loss_{tag}"], rtol=1e-5, atol=1e-6)
+
+
 def test_one_sync_assignment_path_equals_general_path(gpu_device):
     """LinAssignmentThingsLoss: the one-synchronisation path (pag_assign_cost + _AssignNLL, ABI 10) against the general path (explicit label list, tensor ops) -
     loss values and gradients on the golden batch and on random batches with stuff-only rays, invalid rays, an image without things, an image whose

@@ -103,3 +103,52 @@ def test_adam_interoperates_with_torch_state_and_gradscaler(gpu_device):
     h.grad, f.grad = torch.ones_like(h), torch.ones_like(f)
     oc.step()
     assert not torch.equal(h.detach(), h0) and not torch.equal(f.detach(), f0) and "max_exp_avg_sq" in oc.state[f]
+
+
+def test_decoupled_weight_decay_and_hooks_on_fallback_groups(gpu_device):
+    """torch >= 2.7: Adam(decoupled_weight_decay=True) is AdamW (`p *= 1 - lr * wd`); pag_adam_step implements the L2 form, so such a group
+    with a non-zero decay must take torch's implementation (the reference puts weight_decay on the grid groups, trainer.py:272-281) - the
+    trajectory follows torch.optim.Adam(decoupled_weight_decay=True), not the L2 one.  Step hooks fire ONCE per step() although the
+    fallback groups are stepped by torch's own step() from inside ours."""
+    import pagnerf_amd
+    dev = gpu_device
+    pa, pb, pc = _params(dev, 2), _params(dev, 2), _params(dev, 2)
+    kw = dict(lr=1e-2, eps=1e-15, weight_decay=1e-1)
+    ob = torch.optim.Adam(pb, decoupled_weight_decay=True, foreach=False, fused=False, **kw)       # constructed first: marks torch's step as hooked
+    oa = pagnerf_amd.optim.Adam([dict(params=pa[:2], decoupled_weight_decay=True), dict(params=pa[2:], weight_decay=0.0)], **kw)
+    oc = torch.optim.Adam(pc, foreach=False, fused=False, **kw)                                     # L2 form: must NOT be what the tables follow
+    assert not oa._group_ok(oa.param_groups[0]) and oa._group_ok(oa.param_groups[1])
+    fired = []
+    oa.register_step_pre_hook(lambda *a: fired.append("pre"))
+    oa.register_step_post_hook(lambda *a: fired.append("post"))
+    for step in range(5):
+        for p, q, r, g in zip(pa, pb, pc, _grads(pa, step)):
+            p.grad, q.grad, r.grad = g.clone(), g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        oc.step()
+    assert fired == ["pre", "post"] * 5, fired
+    for i in range(2):
+        p, q, r = pa[i].detach(), pb[i].detach(), pc[i].detach()
+        assert float((p - q).abs().max()) <= 4e-6 * float(q.abs().max())
+        assert float((p - r).abs().max()) > 1e-4 * float(r.abs().max())           # the two decay forms really differ on this trajectory
+    assert float(oa.state[pa[0]]["step"]) == 5.0 and float(oa.state[pa[3]]["step"]) == 5.0
+
+
+def test_failed_launch_leaves_step_counters_untouched(gpu_device):
+    """A pag_adam_step call the library rejects (here: lr < 0 smuggled into the group after construction) raises and leaves the step
+    counters where they were - no step is counted for an update that was not applied."""
+    import pagnerf_amd
+    dev = gpu_device
+    p = torch.nn.Parameter(torch.randn(1000, device=dev))
+    o = pagnerf_amd.optim.Adam([p], lr=1e-2, eps=1e-15)
+    p.grad = torch.ones_like(p)
+    o.step()
+    o.param_groups[0]["lr"] = -1.0
+    before = p.detach().clone()
+    with pytest.raises(Exception):
+        o.step()
+    assert float(o.state[p]["step"]) == 1.0 and torch.equal(p.detach(), before)
+    o.param_groups[0]["lr"] = 1e-2
+    o.step()
+    assert float(o.state[p]["step"]) == 2.0 and o._plans[0].count == 2

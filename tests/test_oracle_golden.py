@@ -126,6 +126,22 @@ def test_g6_sigma_sparsity():
     np.testing.assert_allclose(torch.log(1.0 + 2 * s ** 2).numpy(), g["sparsity"], rtol=1e-6)
 
 
+def test_g6_segment_consistency_regularizer():
+    """oracle/regularizers.py against the reference's loss/regularizers.py:5-35 (value and autograd gradient from the reference function,
+    called as pc_nerf/trainer.py:525-527 calls it): every distinct id - 0 included - is a segment, all-column-0 segments are skipped,
+    a 2:1 majority for column 0 forces label 0, the running total is divided by each image's segment count in turn."""
+    from oracle import regularizers as oreg
+    g = golden("g6_reg.npz")
+    x = g["seg_prob"] + np.float32(1e-27)
+    val, grad = oreg.segment_consistency_regularizer(x, g["seg_labels"], want_grad=True)
+    np.testing.assert_allclose(val, g["seg_reg"], rtol=2e-6)
+    assert np.array_equal(grad != 0, g["seg_reg_grad"] != 0)                       # the same (ray, column) entries carry a gradient
+    np.testing.assert_allclose(grad, g["seg_reg_grad"], rtol=2e-6, atol=0)
+    kinds = [best for b in range(x.shape[0]) for _, _, best in oreg.segment_labels(x[b], g["seg_labels"][b])]
+    assert None in kinds and 0 in kinds and any(k not in (None, 0) for k in kinds)  # the fixture exercises all three branches
+    np.testing.assert_allclose(oreg.sigma_sparsity_loss(g["sigma"]), g["sparsity"], rtol=1e-6)
+
+
 def test_g7_hash_input_and_table_gradients():
     """oracle d/d xyz and d/d tables of the hash encoder vs autograd through the reference's HashGridTorch."""
     import torch
