@@ -760,7 +760,7 @@ def run_rank(args):
     # Graph capture is one-time set-up (an eager step that observes the sample count, then the capture): with fewer warm-up steps than that
     # takes it would land inside the K timed steps.  Extra UNTIMED steps until a graph has replayed; reported as graphs.priming_steps.
     priming = 0
-    if job.tracer.use_graphs and not args.pose_opt:      # (every rank takes the same number of steps: the count is a function of the step index)
+    if job.tracer.use_graphs:      # (every rank takes the same number of steps: the count is a function of the step index)
         while priming < 4 and not ((job.graph_stats() or {}).get("replays", 0) > 0):
             job.step()
             priming += 1
@@ -768,7 +768,7 @@ def run_rank(args):
     # call exists to bracket with events: the roofline kernel's duration is then measured over K further EAGER steps right after the
     # timed region (same process, same inputs, HIP events on the launch stream around its C-ABI call).  With --graphs off the events
     # sit inside the timed region itself, as in rounds 1 - 2.
-    graphs_on = job.tracer.use_graphs and not args.pose_opt
+    graphs_on = bool(job.tracer.use_graphs)       # pose-optimisation steps replay graphs too (d origins / d dirs are outputs of the backward graph)
     if graphs_on:
         dt, _ = job.timed(args.steps)
         _, prof = job.timed(args.steps, profile={enc_name})

@@ -22,8 +22,14 @@ Ownership: the outputs handed out are copies; p.grad may alias the capture's sta
 configuration, which first turns such a p.grad into a private copy (_GraphedFn).  With more than one rank
 the backward is captured as two graphs so that gradient hooks fire between them (_Graphed, `split`).
 
-Not taken (the tracer falls back to eager): torch.no_grad() / stage != 'train', extra channels, ray_sparcity_reg > 0, rays that
-require a gradient (pose optimisation), foreign grids.
+Pose optimisation (rays that require a gradient: pc_nerf/ba_pipeline.py:85-92, every step of a configs/bup20/best.yaml run -
+optimize_extrinsics with extrinsics_epoch_end 900 > epochs 800): the per-ray transform stays outside the capture, in ordinary
+autograd; the captured function takes the ray origins / directions as two more static inputs that require a gradient (the samples are
+attached to them by ops.ray_samples inside the capture), and the backward graph hands d origins / d dirs [N,3] back as two more static
+outputs - the position gradient of the main grid's encoder, the per-ray sums of pag_ray_sample_grad and the view embedding's gradient
+all replay with the rest of the backward.
+
+Not taken (the tracer falls back to eager): torch.no_grad() / stage != 'train', extra channels, ray_sparcity_reg > 0, foreign grids.
 """
 import collections
 import os
@@ -61,12 +67,17 @@ class _PostMarch(nn.Module):
         self.capacity, self.channels, self.lod_idx, self.bg_color, self.stage = capacity, frozenset(channels), lod_idx, bg_color, stage
         self.names = None
 
-    def forward(self, samples, depths, deltas, ray_dirs):
+    def forward(self, samples, depths, deltas, ray_dirs, origins=None):
+        """origins (pose optimisation): [N,3] requiring a gradient - only its SHAPE and its place in the autograd graph matter (the
+        samples' values are the march kernel's); with it the samples carry d / d origins and d / d dirs as in the eager path
+        (grids.OccupancyBLAS.raymarch: ops.ray_samples)."""
         tracer, buf = self._t
         cap, k, N = self.capacity, buf.k, buf.N
         ne = cap // k
         smp = samples.reshape(ne, k, 3)
         dep = depths.reshape(ne, k)
+        if origins is not None:
+            smp = ops.ray_samples(origins, ray_dirs, smp, dep, buf.pack_start_c, ops._ray_iota(N, samples.device))
         # pack_start_c = min(pack_start, capacity): these launches are queued before the host has seen the sample count, and a batch that
         # overflows the capacity (its result is discarded afterwards) must not send a per-ray kernel past the capacity-sized tensors
         out = tracer.shade(self.nef, set(self.channels), set(), ray_dirs, N, buf.ridx_entry[:ne], buf.ridx_sample[:cap], buf.pidx[:ne], smp, dep,
@@ -100,6 +111,8 @@ class _GraphedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, runner, gi, *params):
+        """params: the group's real parameters, then the live tensors of the capture's gradient-carrying arguments the group reaches
+        (pose optimisation: ray directions / origins)."""
         ctx.runner, ctx.gi = runner, gi
         ctx.set_materialize_grads(False)      # outputs the loss does not use arrive as None in backward(), not as zero tensors filled per step
         grp = runner.groups[gi]
@@ -136,12 +149,15 @@ class _GraphedFn(torch.autograd.Function):
         if dst:
             ops.copy_batch(dst, src)
         grp.bwd.replay()
-        return (None, None) + tuple(g.detach() if g is not None else None for g in grp.gins)
+        # parameters: the static gradients themselves (see above); argument gradients ([N,3] d dirs / d origins of a pose-optimisation
+        # step): copies - their consumer is the caller's own autograd graph, which may keep or accumulate them
+        n_p = len(grp.params)
+        return (None, None) + tuple(g.detach() for g in grp.gins[:n_p]) + tuple(_fresh(grp.gins[n_p:]))
 
 
 class _Group:
     """One backward graph: the differentiable outputs `out_idx` (indices into _Graphed.outs) -> gradients of `params`."""
-    __slots__ = ("out_idx", "gouts", "bwd", "gins", "params", "zeroed")
+    __slots__ = ("out_idx", "gouts", "bwd", "gins", "params", "zeroed", "arg_sel")
 
 
 class _Graphed:
@@ -161,8 +177,10 @@ class _Graphed:
     hook: the delta grid's table gradient is complete after the panoptic heads' backward and starts its all-reduce while the colour /
     density decoders and the main grid are still running) fires as in an eager backward.  Same kernels, same values."""
 
-    def __init__(self, mod, args, split=()):
-        self.mod, self.args = mod, args
+    def __init__(self, mod, args, split=(), grad_args=()):
+        """grad_args: indices into `args` of static tensors the captured function is differentiated with respect to as well (pose
+        optimisation: the ray directions and the origin stand-in); __call__ then takes the live tensors that stand behind them."""
+        self.mod = mod
         named = [(n, p) for n, p in mod.named_parameters() if p.requires_grad]
         params = [p for _, p in named]
         cur = torch.cuda.current_stream()
@@ -170,7 +188,11 @@ class _Graphed:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             self.alias = {n: p.detach().requires_grad_(True) for n, p in named}
-        leaves = list(self.alias.values())
+            # fresh leaves on the static argument storage (what the march / padding launches write before every replay)
+            args = tuple(a.detach().requires_grad_(True) if i in grad_args else a for i, a in enumerate(args))
+        self.args = args
+        self.grad_args = tuple(grad_args)
+        leaves = list(self.alias.values()) + [args[i] for i in grad_args]
 
         def run():
             return torch.func.functional_call(mod, self.alias, args)
@@ -215,7 +237,8 @@ class _Graphed:
             else:
                 gins = [None] * len(leaves)
             used = [i for i, g in enumerate(gins) if g is not None]
-            grp.params = [params[i] for i in used]     # a parameter this group's outputs do not depend on is not an input of its node
+            grp.params = [params[i] for i in used if i < len(params)]     # a parameter this group's outputs do not depend on is not an input of its node
+            grp.arg_sel = [i - len(params) for i in used if i >= len(params)]      # positions in grad_args of the arguments this group reaches
             grp.gins = [gins[i] for i in used]
             self.groups.append(grp)
         self.generation = 0
@@ -233,7 +256,9 @@ class _Graphed:
                     p.grad = pg.clone()
                     self.unaliased += 1
 
-    def __call__(self):
+    def __call__(self, live_args=()):
+        """live_args: one live tensor per grad_args entry (same order) - the nodes hang the captured gradients on them."""
+        assert len(live_args) == len(self.grad_args)
         self.detach_param_grads()
         self.fwd.replay()
         self.generation += 1
@@ -241,7 +266,7 @@ class _Graphed:
         # autograd runs the node created LAST first: the groups are listed in the order their backward graphs should run
         for gi in reversed(range(len(self.groups))):
             grp = self.groups[gi]
-            outs = _GraphedFn.apply(self, gi, *grp.params)
+            outs = _GraphedFn.apply(self, gi, *grp.params, *[live_args[j] for j in grp.arg_sel])
             for i, o in zip(grp.out_idx + (self.nondiff_idx if gi == 0 else []), outs):
                 res[i] = o
         return tuple(res)
@@ -254,6 +279,7 @@ class _State:
         self.cap = None
         self.buf = None
         self.dirs = None
+        self.orig0 = None           # pose optimisation: [N,3] stand-in for the ray origins inside the capture (shape + autograd position only)
         self.buckets = collections.OrderedDict()
 
     def see(self, count):
@@ -325,7 +351,7 @@ class GraphRunner:
     def eligible(tracer, nef, channels, extra_channels, rays, stage):
         if not torch.is_grad_enabled() or stage != "train" or extra_channels or tracer.ray_sparcity_reg > 0.0:
             return False
-        if rays.origins.requires_grad or rays.dirs.requires_grad or not rays.origins.is_cuda:
+        if not rays.origins.is_cuda:
             return False
         if not getattr(nef, "accepts_ray_index", False) or not getattr(nef.grid, "accepts_max_travel", False):
             return False
@@ -378,7 +404,7 @@ class GraphRunner:
         return (id(nef), raymarch_type, int(rays.origins.shape[0]), int(num_steps), frozenset(channels), lod_idx, bg_color, stage, nef.precision,
                 nef.training, id(lw), lw._version, tuple((id(g.tables), g.tables.dtype, g.rounds_coords(), g.blas_level) for g in grids),
                 float(rays.dist_min), float(rays.dist_max), float(tracer.ray_max_travel), str(rays.origins.device),
-                self._param_sig(nef), self._split(tracer))
+                self._param_sig(nef), self._split(tracer), bool(rays.origins.requires_grad or rays.dirs.requires_grad))
 
     def observe(self, key, count):
         """An eager step of this configuration saw `count` samples: the first capacities are chosen from it."""
@@ -399,6 +425,9 @@ class GraphRunner:
             else:
                 st.buf = ops.MarchBuffers("voxel", N, int(ops.L.load().pag_raymarch_voxel_nugget_capacity(g.blas_level)), int(num_steps), dev)
             st.dirs = torch.empty(N, 3, device=dev)
+        pose = bool(rays.origins.requires_grad or rays.dirs.requires_grad)
+        if pose and st.orig0 is None:
+            st.orig0 = torch.zeros(N, 3, device=dev)
         buf = st.buf
         cap = st.capacity(buf)
         bits = None if g._all_occupied else g.blas_bits
@@ -410,7 +439,8 @@ class GraphRunner:
                                          occupancy_bits=bits, blas_level=g.blas_level,
                                          max_travel=tracer.ray_max_travel if raymarch_type == "voxel" else None, occupancy_coarse_bits=coarse,
                                          pad_capacity=cap, dirs_out=st.dirs)
-        args = (buf.samples[:cap], buf.depths[:cap], buf.deltas[:cap], st.dirs)
+        args = (buf.samples[:cap], buf.depths[:cap], buf.deltas[:cap], st.dirs) + ((st.orig0,) if pose else ())
+        live = (rays.dirs, rays.origins) if pose else ()
         if tracer.use_graphs == "static":
             # same static, padded buffers and optimistic count check - but the post-march part runs as ordinary eager launches: what the graph
             # path gains by never waiting for the sample count (the host runs ahead of the device) without a capture, for callers whose
@@ -419,7 +449,7 @@ class GraphRunner:
             mod = st.bucket(("static", cap), lambda: _PostMarch(nef, tracer, buf, cap, channels, lod_idx, bg_color, stage))
             ops.SAMPLES_HINT, ops.TAIL_ZERO = max(st.counts), True
             try:
-                outs = mod(*args)
+                outs = mod(*args[:3], *live) if pose else mod(*args)       # eager launches: the live rays take the place of the static copies
             finally:
                 ops.SAMPLES_HINT, ops.TAIL_ZERO = None, False
             self.replays += 1
@@ -454,11 +484,11 @@ class GraphRunner:
             ops.SAMPLES_HINT = M            # launch heuristics see the real count, not the padded capacity (same split as the eager path)
             ops.TAIL_ZERO = True            # per-sample tensors that the per-pack kernels fill start as zeros: the fillers carry no gradient
             try:
-                graphed = st.bucket(cap, lambda: _Graphed(mod, args, split=self._split(tracer)))
+                graphed = st.bucket(cap, lambda: _Graphed(mod, args, split=self._split(tracer), grad_args=(3, 4) if pose else ()))
             finally:
                 ops.SAMPLES_HINT, ops.TAIL_ZERO = None, False
             self.captures += 1
-        outs = graphed()
+        outs = graphed(live)
         self.replays += 1
         if mailbox is not None:
             M = self._count(mailbox, buf)

@@ -366,3 +366,63 @@ def test_graph_key_follows_requires_grad(gpu_device):
     et, _ = _fresh_tracers(tracer)
     _, _, ge = _step(nef, et, rays, jit, targets)
     assert g["delta_grid.tables"] is not None and T._rel_l2(g["delta_grid.tables"].float(), ge["delta_grid.tables"].float()) < 1e-5
+
+
+@pytest.mark.parametrize("use", [True, "static"])
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_pose_optimisation_through_the_graph_path(gpu_device, mode, use):
+    """configs/bup20/best.yaml runs EVERY step with learnable extrinsics (optimize_extrinsics, extrinsics_epoch_end 900 > epochs 800:
+    pc_nerf/trainer.py:308, pc_nerf/ba_pipeline.py:85-92): rays that require a gradient take the graph path too.  Against the eager
+    path on the same rays and jitter: forward bit for bit, d loss / d camera_extrinsics (through d origins / d dirs: the main grid's
+    position gradient, the per-ray sums of pag_ray_sample_grad, the view embedding) and every parameter gradient to 1e-5."""
+    import pagnerf_amd
+    from pagnerf_amd.ba_pipeline import BAPipeline
+    dev = gpu_device
+    N, S, C = 96, 32, 3
+    nef, tracer, rays, occ, jitter = ragged_scene(dev, "bf16", N=N, S=S)
+    if mode == "voxel":
+        tracer.raymarch_type, tracer.num_steps, tracer.ray_max_travel = "voxel", 2, 0.8
+    jit = jitter.to(dev)
+    targets = _targets(N, dev)
+    views = torch.eye(4).repeat(C, 1, 1)
+    views[:, :3, 3] = torch.tensor([[0.01, -0.02, 0.0], [0.0, 0.015, -0.01], [-0.02, 0.0, 0.02]])
+    far = 3.0 if mode == "voxel" else rays.dist_max
+
+    def run(tr, steps):
+        pipe = BAPipeline(nef, views, tracer=tr, near=rays.dist_min, far=far).to(dev)
+        cam = (torch.arange(N, device=dev) * C // N)
+        out = []
+        for it in range(steps):
+            for p in list(nef.parameters()) + [pipe.camera_extrinsics]:
+                p.grad = None
+            world = pipe.transform_rays_indexed(rays.origins, rays.dirs, cam)        # camera-frame rays = the scene's rays (identity rotations)
+            assert world.origins.requires_grad and world.dirs.requires_grad
+            rb = tr(nef, channels=CH, rays=world, jitter=jit, stage="train")
+            loss = train_loss(rb.rgb, rb.semantics.float(), rb.inst_embedding.float(), *targets) + rb.depth.sum() * 0.01
+            loss.backward()
+            torch.cuda.synchronize()
+            grads = {k: (v.grad.clone() if v.grad is not None else None) for k, v in hip_leaves(nef).items()}
+            grads["camera_extrinsics"] = pipe.camera_extrinsics.grad.clone()
+            out.append((rb, loss.detach().clone(), grads))
+        return out
+    (rb_e, loss_e, g_e), = run(tracer, 1)
+    assert float(g_e["camera_extrinsics"].abs().sum()) > 0
+    gt = pagnerf_amd.PanopticPackedRFTracer(raymarch_type=tracer.raymarch_type, num_steps=tracer.num_steps, bg_color="white",
+                                            ray_max_travel=tracer.ray_max_travel, use_graphs=use)
+    for it, (rb_g, loss_g, g_g) in enumerate(run(gt, 4)):                  # 0: eager (learns the count), 1: capture, 2-3: replays
+        for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding"):
+            assert torch.equal(getattr(rb_g, ch), getattr(rb_e, ch)), (it, ch)
+        assert torch.equal(loss_g, loss_e), it
+        for name, want in g_e.items():
+            got = g_g[name]
+            assert (got is None) == (want is None), name
+            if want is not None:
+                assert T._rel_l2(got.float(), want.float()) < 1e-5, (it, name, T._rel_l2(got.float(), want.float()))
+    assert gt._graphs.captures == (1 if use is True else 0) and gt._graphs.replays == 3 and gt._graphs.overflows == 0
+    # the same tracer on rays WITHOUT a gradient afterwards: a different configuration (its own capture), same values
+    world = BAPipeline(nef, views, tracer=None, near=rays.dist_min, far=far).to(dev).transform_rays_indexed(rays.origins, rays.dirs, torch.arange(N, device=dev) * C // N)
+    plain = pagnerf_amd.Rays(world.origins.detach(), world.dirs.detach(), rays.dist_min, far)
+    for _ in range(3):
+        rb_p = gt(nef, channels=CH, rays=plain, jitter=jit, stage="train")
+        rb_p.rgb.sum().backward()
+    assert torch.equal(rb_p.rgb, rb_e.rgb) and gt._graphs.captures == (2 if use is True else 0)
