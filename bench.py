@@ -54,7 +54,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--channels", default="all", choices=["all", "rgb"])
+    ap.add_argument("--channels", default="all", choices=["all", "rgb", "rgbd"], help="rgbd = rgb + depth (what best.yaml's inst_outlier_rejection adds to every step)")
+    ap.add_argument("--lin-assign", action="store_true",
+                    help="with --pose-opt --channels all: the instance term as best.yaml forms it (LinAssignmentThingsLoss(outlier_rejection=True) over "
+                         "--images images + segment_consistency_regularizer) instead of fixed instance targets")
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=512)
     ap.add_argument("--grid", default="permuto", choices=["permuto", "hash"])
@@ -217,6 +220,10 @@ class PoseOpt:
     def rays(self):
         return self.pipe.transform_rays_indexed(self.o, self.d, self.cam)
 
+    def points_3d(self, depth):
+        """pc_nerf/trainer.py:508-518 `rays_to_3d_points(rays, rb.depth, cameras)`: the step's base rays unprojected by the rendered depth."""
+        return self.pipe.rays_to_3d_points_indexed(self.o, self.d, depth, self.cam)
+
     def parameters(self):
         return [self.pipe.camera_extrinsics]
 
@@ -275,7 +282,10 @@ class ReferenceFormulationThingsLoss:
         return loss
 
 
-def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assign=None):
+def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assign=None, images=1, points_fn=None, seg_reg=False):
+    """images / points_fn / seg_reg: the instance term over a batch of `images` images as pc_nerf/trainer.py:483-533 forms it under
+    configs/bup20/best.yaml - LinAssignmentThingsLoss per image (outlier rejection from the rendered depth's 3-D points when points_fn is
+    given, :508-518) + segment_consistency_regularizer on the same probabilities (:525-527, weight 1.0)."""
     import torch
     import torch.nn.functional as F
     opt.zero_grad(set_to_none=True)
@@ -285,18 +295,26 @@ def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assig
     # trainer.py:443-446 / best.yaml:116 rgb L1; trainer.py:465-467 nll_loss(log(p + 1e-27), gt); the instance term stands for the
     # per-image linear-assignment NLL (trainer.py:499-520 -> loss/lin_assignment_things.py:80), same arithmetic on a fixed target.
     # pagnerf_amd.loss.render_loss evaluates exactly that sum in one launch (and its gradients in one more).
-    from pagnerf_amd.loss import render_loss, NllTerm
+    from pagnerf_amd.loss import render_loss, NllTerm, segment_consistency_regularizer
     if os.environ.get("PAG_BENCH_TORCH_LOSS"):
         loss = 10.0 * torch.abs(rb.rgb - gt["rgb"]).mean()
         if "semantics" in channels:
             loss = loss + 0.1 * F.nll_loss(torch.log(rb.semantics + 1e-27), gt["sem"], reduction="mean")
             loss = loss + 1000.0 * F.nll_loss(torch.log(rb.inst_embedding + 1e-27), gt["inst"], reduction="mean")
     elif "semantics" in channels and lin_assign is not None:
-        # the instance term as the trainer forms it late in training (trainer.py:483-520, best.yaml inst_loss linear_assignment_things):
+        # the instance term as the trainer forms it late in training (trainer.py:483-533, best.yaml inst_loss linear_assignment_things):
         # per-image Hungarian relabelling of the rendered instance probabilities, then the NLL against the virtual labels
         loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1))
-        inst = rb.inst_embedding.float().reshape(1, -1, rb.inst_embedding.shape[-1])
-        loss = loss + 1000.0 * lin_assign(inst, gt["inst_ids"][None], gt["stuff"][None]).mean()
+        B = images
+        inst = rb.inst_embedding.float().reshape(B, -1, rb.inst_embedding.shape[-1])
+        ids, stuff = gt["inst_ids"].reshape(B, -1), gt["stuff"].reshape(B, -1)
+        reg = segment_consistency_regularizer(inst + 1e-27, ids) if seg_reg else None     # queued BEFORE the assignment's one synchronisation
+        if points_fn is not None:
+            il = lin_assign(inst, ids, stuff, points_fn(rb.depth.detach()).reshape(B, -1, 3))
+        else:
+            il = lin_assign(inst, ids, stuff)
+        il = il.mean() if reg is None else il.mean() + 1.0 * reg                           # `inst_loss += w * reg` broadcasts the scalar over [B, P]; then .mean()
+        loss = loss + 1000.0 * il
     elif "semantics" in channels:
         loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1),
                               NllTerm(rb.inst_embedding, gt["inst"], weight=1000.0))
@@ -446,7 +464,45 @@ def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16):
     if pan:
         out["pag_head_composite_fwd"] = dict(bytes=M * (64 * s + 8 + 4) + N * 200 * 4, flops=0, rebuild_flops=2 * M * 64 * 200)
         out["pag_composite_feats_fwd"] = dict(bytes=M * (6 * s + 4) + N * 6 * 4, flops=0)
+    # pose optimisation (pc_nerf/ba_pipeline.py:85-92): the main grid's position gradient = a second gather pass (xyz, gradient row, the
+    # gathered rows again, d xyz out; its per-XCD partial sums - 96 B per sample written and read once - are scratch, not counted), then the
+    # per-ray sums of d xyz and d xyz * depth (d xyz + depth in, 24 B per ray out)
+    out["pag_%s_encode_bwd_xyz" % grid] = dict(bytes=(12 + C * s + gather + 12) * M, flops=0, scratch_bytes=2 * 8 * 12 * M)
+    out["pag_ray_sample_grad"] = dict(bytes=M * (12 + 4) + N * 24, flops=0)
     return out
+
+
+def kernel_table(prof_all, n_steps, model, pmc_blob=None):
+    """Per C-ABI entry point: calls and device ms per step (HIP events around every call of an eager pass), algorithmic bytes / FLOPs of
+    algorithmic_model() and the fractions of the HBM roof / the dense bf16 MFMA peak they amount to.
+    -> (table, device ms of the decoder entry points, their useful FLOPs)."""
+    import numpy as np
+    kernels, mfma_ms, mfma_flops = {}, 0.0, 0.0
+    for k, v in sorted(prof_all.items()):
+        ms = float(np.sum(v)) / n_steps
+        ent = dict(calls_per_step=len(v) / n_steps, ms_per_step=round(ms, 4))
+        if k in model and ms > 0:
+            md = model[k]
+            by, fl = md["bytes"], md["flops"]
+            ent.update(algorithmic_bytes=int(by), hbm_frac=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            if "bytes_min" in md:
+                ent["algorithmic_bytes_min"] = int(md["bytes_min"])
+            if "scratch_bytes" in md:
+                ent["scratch_bytes"] = int(md["scratch_bytes"])
+            if "parts" in md:
+                ent["bytes_per_sample"] = md["parts"]
+            if pmc_blob is not None:
+                pb = pmc_bytes_per_step(pmc_blob, k, ent["calls_per_step"])
+                if pb:
+                    ent.update(pmc_bytes=pb, pmc_hbm_frac=round(pb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            if fl:
+                ent.update(mfma_tflops=round(fl / (ms * 1e-3) / 1e12, 2), mfma_frac=round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5))
+                mfma_ms += ms
+                mfma_flops += fl
+            if md.get("rebuild_flops"):
+                mfma_ms += ms          # the head's probabilities are rebuilt on the matrix cores: device time of the decoders, no useful FLOPs credited
+        kernels[k.replace("pag_", "")] = ent
+    return kernels, mfma_ms, mfma_flops
 
 
 # C-ABI entry point -> substrings of the kernel names rocprofv3 reports for it (profiles/*_pmc_traffic_per_launch.json keys)
@@ -708,6 +764,7 @@ def run_rank(args):
                 self.rays, self.gt = make_rays(rays_n, dev, seed=1000 + rank)      # per-rank ray shard
             self.opt = make_optimizer(self.nef, extra)
             self.lin_assign = None
+            self.images, self.points_fn, self.seg_reg = 1, None, False
             self.sync = None
             if world > 1:
                 early = [self.nef.delta_grid.tables] if hasattr(self.nef, "delta_grid") else []
@@ -716,7 +773,7 @@ def run_rank(args):
 
         def step(self, channels=None):
             return train_step(self.nef, self.tracer, self.opt, self.rays, self.gt, channels or self.channels, world, self.sync,
-                              lin_assign=self.lin_assign)
+                              lin_assign=self.lin_assign, images=self.images, points_fn=self.points_fn, seg_reg=self.seg_reg)
 
         def timed(self, n_steps, channels=None, profile=None):
             """profile (a set of C-ABI entry points): HIP events around those calls - which only exist on the EAGER path (a graph replay
@@ -751,8 +808,11 @@ def run_rank(args):
                 self.sync.remove()
 
     all_ch = {"rgb", "depth", "semantics", "inst_embedding"}
-    channels = all_ch if args.channels == "all" else {"rgb"}
+    channels = all_ch if args.channels == "all" else ({"rgb", "depth"} if args.channels == "rgbd" else {"rgb"})
     job = Job(args.rays, args.samples, args.grid, channels, raymarch=args.raymarch, pose=args.pose_opt)
+    if args.lin_assign and args.pose_opt and args.channels == "all":
+        from pagnerf_amd.loss import LinAssignmentThingsLoss
+        job.lin_assign, job.images, job.points_fn, job.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True), args.images, job.pose.points_3d, True
     enc_name = "pag_%s_encode_fwd" % args.grid
 
     for _ in range(args.warmup):
@@ -838,29 +898,7 @@ def run_rank(args):
         job.tracer.use_graphs = was_graphs
         model = algorithmic_model(args.grid, M, args.rays, channels, L_, F_, verts, args.precision == "bf16")
         pmc_blob = json.load(open(os.path.join(pdir, cands[-1]))) if (cands and traffic_src is not None) else None
-        kernels, mfma_ms, mfma_flops = {}, 0.0, 0.0
-        for k, v in sorted(prof_all.items()):
-            ms = float(np.sum(v)) / n_bd
-            ent = dict(calls_per_step=len(v) / n_bd, ms_per_step=round(ms, 4))
-            if k in model and ms > 0:
-                md = model[k]
-                by, fl = md["bytes"], md["flops"]
-                ent.update(algorithmic_bytes=int(by), hbm_frac=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-                if "bytes_min" in md:
-                    ent["algorithmic_bytes_min"] = int(md["bytes_min"])
-                if "parts" in md:
-                    ent["bytes_per_sample"] = md["parts"]
-                if pmc_blob is not None:
-                    pb = pmc_bytes_per_step(pmc_blob, k, ent["calls_per_step"])
-                    if pb:
-                        ent.update(pmc_bytes=pb, pmc_hbm_frac=round(pb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-                if fl:
-                    ent.update(mfma_tflops=round(fl / (ms * 1e-3) / 1e12, 2), mfma_frac=round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5))
-                    mfma_ms += ms
-                    mfma_flops += fl
-                if md.get("rebuild_flops"):
-                    mfma_ms += ms          # the head's probabilities are rebuilt on the matrix cores: device time of the decoders, no useful FLOPs credited
-            kernels[k.replace("pag_", "")] = ent
+        kernels, mfma_ms, mfma_flops = kernel_table(prof_all, n_bd, model, pmc_blob)
         line["kernels"] = kernels
         if pmc_blob is not None:
             line["kernels_pmc_source"] = traffic_src
@@ -947,6 +985,53 @@ def run_rank(args):
             torch.cuda.empty_cache()
             return ent
 
+        def best_yaml_regimes(images=6, per_image=4096):
+            from pagnerf_amd.loss import LinAssignmentThingsLoss
+            total = images * per_image
+            out, regimes = dict(rays_per_step=total, images=images, pose_optimisation=True), {}
+            specs = (("dense_rgb", "epochs 0 - 200: dense occupancy, 'ray' march x 512, channels rgb + depth", "ray", 512, {"rgb", "depth"}, False, 6),
+                     ("post_prune_rgb", "epochs 201 - 600: voxel march (2 samples per voxel), channels rgb + depth", "voxel", 2, {"rgb", "depth"}, False, 20),
+                     ("post_prune_all_assign", "epochs 601 - 800: voxel march, all channels, LinAssignmentThingsLoss(outlier_rejection=True) on the "
+                                               "6-image batch + segment_consistency_regularizer", "voxel", 2, set(all_ch), True, 20))
+            for tag, what, rm, smp, chans, assign, n_steps in specs:
+                j = Job(rays_n=total, samples=smp, grid="permuto", channels=chans, raymarch=rm, pose=True)
+                if assign:
+                    j.lin_assign, j.images, j.points_fn, j.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True), images, j.pose.points_3d, True
+                for _ in range(4):                                  # step 0 learns the sample count, step 1 captures, 2 - 3 replay
+                    j.step()
+                d, _ = j.timed(n_steps)
+                ms = d / n_steps * 1e3
+                m = j.samples_per_step()
+                ent = dict(workload=what, ms_per_step=round(ms, 3), rays_s=round(total / ms * 1e3, 1), samples_per_step=int(m), steps=n_steps,
+                           hip_graphs=j.graph_stats())
+                if rm == "voxel":
+                    ent["occupied_fraction"] = round(j.occupied, 4)
+                # eager pass with events around every C-ABI call: where the step's device time goes, with bytes and fractions of the roofs
+                was, j.tracer.use_graphs = j.tracer.use_graphs, False
+                for _ in range(2):
+                    j.step()
+                n_bd = 3
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ops.profile_start()
+                for _ in range(n_bd):
+                    j.step()
+                prof = ops.profile_stop()
+                ent["eager_ms_per_step_with_events"] = round((time.perf_counter() - t0) / n_bd * 1e3, 3)
+                j.tracer.use_graphs = was
+                model = algorithmic_model("permuto", m, total, chans, 24, 2, 4, args.precision == "bf16")
+                table, _, _ = kernel_table(prof, n_bd, model)
+                ent["entry_points"] = {k: v for k, v in table.items() if v["ms_per_step"] >= 0.003}
+                ent["device_ms_per_step"] = round(float(sum(np.sum(v) for v in prof.values())) / n_bd, 3)
+                if assign:
+                    ent["labels_per_image"] = int((torch.unique(j.gt["inst_ids"].reshape(images, -1)[0]) > 0).sum())
+                regimes[tag] = ent
+                j.close()
+                del j
+                torch.cuda.empty_cache()
+            out["regimes"] = regimes
+            return out
+
         if world == 1 and default_cfg:
             # ---- every other single-GPU BASELINE configuration, each a short run (configs[1] is the headline above)
             cfgs = []
@@ -967,29 +1052,40 @@ def run_rank(args):
             cfgs.append(short_run("post-prune regime, rgb only (epochs 201 - 600 of best.yaml: voxel march from 201, panoptic heads from 601): %.0f %% occupancy, permuto"
                                   % (100 * args.occupancy), 20, 5, rays_n=4096, samples=2, grid="permuto", channels={"rgb"}, raymarch="voxel"))
             line["configs"] = cfgs
-            # ---- a whole BUP20 run in one number: configs/bup20/best.yaml schedules 800 epochs - 'ray' march until voxel_raymarch_epoch_start
-            #      = 201 (best.yaml:34; prune_every 201, :187), voxel march after it, the panoptic heads from sem_epoch_start = inst_epoch_start
-            #      = 601 (:89,165) - so a run spends 200 epochs in the dense
-            #      rgb-only step, 400 in the post-prune rgb-only step and 200 in the post-prune all-channel step (the dense all-channel step of the
-            #      headline occurs in none of them: it is the worst case BASELINE.json quotes the metric on)
+            # ---- the 4096-ray, pose-free epoch-weighted number of rounds 3 - 4 (kept for continuity; NOT a step best.yaml executes - its
+            #      batch is 6 images and its extrinsics are trainable in every epoch - see best_yaml_step / schedule_weighted below)
             try:
                 vox_all = next(c for c in cfgs if c["name"].startswith("post-prune regime (f3)"))
                 vox_rgb = next(c for c in cfgs if c["name"].startswith("post-prune regime, rgb only"))
                 parts = [(200, line["rgb_only"]["ms_per_step"]), (400, vox_rgb["ms_per_step"]), (200, vox_all["ms_per_step"])]
                 ms = sum(w * t for w, t in parts) / sum(w for w, _ in parts)
-                line["schedule_weighted"] = dict(ms_per_step=round(ms, 3), rays_s=round(args.rays / ms * 1e3, 1),
-                                                 epochs_and_ms=[dict(epochs=w, ms_per_step=t) for w, t in parts],
-                                                 note="epoch-weighted mean step of a best.yaml run (4096 rays per step): 200 epochs dense rgb-only, 400 post-prune "
-                                                      "rgb-only, 200 post-prune all channels; synthetic occupancy %.0f %% after the prune" % (100 * args.occupancy))
-                # the trainer's own instance term (per-image Hungarian relabelling, trainer.py:483-520) is not in the step measured above: what it adds to a
-                # step was measured on the dense workload (with_lin_assignment); it is host latency around one synchronisation, the same at any sample count
-                la = line.get("with_lin_assignment", {}).get("device_cost_matrix")
-                if la:
-                    extra = max(0.0, la["ms_per_step"] - line["ms_per_step"])
-                    ms2 = sum(w * (t + (extra if k == 2 else 0.0)) for k, (w, t) in enumerate(parts)) / sum(w for w, _ in parts)
-                    line["schedule_weighted"]["with_assignment_term"] = dict(ms_per_step=round(ms2, 3), rays_s=round(args.rays / ms2 * 1e3, 1),
-                                                                             added_ms_in_the_last_200_epochs=round(extra, 3))
+                line["schedule_weighted_4096_no_pose"] = dict(
+                    ms_per_step=round(ms, 3), rays_s=round(args.rays / ms * 1e3, 1), epochs_and_ms=[dict(epochs=w, ms_per_step=t) for w, t in parts],
+                    note="4096 rays per step, NO pose optimisation, fixed instance targets: 200 epochs dense rgb-only, 400 post-prune rgb-only, 200 "
+                         "post-prune all channels; synthetic occupancy %.0f %% after the prune.  best.yaml itself runs 6 x 4096 rays with trainable "
+                         "extrinsics in every epoch: see schedule_weighted" % (100 * args.occupancy))
             except (StopIteration, KeyError):
+                pass
+            # ---- the step `train.sh` -> configs/bup20/best.yaml actually runs, in its three regimes: batch_size 6 (:156) x 4096 rays (:19) = 24 576
+            #      rays per step; optimize_extrinsics (:184) with extrinsics_epoch_start 0 / _end 900 > epochs 800 (:158-160): pc_nerf/trainer.py:308
+            #      keeps the extrinsics trainable in EVERY epoch, so every step goes through pc_nerf/ba_pipeline.py:85-92 with rays that carry a
+            #      gradient; inst_outlier_rejection (:106) adds 'depth' to the channels of every step (trainer.py:432); 'ray' march with 512 steps
+            #      until voxel_raymarch_epoch_start = prune_every = 201 (:34,:187), voxel march with 2 samples per voxel after it; panoptic heads
+            #      from sem_epoch_start = inst_epoch_start = 601 (:89,:165), with the instance term of trainer.py:483-533 = LinAssignmentThingsLoss
+            #      (outlier rejection from the depth's 3-D points, :508-518) + segment_consistency_regularizer (:525-527, weight 1.0 - trainer.py:93).
+            line["best_yaml_step"] = best_yaml_regimes()
+            try:
+                reg = line["best_yaml_step"]["regimes"]
+                parts = [(200, reg["dense_rgb"]["ms_per_step"]), (400, reg["post_prune_rgb"]["ms_per_step"]), (200, reg["post_prune_all_assign"]["ms_per_step"])]
+                ms = sum(w * t for w, t in parts) / sum(w for w, _ in parts)
+                line["schedule_weighted"] = dict(
+                    ms_per_step=round(ms, 3), rays_per_step=6 * 4096, rays_s=round(6 * 4096 / ms * 1e3, 1),
+                    epochs_and_ms=[dict(epochs=w, ms_per_step=t) for w, t in parts],
+                    note="epoch-weighted mean step of a configs/bup20/best.yaml run, every step 6 images x 4096 rays with pose optimisation (BAPipeline, "
+                         "trainable extrinsics) and channels rgb + depth: 200 epochs dense 'ray' march, 400 post-prune voxel march, 200 post-prune with the "
+                         "panoptic heads + LinAssignmentThingsLoss(outlier_rejection=True) on the 6-image batch + segment_consistency_regularizer; "
+                         "synthetic occupancy %.0f %% after the prune; HIP graphs %s" % (100 * args.occupancy, args.graphs))
+            except KeyError:
                 pass
         if world == 1 and default_cfg:
             line["render"] = render_image_line(args, dev, all_ch, out_bytes)

@@ -103,6 +103,29 @@ class BAPipeline(Pipeline):
         dirs = dirs / torch.linalg.norm(dirs, dim=-1, keepdim=True)
         return Rays(origins.float(), dirs.float(), dist_min=self.near, dist_max=self.far)
 
+    @torch.no_grad()
+    def rays_to_3d_points(self, base_rays, depth, cam_ids):
+        """utils/outlier_rejection.py:74-97 as pc_nerf/trainer.py:508-518 calls it (`rays` there are the camera-frame base rays, `depth`
+        the composited depth of the same step, `cameras` the step's current extrinsics): points_cam = dirs * depth (:89), mapped to the
+        world by the cameras' inv_transform_rays (:91, the arithmetic of transform_rays above) and added to the transformed origins (:93).
+        -> [C*n, 3] world points, no gradient (the trainer wraps the call in torch.no_grad())."""
+        idx = self.camera_indices(cam_ids)
+        prm = self.camera_extrinsics[idx]
+        R, t = rotation_6d_to_matrix(prm[:, :6]), prm[:, 6:]
+        o = base_rays.origins.reshape(len(idx), -1, 3).to(prm.device)
+        d = base_rays.dirs.reshape(len(idx), -1, 3).to(prm.device)
+        p_cam = d * depth.reshape(len(idx), -1, 1).to(prm.device)
+        return (torch.matmul(o - t[:, None, :], R) + torch.matmul(p_cam, R)).float().reshape(-1, 3)
+
+    @torch.no_grad()
+    def rays_to_3d_points_indexed(self, origins_c, dirs_c, depth, cam_idx):
+        """Per-ray form of rays_to_3d_points() (ray i belongs to camera cam_idx[i]; see transform_rays_indexed)."""
+        idx = cam_idx.to(self.camera_extrinsics.device).long()
+        R = rotation_6d_to_matrix(self.camera_extrinsics[:, :6]).index_select(0, idx)
+        t = self.camera_extrinsics[:, 6:].index_select(0, idx)
+        v = origins_c - t + dirs_c * depth.reshape(-1, 1)               # R^T (o - t) + R^T (d * depth) = R^T (o - t + d * depth)
+        return (v[:, 0:1] * R[:, 0] + v[:, 1:2] * R[:, 1] + v[:, 2:3] * R[:, 2]).float()
+
     def forward(self, *args, cam_ids=None, **kwargs):
         if isinstance(cam_ids, (tuple, list, torch.Tensor)):                                              # :69-70
             kwargs["rays"] = self.transform_rays(kwargs["rays"], cam_ids)

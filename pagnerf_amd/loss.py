@@ -233,6 +233,50 @@ class LinAssignmentThingsLoss(nn.Module):
         return torch.stack(loss)
 
 
+SEGMENT_SLOTS = 2048        # distinct ground-truth ids per image segment_consistency_regularizer() has room for (more: the result is NaN)
+
+
+def segment_consistency_regularizer(embeddings, labels):
+    """loss/regularizers.py:5-35 on device tensors WITHOUT a host synchronisation: `embeddings` [B,P,I] probabilities (the caller adds the 1e-27,
+    pc_nerf/trainer.py:525-527), `labels` int64 [B,P] -> 0-dim tensor, differentiable with respect to `embeddings`.
+
+    The reference loops over images and segments on the host (unique -> .cpu() -> tensor_split, one bincount / arg-max / nll_loss per segment: a dozen
+    device round trips per segment).  Same quantities here from ~25 launches over the whole batch: the rays' segment slot = rank of their id among the
+    image's sorted distinct ids - EVERY distinct value is a segment, 0 included (:11-18); per (image, slot) the histogram of the rays' arg-max column (:22);
+    slots whose rays all predict column 0 are skipped (:24-25); label = first most frequent column among 1.. (:27), 0 when bins[0] * 0.5 > bins[label]
+    (:29-30); term = mean over the slot's rays of -log p[ray, label] (:32); after each image the RUNNING total is divided by that image's number of
+    segments (:33); finally by the number of images (:35).  Values agree with the reference up to the fp32 summation order of the per-segment means
+    (tests/test_gpu_loss.py against tests/golden/g6_reg.npz: value and gradient of the reference function)."""
+    B, P, I = embeddings.shape
+    S = min(P, SEGMENT_SLOTS)
+    arg = embeddings.detach().argmax(-1)                                                   # [B,P]  :22
+    srt, order = torch.sort(labels, dim=1)                                                 # :11-12
+    new = torch.ones_like(srt, dtype=torch.bool)
+    new[:, 1:] = srt[:, 1:] != srt[:, :-1]
+    slot_sorted = torch.cumsum(new, dim=1) - 1
+    n_seg = slot_sorted[:, -1] + 1                                                         # [B] distinct ids per image
+    slot = torch.empty_like(slot_sorted).scatter_(1, order, slot_sorted).clamp_(max=S - 1)  # [B,P] slot of each ray
+    hist = torch.zeros(B, S * I, dtype=torch.int32, device=embeddings.device)
+    hist.scatter_add_(1, slot * I + arg, torch.ones(1, dtype=torch.int32, device=embeddings.device).expand(B, P))
+    hist = hist.view(B, S, I)
+    rest = hist[..., 1:]
+    best = rest.argmax(-1) + 1                                                             # :27 (ties: the lowest column, as bincount().argmax())
+    skipped = rest.sum(-1) == 0                                                            # :24-25 (and the slots no ray maps to)
+    b0 = hist[..., 0]
+    bb = hist.gather(-1, best[..., None])[..., 0]
+    best = torch.where(b0 * 0.5 > bb, torch.zeros_like(best), best)                        # :29-30
+    lab_ray = best.gather(1, slot)                                                         # [B,P]
+    use = ~skipped.gather(1, slot)
+    nll = -torch.log(embeddings.gather(-1, lab_ray[..., None])[..., 0])                    # :32
+    per_seg = torch.zeros(B, S, dtype=nll.dtype, device=nll.device).scatter_add(1, slot, torch.where(use, nll, torch.zeros_like(nll)))
+    per_img = (per_seg / hist.sum(-1).clamp(min=1)).sum(1)                                 # segment means, summed per image
+    reg = per_img.new_zeros(())
+    for b in range(B):
+        reg = (reg + per_img[b]) / n_seg[b]                                                # :33 - the running total, earlier images included
+    reg = reg / B                                                                          # :35
+    return torch.where((n_seg > S).any(), torch.full_like(reg, float("nan")), reg)         # more ids than slots: loud, not wrong
+
+
 class LinAssignmentLoss(nn.Module):
     def __init__(self, *args, **kwargs):
         super().__init__()

@@ -556,3 +556,17 @@ def test_batch_render_keeps_channels_that_appear_in_later_chunks():
     rb = pagnerf_amd.batch_render(P(), rays, render_batch=4)
     assert rb.rgb.shape == (10, 3) and rb.depth.shape == (6, 1) and float(rb.reg) == 1.0
     assert torch.equal(rb.rgb[:, 0], torch.tensor([1.0] * 4 + [2.0] * 4 + [3.0] * 2))
+
+
+def test_segment_consistency_regularizer_host_logic_vs_reference_golden():
+    """pagnerf_amd.loss.segment_consistency_regularizer is plain tensor ops (no C-ABI call): on CPU tensors it reproduces the value and gradient the
+    reference's loss/regularizers.py:5-35 gave for the g6 batch (the GPU run of the same check: tests/test_gpu_loss.py)."""
+    import numpy as np
+    from conftest import golden
+    from pagnerf_amd import loss as pl
+    g = golden("g6_reg.npz")
+    x = (torch.from_numpy(g["seg_prob"]) + 1e-27).requires_grad_(True)
+    val = pl.segment_consistency_regularizer(x, torch.from_numpy(g["seg_labels"]))
+    val.backward()
+    np.testing.assert_allclose(float(val.detach()), float(g["seg_reg"]), rtol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["seg_reg_grad"], rtol=1e-5, atol=0)

@@ -216,3 +216,58 @@ def test_render_loss_matches_trainer_formulas(gpu_device):
     assert torch.equal(a, b)
     only = pl.render_loss(term_a=pl.NllTerm(inst.to(dev), inst_t.to(dev)))[0]
     assert abs(only.item() - F.nll_loss(torch.log(inst.double() + 1e-27), inst_t).item()) < 1e-5 * abs(only.item())
+
+
+def test_segment_consistency_regularizer_vs_reference_golden(gpu_device):
+    """pagnerf_amd.loss.segment_consistency_regularizer (device tensors, no host synchronisation) against the value and the autograd gradient the
+    reference's loss/regularizers.py:5-35 produced for the g6 batch (skipped segment, forced-0 segment, one-ray segment, large ids, three images with
+    different segment counts), and against the CPU oracle on a random batch."""
+    from pagnerf_amd import loss as pl
+    from oracle import regularizers as oreg
+    dev = gpu_device
+    g = golden("g6_reg.npz")
+    x = (torch.from_numpy(g["seg_prob"]).to(dev) + 1e-27).requires_grad_(True)
+    lab = torch.from_numpy(g["seg_labels"]).to(dev)
+    val = pl.segment_consistency_regularizer(x, lab)
+    val.backward()
+    np.testing.assert_allclose(float(val.detach()), float(g["seg_reg"]), rtol=1e-5)
+    assert np.array_equal(x.grad.cpu().numpy() != 0, g["seg_reg_grad"] != 0)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["seg_reg_grad"], rtol=1e-5, atol=0)
+    rs = np.random.RandomState(4)
+    B, P, I = 6, 4096, 200                                           # the shape of a best.yaml step
+    prob = torch.softmax(torch.from_numpy(rs.standard_normal(size=(B, P, I)).astype(np.float32)) * 3, -1)
+    labels = torch.from_numpy(rs.choice([0, 0, 0, 1001, 1002, 1007, 1013, 2000], size=(B, P)).astype(np.int64))
+    want = oreg.segment_consistency_regularizer(prob.numpy() + np.float32(1e-27), labels.numpy())
+    got = pl.segment_consistency_regularizer(prob.to(dev) + 1e-27, labels.to(dev))
+    np.testing.assert_allclose(float(got), float(want), rtol=1e-5)
+    # more distinct ids than slots: NaN, not a wrong number
+    many = torch.arange(pl.SEGMENT_SLOTS + 5, device=dev)[None]
+    pm = torch.softmax(torch.randn(1, pl.SEGMENT_SLOTS + 5, 8, device=dev), -1)
+    assert torch.isnan(pl.segment_consistency_regularizer(pm, many))
+
+
+def test_rays_to_3d_points_vs_oracle(gpu_device):
+    """BAPipeline.rays_to_3d_points / _indexed (utils/outlier_rejection.py:74-97 through the restated camera transform) against
+    oracle.regularizers.rays_to_3d_points per camera."""
+    from pagnerf_amd.ba_pipeline import BAPipeline, rotation_6d_to_matrix
+    from oracle import regularizers as oreg
+    import pagnerf_amd
+    dev = gpu_device
+    gen = torch.Generator().manual_seed(3)
+    C, n = 3, 50
+    views = torch.eye(4).repeat(C, 1, 1)
+    q, _ = torch.linalg.qr(torch.randn(C, 3, 3, generator=gen))
+    views[:, :3, :3] = q
+    views[:, :3, 3] = torch.randn(C, 3, generator=gen) * 0.1
+    pipe = BAPipeline(torch.nn.Module(), views).to(dev)
+    o, d = torch.randn(C * n, 3, generator=gen) * 0.01, torch.nn.functional.normalize(torch.randn(C * n, 3, generator=gen), dim=-1)
+    depth = torch.rand(C * n, 1, generator=gen)
+    got = pipe.rays_to_3d_points(pagnerf_amd.Rays(o.to(dev), d.to(dev)), depth.to(dev), torch.arange(C)).cpu()
+    got_i = pipe.rays_to_3d_points_indexed(o.to(dev), d.to(dev), depth.to(dev), torch.arange(C * n, device=dev) // n).cpu()
+    R = rotation_6d_to_matrix(pipe.camera_extrinsics.detach().cpu()[:, :6])
+    t = pipe.camera_extrinsics.detach().cpu()[:, 6:]
+    for c in range(C):
+        sl = slice(c * n, (c + 1) * n)
+        want = oreg.rays_to_3d_points(o[sl].numpy(), d[sl].numpy(), depth[sl, 0].numpy(), R[c].numpy(), t[c].numpy())
+        np.testing.assert_allclose(got[sl].numpy(), want, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got_i[sl].numpy(), want, rtol=1e-5, atol=1e-6)
