@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--raymarch", default="ray", choices=["ray", "voxel"])
     ap.add_argument("--occupancy", type=float, default=0.1, help="voxel mode: fraction of occupied 128^3 cells after the synthetic prune")
     ap.add_argument("--pose-opt", action="store_true", help="BAPipeline: rays from learnable camera extrinsics (configs[3])")
+    ap.add_argument("--two-call", action="store_true", help="with --lin-assign: the begin / rgb backward / finish / rest backward form (INTEGRATION.md)")
     ap.add_argument("--images", type=int, default=6, help="--pose-opt: images per step (rays are split evenly over them)")
     ap.add_argument("--table-dtype", default="fp32", choices=["fp32", "fp16"], help="grid tables (BASELINE configs[4]: fp16 features)")
     ap.add_argument("--fp32-coords", action="store_true", help="permuto grids: skip the fp16 coordinate rounding of the reference's autocast")
@@ -215,7 +216,7 @@ class PoseOpt:
         o = torch.zeros(total_rays, 3)
         d = torch.cat([(torch.rand(total_rays, 2, generator=gen) - 0.5) * 0.7, -torch.ones(total_rays, 1)], 1)
         cam = torch.arange(total_rays) // max(per, 1)
-        self.o, self.d, self.cam = o[lo:hi].to(dev), d[lo:hi].to(dev), cam[lo:hi].clamp(max=C - 1).to(dev)
+        self.o, self.d, self.cam = o[lo:hi].to(dev), d[lo:hi].to(dev), cam[lo:hi].clamp(max=C - 1).int().to(dev)
 
     def rays(self):
         return self.pipe.transform_rays_indexed(self.o, self.d, self.cam)
@@ -282,7 +283,7 @@ class ReferenceFormulationThingsLoss:
         return loss
 
 
-def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assign=None, images=1, points_fn=None, seg_reg=False):
+def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assign=None, images=1, points_fn=None, seg_reg=False, overlap=False):
     """images / points_fn / seg_reg: the instance term over a batch of `images` images as pc_nerf/trainer.py:483-533 forms it under
     configs/bup20/best.yaml - LinAssignmentThingsLoss per image (outlier rejection from the rendered depth's 3-D points when points_fn is
     given, :508-518) + segment_consistency_regularizer on the same probabilities (:525-527, weight 1.0)."""
@@ -304,15 +305,31 @@ def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assig
     elif "semantics" in channels and lin_assign is not None:
         # the instance term as the trainer forms it late in training (trainer.py:483-533, best.yaml inst_loss linear_assignment_things):
         # per-image Hungarian relabelling of the rendered instance probabilities, then the NLL against the virtual labels
-        loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1))
         B = images
         inst = rb.inst_embedding.float().reshape(B, -1, rb.inst_embedding.shape[-1])
         ids, stuff = gt["inst_ids"].reshape(B, -1), gt["stuff"].reshape(B, -1)
+        pts = points_fn(rb.depth.detach()).reshape(B, -1, 3) if points_fn is not None else None
+        if overlap and hasattr(lin_assign, "begin"):
+            # two-call form: the assignment's launches and copies first, then everything that does not need its result - the
+            # regulariser, the semantic term, and the colour / density / main-grid half of the backward (`loss_rgb.backward()`: the tracer's
+            # graphs are split, graph_split=True) - is queued while the host waits for the cost matrices and runs SciPy
+            pending = lin_assign.begin(inst, ids, stuff, pts)
+            loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0)
+            loss.backward()
+            reg = segment_consistency_regularizer(inst + 1e-27, ids) if seg_reg else None
+            rest, _ = render_loss(term_a=NllTerm(rb.semantics, gt["sem"], weight=0.1))
+            il = lin_assign.finish(pending)
+            il = il.mean() if reg is None else il.mean() + 1.0 * reg
+            rest = rest + 1000.0 * il
+            rest.backward()
+            loss = loss.detach() + rest.detach()
+            if world > 1:
+                sync.finish()
+            opt.step()
+            return loss
+        loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1))
         reg = segment_consistency_regularizer(inst + 1e-27, ids) if seg_reg else None     # queued BEFORE the assignment's one synchronisation
-        if points_fn is not None:
-            il = lin_assign(inst, ids, stuff, points_fn(rb.depth.detach()).reshape(B, -1, 3))
-        else:
-            il = lin_assign(inst, ids, stuff)
+        il = lin_assign(inst, ids, stuff, pts) if pts is not None else lin_assign(inst, ids, stuff)
         il = il.mean() if reg is None else il.mean() + 1.0 * reg                           # `inst_loss += w * reg` broadcasts the scalar over [B, P]; then .mean()
         loss = loss + 1000.0 * il
     elif "semantics" in channels:
@@ -764,7 +781,7 @@ def run_rank(args):
                 self.rays, self.gt = make_rays(rays_n, dev, seed=1000 + rank)      # per-rank ray shard
             self.opt = make_optimizer(self.nef, extra)
             self.lin_assign = None
-            self.images, self.points_fn, self.seg_reg = 1, None, False
+            self.images, self.points_fn, self.seg_reg, self.overlap = 1, None, False, False
             self.sync = None
             if world > 1:
                 early = [self.nef.delta_grid.tables] if hasattr(self.nef, "delta_grid") else []
@@ -773,7 +790,7 @@ def run_rank(args):
 
         def step(self, channels=None):
             return train_step(self.nef, self.tracer, self.opt, self.rays, self.gt, channels or self.channels, world, self.sync,
-                              lin_assign=self.lin_assign, images=self.images, points_fn=self.points_fn, seg_reg=self.seg_reg)
+                              lin_assign=self.lin_assign, images=self.images, points_fn=self.points_fn, seg_reg=self.seg_reg, overlap=self.overlap)
 
         def timed(self, n_steps, channels=None, profile=None):
             """profile (a set of C-ABI entry points): HIP events around those calls - which only exist on the EAGER path (a graph replay
@@ -813,6 +830,8 @@ def run_rank(args):
     if args.lin_assign and args.pose_opt and args.channels == "all":
         from pagnerf_amd.loss import LinAssignmentThingsLoss
         job.lin_assign, job.images, job.points_fn, job.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True), args.images, job.pose.points_3d, True
+        if args.two_call:
+            job.overlap, job.tracer.graph_split = True, True
     enc_name = "pag_%s_encode_fwd" % args.grid
 
     for _ in range(args.warmup):
@@ -943,17 +962,23 @@ def run_rank(args):
             # ---- the late-training step as the trainer runs it: instance term = LinAssignmentThingsLoss on the rendered probabilities
             from pagnerf_amd.loss import LinAssignmentThingsLoss
             la = {}
-            for tag, mod in (("device_cost_matrix", LinAssignmentThingsLoss()), ("reference_formulation", ReferenceFormulationThingsLoss())):
+            for tag, mod in (("device_cost_matrix", LinAssignmentThingsLoss()), ("device_cost_matrix_two_call", LinAssignmentThingsLoss()),
+                             ("reference_formulation", ReferenceFormulationThingsLoss())):
                 job.lin_assign = mod
-                for _ in range(2):
+                two = tag.endswith("two_call")
+                job.overlap, job.tracer.graph_split = two, (True if two else None)       # two backward graphs (rgb | panoptic), called in that order
+                for _ in range(4 if two else 2):
                     job.step()
                 n_la = max(3, args.steps // 2)
                 d_la, _ = job.timed(n_la)
                 la[tag] = dict(ms_per_step=round(d_la / n_la * 1e3, 3), rays_s=round(args.rays * n_la / d_la, 1))
-            job.lin_assign = None
+            job.lin_assign, job.overlap, job.tracer.graph_split = None, False, None
             la["labels_per_image"] = int((torch.unique(job.gt["inst_ids"]) > 0).sum())
             la["note"] = ("same step with the instance term of trainer.py:483-520 (per-image Hungarian relabelling + NLL); device_cost_matrix = "
-                          "pagnerf_amd.loss.LinAssignmentThingsLoss: pag_assign_cost (ids, sums, cost rows on the device), ONE copy + synchronisation, SciPy, pag_assign_nll; reference_formulation = one masked sum and one device-to-host copy per label")
+                          "pagnerf_amd.loss.LinAssignmentThingsLoss: pag_assign_cost (ids, sums, cost rows on the device), ONE copy + wait, SciPy, pag_assign_nll; "
+                          "device_cost_matrix_two_call = the same with loss_fn.begin() / rgb_loss.backward() / loss_fn.finish() / rest.backward(): the colour / "
+                          "density / main-grid backward runs while the host waits and solves the assignment; reference_formulation = one masked sum and one "
+                          "device-to-host copy per label")
             line["with_lin_assignment"] = la
         job.close()
         del job
@@ -989,14 +1014,20 @@ def run_rank(args):
             from pagnerf_amd.loss import LinAssignmentThingsLoss
             total = images * per_image
             out, regimes = dict(rays_per_step=total, images=images, pose_optimisation=True), {}
-            specs = (("dense_rgb", "epochs 0 - 200: dense occupancy, 'ray' march x 512, channels rgb + depth", "ray", 512, {"rgb", "depth"}, False, 6),
-                     ("post_prune_rgb", "epochs 201 - 600: voxel march (2 samples per voxel), channels rgb + depth", "voxel", 2, {"rgb", "depth"}, False, 20),
-                     ("post_prune_all_assign", "epochs 601 - 800: voxel march, all channels, LinAssignmentThingsLoss(outlier_rejection=True) on the "
-                                               "6-image batch + segment_consistency_regularizer", "voxel", 2, set(all_ch), True, 20))
+            late = ("epochs 601 - 800: voxel march, all channels, LinAssignmentThingsLoss(outlier_rejection=True) on the 6-image batch + "
+                    "segment_consistency_regularizer")
+            specs = (("dense_rgb", "epochs 0 - 200: dense occupancy, 'ray' march x 512, channels rgb + depth", "ray", 512, {"rgb", "depth"}, 0, 6),
+                     ("post_prune_rgb", "epochs 201 - 600: voxel march (2 samples per voxel), channels rgb + depth", "voxel", 2, {"rgb", "depth"}, 0, 20),
+                     ("post_prune_all_assign_one_backward", late + "; ONE loss.backward() after the assignment (the reference's loop as it stands)", "voxel", 2,
+                      set(all_ch), 1, 20),
+                     ("post_prune_all_assign", late + "; two-call form (INTEGRATION.md): loss_rgb.backward() - colour / density / main grid / pose - is queued "
+                      "before the host waits for the cost matrices, the panoptic half follows the assignment", "voxel", 2, set(all_ch), 2, 20))
             for tag, what, rm, smp, chans, assign, n_steps in specs:
                 j = Job(rays_n=total, samples=smp, grid="permuto", channels=chans, raymarch=rm, pose=True)
                 if assign:
                     j.lin_assign, j.images, j.points_fn, j.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True), images, j.pose.points_3d, True
+                if assign == 2:
+                    j.overlap, j.tracer.graph_split = True, True
                 for _ in range(4):                                  # step 0 learns the sample count, step 1 captures, 2 - 3 replay
                     j.step()
                 d, _ = j.timed(n_steps)
@@ -1076,7 +1107,8 @@ def run_rank(args):
             line["best_yaml_step"] = best_yaml_regimes()
             try:
                 reg = line["best_yaml_step"]["regimes"]
-                parts = [(200, reg["dense_rgb"]["ms_per_step"]), (400, reg["post_prune_rgb"]["ms_per_step"]), (200, reg["post_prune_all_assign"]["ms_per_step"])]
+                parts = [(200, reg["dense_rgb"]["ms_per_step"]), (400, reg["post_prune_rgb"]["ms_per_step"]),
+                         (200, min(reg["post_prune_all_assign"]["ms_per_step"], reg["post_prune_all_assign_one_backward"]["ms_per_step"]))]
                 ms = sum(w * t for w, t in parts) / sum(w for w, _ in parts)
                 line["schedule_weighted"] = dict(
                     ms_per_step=round(ms, 3), rays_per_step=6 * 4096, rays_s=round(6 * 4096 / ms * 1e3, 1),

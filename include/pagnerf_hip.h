@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 10
+#define PAG_ABI_VERSION 11
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -597,6 +597,25 @@ int pag_render_loss_bwd(const float *g, const float *fwd_out, const float *rgb, 
 int pag_adam_step(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                   const int64_t *numel, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                   void *stream);
+
+/* ---- pose optimisation: the per-ray camera transform (round 5, ABI 11) -------------------------------------------------------------
+ * pc_nerf/ba_pipeline.py:85-92 `transform_rays` (kaolin `inv_transform_rays` on the 'matrix_6dof_rotation' camera parameters registered at
+ * :49-51, then re-normalised directions) - what configs/bup20/best.yaml runs at the head of EVERY train step (optimize_extrinsics with
+ * extrinsics_epoch_end 900 > epochs 800, pc_nerf/trainer.py:308) - and its gradient.
+ *   params f32 [C,9] = (a1, a2, t) per camera:  b1 = a1/|a1|, b2 = normalise(a2 - (b1.a2) b1), b3 = b1 x b2,  R rows = (b1, b2, b3)
+ *   cam i32 [ceil(N / rays_per_entry)]: ray i belongs to camera cam[i / rays_per_entry] (rays_per_entry = 1: one index per ray; = rays per
+ *   image: one per image, the layout of `transform_rays`)
+ *   origins_w[i] = sum_k (origins_c[i] - t)[k] R[k]        dirs_w[i] = normalise(sum_k dirs_c[i][k] R[k])          all f32 [N,3]
+ * _bwd: d_params f32 [C,9] = d loss / d params from g_origins / g_dirs f32 [N,3] (either may be NULL = zero); EVERY row is written (zeros
+ * for cameras without a ray in the batch); one workgroup per camera, fixed summation order (bitwise reproducible). */
+int pag_pose_rays_fwd(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
+                      int64_t N, float *origins_w, float *dirs_w, void *stream);
+int pag_pose_rays_bwd(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
+                      int64_t N, const float *g_origins, const float *g_dirs, float *d_params, void *stream);
+
+/* Gradient of pag_view_embed with respect to the directions (the view direction depends on the camera rotation: pc_nerf/ba_pipeline.py:89-90
+ * -> pc_nerf/panoptic_delta_nef.py:196-200): d_dirs f32 [R,3] from g_out f32 [R, width].  (ABI 11) */
+int pag_view_embed_bwd(const float *dirs, int64_t R, int n_freq, int width, const float *g_out, float *d_dirs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,14 +11,17 @@ UNPINNED, recalled from the public kaolin sources):
   view matrix  V = [R | t] with rows of R = (b1, b2, b3)      (world -> camera)
   inv_transform_rays: origins_w = R^T (o_c - t),  dirs_w = R^T d_c
 
-These are per-RAY 3x3 products (N = 24 576 per step at best.yaml sizes) and stay in torch; what they
-make necessary on the hot path is the pose gradient through the packed samples: d loss / d xyz from
+These are per-RAY 3x3 products (N = 24 576 per step at best.yaml sizes).  On the GPU they are one launch
+each way (ops.pose_rays: pag_pose_rays_fwd / _bwd - the tensor-op form below is ~25 launches forward and
+~60 backward, 0.8 ms of a 3 ms post-prune step); CPU tensors (plumbing tests) take the tensor ops.  What
+they make necessary on the hot path is the pose gradient through the packed samples: d loss / d xyz from
 the encoders (pag_*_encode_bwd_xyz), the per-ray sums of ops.ray_samples and the view-embedding
-gradient of the colour decoder.
+gradient of the colour decoder (pag_view_embed_bwd).
 """
 import torch
 import torch.nn as nn
 
+from . import ops
 from .core import Pipeline, Rays
 
 
@@ -77,6 +80,11 @@ class BAPipeline(Pipeline):
     def transform_rays(self, base_rays, cam_ids):
         """:85-92 - base rays of len(cam_ids) images, [C*n,3] camera-frame -> world-frame Rays (dirs unit length)."""
         idx = self.camera_indices(cam_ids)
+        if self.camera_extrinsics.is_cuda and base_rays.origins.numel() and base_rays.origins.numel() % (3 * len(idx)) == 0:
+            dev = self.camera_extrinsics.device
+            o, d = base_rays.origins.reshape(-1, 3).to(dev), base_rays.dirs.reshape(-1, 3).to(dev)
+            ow, dw = ops.pose_rays(self.camera_extrinsics, idx.int(), o.shape[0] // len(idx), o, d)       # one launch (pag_pose_rays_fwd)
+            return Rays(ow, dw, dist_min=self.near, dist_max=self.far)
         prm = self.camera_extrinsics[idx]
         R = rotation_6d_to_matrix(prm[:, :6])                       # [C,3,3] world -> camera
         t = prm[:, 6:]
@@ -90,6 +98,11 @@ class BAPipeline(Pipeline):
     def transform_rays_indexed(self, origins_c, dirs_c, cam_idx):
         """Per-ray form of transform_rays(): ray i belongs to camera `cam_idx[i]` (row of camera_extrinsics), so a ray shard of a
         multi-GPU step may start and end in the middle of an image.  The arithmetic of :85-92 (see the note below)."""
+        if self.camera_extrinsics.is_cuda and origins_c.numel():
+            cam = cam_idx if (cam_idx.dtype == torch.int32 and cam_idx.device == self.camera_extrinsics.device) else \
+                cam_idx.to(device=self.camera_extrinsics.device, dtype=torch.int32)
+            ow, dw = ops.pose_rays(self.camera_extrinsics, cam, 1, origins_c.reshape(-1, 3), dirs_c.reshape(-1, 3))
+            return Rays(ow, dw, dist_min=self.near, dist_max=self.far)
         R_all = rotation_6d_to_matrix(self.camera_extrinsics[:, :6])      # [C,3,3] world -> camera, once per camera
         idx = cam_idx.to(self.camera_extrinsics.device).long()
         R = R_all.index_select(0, idx)                                   # [n,3,3]

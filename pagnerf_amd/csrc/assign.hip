@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256) void assign_nll_fwd_kernel(const float *__rest
         valid[ray] = ok ? 1 : 0;
         const float pv = (v >= 0 && v < n_cols) ? row[v] : 0.0f;
         nll[ray] = -logf(__fadd_rn(pv, 1e-27f));
-        if (ok && v != (int64_t)arg) atomicOr(wrong, 1);
+        // the image's `any wrong` flag: a plain store of 1 by whoever finds it still 0 (benign race: every writer stores the same value).  One
+        // atomicOr per wrong ray - 24 576 of them on six words in an untrained step - serialised in the L2: 0.2 ms of a 0.01 ms kernel.
+        if (ok && v != (int64_t)arg && __hip_atomic_load(wrong, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(wrong, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __global__ __launch_bounds__(256) void assign_nll_finish_kernel(float *__restrict__ nll, const uint8_t *__restrict__ valid, const int32_t *__restrict__ wrong, int64_t P) {

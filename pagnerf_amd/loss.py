@@ -161,6 +161,12 @@ class LinAssignmentThingsLoss(nn.Module):
         return self._ws
 
     def _fast(self, prob, labels_gt, stuff_mask, points_3d=None):
+        return self._finish(self._begin(prob, labels_gt, stuff_mask, points_3d))
+
+    def _begin(self, prob, labels_gt, stuff_mask, points_3d=None):
+        """Queue the device side of the assignment (ids, sums, cost rows, id ranges: pag_assign_cost) and the copies to pinned memory, and record an EVENT
+        behind them: whatever the caller queues on the stream afterwards (other loss terms, the part of the backward that does not depend on the
+        instance term) runs while the host waits for that event and solves the assignments in _finish()."""
         B, P, I = prob.shape
         w = self._workspace(B, P, I, prob.device)
         st = L.stream()
@@ -180,7 +186,16 @@ class LinAssignmentThingsLoss(nn.Module):
                   w["psums"].data_ptr(), w["pcounts"].data_ptr(), w["lo_hi"].data_ptr(), st)          # every image of the step in one set of launches
         for name in names:
             w["h_" + name].copy_(w[name], non_blocking=True)
-        torch.cuda.current_stream(prob.device).synchronize()           # the step's one wait for the device (the stream the launches above went to)
+        ev = w.get("event")
+        if ev is None:
+            ev = w["event"] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(prob.device))
+        return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts)
+
+    def _finish(self, pending):
+        prob, labels_gt, stuff_mask, rej, w, _pts = pending
+        B, P, I = prob.shape
+        w["event"].synchronize()                                       # the step's one wait for the device: only for what _begin() queued
         info = w["h_info"].numpy()
         if info[:, 1].any():
             return None                                                # more distinct ids than the device-side set holds: general path
@@ -191,7 +206,7 @@ class LinAssignmentThingsLoss(nn.Module):
             if n == 0:
                 continue
             cost = w["h_cost"].numpy()[b, :n].astype(np.float64)
-            if points_3d is not None:
+            if rej:
                 lh = w["h_lo_hi"].numpy()[b, :n]
                 ids = np.arange(I - 1)[None, :]
                 cost[~((lh[:, :1] <= ids) & (ids <= lh[:, 1:]))] = 10000                        # utils/outlier_rejection.py:8-51
@@ -202,26 +217,60 @@ class LinAssignmentThingsLoss(nn.Module):
         self.last_virtual_labels = virt       # i64 [B, P]: the virtual ground truth of :23-54 this step trained against (defined on valid rays: stuff | id > 0)
         return loss
 
-    def forward(self, inst_probabilities, labels_gt, stuff_mask, points_3d=None, *args, **kwargs):
-        p3 = inst_probabilities
+    # ---- two-call form (this build's addition) ---------------------------------------------------------------------------------------------------
+    def begin(self, inst_probabilities, labels_gt, stuff_mask, points_3d=None):
+        """forward() split in two so that device work can be queued between the launches and the host's wait:
+
+            pending = loss_fn.begin(inst, ids, stuff, points_3d)     # pag_assign_cost + copies + event; returns at once
+            ...queue anything that does not need the instance loss (other loss terms; `rgb_loss.backward()`: the colour / density / main-grid
+               half of the backward - see INTEGRATION.md)...
+            inst_loss = loss_fn.finish(pending)                      # waits for the event, SciPy per image (:45), pag_assign_nll_fwd
+
+        finish(begin(...)) == forward(...) (same launches, same values)."""
+        fast = self._gate(inst_probabilities, labels_gt, stuff_mask, points_3d)
+        if fast is None:
+            return ("general", inst_probabilities, labels_gt, stuff_mask, points_3d)
+        return ("fast", self._begin(*fast), inst_probabilities, labels_gt, stuff_mask, points_3d)
+
+    def finish(self, pending):
+        if pending[0] == "fast":
+            out = self._finish(pending[1])
+            if out is not None:
+                return out
+            pending = ("general",) + pending[2:]
+        _, p3, gt, sm, pts = pending
+        return self._general(p3, gt, sm, pts)
+
+    def _gate(self, p3, labels_gt, stuff_mask, points_3d):
+        """Arguments of the one-synchronisation path, or None when the inputs are outside what its launches read through raw pointers."""
         assert (self.outlier_rejection and points_3d is not None) or not self.outlier_rejection, "Outlier rejection requires 3d points"      # :36-37
-        if (self.fast_path and torch.is_tensor(p3) and p3.is_cuda and p3.dim() == 3 and p3.dtype == torch.float32
+        if not (self.fast_path and torch.is_tensor(p3) and p3.is_cuda and p3.dim() == 3 and p3.dtype == torch.float32
                 and p3.stride(2) == 1 and 2 <= p3.shape[2] <= 1025 and torch.is_tensor(labels_gt) and labels_gt.dtype == torch.int64
                 and labels_gt.shape == p3.shape[:2] and torch.is_tensor(stuff_mask) and stuff_mask.shape == p3.shape[:2]
                 and labels_gt.device == p3.device and stuff_mask.device == p3.device):
-            # (everything the launches read through raw pointers lives on the probabilities' device and has the shape the kernels index with;
-            # anything else - a CPU label tensor, a ragged list of points - takes the general path below, which raises Python errors)
-            pts = None
-            if self.outlier_rejection:
-                pts = points_3d if torch.is_tensor(points_3d) else torch.stack(list(points_3d))
-            if pts is None or (pts.device == p3.device and tuple(pts.shape) == (p3.shape[0], p3.shape[1], 3)):
-                gt_c = labels_gt.contiguous()
-                sm_c = stuff_mask.contiguous()
-                # any non-zero entry is True, as torch.logical_or (:60) reads it (a plain .to(uint8) would wrap 256 to 0 and truncate 0.5)
-                sm_c = sm_c.view(torch.uint8) if sm_c.dtype == torch.bool else (sm_c != 0).view(torch.uint8)
-                out = self._fast(p3, gt_c, sm_c, pts)
-                if out is not None:
-                    return out
+            return None
+        # (everything the launches read through raw pointers lives on the probabilities' device and has the shape the kernels index with;
+        # anything else - a CPU label tensor, a ragged list of points - takes the general path, which raises Python errors)
+        pts = None
+        if self.outlier_rejection:
+            pts = points_3d if torch.is_tensor(points_3d) else torch.stack(list(points_3d))
+            if not (pts.device == p3.device and tuple(pts.shape) == (p3.shape[0], p3.shape[1], 3)):
+                return None
+        gt_c = labels_gt.contiguous()
+        sm_c = stuff_mask.contiguous()
+        # any non-zero entry is True, as torch.logical_or (:60) reads it (a plain .to(uint8) would wrap 256 to 0 and truncate 0.5)
+        sm_c = sm_c.view(torch.uint8) if sm_c.dtype == torch.bool else (sm_c != 0).view(torch.uint8)
+        return p3, gt_c, sm_c, pts
+
+    def forward(self, inst_probabilities, labels_gt, stuff_mask, points_3d=None, *args, **kwargs):
+        fast = self._gate(inst_probabilities, labels_gt, stuff_mask, points_3d)
+        if fast is not None:
+            out = self._fast(*fast)
+            if out is not None:
+                return out
+        return self._general(inst_probabilities, labels_gt, stuff_mask, points_3d)
+
+    def _general(self, inst_probabilities, labels_gt, stuff_mask, points_3d=None):
         loss = []
         for i, (p, gt, m) in enumerate(zip(inst_probabilities, labels_gt, stuff_mask)):
             valid = torch.logical_or(m, gt > 0)                                             # :60

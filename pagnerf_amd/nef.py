@@ -182,9 +182,12 @@ class PanopticDeltaNeF(nn.Module):
             src, index = ray_dirs, ridx
         else:
             src, index = ray_d, torch.arange(ray_d.shape[0], device=ray_d.device, dtype=torch.int32)
-        if self.embedder_type == "positional" and src.is_cuda and not (src.requires_grad and torch.is_grad_enabled()):
+        if self.embedder_type == "positional" and src.is_cuda:
             width = 3 + 6 * self.view_multires
-            return ops.view_embed(src, self.view_multires, width + (-width) % 8), index      # one launch (pag_view_embed)
+            width += (-width) % 8
+            if src.requires_grad and torch.is_grad_enabled():                                # pose optimisation: d / d dirs through pag_view_embed_bwd
+                return ops.view_embed_grad(src, self.view_multires, width), index
+            return ops.view_embed(src, self.view_multires, width), index                     # one launch (pag_view_embed)
         pe = positional_embed(-src.float(), self.view_multires) if self.embedder_type == "positional" else -src.float()
         return F.pad(pe, (0, (-pe.shape[1]) % 8)).contiguous(), index
 

@@ -869,6 +869,76 @@ def view_embed(dirs, n_freq, width):
     return out
 
 
+class _ViewEmbed(torch.autograd.Function):
+    """view_embed() with d / d dirs (pose optimisation: the view direction depends on the camera rotation, ba_pipeline.py:89-90):
+    pag_view_embed forward - the SAME values as the gradient-free path - and pag_view_embed_bwd instead of the ~25 launches of the
+    tensor-op form's forward + backward."""
+
+    @staticmethod
+    def forward(ctx, dirs, n_freq, width):
+        d = dirs.detach().contiguous().float()
+        ctx.save_for_backward(d)
+        ctx.cfg = (int(n_freq), int(width))
+        out = torch.empty(d.shape[0], width, device=d.device)
+        _call("pag_view_embed", L.ptr(d), d.shape[0], int(n_freq), int(width), L.ptr(out), L.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        n_freq, width = ctx.cfg
+        g = g.contiguous().float()
+        out = torch.empty_like(d)
+        _call("pag_view_embed_bwd", L.ptr(d), d.shape[0], n_freq, width, L.ptr(g), L.ptr(out), L.stream())
+        return out, None, None
+
+
+def view_embed_grad(dirs, n_freq, width):
+    """view_embed() differentiable with respect to `dirs` (f32 [R,3] on the GPU)."""
+    _check_gpu(dirs)
+    return _ViewEmbed.apply(dirs, n_freq, width)
+
+
+class _PoseRays(torch.autograd.Function):
+    """pc_nerf/ba_pipeline.py:85-92 as one launch each way (pag_pose_rays_fwd / _bwd): camera-frame rays -> world-frame rays through the
+    camera parameters [C,9], differentiable with respect to the parameters."""
+
+    @staticmethod
+    def forward(ctx, params, cam, rays_per_entry, origins_c, dirs_c):
+        p = params.detach().contiguous().float()
+        oc, dc = origins_c.detach().contiguous().float(), dirs_c.detach().contiguous().float()
+        N = oc.shape[0]
+        ow, dw = torch.empty(N, 3, device=p.device), torch.empty(N, 3, device=p.device)
+        _call("pag_pose_rays_fwd", L.ptr(p), p.shape[0], L.ptr(cam), int(rays_per_entry), L.ptr(oc), L.ptr(dc), N, L.ptr(ow), L.ptr(dw), L.stream())
+        ctx.save_for_backward(p, cam, oc, dc)
+        ctx.rpe = int(rays_per_entry)
+        ctx.set_materialize_grads(False)
+        return ow, dw
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        p, cam, oc, dc = ctx.saved_tensors
+        if g_o is None and g_d is None:
+            return None, None, None, None, None
+        g_o = g_o.contiguous().float() if g_o is not None else None
+        g_d = g_d.contiguous().float() if g_d is not None else None
+        d_params = torch.empty_like(p)
+        _call("pag_pose_rays_bwd", L.ptr(p), p.shape[0], L.ptr(cam), ctx.rpe, L.ptr(oc), L.ptr(dc), oc.shape[0], L.ptr(g_o), L.ptr(g_d), L.ptr(d_params),
+              L.stream())
+        return d_params, None, None, None, None
+
+
+def pose_rays(params, cam, rays_per_entry, origins_c, dirs_c):
+    """-> (origins_w, dirs_w) f32 [N,3]: ray i through camera cam[i // rays_per_entry] (row of params f32 [C,9] = a1, a2, t); cam i32."""
+    _check_gpu(params, cam, origins_c, dirs_c)
+    if origins_c.shape != dirs_c.shape or origins_c.dim() != 2 or origins_c.shape[1] != 3:
+        raise RuntimeError("pose_rays: origins / dirs must both be [N,3], got %s and %s" % (tuple(origins_c.shape), tuple(dirs_c.shape)))
+    n_entries = (origins_c.shape[0] + rays_per_entry - 1) // rays_per_entry
+    if cam.dtype != torch.int32 or cam.numel() < n_entries or params.dim() != 2 or params.shape[1] != 9:
+        raise RuntimeError("pose_rays: cam must be int32 with one entry per %d rays, params [C,9]" % rays_per_entry)
+    return _PoseRays.apply(params, cam.contiguous(), int(rays_per_entry), origins_c, dirs_c)
+
+
 class _RaySamples(torch.autograd.Function):
     """samples = origins[ray] + dirs[ray] * depth with the march kernel's values as the forward result (bit-identical to
     the non-differentiable path) and d/d origins, d/d dirs as per-ray segmented sums - what autograd gives through

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_assignment_entry_points_validate_without_gpu(lib):
@@ -44,6 +44,22 @@ def test_assignment_entry_points_validate_without_gpu(lib):
     assert b"max_rows" in lib.pag_last_error_string()
     assert lib.pag_assign_nll_fwd(buf, 1, 5, 0, 100, 200, buf, None, buf, buf, buf, 199, 1, buf, buf, buf, buf, None) == -1
     assert lib.pag_assign_nll_bwd(buf, 1, 5, 0, 200, 200, buf, buf, buf, None, buf, None) == -1                              # NULL grad
+
+
+def test_pose_entry_points_validate_without_gpu(lib):
+    """pag_pose_rays_fwd / _bwd, pag_view_embed_bwd (ABI 11): empty batches are no-ops, bad sizes and NULL buffers are rejected before any launch."""
+    buf = (ctypes.c_float * 16)()
+    assert lib.pag_pose_rays_fwd(None, 1, None, 1, None, None, 0, None, None, None) == 0                       # no ray: nothing to do
+    assert lib.pag_pose_rays_fwd(buf, 1, None, 1, buf, buf, 4, buf, buf, None) == -1                          # NULL camera index
+    assert b"NULL" in lib.pag_last_error_string()
+    assert lib.pag_pose_rays_fwd(buf, 0, buf, 1, buf, buf, 4, buf, buf, None) == -1                           # no camera
+    assert lib.pag_pose_rays_fwd(buf, 1, buf, 0, buf, buf, 4, buf, buf, None) == -1                           # rays_per_entry < 1
+    assert b"rays_per_entry" in lib.pag_last_error_string()
+    assert lib.pag_pose_rays_fwd(buf, 1, buf, 1, buf, buf, 4, None, buf, None) == -1                          # NULL output
+    assert lib.pag_pose_rays_bwd(buf, 1, buf, 1, buf, buf, 4, buf, buf, None, None) == -1                     # NULL d_params
+    assert lib.pag_view_embed_bwd(None, 0, 4, 32, None, None, None) == 0
+    assert lib.pag_view_embed_bwd(buf, 2, 4, 16, buf, buf, None) == -1                                        # width < 3 + 6 n_freq
+    assert lib.pag_view_embed_bwd(buf, 2, 4, 32, None, buf, None) == -1
 
 
 def test_regular_library_carries_no_instrumentation(lib):

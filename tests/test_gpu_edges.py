@@ -228,3 +228,86 @@ def test_rays_without_samples_keep_the_background_without_prefilled_buffers(gpu_
             assert torch.equal(rb.rgb[miss], torch.full_like(rb.rgb[miss], 1.0 if bg == "white" else 0.0))
             for ch in ("depth", "alpha", "semantics", "inst_embedding"):
                 assert float(getattr(rb, ch)[miss].abs().max()) == 0.0, ch
+
+
+def test_pose_rays_kernels_vs_tensor_ops(gpu_device):
+    """pag_pose_rays_fwd / _bwd (pc_nerf/ba_pipeline.py:85-92 as one launch each way) against the tensor-op restatement of the same map and torch
+    autograd through it: per-ray camera indices in arbitrary order, per-image indices (rays_per_entry = rays per image), cameras without a ray
+    (zero gradient row), repeated cameras, non-unit a1 / non-orthogonal a2 (the Gram-Schmidt chain), bitwise reproducible gradients."""
+    from pagnerf_amd import ops
+    from pagnerf_amd.ba_pipeline import BAPipeline, rotation_6d_to_matrix
+    dev = gpu_device
+    gen = torch.Generator().manual_seed(11)
+    C, N = 7, 1000
+    prm = torch.randn(C, 9, generator=gen)
+    prm[:, :3] *= 1.7                                                     # |a1| != 1
+    oc = torch.randn(N, 3, generator=gen) * 0.1
+    dc = torch.randn(N, 3, generator=gen)
+    cam = torch.randint(0, C - 2, (N,), generator=gen)                    # cameras C-2, C-1 see no ray
+    go, gd = torch.randn(N, 3, generator=gen), torch.randn(N, 3, generator=gen)
+
+    def ref(p, cam_idx):
+        R = rotation_6d_to_matrix(p[:, :6]).index_select(0, cam_idx)
+        t = p[:, 6:].index_select(0, cam_idx)
+        v = oc.double() - t
+        o = v[:, 0:1] * R[:, 0] + v[:, 1:2] * R[:, 1] + v[:, 2:3] * R[:, 2]
+        d = dc.double()[:, 0:1] * R[:, 0] + dc.double()[:, 1:2] * R[:, 1] + dc.double()[:, 2:3] * R[:, 2]
+        return o, d / torch.linalg.norm(d, dim=-1, keepdim=True)
+    for rpe, cam_t in ((1, cam), (125, torch.tensor([0, 3, 3, 1, 4, 0, 2, 4]))):
+        cam_ray = cam_t if rpe == 1 else cam_t.repeat_interleave(rpe)
+        pr = prm.double().clone().requires_grad_(True)
+        o_r, d_r = ref(pr, cam_ray)
+        ((o_r * go.double()).sum() + (d_r * gd.double()).sum()).backward()
+        pg = prm.to(dev).requires_grad_(True)
+        o_g, d_g = ops.pose_rays(pg, cam_t.int().to(dev), rpe, oc.to(dev), dc.to(dev))
+        np.testing.assert_allclose(o_g.detach().cpu().numpy(), o_r.detach().float().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(d_g.detach().cpu().numpy(), d_r.detach().float().numpy(), rtol=1e-5, atol=1e-6)
+        ((o_g * go.to(dev)).sum() + (d_g * gd.to(dev)).sum()).backward()
+        want = pr.grad.float()
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
+        assert float(pg.grad[C - 2:].abs().max()) == 0.0                 # cameras without a ray: rows written, zero
+        first = pg.grad.clone()
+        pg.grad = None
+        o2, d2 = ops.pose_rays(pg, cam_t.int().to(dev), rpe, oc.to(dev), dc.to(dev))
+        ((o2 * go.to(dev)).sum() + (d2 * gd.to(dev)).sum()).backward()
+        assert torch.equal(pg.grad, first)                                # fixed summation order
+        # only one of the two outputs used: the other gradient is None, not a zero tensor
+        pg.grad = None
+        o3, _ = ops.pose_rays(pg, cam_t.int().to(dev), rpe, oc.to(dev), dc.to(dev))
+        (o3 * go.to(dev)).sum().backward()
+        pr2 = prm.double().clone().requires_grad_(True)
+        (ref(pr2, cam_ray)[0] * go.double()).sum().backward()
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), pr2.grad.float().numpy(), rtol=2e-4, atol=2e-4 * float(pr2.grad.abs().max()))
+    # BAPipeline on the GPU uses the kernels in both forms and they agree with each other
+    views = torch.eye(4).repeat(4, 1, 1)
+    views[:, :3, 3] = torch.randn(4, 3, generator=gen) * 0.1
+    pipe = BAPipeline(torch.nn.Module(), views, anchor_frame_idxs=[0]).to(dev)
+    import pagnerf_amd
+    base = pagnerf_amd.Rays(oc[:800].to(dev), dc[:800].to(dev))
+    a = pipe.transform_rays(base, [2, 0, 3, 1])
+    b = pipe.transform_rays_indexed(oc[:800].to(dev), dc[:800].to(dev), torch.tensor([2, 0, 3, 1]).repeat_interleave(200).to(dev))
+    assert torch.equal(a.origins, b.origins) and torch.equal(a.dirs, b.dirs) and a.origins.requires_grad
+    (a.origins.sum() + a.dirs[:, 0].sum()).backward()
+    assert float(pipe.camera_extrinsics.grad[0].abs().max()) == 0.0 and float(pipe.camera_extrinsics.grad[1:].abs().min()) >= 0.0     # anchor frame masked (:56-60)
+
+
+def test_view_embed_gradient_vs_tensor_ops(gpu_device):
+    """ops.view_embed_grad: forward = pag_view_embed (the gradient-free path's values), backward = pag_view_embed_bwd, against torch autograd through the
+    tensor-op form of wisp's PositionalEmbedder on -dirs."""
+    from pagnerf_amd import ops
+    from pagnerf_amd.nef import positional_embed
+    dev = gpu_device
+    gen = torch.Generator().manual_seed(2)
+    for n_freq, R in ((4, 1000), (0, 5), (6, 33)):
+        d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+        width = 3 + 6 * n_freq
+        width += (-width) % 8
+        g = torch.randn(R, width, generator=gen)
+        dr = d.double().clone().requires_grad_(True)
+        pe = positional_embed(-dr, n_freq) if n_freq else -dr
+        (pe * g[:, :pe.shape[1]].double()).sum().backward()
+        dg = d.to(dev).requires_grad_(True)
+        out = ops.view_embed_grad(dg, n_freq, width)
+        assert torch.equal(out.detach(), ops.view_embed(d.to(dev), n_freq, width))
+        (out * g.to(dev)).sum().backward()
+        np.testing.assert_allclose(dg.grad.cpu().numpy(), dr.grad.float().numpy(), rtol=1e-4, atol=1e-4)
