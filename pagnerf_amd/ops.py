@@ -178,8 +178,7 @@ def _encode_bwd_xyz(spec, xyz, tables, grad_out, feat_scale, flags=None):
     flags = spec.flags if flags is None else flags
     fs = L.host_floats(feat_scale)
     sm, sc, lay = _layout_args(grad_out)
-    d_xyz = torch.empty(M, 3, device=xyz.device)
-    ws = torch.empty(8 * M * 3, device=xyz.device)
+    d_xyz, ws = torch.empty(M, 3, device=xyz.device), torch.empty(8 * M * 3, device=xyz.device)
     if spec.kind == "hash":
         _call("pag_hash_encode_bwd_xyz", L.ptr(xyz), M, L.ptr(tables), L.dtype_code(tables), grad_out.data_ptr(), L.dtype_code(grad_out),
               sm, sc, lay, spec.L, spec.F, spec.log2_T, spec.res, fs, L.ptr(d_xyz), L.ptr(ws), ws.numel() * 4, flags, L.stream())
