@@ -197,6 +197,20 @@ def make_rays(n, dev, seed):
     return pagnerf_amd.Rays(o.to(dev), d.to(dev), dist_min=0.0, dist_max=1.9), {k: v.to(dev) for k, v in gt.items()}
 
 
+def sphere_gt(origins, dirs):
+    """Closed-form colours of a textured sphere of radius 0.5 at the origin under a white background for world-frame rays (the analytic scene of
+    scripts/train_synthetic.py): a LEARNABLE scene - after a few hundred steps the model has empty space (sigma = relu(pre) = 0 exactly) around a
+    surface, which is what real training batches look like and what the backward's zero-gradient early-outs act on."""
+    import torch
+    o, d = origins.detach().float().cpu(), dirs.detach().float().cpu()
+    b = (o * d).sum(-1)
+    disc = b * b - ((o * o).sum(-1) - 0.25)
+    hit = disc > 0
+    t = -b - torch.sqrt(disc.clamp_min(0))
+    p = o + d * t[:, None]
+    return torch.where(hit[:, None], 0.5 + 0.5 * torch.sin(p * 9.0 + torch.tensor([0.0, 2.0, 4.0])), torch.ones(o.shape[0], 3)), hit
+
+
 class PoseOpt:
     """configs[3]: rays of `images` cameras generated from learnable extrinsics (pc_nerf/ba_pipeline.py:85-92).  The camera-frame base
     rays of the whole step are fixed; a rank transforms its own contiguous block with per-ray camera indices."""
@@ -1022,8 +1036,20 @@ def run_rank(args):
                       set(all_ch), 1, 20),
                      ("post_prune_all_assign", late + "; two-call form (INTEGRATION.md): loss_rgb.backward() - colour / density / main grid / pose - is queued "
                       "before the host waits for the cost matrices, the panoptic half follows the assignment", "voxel", 2, set(all_ch), 2, 20))
+            specs = specs + (("dense_rgb_trained_scene", "the dense regime on a LEARNABLE scene (analytic textured sphere, white background) after 300 training steps: most "
+                              "samples in front of the surface are empty space with sigma = relu(pre) = 0 exactly, their gradients are exactly zero and the encoders' backward "
+                              "skips their waves (bin pass) and row requests (position gradient), bit-identically; the untrained random scene of the other lines has no such samples", "ray", 512, {"rgb", "depth"}, 3, 6),)
             for tag, what, rm, smp, chans, assign, n_steps in specs:
                 j = Job(rays_n=total, samples=smp, grid="permuto", channels=chans, raymarch=rm, pose=True)
+                trained = assign == 3
+                if trained:
+                    assign = 0
+                    with torch.no_grad():
+                        r0 = j.rays()
+                    rgb_gt, hit = sphere_gt(r0.origins, r0.dirs)
+                    j.gt["rgb"] = rgb_gt.to(dev)
+                    for _ in range(300):
+                        j.step()
                 if assign:
                     j.lin_assign, j.images, j.points_fn, j.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True), images, j.pose.points_3d, True
                 if assign == 2:
@@ -1037,6 +1063,15 @@ def run_rank(args):
                            hip_graphs=j.graph_stats())
                 if rm == "voxel":
                     ent["occupied_fraction"] = round(j.occupied, 4)
+                if trained:
+                    with torch.no_grad():
+                        rr = j.rays()
+                        mo = j.nef.grid.raymarch(rr, level=None, num_samples=smp, raymarch_type=rm)
+                        dens = j.nef(coords=mo[2], ray_d=rr.dirs.index_select(0, mo[0]), channels="density").reshape(-1)
+                    ent["pretraining_steps"] = 300
+                    ent["samples_with_sigma_exactly_zero"] = round(float((dens == 0).float().mean()), 4)
+                    ent["rays_hitting_the_sphere"] = round(float(hit.float().mean()), 4)
+                    del dens, mo
                 # eager pass with events around every C-ABI call: where the step's device time goes, with bytes and fractions of the roofs
                 was, j.tracer.use_graphs = j.tracer.use_graphs, False
                 for _ in range(2):

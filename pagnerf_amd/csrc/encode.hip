@@ -284,6 +284,14 @@ __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void permuto_bwd_kernel(const 
 // fetches the same 8 / 4 rows, contracts them with the incoming gradient and chains through the weight
 // derivatives.  Same XCD-pinned launch as the forward; group g writes its partial sum to part[g][m][3] and a tiny
 // second kernel adds the 8 groups (deterministic, no atomics).
+// any of the eight bf16 values of a gradient piece other than +-0 (NaN counts as non-zero)
+typedef bf16_t bf16x8_piece __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bool piece_nonzero(const bf16x8_piece &t) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 b = __builtin_bit_cast(u32x4, t);
+    return ((b[0] | b[1] | b[2] | b[3]) & 0x7FFF7FFFu) != 0u;
+}
+
 template <int KIND /*0 hash, 1 permuto*/, typename TableT, typename GradT, int F, int LPX>
 __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables,
                                                        const GradT *__restrict__ go, int64_t sm, int64_t sc, int grouped,
@@ -304,6 +312,14 @@ __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const flo
         bf16x8_t t = *reinterpret_cast<const bf16x8_t *>(reinterpret_cast<const bf16_t *>(go) + ((int64_t)g * M + i) * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) gpiece[e] = (float)t[e];
+        // A sample whose gradient piece is exactly zero (+-0: empty space of a trained scene - sigma = relu(pre) = 0, so neither the colour nor the
+        // density path sends anything back -, filler samples of a padded batch) gets d xyz = 0 without its 4 x LPX row requests: the same value
+        // the products with zero give (scripts/zero_weight_tiles.py: 93 % of the samples of the trained analytic scene).
+        if (!piece_nonzero(t)) {
+            float *o = part + ((int64_t)g * M + i) * 3;
+            o[0] = 0.0f, o[1] = 0.0f, o[2] = 0.0f;
+            return;
+        }
     }
     float e[LPX][NV][F];
     float w[LPX][4];         // hash: wx, wy, wz, -   permuto: unused
@@ -590,11 +606,18 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
     // grouped (LPX = ceil(L/8)): blockIdx.y = XCD group g, levels g, g+8, ... share ONE counting sort and the 16-byte
     // gradient piece is read once.  strided (LPX = 1): blockIdx.y = level.
     float gpiece[8];
+    bool wave_live = true;
     if (grouped) {
         typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
         bf16x8_t t = *reinterpret_cast<const bf16x8_t *>(reinterpret_cast<const bf16_t *>(go) + ((int64_t)blockIdx.y * M + ic) * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) gpiece[e] = (float)t[e];
+        // A wave whose 64 samples all carry an exactly-zero gradient piece (empty space of a trained scene: sigma = relu(pre) = 0, so neither the
+        // colour nor the density path sends anything back; the filler samples of a padded batch) would emit entries whose values are all +-0: they
+        // add nothing in pass 2 (fixed-point sums).  Such a wave skips the lattice, the merges and the counting of all its levels and only keeps
+        // the workgroup's barriers (scripts/zero_weight_tiles.py: 85 % of the 32-sample tiles of the trained analytic scene).  Wave-uniform on purpose:
+        // the merge of adjacent lanes relies on consecutive lanes being consecutive entries.
+        wave_live = __ballot(live && piece_nonzero(t)) != 0ull;
     }
     const float *scale = KIND == 0 ? hp.scale : pp.scale;
     const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
@@ -613,6 +636,11 @@ __global__ __launch_bounds__(tile_samples(KIND == 0 ? 8 : 4), (KIND == 1 ? PAG_B
         const int level = grouped ? xcd8_level((int)blockIdx.y, j) : (int)blockIdx.y;
         const bool lv = level < L;
         const int lc = lv ? level : L - 1;
+        if (!wave_live) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) emit[j][k] = false;
+            continue;
+        }
         float w[NV];
         float gv[F];
         if (KIND == 0) {

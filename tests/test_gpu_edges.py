@@ -311,3 +311,50 @@ def test_view_embed_gradient_vs_tensor_ops(gpu_device):
         assert torch.equal(out.detach(), ops.view_embed(d.to(dev), n_freq, width))
         (out * g.to(dev)).sum().backward()
         np.testing.assert_allclose(dg.grad.cpu().numpy(), dr.grad.float().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("pose", [False, True])
+def test_zero_gradient_tiles_take_the_early_outs_with_the_same_gradients(gpu_device, pose):
+    """Samples whose upstream gradient is exactly zero (in a trained scene: empty space, sigma = relu(pre) = 0; here: rays the loss does not use) make the
+    backward kernels skip whole waves of the table gradient's bin pass and the row requests of the position gradient.
+    The skipped work contributes exact zeros, so: gradients of `loss over the rays in S` computed on the FULL batch (most tiles dead: runs of 24 unused rays =
+    24 x 64 samples) equal - up to the fp32 summation order of the weight-gradient slabs - the gradients of the same loss on a batch that holds only the
+    rays of S (nothing to skip), for every parameter and, with pose optimisation, for the camera extrinsics."""
+    import pagnerf_amd
+    import test_gpu_parity as T
+    from pagnerf_amd.ba_pipeline import BAPipeline
+    dev = gpu_device
+    N, S = 256, 64
+    nef, tracer, rays, occ, jitter = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=12)
+    keep = (torch.arange(N) % 32) >= 24                       # 8 of every 32 rays carry the loss: runs of 24 x 64 = 1536 samples without a gradient
+    gen = torch.Generator().manual_seed(4)
+    G = torch.randn(N, 3, generator=gen).to(dev) * keep[:, None].to(dev)
+    Gd = torch.randn(N, 1, generator=gen).to(dev) * keep[:, None].to(dev)
+    views = torch.eye(4).repeat(2, 1, 1)
+    views[:, :3, 3] = torch.tensor([[0.01, -0.02, 0.0], [0.0, 0.015, -0.01]])
+    pipe = BAPipeline(nef, views, tracer=tracer, near=rays.dist_min, far=rays.dist_max).to(dev)
+    cam = (torch.arange(N, device=dev) * 2 // N).int()
+    jit = jitter.to(dev)
+
+    def run(sel):
+        for p in list(nef.parameters()) + [pipe.camera_extrinsics]:
+            p.grad = None
+        o, d = rays.origins[sel], rays.dirs[sel]
+        r = pipe.transform_rays_indexed(o, d, cam[sel]) if pose else pagnerf_amd.Rays(o, d, rays.dist_min, rays.dist_max)
+        rb = tracer(nef, channels={"rgb", "depth"}, rays=r, jitter=jit[sel], stage="train")
+        ((rb.rgb * G[sel]).sum() + (rb.depth * Gd[sel]).sum()).backward()
+        out = {n: p.grad.clone() for n, p in nef.named_parameters() if p.grad is not None}
+        if pose:
+            out["camera_extrinsics"] = pipe.camera_extrinsics.grad.clone()
+        return rb, out
+    all_rays = torch.arange(N, device=dev)
+    rb_full, g_full = run(all_rays)
+    rb_sub, g_sub = run(all_rays[keep.to(dev)])
+    assert torch.equal(rb_full.rgb[keep.to(dev)], rb_sub.rgb)
+    assert set(g_full) == set(g_sub) and "grid.tables" in g_full
+    for name, want in g_sub.items():
+        got = g_full[name]
+        assert float(want.abs().sum()) > 0, name
+        assert T._rel_l2(got.float(), want.float()) < 2e-5, (name, T._rel_l2(got.float(), want.float()))
+    # rows of the table that only unused rays touch stay exactly zero
+    assert float((g_full["grid.tables"][g_sub["grid.tables"] == 0]).abs().max()) == 0.0
