@@ -76,8 +76,9 @@ def parse(argv=None):
                     help="PanopticPackedRFTracer(use_graphs=...): on = replay the post-march part of the step as HIP graphs (no pose-opt; at N > 1 the "
                          "backward is captured as two graphs so the delta table's all-reduce starts between them); static = static padded buffers + "
                          "optimistic count check with eager launches; off = eager")
-    ap.add_argument("--grad-sync", default="fp32", choices=["fp32", "bf16"],
-                    help="N > 1: table gradients as RCCL fp32 all-reduce (default) or bf16 messages with fp32 accumulation (shard._DirectReduce)")
+    ap.add_argument("--grad-sync", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="N > 1: table gradients as RCCL fp32 all-reduce, as bf16 messages with fp32 accumulation (shard._DirectReduce), or (default) chosen "
+                         "by regime: bf16 when the measured step is shorter than 4 x the predicted exposed fp32 exchange (shard.GradSync(comm_dtype='auto'))")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: process group, shard collectives, timing and JSON plumbing only")
     return ap.parse_args(argv)
 
@@ -680,7 +681,7 @@ def dry_run_rank(args, world, rank):
         dist.all_reduce(seen)
     torch.manual_seed(0)
     params = [torch.nn.Parameter(torch.zeros(64, 8)), torch.nn.Parameter(torch.zeros(16))]
-    comm = torch.bfloat16 if args.grad_sync == "bf16" else None
+    comm = {"bf16": torch.bfloat16, "fp32": None, "auto": "auto"}[args.grad_sync]
     sync = shard.GradSync(params, early=[params[0]], comm_dtype=comm, big=256) if world > 1 else None
     n_local = 8
 
@@ -707,6 +708,26 @@ def dry_run_rank(args, world, rank):
         mean = sum(r + 1 for r in range(world)) / world
         assert torch.allclose(params[0].grad, torch.full((64, 8), mean), rtol=2.0 ** -7 if comm is not None else 1e-6), \
             "GradSync over the bench's process group gave a wrong mean"
+        # the weak-scaling regime lines of the real run, as plumbing: three "regimes" whose step time is a sleep, each with its own GradSync(comm_dtype=
+        # "auto") over a table-sized gradient that is NOT early (the exposed exchange); the assumed bus bandwidth is set so that the predicted fp32
+        # exchange is 1 ms - the 6 ms "dense" step keeps fp32, the sub-millisecond "post-prune" steps switch to the bf16 direct reduce
+        weak = []
+        tab_bytes = 64 * 8 * 4
+        bus = 2.0 * (world - 1) / world * tab_bytes / 1e-3 / 1e9
+        for name, sleep_ms in (("weak_dense_all_channels", 6.0), ("weak_post_prune_rgb", 0.3), ("weak_post_prune_all_channels", 0.6)):
+            ps = [torch.nn.Parameter(torch.zeros(64, 8)), torch.nn.Parameter(torch.zeros(16))]
+            sy = shard.GradSync(ps, comm_dtype="auto", big=256, bus_gbs=bus)
+            t1 = time.perf_counter()
+            n_it = shard.AUTO_WARM + 4
+            for _ in range(n_it):
+                for q_ in ps:
+                    q_.grad = None
+                ((ps[0] * (rank + 1)).sum() + (ps[1] * 2).sum()).backward()
+                time.sleep(sleep_ms * 1e-3)
+                sy.finish()
+            weak.append(dict(name=name, ms_per_step=round((time.perf_counter() - t1) / n_it * 1e3, 3), grad_sync=sy.auto_decision))
+            assert torch.allclose(ps[0].grad, torch.full((64, 8), mean), rtol=2.0 ** -7)
+            sy.remove()
         lo, hi = shard.shard_bounds(n_local * world, rank, world)
         rb = shard.all_gather_render(RenderBuffer(rgb=torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)), n_local * world)
         assert torch.equal(rb.rgb[:, 0], torch.arange(n_local * world, dtype=torch.float32))
@@ -715,7 +736,8 @@ def dry_run_rank(args, world, rank):
                               steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / max(args.steps, 1) * 1e3, 3),
                               higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.precision, data="synthetic",
                               config=dict(workload="DRY RUN: no kernels, gloo on CPU tensors - plumbing check only"),
-                              dry_run=True, rccl_ranks_seen=int(seen.item()), backend="gloo", grad_sync=args.grad_sync)), flush=True)
+                              dry_run=True, rccl_ranks_seen=int(seen.item()), backend="gloo", grad_sync=args.grad_sync,
+                              weak_regimes=(weak if world > 1 else None))), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -800,7 +822,7 @@ def run_rank(args):
             if world > 1:
                 early = [self.nef.delta_grid.tables] if hasattr(self.nef, "delta_grid") else []
                 self.sync = shard.GradSync(list(self.nef.parameters()) + list(extra), early=early,
-                                           comm_dtype=torch.bfloat16 if args.grad_sync == "bf16" else None)
+                                           comm_dtype={"bf16": torch.bfloat16, "fp32": None, "auto": "auto"}[args.grad_sync])
 
         def step(self, channels=None):
             return train_step(self.nef, self.tracer, self.opt, self.rays, self.gt, channels or self.channels, world, self.sync,
@@ -916,7 +938,7 @@ def run_rank(args):
                     raymarch=args.raymarch, half_coords=(args.grid == "permuto" and not args.fp32_coords), table_dtype=args.table_dtype,
                     hip_graphs=bool(graphs_on and job.tracer.use_graphs is True), static_buffers=bool(job.tracer.use_graphs == "static"),
                     parallelism="ray-sharded data parallel x%d" % world),
-        rccl_ranks_seen=ranks_seen, backend=backend, grad_sync=(args.grad_sync if world > 1 else None), roofline=roofline,
+        rccl_ranks_seen=ranks_seen, backend=backend, grad_sync=((job.sync.auto_decision or args.grad_sync) if world > 1 else None), roofline=roofline,
         graphs=(dict(job.graph_stats(), priming_steps=priming) if job.graph_stats() is not None else None))
 
     if not args.no_aux:
@@ -1019,6 +1041,8 @@ def run_rank(args):
             if e:
                 ent["request_rate"] = request_rate(j.nef, j.rays, j.tracer, float(np.mean(e)), kw.get("table_dtype") or args.table_dtype)
             ent["hip_graphs"] = j.graph_stats()
+            if j.sync is not None:
+                ent["grad_sync"] = j.sync.auto_decision or dict(comm_dtype="bf16" if j.sync.comm_dtype is not None else "fp32", decided="flag")
             j.close()
             del j
             torch.cuda.empty_cache()
@@ -1157,6 +1181,13 @@ def run_rank(args):
         if world == 1 and default_cfg:
             line["render"] = render_image_line(args, dev, all_ch, out_bytes)
         if world > 1 and default_cfg:
+            # ---- weak scaling of the regimes that dominate a best.yaml schedule (4096 rays per GPU): the table exchange costs the same whatever the batch,
+            #      so the short post-prune steps are where it shows; grad_sync = what GradSync(comm_dtype="auto") decided for each
+            line["weak_regimes"] = [
+                short_run("weak: post-prune voxel march, rgb only, 4096 rays per GPU", 30, shard.AUTO_WARM + 6, rays_n=4096, samples=2, grid="permuto",
+                          channels={"rgb"}, raymarch="voxel"),
+                short_run("weak: post-prune voxel march, all channels, 4096 rays per GPU", 30, shard.AUTO_WARM + 6, rays_n=4096, samples=2, grid="permuto",
+                          channels=all_ch, raymarch="voxel")]
             # ---- strong scaling, BASELINE configs[3]: one 24 576-ray step (6 images, pose-opt) split over the ranks
             total = 6 * 4096
             ent = short_run("configs[3]: 6 images x 4096 rays, ba_pipeline pose-opt, %d rays per GPU" % (total // world), 10, 3,

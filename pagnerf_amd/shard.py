@@ -10,6 +10,8 @@ of rays against replicated tables / decoders / occupancy.  Two collectives exist
 Both are single large messages - on MI355X's point-to-point xGMI mesh a ring is bound by one link, so
 fewer, larger collectives let RCCL spread traffic over all 7 links.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -194,6 +196,16 @@ def allreduce_grads(params, average=True, big=1 << 20, comm_dtype=None):
             g /= world
 
 
+AUTO_BUS_GBS = 250.0       # bus bandwidth of a large-message RCCL all-reduce assumed by comm_dtype="auto" (200 - 300 GB/s on an 8-GPU xGMI node)
+AUTO_FACTOR = 4.0          # "auto" switches to bf16 direct reduce when the step is shorter than AUTO_FACTOR x the predicted exposed fp32 exchange
+AUTO_WARM = 3              # steps observed before "auto" decides (the first ones hold captures / allocator warm-up)
+
+
+def predicted_exchange_ms(nbytes, world, bus_gbs=AUTO_BUS_GBS):
+    """Time of a ring all-reduce of `nbytes` per rank at `bus_gbs` of bus bandwidth: 2 (W-1)/W x bytes / bandwidth (the model of DESIGN section 6)."""
+    return 2.0 * (world - 1) / max(world, 1) * nbytes / (bus_gbs * 1e9) * 1e3
+
+
 class GradSync:
     """Gradient exchange of a training step with the early part overlapped with the rest of the backward.
 
@@ -202,11 +214,22 @@ class GradSync:
     finish() waits for them, exchanges everything else as one flat all-reduce and averages.  On the xGMI mesh the 50 MB
     early message therefore travels while the GPU still computes; only the main table (produced last) is exposed."""
 
-    def __init__(self, params, early=(), average=True, comm_dtype=None, big=1 << 20):
+    def __init__(self, params, early=(), average=True, comm_dtype=None, big=1 << 20, bus_gbs=AUTO_BUS_GBS):
         """comm_dtype=torch.bfloat16: table-sized gradients travel as bf16 messages with fp32 accumulation (_DirectReduce): half the
-        bytes of the fp32 all-reduce and direct per-link transfers; the default (None) keeps RCCL's fp32 all-reduce."""
+        bytes of the fp32 all-reduce and direct per-link transfers; the default (None) keeps RCCL's fp32 all-reduce.
+        comm_dtype="auto": chosen by REGIME after AUTO_WARM steps - the exposed part of the fp32 exchange is the largest table-sized gradient
+        that is not `early` (the main table: ~0.35 ms at 8 ranks whatever the batch); when the measured step (maximum over the ranks, agreed
+        through one all-reduce so that every rank switches at the same step) is shorter than AUTO_FACTOR x that prediction - the post-prune
+        regimes, where a 0.5 - 1 ms step would spend a third or more of its time waiting for the table - the bf16 direct reduce takes over;
+        long steps (the dense regime) keep the exact fp32 all-reduce.  `auto_decision` records what was decided and from which numbers."""
         self.params = list(params)
         self.average = average
+        self._auto = comm_dtype == "auto"
+        self.bus_gbs = float(bus_gbs)
+        self.auto_decision = None
+        self._t_prev, self._intervals = None, []
+        if self._auto:
+            comm_dtype = None
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.big = big
         self.early = [p for p in early]
@@ -226,6 +249,28 @@ class GradSync:
             op, divide = _reduce_op(self.average)
             self._handles.append((p, dist.all_reduce(p.grad, op=op, async_op=True), divide))
 
+    def _decide(self, world):
+        """comm_dtype="auto": one collective decision from the step cadence seen so far (called from finish(), after this step's exchange)."""
+        now = time.perf_counter()
+        if self._t_prev is not None:
+            self._intervals.append((now - self._t_prev) * 1e3)
+        self._t_prev = now
+        if len(self._intervals) < AUTO_WARM + 1:
+            return
+        step_ms = sum(self._intervals[1:]) / (len(self._intervals) - 1)            # the first interval holds one-time set-up
+        grads = [p.grad for p in self.params if p.grad is not None and id(p) not in self._early_ids and p.grad.numel() >= self.big]
+        exposed = max([g.numel() * g.element_size() for g in grads], default=0)
+        dev = next((p.grad.device for p in self.params if p.grad is not None), torch.device("cpu"))
+        t = torch.tensor([step_ms], device=dev, dtype=torch.float64 if dev.type == "cpu" else torch.float32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                                   # every rank decides from the same number
+        step_ms = float(t.item())
+        pred = predicted_exchange_ms(exposed, world, self.bus_gbs)
+        use_bf16 = exposed > 0 and step_ms < AUTO_FACTOR * pred
+        self.comm_dtype = torch.bfloat16 if use_bf16 else None
+        self.auto_decision = dict(step_ms=round(step_ms, 4), exposed_bytes=int(exposed), predicted_fp32_exchange_ms=round(pred, 4), factor=AUTO_FACTOR,
+                                  bus_gbs=self.bus_gbs, comm_dtype="bf16" if use_bf16 else "fp32", decided_after_steps=len(self._intervals) + 1)
+        self._auto = False
+
     def finish(self):
         _, world = world_info()
         if _single():
@@ -240,6 +285,8 @@ class GradSync:
             if divide:
                 p.grad /= world
         self._handles = []
+        if self._auto:
+            self._decide(world)
 
     def remove(self):
         for h in self._hooks:

@@ -327,13 +327,18 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["warmup"] == 1
-    # the driver's largest launch: 8 ranks (gloo here), once with the fp32 all-reduce and once with bf16 messages + fp32 accumulation
-    for extra in ([], ["--grad-sync", "bf16"]):
+    # the weak-scaling regime lines: GradSync(comm_dtype="auto") keeps the fp32 all-reduce for the long (dense) step and switches to the bf16 direct
+    # reduce for the short post-prune steps (step < 4 x the predicted exposed exchange), every rank at the same step
+    weak = {w["name"]: w["grad_sync"] for w in d["weak_regimes"]}
+    assert weak["weak_dense_all_channels"]["comm_dtype"] == "fp32" and weak["weak_post_prune_rgb"]["comm_dtype"] == "bf16"
+    assert weak["weak_post_prune_all_channels"]["comm_dtype"] == "bf16" and all(abs(w["predicted_fp32_exchange_ms"] - 1.0) < 1e-6 for w in weak.values())
+    # the driver's largest launch: 8 ranks (gloo here), with the fp32 all-reduce and with bf16 messages + fp32 accumulation
+    for extra in (["--grad-sync", "fp32"], ["--grad-sync", "bf16"]):
         r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"] + extra,
                             capture_output=True, text=True, env=dict(env, OMP_NUM_THREADS="1"), timeout=900)
         assert r8.returncode == 0, r8.stderr[-2000:]
         d8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][0])
-        assert d8["n_gpus"] == 8 and d8["rccl_ranks_seen"] == 8 and d8["grad_sync"] == (extra[1] if extra else "fp32")
+        assert d8["n_gpus"] == 8 and d8["rccl_ranks_seen"] == 8 and d8["grad_sync"] == extra[1]
     # N = 1 dry run: no spawn, same schema
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
                         capture_output=True, text=True, env=env, timeout=600)

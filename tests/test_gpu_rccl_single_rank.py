@@ -71,6 +71,17 @@ for name, p in hip_leaves(nef).items():
 st = next(iter(gt._graphs.states.values())); graphed = next(iter(st.buckets.values()))
 assert len(graphed.groups) == 2 and gt._graphs.replays >= 3
 sync.remove()
+# comm_dtype="auto" through RCCL: the decision's MAX all-reduce, then the chosen exchange; a huge assumed bus bandwidth keeps fp32, a tiny one switches to bf16
+for bus, want in ((1e9, "fp32"), (1e-6, "bf16")):
+    tab = torch.nn.Parameter(torch.zeros(1 << 17, device=dev))
+    sy = shard.GradSync([tab], comm_dtype="auto", big=1 << 16, bus_gbs=bus)
+    for it in range(shard.AUTO_WARM + 3):
+        tab.grad = torch.randn(tab.shape, device=dev, generator=gen); ref = tab.grad.clone()
+        sy.finish(); torch.cuda.synchronize()
+        exact = want == "fp32" or it < shard.AUTO_WARM + 2          # the decision falls at the END of finish() number AUTO_WARM + 2: that step still went out in fp32
+        assert torch.equal(tab.grad, ref if exact else ref.bfloat16().float()), (bus, it)
+    assert sy.auto_decision["comm_dtype"] == want, sy.auto_decision
+    sy.remove()
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_SINGLE_RANK_OK")

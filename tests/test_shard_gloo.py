@@ -96,6 +96,23 @@ def _worker(rank, world, port, n, q):
             assert bool((err <= bound).all()), (early, float((err / bound).max()))
             assert tab.grad.dtype == torch.float32 and torch.allclose(small.grad, torch.full((5,), sum(range(1, world + 1)) / world))
             sync.remove()
+        # comm_dtype="auto": the regime decides.  A "slow interconnect" (tiny bus bandwidth: the predicted fp32 exchange dwarfs the step) switches to the bf16
+        # direct reduce after AUTO_WARM steps, a fast one keeps the exact fp32 all-reduce; both ranks switch at the same step; results stay right across it
+        for bus, want in ((1e-6, "bf16"), (1e9, "fp32")):
+            tab, small = torch.nn.Parameter(torch.zeros(n_big, 2)), torch.nn.Parameter(torch.zeros(5))
+            sync = shard.GradSync([tab, small], comm_dtype="auto", big=1000, bus_gbs=bus)
+            for step in range(shard.AUTO_WARM + 4):
+                tab.grad = small.grad = None
+                ((tab * gtab).sum() + (small * (rank + 1.0)).sum()).backward()
+                sync.finish()
+                err = (tab.grad.double() - exact).abs()
+                assert bool((err <= bound).all()), (bus, step)
+                if sync.auto_decision is None:
+                    assert bool((err <= 1e-6 * torch.stack(all_g).abs().double().mean(0) + 1e-12).all())     # before the decision: fp32 all-reduce
+            assert sync.auto_decision is not None and sync.auto_decision["comm_dtype"] == want, sync.auto_decision
+            assert sync.auto_decision["exposed_bytes"] == n_big * 2 * 4 and (sync.comm_dtype is torch.bfloat16) == (want == "bf16")
+            sync.remove()
+        assert abs(shard.predicted_exchange_ms(50.33e6, 8) - 2 * 7 / 8 * 50.33e6 / 250e9 * 1e3) < 1e-9
         # every rank ends with the SAME reduced tensor (the all_gather distributes one rounded value per element)
         chk = [torch.empty_like(tab.grad) for _ in range(world)]
         dist.all_gather(chk, tab.grad.detach())
