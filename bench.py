@@ -122,13 +122,14 @@ def spawn_ranks(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ workload
-def make_model(args, dev, seed, grid=None, num_lods=None, log2T=None, finest=None, table_dtype=None):
+def make_model(args, dev, seed, grid=None, num_lods=None, log2T=None, finest=None, table_dtype=None, heads=None):
     import torch
     import pagnerf_amd
     grid = grid or args.grid
     torch.manual_seed(seed)
     tdt = torch.float16 if (table_dtype or args.table_dtype) == "fp16" else torch.float32
-    common = dict(feature_dim=2, num_classes=6, num_instances=200, sem_num_layers=1, sem_softmax=True, inst_num_layers=2,
+    sem_l, inst_l = heads or (1, 2)        # best.yaml:92,74; (2, 1) = lin_assign_delta_app.yaml / lin_assign_direct_app.yaml / contrastive_delta_app.yaml
+    common = dict(feature_dim=2, num_classes=6, num_instances=200, sem_num_layers=sem_l, sem_softmax=True, inst_num_layers=inst_l,
                   inst_softmax=True, panoptic_features_type="delta", hidden_dim=64, num_layers=1, view_multires=4,
                   precision=args.precision, blas_level=7, table_dtype=tdt)
     if grid == "permuto":        # configs/bup20/best.yaml:47-65
@@ -1129,6 +1130,9 @@ def run_rank(args):
                                   rays_n=256, samples=64, grid="hash", channels={"rgb"}))
             cfgs.append(short_run("configs[2]: hash L=16 T=2^19 (16..2048) + fused MFMA decoders, 4096 rays x 512, all channels", 20, 5,
                                   rays_n=4096, samples=512, grid="hash", channels=all_ch))
+            cfgs.append(short_run("other shipped head shapes (sem_num_layers 2 / inst_num_layers 1: lin_assign_delta_app.yaml:117,120 and three more YAMLs): 4096 rays x 512, "
+                                  "permuto, all channels - the two-layer 200-way head takes the generic decoder kernels", 10, 3,
+                                  rays_n=4096, samples=512, grid="permuto", channels=all_ch, heads=(2, 1)))
             cfgs.append(short_run("configs[3] on ONE GPU: 6 images x 4096 rays, ba_pipeline pose-opt, permuto, all channels", 5, 2,
                                   rays_n=24576, samples=512, grid="permuto", channels=all_ch, pose=True))
             cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp16 tables + bf16 features, rgb", 10, 3,

@@ -581,11 +581,12 @@ def test_composite_backward_vs_oracle_autograd(gpu_device):
 
 
 # ------------------------------------------------------------------------------- end to end + properties
-def _make_scene(dev, precision, seed=0, L_perm=24, cap_log2=14, N=256, S=64, level=5):
+def _make_scene(dev, precision, seed=0, L_perm=24, cap_log2=14, N=256, S=64, level=5, heads=(1, 2)):
+    """heads = (sem_num_layers, inst_num_layers): best.yaml's (1, 2) by default."""
     import pagnerf_amd
     torch.manual_seed(seed)
     nef = pagnerf_amd.PanopticDeltaNeF(grid_type="PermutoGrid", feature_dim=2, num_lods=L_perm, num_classes=6, num_instances=200,
-                                       sem_num_layers=1, sem_softmax=True, inst_num_layers=2, inst_softmax=True,
+                                       sem_num_layers=heads[0], sem_softmax=True, inst_num_layers=heads[1], inst_softmax=True,
                                        panoptic_features_type="delta", capacity_log_2=cap_log2, delta_capacity_log_2=cap_log2,
                                        coarsest_scale=1.0, finest_scale=1e-4, blas_level=level, precision=precision)
     gen = torch.Generator().manual_seed(seed)
