@@ -423,15 +423,16 @@ int pag_raymarch_voxel_pack(const float *origins, const float *dirs, int64_t N, 
 /* The same two passes with ONE walk: pass 1 also records every kept nugget (t_in, t_out) and its cell, pass 2 turns them into the
  * packed arrays in parallel (one wave per ray) instead of walking every ray a second time.  Outputs are bit-identical to
  * pag_raymarch_voxel_count / _pack.
- *   nugget_t     f32 [cap][N][2], nugget_cell i32 [cap][N]  caller-allocated scratch, cap = pag_raymarch_voxel_nugget_capacity(blas_level)
- *                (3 * 2^blas_level + 3: the most cells a ray can cross) */
+ *   nugget_t     f32 [2][cap][N][2], nugget_cell i32 [2][cap][N]  caller-allocated scratch, cap = pag_raymarch_voxel_nugget_capacity(blas_level)
+ *                (3 * 2^blas_level + 3: the most cells a ray can cross).  First half: the walk's candidates, [step][ray]; second half (ABI 11): the
+ *                kept nuggets ray-major, [ray][slot] - what _pack_nuggets (which takes blas_level for `cap`) reads */
 int64_t pag_raymarch_voxel_nugget_capacity(int blas_level);
 int pag_raymarch_voxel_count_nuggets(const float *origins, const float *dirs, int64_t N, int samples_per_voxel,
                                      float dist_min, float dist_max, const uint32_t *occupancy_bits,
                                      const uint32_t *occupancy_coarse, int blas_level, float max_travel,
                                      int32_t *counts, float *nugget_t, int32_t *nugget_cell, void *stream);
 int pag_raymarch_voxel_pack_nuggets(const float *origins, const float *dirs, int64_t N, int samples_per_voxel,
-                                    const int64_t *offsets, const float *nugget_t, const int32_t *nugget_cell,
+                                    const int64_t *offsets, const float *nugget_t, const int32_t *nugget_cell, int blas_level,
                                     int32_t *ridx, int32_t *pidx, float *samples, float *depths, float *deltas,
                                     uint8_t *boundary, int32_t *ridx_sample, int64_t *ridx64, void *stream);
 
@@ -607,11 +608,13 @@ int pag_adam_step(int n_tensors, float *const *params, const float *const *grads
  *   image: one per image, the layout of `transform_rays`)
  *   origins_w[i] = sum_k (origins_c[i] - t)[k] R[k]        dirs_w[i] = normalise(sum_k dirs_c[i][k] R[k])          all f32 [N,3]
  * _bwd: d_params f32 [C,9] = d loss / d params from g_origins / g_dirs f32 [N,3] (either may be NULL = zero); EVERY row is written (zeros
- * for cameras without a ray in the batch); one workgroup per camera, fixed summation order (bitwise reproducible). */
+ * for cameras without a ray in the batch); two launches (per-(camera, ray slice) partial sums into `workspace`, >= pag_pose_rays_bwd_workspace_bytes(C)
+ * bytes; then one thread per camera), fixed summation order (bitwise reproducible). */
 int pag_pose_rays_fwd(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
                       int64_t N, float *origins_w, float *dirs_w, void *stream);
+int64_t pag_pose_rays_bwd_workspace_bytes(int64_t C);
 int pag_pose_rays_bwd(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
-                      int64_t N, const float *g_origins, const float *g_dirs, float *d_params, void *stream);
+                      int64_t N, const float *g_origins, const float *g_dirs, float *d_params, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Gradient of pag_view_embed with respect to the directions (the view direction depends on the camera rotation: pc_nerf/ba_pipeline.py:89-90
  * -> pc_nerf/panoptic_delta_nef.py:196-200): d_dirs f32 [R,3] from g_out f32 [R, width].  (ABI 11) */

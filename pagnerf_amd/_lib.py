@@ -106,7 +106,7 @@ _SIGS = {
                                         c_vp, c_vp, c_vp]),
     "pag_raymarch_voxel_nugget_capacity": (c_i64, [c_i32]),
     "pag_raymarch_voxel_count_nuggets": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
-    "pag_raymarch_voxel_pack_nuggets": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_raymarch_voxel_pack_nuggets": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_ray_sample_grad": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "pag_affine_xcd8_fwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "pag_affine_xcd8_bwd_dx": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
@@ -130,7 +130,8 @@ _SIGS = {
     "pag_adam_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, c_i64, c_vp]),
     "pag_pose_rays_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
-    "pag_pose_rays_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "pag_pose_rays_bwd_workspace_bytes": (c_i64, [c_i64]),
+    "pag_pose_rays_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pag_view_embed_bwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
 }
 

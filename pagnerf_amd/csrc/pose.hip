@@ -69,19 +69,24 @@ __global__ __launch_bounds__(256) void pose_rays_fwd_kernel(const float *__restr
     for (int j = 0; j < 3; ++j) dw[i * 3 + j] = u[j] / n;
 }
 
-// One workgroup per camera row: its rays' contributions to d R (9) and d t (3) are summed in a fixed order (thread-strided partial sums,
-// then a tree over the workgroup), the chain through the Gram-Schmidt construction is applied once per camera.  Cameras without a ray in
-// the batch get a zero row.  C x N camera-index reads (42 x 24 576 on BUP20): noise beside one pass over the rays.
+// Two launches, fixed summation order (bitwise reproducible).  Stage 1: workgroup (camera c, slice s) walks slice s of the rays (N / POSE_SLICES
+// consecutive rays) and sums the contributions of camera c's rays to d R (9) and d t (3): thread-strided partial sums, then a tree over the
+// workgroup -> part[c][s][12].  Stage 2: one thread per camera adds its slices in order and applies the chain through the Gram-Schmidt
+// construction once.  Cameras without a ray in the batch get a zero row.  (One workgroup per camera over ALL rays - 6 workgroups on the chip for
+// a best.yaml step - took 67 us; C x N camera-index reads, 42 x 24 576 on BUP20, are noise either way.)
+constexpr int POSE_SLICES = 32;
 __global__ __launch_bounds__(256) void pose_rays_bwd_kernel(const float *__restrict__ params, const int32_t *__restrict__ cam, int64_t rays_per_entry,
                                                             const float *__restrict__ oc, const float *__restrict__ dc, int64_t N,
-                                                            const float *__restrict__ g_o, const float *__restrict__ g_d, float *__restrict__ d_params) {
-    const int c = blockIdx.x;
+                                                            const float *__restrict__ g_o, const float *__restrict__ g_d, float *__restrict__ part) {
+    const int c = blockIdx.x, sl = blockIdx.y;
     const float *p = params + (int64_t)c * 9;
     const Rot r = rotation(p);
     float acc[12];        // d R[k][j] at 3k + j, d t at 9..11
 #pragma unroll
     for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
-    for (int64_t i = threadIdx.x; i < N; i += 256) {
+    const int64_t per = (N + POSE_SLICES - 1) / POSE_SLICES;
+    const int64_t lo = sl * per, hi = lo + per < N ? lo + per : N;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
         if (cam[i / rays_per_entry] != c) continue;
         float v[3], d[3], u[3], go[3], gd[3];
 #pragma unroll
@@ -118,8 +123,21 @@ __global__ __launch_bounds__(256) void pose_rays_bwd_kernel(const float *__restr
             for (int q = 0; q < 12; ++q) red[threadIdx.x][q] += red[threadIdx.x + s][q];
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
-    const float *G = red[0];
+    if (threadIdx.x < 12) part[((int64_t)c * POSE_SLICES + sl) * 12 + threadIdx.x] = red[0][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void pose_rays_bwd_finish_kernel(const float *__restrict__ params, int64_t C, const float *__restrict__ part,
+                                                                  float *__restrict__ d_params) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const float *p = params + c * 9;
+    const Rot r = rotation(p);
+    float G[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) G[q] = 0.0f;
+    for (int s = 0; s < POSE_SLICES; ++s)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) G[q] += part[(c * POSE_SLICES + s) * 12 + q];
     float gb1[3] = {G[0], G[1], G[2]}, gb2[3] = {G[3], G[4], G[5]}, gb3[3] = {G[6], G[7], G[8]};
     float t1[3], t2[3];
     cross3(r.b[1], gb3, t1);           // b3 = b1 x b2:  d b1 . (b2 x g3),  d b2 . (g3 x b1)
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(256) void pose_rays_bwd_kernel(const float *__restr
 #pragma unroll
     for (int j = 0; j < 3; ++j) gp[j] = (gb2[j] - r.b[1][j] * b2g) / r.n2;     // b2 = q / |q|
     const float b1gp = dot3(r.b[0], gp);
-    float *o = d_params + (int64_t)c * 9;
+    float *o = d_params + c * 9;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         o[3 + j] = gp[j] - r.b[0][j] * b1gp;                                  // q = a2 - (b1 . a2) b1
@@ -186,13 +204,18 @@ extern "C" int pag_pose_rays_fwd(const float *params, int64_t C, const int32_t *
     return PAG_OK;
 }
 
+extern "C" int64_t pag_pose_rays_bwd_workspace_bytes(int64_t C) { return C > 0 ? C * POSE_SLICES * 12 * (int64_t)sizeof(float) : 0; }
+
 extern "C" int pag_pose_rays_bwd(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
-                                 int64_t N, const float *g_origins, const float *g_dirs, float *d_params, void *stream) {
+                                 int64_t N, const float *g_origins, const float *g_dirs, float *d_params, void *workspace, int64_t workspace_bytes,
+                                 void *stream) {
     int rc = pose_check("pag_pose_rays_bwd", params, C, cam, rays_per_entry, origins_c, dirs_c, N);
     if (rc) return rc;
     PAG_CHECK_ARG(d_params && params, "pag_pose_rays_bwd: NULL params / d_params");
-    hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, params, cam, rays_per_entry, origins_c, dirs_c, N, g_origins,
-                       g_dirs, d_params);
+    PAG_CHECK_ARG(workspace && workspace_bytes >= pag_pose_rays_bwd_workspace_bytes(C), "pag_pose_rays_bwd: workspace smaller than pag_pose_rays_bwd_workspace_bytes(C)");
+    hipLaunchKernelGGL(pose_rays_bwd_kernel, dim3((unsigned)C, POSE_SLICES), dim3(256), 0, (hipStream_t)stream, params, cam, rays_per_entry, origins_c, dirs_c, N,
+                       g_origins, g_dirs, (float *)workspace);
+    hipLaunchKernelGGL(pose_rays_bwd_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, params, C, (const float *)workspace, d_params);
     PAG_CHECK_LAUNCH("pag_pose_rays_bwd");
     return PAG_OK;
 }

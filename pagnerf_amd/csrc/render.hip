@@ -310,42 +310,87 @@ __global__ __launch_bounds__(64) void voxel_walk_kernel(MarchArgs a, int32_t *__
     counts[ray] = n;
 }
 
+// Memory layout: the walk (a lane per ray) writes candidate n of ray r at [n][r] - consecutive lanes, consecutive addresses.  This kernel works a lane
+// per CANDIDATE: read straight from [n][r] its lanes would be N x 8 bytes apart (64 separate lines per load: 65 us for 24 576 rays), so a workgroup takes
+// 64 rays and moves 64 candidates of each through an LDS tile - loaded along the rays, read along the candidates.  The kept nuggets leave in RAY-MAJOR
+// order ([r][slot], `cap` slots per ray): consecutive kept lanes write consecutive addresses, and the pack kernel (a lane per nugget) reads them the same way.
+constexpr int SEL_RAYS = 64;
 __global__ __launch_bounds__(256) void voxel_select_kernel(const uint32_t *__restrict__ occ, int64_t N, int k, float max_travel, int32_t *counts,
-                                                           float2 *nug_t, int32_t *nug_cell) {
-    const int lane = threadIdx.x & 63;
-    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= N) return;
-    const int ncand = counts[ray];
-    const float fr0 = __fdiv_rn(0.5f, (float)k);
-    float first = 0.0f;
-    bool have_first = false;
-    int n = 0;
-    for (int j0 = 0; j0 < ncand; j0 += 64) {
-        const int j = j0 + lane;
-        float2 tt = float2{0.0f, 0.0f};
-        int32_t cell = 0;
-        bool keep = false;
-        if (j < ncand) {
-            tt = nug_t[(int64_t)j * N + ray];
-            cell = nug_cell[(int64_t)j * N + ray];
-            keep = occ ? ((occ[cell >> 5] >> (cell & 31)) & 1u) : true;
-        }
-        const float dep0 = __fadd_rn(tt.x, __fmul_rn(__fsub_rn(tt.y, tt.x), fr0));
-        unsigned long long m = __ballot(keep);
-        if (!have_first && m) {             // depth of the ray's first sample = first kept candidate (wave-uniform)
-            first = __shfl(dep0, __ffsll((long long)m) - 1);
-            have_first = true;
-        }
-        keep = keep && (__fsub_rn(dep0, first) < max_travel);
-        m = __ballot(keep);
-        if (keep) {                          // in place: the target index never exceeds the candidate's own, and this chunk is already in registers
-            const int dst = n + __popcll(m & ((1ull << lane) - 1ull));
-            nug_t[(int64_t)dst * N + ray] = tt;
-            nug_cell[(int64_t)dst * N + ray] = cell;
-        }
-        n += __popcll(m);
+                                                           const float2 *__restrict__ cand_t, const int32_t *__restrict__ cand_cell, int64_t cap,
+                                                           float2 *__restrict__ sel_t, int32_t *__restrict__ sel_cell) {
+    __shared__ float2 tile_t[64][SEL_RAYS + 1];
+    __shared__ int32_t tile_c[64][SEL_RAYS + 1];
+    __shared__ int32_t s_cnt[SEL_RAYS], s_n[SEL_RAYS], s_have[SEL_RAYS];
+    __shared__ float s_first[SEL_RAYS];
+    __shared__ int32_t s_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * SEL_RAYS;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    if (tid < SEL_RAYS) {
+        const int32_t c = (r0 + tid < N) ? counts[r0 + tid] : 0;
+        s_cnt[tid] = c;
+        s_n[tid] = 0;
+        s_have[tid] = 0;
+        s_first[tid] = 0.0f;
+        int32_t m = c;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+        if (lane == 0) atomicMax(&s_max, m);
     }
-    if (lane == 0) counts[ray] = n * k;
+    __syncthreads();
+    const int ncand_max = s_max;
+    const float fr0 = __fdiv_rn(0.5f, (float)k);
+    for (int j0 = 0; j0 < ncand_max; j0 += 64) {
+        // tile[jj][r] <- candidate j0 + jj of ray r0 + r: thread (wave, lane = r) loads rows jj = wave, wave + 4, ... (256-byte / 512-byte coalesced rows)
+        const bool ray_ok = r0 + lane < N;
+        const int cnt_l = s_cnt[lane];
+#pragma unroll 4
+        for (int jj = wave; jj < 64; jj += 4) {
+            const int j = j0 + jj;
+            if (ray_ok && j < cnt_l) {
+                tile_t[jj][lane] = cand_t[(int64_t)j * N + r0 + lane];
+                tile_c[jj][lane] = cand_cell[(int64_t)j * N + r0 + lane];
+            }
+        }
+        __syncthreads();
+        for (int rr = 0; rr < SEL_RAYS / 4; ++rr) {          // wave w owns rays w * 16 .. w * 16 + 15 of the group
+            const int rl = wave * (SEL_RAYS / 4) + rr;
+            const int64_t ray = r0 + rl;
+            const int ncand = s_cnt[rl];
+            if (ray >= N || j0 >= ncand) continue;            // wave-uniform
+            const int j = j0 + lane;
+            float2 tt = float2{0.0f, 0.0f};
+            int32_t cell = 0;
+            bool keep = false;
+            if (j < ncand) {
+                tt = tile_t[lane][rl];
+                cell = tile_c[lane][rl];
+                keep = occ ? ((occ[cell >> 5] >> (cell & 31)) & 1u) : true;
+            }
+            const float dep0 = __fadd_rn(tt.x, __fmul_rn(__fsub_rn(tt.y, tt.x), fr0));
+            unsigned long long m = __ballot(keep);
+            float first = s_first[rl];
+            if (!s_have[rl] && m) {             // depth of the ray's first sample = first kept candidate (wave-uniform)
+                first = __shfl(dep0, __ffsll((long long)m) - 1);
+                if (lane == 0) {
+                    s_first[rl] = first;
+                    s_have[rl] = 1;
+                }
+            }
+            keep = keep && (__fsub_rn(dep0, first) < max_travel);
+            m = __ballot(keep);
+            const int n = s_n[rl];
+            if (keep) {
+                const int64_t dst = ray * cap + n + __popcll(m & ((1ull << lane) - 1ull));
+                sel_t[dst] = tt;
+                sel_cell[dst] = cell;
+            }
+            if (lane == 0) s_n[rl] = n + __popcll(m);
+        }
+        __syncthreads();      // the tile is overwritten by the next chunk
+    }
+    if (tid < SEL_RAYS && r0 + tid < N) counts[r0 + tid] = s_n[tid] * k;
 }
 
 // The packed outputs of a ray from the nuggets its (single) walk recorded: one wave per ray, a lane per nugget - the second sequential walk of
@@ -353,7 +398,7 @@ __global__ __launch_bounds__(256) void voxel_select_kernel(const uint32_t *__res
 // copy.  Same fp32 expressions on the same (t_in, t_out) -> the same bits.
 __global__ __launch_bounds__(256) void voxel_pack_nuggets_kernel(const float *__restrict__ origins, const float *__restrict__ dirs, int64_t N, int k,
                                                                  const int64_t *__restrict__ offsets, const float2 *__restrict__ nug_t,
-                                                                 const int32_t *__restrict__ nug_cell, int32_t *ridx, int32_t *pidx, float *samples,
+                                                                 const int32_t *__restrict__ nug_cell, int64_t cap, int32_t *ridx, int32_t *pidx, float *samples,
                                                                  float *depths, float *deltas, uint8_t *boundary, int32_t *ridx_sample, int64_t *ridx64) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -363,12 +408,12 @@ __global__ __launch_bounds__(256) void voxel_pack_nuggets_kernel(const float *__
     const float o[3] = {origins[ray * 3], origins[ray * 3 + 1], origins[ray * 3 + 2]};
     const float d[3] = {dirs[ray * 3], dirs[ray * 3 + 1], dirs[ray * 3 + 2]};
     for (int n = lane; n < cnt; n += 64) {
-        const float2 tt = nug_t[(int64_t)n * N + ray];
+        const float2 tt = nug_t[ray * cap + n];               // ray-major, as voxel_select_kernel leaves them
         const float t = tt.x, span = __fsub_rn(tt.y, tt.x);
         const int64_t g = base + n;
         ridx[g] = (int32_t)ray;
         if (ridx64) ridx64[g] = ray;
-        pidx[g] = nug_cell[(int64_t)n * N + ray];
+        pidx[g] = nug_cell[ray * cap + n];
         const float dl = __fdiv_rn(span, (float)k);
         for (int i = 0; i < k; ++i) {
             const float fr = __fdiv_rn((float)i + 0.5f, (float)k);
@@ -634,6 +679,57 @@ __global__ __launch_bounds__(256) void composite_feats_fwd_kernel(const int64_t 
     }
 }
 
+// The same sum for 64 bf16 channels (the per-ray sum of the colour decoder's dz_0 rows behind the view embedding's gradient, pose optimisation:
+// 128 B per sample, 1.6 GB per dense 24 576-ray step).  The generic kernel above gives a lane 4 channels - 16 of 64 lanes busy on a 64-channel row,
+// 2.4 TB/s.  Here a wave covers EIGHT rows per load instruction (lane = row l / 8, 16-byte piece l % 8: one full 1 KB request), four such groups
+// in flight, fp32 partial sums per lane, the eight row-lanes combined by three shuffles at the end; one wave per ray quarter as before.
+__global__ __launch_bounds__(256) void composite_feats64_bf16_fwd_kernel(const int64_t *pack_start, const int32_t *ray_of_pack, const float *weights,
+                                                                         const float *alpha, const bf16_t *feats, float *out) {
+    typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, piece = lane & 7;
+    const int64_t pk = blockIdx.x;
+    const int64_t beg = pack_start[pk], end = pack_start[pk + 1];
+    const int64_t n = end - beg, q = (n + 3) / 4;
+    const int64_t lo = beg + wave * q, hi = min(end, lo + q);
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t i0 = lo; i0 < hi; i0 += 32) {
+        bf16x8 fv[4];
+        float wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + 8 * u + sub;
+            const bool ok = i < hi;
+            const int64_t ic = ok ? i : lo;
+            fv[u] = *reinterpret_cast<const bf16x8 *>(feats + ic * 64 + 8 * piece);
+            wv[u] = ok ? weights[ic] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += wv[u] * (float)fv[u][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = acc[k];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[k] = v;
+    }
+    if (sub == 0)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part[wave][8 * piece + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int ray = ray_of_pack[pk];
+        const float v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        out[(int64_t)ray * 64 + threadIdx.x] = alpha[ray] * v;
+    }
+}
+
+
 // narrow features (C <= 16, e.g. the semantic classes): one WAVE per ray with the SAMPLE on the lane - a workgroup per
 // ray with the channel on the lane would leave 250 of 256 lanes idle and walk the ray one dependent load at a time
 template <typename FT>
@@ -716,37 +812,51 @@ extern "C" int pag_raymarch_count(const float *origins, const float *dirs, int64
 }
 
 namespace {
+// Exclusive prefix sums of counts[0..N) for ONE workgroup of 16 waves, coalesced: wave w owns a contiguous segment (a multiple of 64 counts), sums it
+// (pass 1: one 256-byte load per 64 rays), the sixteen totals meet in LDS, and pass 2 walks the segment again - from the L1 now - with a
+// wave scan per 64 counts and a running carry.  emit(i, exclusive_prefix) is called for every i < N; returns the total.  Before: every THREAD
+// summed a contiguous chunk of N / 1024 counts - lanes 96 bytes apart at 24 576 rays, 24 dependent uncoalesced loads per pass: 64 us of a 3 ms step.
+template <typename Emit>
+__device__ __forceinline__ int64_t block_exclusive_scan(const int32_t *__restrict__ counts, int64_t N, int64_t *wave_tot /* LDS [16] */, bool want_prefix, Emit emit) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t seg = (((N + 15) / 16) + 63) / 64 * 64;
+    const int64_t wlo = min(N, wave * seg), whi = min(N, wlo + seg);
+    int64_t s = 0;
+    for (int64_t i = wlo + lane; i < whi; i += 64) s += counts[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) wave_tot[wave] = s;
+    __syncthreads();
+    int64_t carry = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        carry += w < wave ? wave_tot[w] : 0;
+        total += wave_tot[w];
+    }
+    if (!want_prefix) return total;
+    for (int64_t i0 = wlo; i0 < whi; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const int32_t c = i < whi ? counts[i] : 0;
+        int32_t incl = c;              // a ray holds < 2^15 samples: 64 of them stay far below 2^31
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (i < whi) emit(i, carry + (int64_t)(incl - c));
+        carry += (int64_t)__shfl(incl, 63);
+    }
+    return total;
+}
+
 // pack_start[i] = sum of counts[0..i), pack_start[N] = total: ONE workgroup, every thread owns a contiguous chunk (sum, block
 // scan of the 1024 chunk sums, prefix write).  Replaces the cast / scan-init / scan / subtract / concatenate launches the same
 // result costs as tensor ops at the head of every training step (N = 4096 rays: 4 counts per thread).
 __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int32_t *__restrict__ counts, int64_t N, int64_t *__restrict__ pack_start,
                                                             int64_t *total_host) {
     __shared__ int64_t wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t chunk = (N + 1023) / 1024;
-    const int64_t lo = tid * chunk, hi = lo + chunk < N ? lo + chunk : N;
-    int64_t sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += counts[i];
-    int64_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int64_t base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        base += w < wave ? wave_tot[w] : 0;
-        total += wave_tot[w];
-    }
-    int64_t run = base + incl - sum;
-    for (int64_t i = lo; i < hi; ++i) {
-        pack_start[i] = run;
-        run += counts[i];
-    }
-    if (tid == 0) {
+    const int64_t total = block_exclusive_scan(counts, N, wave_tot, true, [&](int64_t i, int64_t ex) { pack_start[i] = ex; });
+    if (threadIdx.x == 0) {
         pack_start[N] = total;
         // optional host-visible copy (pinned memory): the host polls it instead of a stream-synchronising read-back
         if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -810,37 +920,16 @@ __global__ __launch_bounds__(1024) void pack_offsets_pad_kernel(const int32_t *_
                                                                 PadArgs a, int64_t *__restrict__ pack_start_clamped, const float *__restrict__ dirs_src,
                                                                 float *__restrict__ dirs_dst) {
     __shared__ int64_t wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t chunk = (N + 1023) / 1024;
-    const int64_t lo = tid * chunk, hi = lo + chunk < N ? lo + chunk : N;
-    int64_t sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += counts[i];
-    int64_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int64_t base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        base += w < wave ? wave_tot[w] : 0;
-        total += wave_tot[w];
-    }
-    if (blockIdx.x == 0) {
-        int64_t run = base + incl - sum;
-        for (int64_t i = lo; i < hi; ++i) {
-            pack_start[i] = run;
-            pack_start_clamped[i] = run < a.capacity ? run : a.capacity;
-            run += counts[i];
-        }
-        if (tid == 0) {
-            pack_start[N] = total;
-            pack_start_clamped[N] = total < a.capacity ? total : a.capacity;
-            if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    const int tid = threadIdx.x;
+    const bool writer = blockIdx.x == 0;          // every workgroup repeats the (tiny) scan to learn the total; workgroup 0 writes the tables
+    const int64_t total = block_exclusive_scan(counts, N, wave_tot, writer, [&](int64_t i, int64_t ex) {
+        pack_start[i] = ex;
+        pack_start_clamped[i] = ex < a.capacity ? ex : a.capacity;
+    });
+    if (writer && tid == 0) {
+        pack_start[N] = total;
+        pack_start_clamped[N] = total < a.capacity ? total : a.capacity;
+        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     pad_tail(a, total, N);
     if (dirs_dst)
@@ -1062,6 +1151,9 @@ extern "C" int pag_composite_feats_fwd(const int64_t *pack_start, const int32_t 
         else
             hipLaunchKernelGGL((composite_feats_small_fwd_kernel<bf16_t>), g, dim3(256), 0, (hipStream_t)stream, pack_start, ray_of_pack, P,
                                weights, alpha, (const bf16_t *)feats, C, out);
+    } else if (feat_dtype == PAG_BF16 && C == 64 && (reinterpret_cast<uintptr_t>(feats) & 15) == 0) {
+        hipLaunchKernelGGL(composite_feats64_bf16_fwd_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pack_start, ray_of_pack, weights, alpha,
+                           (const bf16_t *)feats, out);
     } else {
         const bool vec = (C % 4) == 0;
         const dim3 g((unsigned)P);
@@ -1150,32 +1242,31 @@ extern "C" int pag_raymarch_voxel_count_nuggets(const float *origins, const floa
     if (N == 0) return PAG_OK;
     PAG_CHECK_ARG(origins && dirs && counts && nugget_t && nugget_cell, "pag_raymarch_voxel_count_nuggets: NULL input/output");
     MarchArgs a{origins, dirs, nullptr, nullptr, occupancy_bits, N, 0, blas_level, dist_min, dist_max};
-#ifdef PAG_VOXEL_ONE_PHASE      // the single sequential walk (kept for A/B measurements)
-    const size_t lds = occupancy_coarse ? voxel_coarse_lds(blas_level) : 0;
-    hipLaunchKernelGGL((voxel_march_kernel<false>), dim3((unsigned)((N + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a, samples_per_voxel,
-                       max_travel, occupancy_coarse, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       reinterpret_cast<float2 *>(nugget_t), nugget_cell);
-#else
     (void)occupancy_coarse;      // the walk no longer reads the occupancy: the coarse grid has nothing to shortcut
-    hipLaunchKernelGGL(voxel_walk_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a, counts,
-                       reinterpret_cast<float2 *>(nugget_t), nugget_cell);
-    hipLaunchKernelGGL(voxel_select_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, occupancy_bits, N, samples_per_voxel,
-                       max_travel, counts, reinterpret_cast<float2 *>(nugget_t), nugget_cell);
-#endif
+    // first half of the scratch: the walk's candidates [step][ray]; second half: the kept nuggets, ray-major [ray][slot] (voxel_select_kernel)
+    const int64_t cap = pag_raymarch_voxel_nugget_capacity(blas_level);
+    float2 *cand_t = reinterpret_cast<float2 *>(nugget_t), *sel_t = cand_t + cap * N;
+    int32_t *cand_cell = nugget_cell, *sel_cell = nugget_cell + cap * N;
+    hipLaunchKernelGGL(voxel_walk_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a, counts, cand_t, cand_cell);
+    hipLaunchKernelGGL(voxel_select_kernel, dim3((unsigned)((N + SEL_RAYS - 1) / SEL_RAYS)), dim3(256), 0, (hipStream_t)stream, occupancy_bits, N, samples_per_voxel,
+                       max_travel, counts, (const float2 *)cand_t, (const int32_t *)cand_cell, cap, sel_t, sel_cell);
     PAG_CHECK_LAUNCH("pag_raymarch_voxel_count_nuggets");
     return PAG_OK;
 }
 
 extern "C" int pag_raymarch_voxel_pack_nuggets(const float *origins, const float *dirs, int64_t N, int samples_per_voxel, const int64_t *offsets,
-                                               const float *nugget_t, const int32_t *nugget_cell, int32_t *ridx, int32_t *pidx, float *samples,
+                                               const float *nugget_t, const int32_t *nugget_cell, int blas_level, int32_t *ridx, int32_t *pidx, float *samples,
                                                float *depths, float *deltas, uint8_t *boundary, int32_t *ridx_sample, int64_t *ridx64, void *stream) {
     PAG_CHECK_ARG(N >= 0, "pag_raymarch_voxel_pack_nuggets: N < 0");
+    PAG_CHECK_ARG(blas_level >= 0 && blas_level <= 10, "pag_raymarch_voxel_pack_nuggets: blas_level %d not in [0,10]", blas_level);
     PAG_CHECK_ARG(samples_per_voxel >= 1 && samples_per_voxel <= 64, "pag_raymarch_voxel_pack_nuggets: samples_per_voxel %d not in [1,64]", samples_per_voxel);
     if (N == 0) return PAG_OK;
     PAG_CHECK_ARG(origins && dirs && offsets && nugget_t && nugget_cell && ridx && pidx && samples && depths && deltas && boundary,
                   "pag_raymarch_voxel_pack_nuggets: NULL input/output");
+    const int64_t cap = pag_raymarch_voxel_nugget_capacity(blas_level);      // the kept nuggets sit ray-major in the second half of the scratch
     hipLaunchKernelGGL(voxel_pack_nuggets_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, origins, dirs, N, samples_per_voxel,
-                       offsets, reinterpret_cast<const float2 *>(nugget_t), nugget_cell, ridx, pidx, samples, depths, deltas, boundary, ridx_sample, ridx64);
+                       offsets, reinterpret_cast<const float2 *>(nugget_t) + cap * N, nugget_cell + cap * N, cap, ridx, pidx, samples, depths, deltas, boundary,
+                       ridx_sample, ridx64);
     PAG_CHECK_LAUNCH("pag_raymarch_voxel_pack_nuggets");
     return PAG_OK;
 }

@@ -922,8 +922,10 @@ class _PoseRays(torch.autograd.Function):
         g_o = g_o.contiguous().float() if g_o is not None else None
         g_d = g_d.contiguous().float() if g_d is not None else None
         d_params = torch.empty_like(p)
+        ws_bytes = L.load().pag_pose_rays_bwd_workspace_bytes(p.shape[0])
+        ws = torch.empty(ws_bytes // 4, device=p.device)
         _call("pag_pose_rays_bwd", L.ptr(p), p.shape[0], L.ptr(cam), ctx.rpe, L.ptr(oc), L.ptr(dc), oc.shape[0], L.ptr(g_o), L.ptr(g_d), L.ptr(d_params),
-              L.stream())
+              L.ptr(ws), ws_bytes, L.stream())
         return d_params, None, None, None, None
 
 
@@ -1017,9 +1019,9 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     # bytes of scratch the rays are walked twice instead (pag_raymarch_voxel_count / _pack)
     cap = int(L.load().pag_raymarch_voxel_nugget_capacity(blas_level))
     nug_t = nug_cell = None
-    if N and cap * N * 12 <= VOXEL_SCRATCH_MAX:
-        nug_t = torch.empty(cap, N, 2, device=dev)
-        nug_cell = torch.empty(cap, N, device=dev, dtype=torch.int32)
+    if N and 2 * cap * N * 12 <= VOXEL_SCRATCH_MAX:
+        nug_t = torch.empty(2, cap, N, 2, device=dev)              # [0]: the walk's candidates [step][ray], [1]: the kept nuggets [ray][slot]
+        nug_cell = torch.empty(2, cap, N, device=dev, dtype=torch.int32)
         _call("pag_raymarch_voxel_count_nuggets", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse,
               blas_level, travel, L.ptr(counts), L.ptr(nug_t), L.ptr(nug_cell), st)
     elif N:
@@ -1047,7 +1049,7 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     ridx_sample = torch.empty(Mn * k, device=dev, dtype=torch.int32) if want_packs else None
     ridx64 = torch.empty(Mn, device=dev, dtype=torch.int64) if want_packs else None
     if Mn and nug_t is not None:
-        _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(pack_start), L.ptr(nug_t), L.ptr(nug_cell),
+        _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(pack_start), L.ptr(nug_t), L.ptr(nug_cell), blas_level,
               L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), L.ptr(ridx_sample), L.ptr(ridx64), st)
     elif Mn:
         _call("pag_raymarch_voxel_pack", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse, blas_level,
@@ -1082,8 +1084,8 @@ class MarchBuffers:
         # the host knows the sample count - no per-ray kernel can walk past the capacity when a batch overflows it
         self.pack_start_c = torch.zeros(self.N + 1, device=dev, dtype=torch.int64)
         if mode == "voxel":
-            self.nug_t = torch.empty(int(per_ray), self.N, 2, device=dev)
-            self.nug_cell = torch.empty(int(per_ray), self.N, device=dev, dtype=torch.int32)
+            self.nug_t = torch.empty(2, int(per_ray), self.N, 2, device=dev)
+            self.nug_cell = torch.empty(2, int(per_ray), self.N, device=dev, dtype=torch.int32)
 
     def pad_to(self, capacity):
         """Queue pag_pad_packed: samples [M, capacity) become filler samples outside every pack (pack_start is left alone) and
@@ -1144,7 +1146,7 @@ def march_into(buf, origins, dirs, dist_min, dist_max, num_samples, jitter=None,
         _call("pag_raymarch_voxel_count_nuggets", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse,
               blas_level, travel, L.ptr(buf.counts), L.ptr(buf.nug_t), L.ptr(buf.nug_cell), st)
         _offsets(buf, N, mb_ptr, st, pad_capacity, dirs, dirs_out)
-        _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(buf.pack_start), L.ptr(buf.nug_t), L.ptr(buf.nug_cell),
+        _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(buf.pack_start), L.ptr(buf.nug_t), L.ptr(buf.nug_cell), blas_level,
               L.ptr(buf.ridx_entry), L.ptr(buf.pidx), L.ptr(buf.samples), L.ptr(buf.depths), L.ptr(buf.deltas), L.ptr(buf.boundary),
               L.ptr(buf.ridx_sample), L.ptr(buf.ridx64), st)
     return mailbox, jitter

@@ -56,7 +56,9 @@ def test_pose_entry_points_validate_without_gpu(lib):
     assert lib.pag_pose_rays_fwd(buf, 1, buf, 0, buf, buf, 4, buf, buf, None) == -1                           # rays_per_entry < 1
     assert b"rays_per_entry" in lib.pag_last_error_string()
     assert lib.pag_pose_rays_fwd(buf, 1, buf, 1, buf, buf, 4, None, buf, None) == -1                          # NULL output
-    assert lib.pag_pose_rays_bwd(buf, 1, buf, 1, buf, buf, 4, buf, buf, None, None) == -1                     # NULL d_params
+    assert lib.pag_pose_rays_bwd(buf, 1, buf, 1, buf, buf, 4, buf, buf, None, buf, 1 << 20, None) == -1        # NULL d_params
+    assert lib.pag_pose_rays_bwd(buf, 1, buf, 1, buf, buf, 4, buf, buf, buf, buf, 8, None) == -1               # workspace too small
+    assert b"workspace" in lib.pag_last_error_string() and lib.pag_pose_rays_bwd_workspace_bytes(6) == 6 * 32 * 12 * 4
     assert lib.pag_view_embed_bwd(None, 0, 4, 32, None, None, None) == 0
     assert lib.pag_view_embed_bwd(buf, 2, 4, 16, buf, buf, None) == -1                                        # width < 3 + 6 n_freq
     assert lib.pag_view_embed_bwd(buf, 2, 4, 32, None, buf, None) == -1
