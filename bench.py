@@ -620,7 +620,7 @@ def request_rate(nef, rays, tracer, enc_ms, table_dtype):
 
 
 # ------------------------------------------------------------------------------------------- forward-only render (validation path)
-def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=8000, images=2):
+def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=8000, images=2, pruned=False):
     """The reference's OTHER caller of the path: pc_nerf/trainer.py:943-999 validate -> :637-649 batch_render - one H x W image
     (BUP20: 720 x 1280) through pagnerf_amd.batch_render under torch.no_grad(), render_batch = 8000 rays x 512 samples
     (best.yaml:143,146), dense occupancy (every sample survives: the worst case for the renderer).  Reported for all channels and for
@@ -631,12 +631,24 @@ def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=
     import pagnerf_amd
     from pagnerf_amd import ops
     nef = make_model(args, dev, seed=0).eval()
-    tracer = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=512, bg_color="white", use_graphs=False)
-    pipe = pagnerf_amd.Pipeline(nef, tracer)
     n = H * W
     rays, _ = make_rays(n, dev, seed=77)
-    out = dict(image="%d x %d = %d rays x 512 samples, render_batch %d (%d traces per image), dense occupancy, torch.no_grad()"
-                     % (H, W, n, render_batch, (n + render_batch - 1) // render_batch))
+    if pruned:
+        # what every validation after epoch 201 runs (pc_nerf/trainer.py:362-366 switches nef and tracer to the voxel march with samples_per_voxel
+        # steps when voxel_raymarch_epoch_start = 201 is reached, best.yaml:34,31; validate() -> batch_render, :637-649, uses the tracer as it stands)
+        occ = synthetic_prune(nef, args.occupancy)
+        tracer = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="voxel", num_steps=2, bg_color="white", ray_max_travel=6.0, use_graphs=False)
+        with torch.no_grad():
+            warm = pagnerf_amd.Rays(rays.origins[:render_batch], rays.dirs[:render_batch], rays.dist_min, rays.dist_max)
+            mo = nef.grid.raymarch(warm, level=None, num_samples=2, raymarch_type="voxel", max_travel=6.0)
+        out = dict(image="%d x %d = %d rays, voxel march (2 samples per voxel) on the pruned grid (%.1f %% of 128^3 cells occupied: ~%d samples per ray), render_batch %d "
+                         "(%d traces per image), torch.no_grad()" % (H, W, n, 100 * occ, int(mo[2].shape[0] * 2 / render_batch), render_batch,
+                                                                     (n + render_batch - 1) // render_batch))
+    else:
+        tracer = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=512, bg_color="white", use_graphs=False)
+        out = dict(image="%d x %d = %d rays x 512 samples, render_batch %d (%d traces per image), dense occupancy, torch.no_grad()"
+                         % (H, W, n, render_batch, (n + render_batch - 1) // render_batch))
+    pipe = pagnerf_amd.Pipeline(nef, tracer)
     bps = 12 + 24 * 4 * 2 * (2 if args.table_dtype == "fp16" else 4) + 24 * 2 * out_bytes
     with torch.no_grad():
         for tag, chans in (("all_channels", sorted(all_ch)), ("rgb_depth", ["depth", "rgb"])):
@@ -654,9 +666,11 @@ def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=
             prof = ops.profile_stop()
             per = {k.replace("pag_", ""): round(float(np.sum(v)), 3) for k, v in sorted(prof.items()) if float(np.sum(v)) > 0.05}
             enc = prof.get("pag_%s_encode_fwd" % args.grid, [])
-            ent = dict(channels=chans, ms_per_image=round(dt * 1e3, 2), rays_s=round(n / dt, 1), samples_s=round(n * 512 / dt, 1),
+            ent = dict(channels=chans, ms_per_image=round(dt * 1e3, 2), rays_s=round(n / dt, 1),
                        entry_points_ms_per_image=per, device_ms_per_image=round(float(sum(np.sum(v) for v in prof.values())), 2))
-            if enc:
+            if not pruned:
+                ent["samples_s"] = round(n * 512 / dt, 1)
+            if enc and not pruned:
                 m_launch = render_batch * 512
                 full = [e for e in enc][:n // render_batch]          # the full-size launches (the last chunk of an image is shorter)
                 ent["encode_fwd"] = dict(launches=len(enc), avg_launch_ms=round(float(np.mean(full)), 4),
@@ -1184,6 +1198,7 @@ def run_rank(args):
                 pass
         if world == 1 and default_cfg:
             line["render"] = render_image_line(args, dev, all_ch, out_bytes)
+            line["render_pruned"] = render_image_line(args, dev, all_ch, out_bytes, pruned=True)
         if world > 1 and default_cfg:
             # ---- weak scaling of the regimes that dominate a best.yaml schedule (4096 rays per GPU): the table exchange costs the same whatever the batch,
             #      so the short post-prune steps are where it shows; grad_sync = what GradSync(comm_dtype="auto") decided for each

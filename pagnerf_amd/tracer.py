@@ -23,13 +23,17 @@ _TRACE_PARAMS = {}      # per tracer class: trace()'s parameters (inspect.signat
 class PanopticPackedRFTracer(nn.Module):
     def __init__(self, ray_sparcity_reg=0.0, ray_max_travel=6.0, raymarch_type="voxel", num_steps=64, step_size=1.0,
                  bg_color="white", use_graphs=None, graph_split=None, **kwargs):
-        """use_graphs (this build's addition, default: the PAG_GRAPHS environment variable, else off): training-time traces replay the
-        post-march part of the step - forward and backward - as HIP graphs over static, padded sample buffers (pagnerf_amd/graphs.py).
-        Same channels, same values; what changes is that the host neither waits for the sample count nor issues ~35 launches per step."""
+        """use_graphs (this build's addition; default: the PAG_GRAPHS environment variable, else ON since round 5): training-time traces
+        (`stage='train'` with gradients enabled, as pc_nerf/trainer.py:435 calls the pipeline) replay the post-march part of the step - forward
+        and backward - as HIP graphs over static, padded sample buffers (pagnerf_amd/graphs.py).  Same channels, same values; what changes is
+        that the host neither waits for the sample count nor issues ~35 launches per step (the 0.5 - 3 ms post-prune steps, three quarters of a
+        best.yaml run, are host-bound without it).  Validation / no_grad traces, extra channels and foreign nefs / grids take the eager path by
+        themselves; `use_graphs=False` (or PAG_GRAPHS=0) switches the graphs off, "static" keeps the static buffers without the capture.
+        Ownership rules of the graph path: INTEGRATION.md section 6."""
         super().__init__()
         import os
         if use_graphs is None:
-            use_graphs = os.environ.get("PAG_GRAPHS", "0")
+            use_graphs = os.environ.get("PAG_GRAPHS", "1")
             use_graphs = "static" if use_graphs == "static" else bool(int(use_graphs))
         # True: HIP graphs; "static": the graph path's static padded buffers and optimistic sample-count check with eager launches (no capture)
         self.use_graphs = "static" if use_graphs == "static" else bool(use_graphs)

@@ -10,6 +10,11 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# A tracer built without `use_graphs` replays HIP graphs from its second training trace on (the product default since round 5).  The tests' reference
+# tracers mean the EAGER path (one launch per kernel, the thing the graph path is compared with); tests of the graph path say use_graphs=True /
+# "static" themselves, and tests/test_abi_and_host.py::test_tracer_defaults_to_graphs checks the default without this variable.
+os.environ.setdefault("PAG_GRAPHS", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -593,3 +593,17 @@ def test_segment_consistency_regularizer_host_logic_vs_reference_golden():
     val.backward()
     np.testing.assert_allclose(float(val.detach()), float(g["seg_reg"]), rtol=1e-5)
     np.testing.assert_allclose(x.grad.numpy(), g["seg_reg_grad"], rtol=1e-5, atol=0)
+
+
+def test_tracer_defaults_to_graphs(monkeypatch):
+    """Drop-in default: a tracer constructed the way the reference constructs it - no `use_graphs` keyword - takes the HIP-graph
+    path for training traces; PAG_GRAPHS=0 / use_graphs=False switch it off, "static" selects the uncaptured static-buffer form."""
+    import pagnerf_amd
+    monkeypatch.delenv("PAG_GRAPHS", raising=False)
+    assert pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=512).use_graphs is True
+    assert pagnerf_amd.PanopticPackedRFTracer(use_graphs=False).use_graphs is False
+    assert pagnerf_amd.PanopticPackedRFTracer(use_graphs="static").use_graphs == "static"
+    monkeypatch.setenv("PAG_GRAPHS", "0")
+    assert pagnerf_amd.PanopticPackedRFTracer().use_graphs is False
+    monkeypatch.setenv("PAG_GRAPHS", "static")
+    assert pagnerf_amd.PanopticPackedRFTracer().use_graphs == "static"

@@ -426,3 +426,43 @@ def test_pose_optimisation_through_the_graph_path(gpu_device, mode, use):
         rb_p = gt(nef, channels=CH, rays=plain, jitter=jit, stage="train")
         rb_p.rgb.sum().backward()
     assert torch.equal(rb_p.rgb, rb_e.rgb) and gt._graphs.captures == (2 if use is True else 0)
+
+
+def test_default_constructed_tracer_replays_graphs_in_a_reference_style_loop(gpu_device, monkeypatch):
+    """The product default: a tracer built without `use_graphs` (as the reference's YAML builds it) in the reference's loop - zero_grad(set_to_none=True),
+    pipeline(..., stage='train'), GradScaler backward / step (pc_nerf/trainer.py:426-435,582-584) - replays HIP graphs from its third step on; a
+    validation trace in between (no_grad, stage='val') takes the eager path and does not disturb the capture; the training curve follows the eager tracer's."""
+    import pagnerf_amd
+    monkeypatch.delenv("PAG_GRAPHS", raising=False)
+    dev = gpu_device
+    N, S = 256, 48
+    curves = {}
+    for use in (None, False):
+        nef, _, rays, occ, jitter = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=12)
+        tr = pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=S, bg_color="white") if use is None else \
+            pagnerf_amd.PanopticPackedRFTracer(raymarch_type="ray", num_steps=S, bg_color="white", use_graphs=False)
+        assert tr.use_graphs is (True if use is None else False)
+        pipe = pagnerf_amd.Pipeline(nef, tr)
+        opt = pagnerf_amd.optim.Adam(nef.parameters(), lr=1e-3, eps=1e-15)
+        scaler = torch.amp.GradScaler("cuda", init_scale=128.0)
+        gen = torch.Generator().manual_seed(1)
+        out = []
+        for it in range(10):
+            jit = torch.rand(N, S, generator=gen).to(dev)
+            gtc = torch.rand(N, 3, generator=gen).to(dev)
+            opt.zero_grad(set_to_none=True)
+            rb = pipe(rays=rays, lod_idx=None, channels=["rgb", "semantics", "inst_embedding", "depth"], stage="train", jitter=jit)
+            loss = 10.0 * torch.abs(rb.rgb - gtc).mean() - 0.1 * torch.log(rb.semantics[:, 0] + 1e-27).mean() - torch.log(rb.inst_embedding[:, 3] + 1e-27).mean()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            out.append(float(loss.detach()))
+            if it == 5:
+                with torch.no_grad():
+                    val = pipe(rays=rays, lod_idx=None, channels=["rgb"])            # trace()'s default stage is 'val'
+                assert val.rgb.shape == (N, 3)
+        curves[use] = out
+        if use is None:
+            g = tr._graphs
+            assert g is not None and g.captures == 1 and g.replays >= 8 and g.overflows == 0, (g.captures, g.replays, g.overflows)
+    np.testing.assert_allclose(curves[None], curves[False], rtol=2e-3)
