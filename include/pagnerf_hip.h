@@ -616,6 +616,25 @@ int64_t pag_pose_rays_bwd_workspace_bytes(int64_t C);
 int pag_pose_rays_bwd(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
                       int64_t N, const float *g_origins, const float *g_dirs, float *d_params, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The position gradient of pag_*_encode_bwd_xyz reduced PER RAY inside the gather pass (pose optimisation, pc_nerf/ba_pipeline.py:85-92: the packed samples
+ * are origin[ray] + dir[ray] * depth, so what is wanted of d loss / d xyz is its per-ray sum and its per-ray sum weighted by depth):
+ *   out f32 [N,6], row r = (sum of d xyz over ray r's samples | sum of d xyz * depth); rays without samples get zeros.
+ *   ridx i32 [M] = ray of each packed sample (non-decreasing), depths f32 [M], pack_start i64 [N+1] (one pack per ray, empty packs allowed);
+ *   workspace >= pag_encode_bwd_rays_workspace_bytes(M, N) (6 floats per (XCD group, wave of 64 samples, ray) instead of 8 x 3 floats per sample).
+ * Replaces pag_*_encode_bwd_xyz + pag_ray_sample_grad where the samples come straight from the ray march (fixed summation order: bitwise reproducible;
+ * the sums are formed in a different order than by those two calls, so the values agree to fp32 rounding, not bit for bit).  Other arguments as
+ * pag_*_encode_bwd_xyz.  (ABI 11) */
+int64_t pag_encode_bwd_rays_workspace_bytes(int64_t M, int64_t N);
+int pag_hash_encode_bwd_rays(const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out, int grad_dtype,
+                             int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T,
+                             const float *resolutions_host, const float *feat_scale_host, const int32_t *ridx, const float *depths,
+                             const int64_t *pack_start, int64_t N, float *out, void *workspace, int64_t workspace_bytes, int flags, void *stream);
+int pag_permuto_encode_bwd_rays(const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out, int grad_dtype,
+                                int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
+                                const float *scale_factor_host, const float *shift_host, const float *feat_scale_host, const int32_t *ridx,
+                                const float *depths, const int64_t *pack_start, int64_t N, float *out, void *workspace, int64_t workspace_bytes,
+                                int flags, void *stream);
+
 /* Gradient of pag_view_embed with respect to the directions (the view direction depends on the camera rotation: pc_nerf/ba_pipeline.py:89-90
  * -> pc_nerf/panoptic_delta_nef.py:196-200): d_dirs f32 [R,3] from g_out f32 [R, width].  (ABI 11) */
 int pag_view_embed_bwd(const float *dirs, int64_t R, int n_freq, int width, const float *g_out, float *d_dirs, void *stream);

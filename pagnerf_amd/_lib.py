@@ -133,6 +133,11 @@ _SIGS = {
     "pag_pose_rays_bwd_workspace_bytes": (c_i64, [c_i64]),
     "pag_pose_rays_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pag_view_embed_bwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "pag_encode_bwd_rays_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "pag_hash_encode_bwd_rays": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_vp, c_i64,
+                                         c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "pag_permuto_encode_bwd_rays": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_u32, c_fp, c_fp, c_fp, c_vp, c_vp, c_vp,
+                                            c_i64, c_vp, c_vp, c_i64, c_i32, c_vp]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -284,6 +284,22 @@ __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void permuto_bwd_kernel(const 
 // fetches the same 8 / 4 rows, contracts them with the incoming gradient and chains through the weight
 // derivatives.  Same XCD-pinned launch as the forward; group g writes its partial sum to part[g][m][3] and a tiny
 // second kernel adds the 8 groups (deterministic, no atomics).
+// lane-crossing helpers of the segmented scans (position gradient per ray; the bin pass's merge of adjacent lanes)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int src) {
+    return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, 0xF, true);   // masked / out-of-row sources read as 0 = the scan identity
+}
+template <int F, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(float (&v)[F], int &f) {
+    // element = (f: a run head lies between the source lane (exclusive) and this lane (inclusive), v: sum since that head)
+    const int fp = dpp_i<CTRL, ROW_MASK>(f);
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        const float vp = __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v[k])));
+        v[k] = f ? v[k] : v[k] + vp;
+    }
+    f |= fp;
+}
 // any of the eight bf16 values of a gradient piece other than +-0 (NaN counts as non-zero)
 typedef bf16_t bf16x8_piece __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bool piece_nonzero(const bf16x8_piece &t) {
@@ -292,14 +308,13 @@ __device__ __forceinline__ bool piece_nonzero(const bf16x8_piece &t) {
     return ((b[0] | b[1] | b[2] | b[3]) & 0x7FFF7FFFu) != 0u;
 }
 
+// d loss / d xyz of sample i from the levels of XCD group g: dx[3] (zero, without a single row request, when the sample's gradient piece is exactly zero)
 template <int KIND /*0 hash, 1 permuto*/, typename TableT, typename GradT, int F, int LPX>
-__global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables,
-                                                       const GradT *__restrict__ go, int64_t sm, int64_t sc, int grouped,
-                                                       HashParams hp, PermutoParams pp, float *__restrict__ part) {
+__device__ __forceinline__ void xyz_grad_sample(const float *__restrict__ xyz, int64_t i, int64_t M, int g, const TableT *__restrict__ tables,
+                                                const GradT *__restrict__ go, int64_t sm, int64_t sc, int grouped, const HashParams &hp,
+                                                const PermutoParams &pp, float (&dx)[3]) {
     constexpr int NV = KIND == 0 ? 8 : 4;
-    const int g = blockIdx.x & 7;
-    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
-    if (i >= M) return;
+    dx[0] = 0.0f, dx[1] = 0.0f, dx[2] = 0.0f;
     const int L = KIND == 0 ? hp.L : pp.L;
     const float *scale = KIND == 0 ? hp.scale : pp.scale;
     const bool has_scale = KIND == 0 ? hp.has_scale : pp.has_scale;
@@ -315,11 +330,7 @@ __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const flo
         // A sample whose gradient piece is exactly zero (+-0: empty space of a trained scene - sigma = relu(pre) = 0, so neither the colour nor the
         // density path sends anything back -, filler samples of a padded batch) gets d xyz = 0 without its 4 x LPX row requests: the same value
         // the products with zero give (scripts/zero_weight_tiles.py: 93 % of the samples of the trained analytic scene).
-        if (!piece_nonzero(t)) {
-            float *o = part + ((int64_t)g * M + i) * 3;
-            o[0] = 0.0f, o[1] = 0.0f, o[2] = 0.0f;
-            return;
-        }
+        if (!piece_nonzero(t)) return;
     }
     float e[LPX][NV][F];
     float w[LPX][4];         // hash: wx, wy, wz, -   permuto: unused
@@ -345,7 +356,6 @@ __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const flo
             for (int k = 0; k < 4; ++k) gather_row<F>(tab, idx[k], e[j][k]);      // scalar base + 32-bit offset, as the forward
         }
     }
-    float dx[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < LPX; ++j) {
         const int l = xcd8_level(g, j);
@@ -400,9 +410,88 @@ __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const flo
             dx[2] += (gE[0] + gE[1] + gE[2] - 3.0f * gE[3]) * pp.sf[l][2];
         }
     }
+}
+
+template <int KIND, typename TableT, typename GradT, int F, int LPX>
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables,
+                                                       const GradT *__restrict__ go, int64_t sm, int64_t sc, int grouped,
+                                                       HashParams hp, PermutoParams pp, float *__restrict__ part) {
+    const int g = blockIdx.x & 7;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
+    if (i >= M) return;
+    float dx[3];
+    xyz_grad_sample<KIND, TableT, GradT, F, LPX>(xyz, i, M, g, tables, go, sm, sc, grouped, hp, pp, dx);
     float *o = part + ((int64_t)g * M + i) * 3;
     o[0] = dx[0], o[1] = dx[1], o[2] = dx[2];
 }
+
+// The same pass reduced PER RAY before anything is written (pose optimisation: what the position gradient is wanted for is d loss / d origin = sum of
+// d xyz over a ray's samples and d loss / d dir = sum of d xyz * depth, pc_nerf/ba_pipeline.py:85-92 through samples = origin + dir * depth).  The
+// per-sample form writes 8 partial planes [M,3] (96 B per sample), adds them (108 B more) and sums per ray (16 B more): 1.4 GB and two further
+// launches for a dense 24 576-ray step.  Here a wave - 64 consecutive samples, sorted by ray - forms (dx, dx * depth) per lane, sums the lanes of
+// each ray with a segmented DPP scan and its tail lanes write one 6-float slot per (group, wave, ray): slot row = wave + ray (strictly increasing
+// along the samples: every (wave, ray) pair has a row of its own, `waves + N` rows per group) - 3 B per sample on 512-sample rays.  ray_slots_sum_kernel
+// adds a ray's rows (fixed order: bitwise reproducible).
+template <int KIND, typename TableT, typename GradT, int F, int LPX>
+__global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void xyz_grad_rays_kernel(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables,
+                                                       const GradT *__restrict__ go, int64_t sm, int64_t sc, int grouped,
+                                                       HashParams hp, PermutoParams pp, const int32_t *__restrict__ ridx,
+                                                       const float *__restrict__ depths, float *__restrict__ slots, int64_t slot_rows) {
+    const int g = blockIdx.x & 7;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)(blockIdx.x >> 3) * PAG_ENC_FWD_THREADS + threadIdx.x;
+    const int64_t wave = i >> 6;
+    if ((wave << 6) >= M) return;                    // whole wave past the end (wave-uniform)
+    const bool in_range = i < M;
+    const int64_t ic = in_range ? i : M - 1;
+    float dx[3] = {0.0f, 0.0f, 0.0f};
+    if (in_range) xyz_grad_sample<KIND, TableT, GradT, F, LPX>(xyz, i, M, g, tables, go, sm, sc, grouped, hp, pp, dx);
+    const int ray = ridx[ic];
+    const float dep = depths[ic];
+    float v[6] = {dx[0], dx[1], dx[2], dx[0] * dep, dx[1] * dep, dx[2] * dep};
+    const int prev = dpp_i<0x138, 0xF>(ray);         // wave_shr:1 (lane 0 reads 0: it is a head regardless)
+    int f = (lane == 0 || prev != ray) ? 1 : 0;      // first lane of a ray's run
+    const unsigned long long heads = __ballot(f != 0);
+    seg_step<6, 0x111, 0xF>(v, f);                   // segmented inclusive scan: row_shr 1 / 2 / 4 / 8, then across the 16-lane rows
+    seg_step<6, 0x112, 0xF>(v, f);
+    seg_step<6, 0x114, 0xF>(v, f);
+    seg_step<6, 0x118, 0xF>(v, f);
+    seg_step<6, 0x142, 0xA>(v, f);
+    seg_step<6, 0x143, 0xC>(v, f);
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (tail) {
+        float *o = slots + ((int64_t)g * slot_rows + wave + ray) * 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) o[c] = v[c];
+    }
+}
+
+// out[ray] = (d origin | d dir) = sum over the ray's slot rows: groups x (waves its samples span); one wave per ray, lane = (group, wave) pair
+__global__ __launch_bounds__(256) void ray_slots_sum_kernel(const int64_t *__restrict__ pack_start, int64_t N, const float *__restrict__ slots, int64_t slot_rows,
+                                                            int groups, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= N) return;
+    const int64_t beg = pack_start[ray], end = pack_start[ray + 1];
+    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (end > beg) {
+        const int64_t w0 = beg >> 6, nw = ((end - 1) >> 6) - w0 + 1;
+        for (int64_t q = lane; q < nw * groups; q += 64) {
+            const int64_t gq = q / nw, wq = w0 + q % nw;
+            const float *o = slots + (gq * slot_rows + wq + ray) * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a[c] += o[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a[c] += __shfl_xor(a[c], d);
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out[ray * 6 + c] = a[c];
+}
+
 
 __global__ __launch_bounds__(256) void xyz_grad_sum_kernel(const float *__restrict__ part, int64_t n, int groups, float *__restrict__ out) {
     // four consecutive floats per lane and group (16-byte loads: eight of them in flight per lane instead of eight 4-byte ones - the pass moves 108 B per
@@ -493,21 +582,6 @@ __device__ __forceinline__ void unpack_entry(uint64_t e, uint32_t &key12, float 
 // and that lane's v[] holds the run's sum.  Skipped (wave-uniformly) when the wave has few repeats.
 // The segmented inclusive scan runs on DPP moves (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 and
 // row_bcast:31 to carry the row totals across) - VALU-rate lane crossings instead of ds_bpermute through the LDS.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i(int src) {
-    return __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, 0xF, true);   // masked / out-of-row sources read as 0 = the scan identity
-}
-template <int F, int CTRL, int ROW_MASK>
-__device__ __forceinline__ void seg_step(float (&v)[F], int &f) {
-    // element = (f: a run head lies between the source lane (exclusive) and this lane (inclusive), v: sum since that head)
-    const int fp = dpp_i<CTRL, ROW_MASK>(f);
-#pragma unroll
-    for (int k = 0; k < F; ++k) {
-        const float vp = __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v[k])));
-        v[k] = f ? v[k] : v[k] + vp;
-    }
-    f |= fp;
-}
 // max over the wave on DPP moves; the result is valid in lane 63 (row_shr inside the 16-lane rows, row_bcast across them)
 __device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
     v = max(v, (uint32_t)dpp_i<0x111, 0xF>((int)v));
@@ -1408,10 +1482,18 @@ static int permuto_encode_bwd_impl(bool overwrite, const float *xyz, int64_t M, 
     return PAG_OK;
 }
 
+struct RaysArgs {            // per-ray reduction of the position gradient (launch_xyz_grad): NULL ridx = the per-sample form
+    const int32_t *ridx = nullptr;
+    const float *depths = nullptr;
+    const int64_t *pack_start = nullptr;
+    int64_t N = 0;
+};
+static int64_t rays_slot_rows(int64_t M, int64_t N) { return (M + 63) / 64 + N; }
+
 template <int KIND>
 static int launch_xyz_grad(const char *name, const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out,
                            int grad_dtype, int64_t sm, int64_t sc, int layout, int n_levels, int n_feat, const HashParams &hp,
-                           const PermutoParams &pp, float *d_xyz, void *workspace, int64_t workspace_bytes, hipStream_t st) {
+                           const PermutoParams &pp, float *d_xyz, void *workspace, int64_t workspace_bytes, hipStream_t st, const RaysArgs &ra = RaysArgs()) {
     PAG_CHECK_ARG(table_dtype == PAG_F32 || table_dtype == PAG_F16, "%s: table dtype must be F32 or F16", name);
     PAG_CHECK_ARG(grad_dtype == PAG_F32 || grad_dtype == PAG_BF16, "%s: grad dtype must be F32 or BF16", name);
     const int grouped = layout == PAG_LAYOUT_XCD8;
@@ -1420,11 +1502,27 @@ static int launch_xyz_grad(const char *name, const float *xyz, int64_t M, const 
     if (M == 0) return PAG_OK;
     PAG_CHECK_ARG(tables && grad_out && d_xyz && workspace, "%s: NULL tables/grad_out/d_xyz/workspace", name);
     const int groups = n_levels < 8 ? n_levels : 8;
-    PAG_CHECK_ARG(workspace_bytes >= (int64_t)8 * M * 3 * (int64_t)sizeof(float), "%s: workspace smaller than 8*M*3 floats", name);
-    float *part = (float *)workspace;
     const int lpx = (n_levels + 7) / 8;
     dim3 grid(encode_grid(M)), block(PAG_ENC_FWD_THREADS);
     bool launched = false;
+    if (ra.ridx) {       // reduced per ray inside the pass: d_xyz = out f32 [N,6] (d origin | d dir)
+        PAG_CHECK_ARG(ra.depths && ra.pack_start && ra.N >= 1, "%s: per-ray form needs ridx, depths, pack_start and N >= 1", name);
+        const int64_t rows_ = rays_slot_rows(M, ra.N);
+        PAG_CHECK_ARG(workspace_bytes >= 8 * rows_ * 6 * (int64_t)sizeof(float), "%s: workspace smaller than 8 * (ceil(M / 64) + N) * 6 floats", name);
+        float *slots = (float *)workspace;
+#define PAG_XR(TT, GT) PAG_DISPATCH_ALL((xyz_grad_rays_kernel<KIND, TT, GT, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const TT *)tables, (const GT *)grad_out, sm, sc, grouped, hp, pp, ra.ridx, ra.depths, slots, rows_)))
+        if (table_dtype == PAG_F32 && grad_dtype == PAG_F32) { PAG_XR(float, float) }
+        else if (table_dtype == PAG_F32 && grad_dtype == PAG_BF16) { PAG_XR(float, bf16_t) }
+        else if (table_dtype == PAG_F16 && grad_dtype == PAG_F32) { PAG_XR(__half, float) }
+        else { PAG_XR(__half, bf16_t) }
+#undef PAG_XR
+        PAG_CHECK_ARG(launched, "%s: unsupported (n_feat=%d, n_levels=%d)", name, n_feat, n_levels);
+        ray_slots_sum_kernel<<<dim3((unsigned)((ra.N + 3) / 4)), dim3(256), 0, st>>>(ra.pack_start, ra.N, slots, rows_, groups, d_xyz);
+        PAG_CHECK_LAUNCH(name);
+        return PAG_OK;
+    }
+    PAG_CHECK_ARG(workspace_bytes >= (int64_t)8 * M * 3 * (int64_t)sizeof(float), "%s: workspace smaller than 8*M*3 floats", name);
+    float *part = (float *)workspace;
     if (table_dtype == PAG_F32 && grad_dtype == PAG_F32) {
         PAG_DISPATCH_ALL((xyz_grad_kernel<KIND, float, float, F, LPX><<<grid, block, 0, st>>>(xyz, M, (const float *)tables, (const float *)grad_out, sm, sc, grouped, hp, pp, part)))
     } else if (table_dtype == PAG_F32 && grad_dtype == PAG_BF16) {
@@ -1475,6 +1573,57 @@ extern "C" int pag_permuto_encode_bwd_xyz(const float *xyz, int64_t M, const voi
     HashParams unused{};
     return launch_xyz_grad<1>("pag_permuto_encode_bwd_xyz", xyz, M, tables, table_dtype, grad_out, grad_dtype, g_stride_m, g_stride_c,
                               layout, n_levels, n_feat, unused, p, d_xyz, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Position gradient reduced per ray (d origin | d dir, f32 [N,6]) in the gather pass itself: see xyz_grad_rays_kernel.
+extern "C" int64_t pag_encode_bwd_rays_workspace_bytes(int64_t M, int64_t N) {
+    return (M > 0 && N > 0) ? 8 * rays_slot_rows(M, N) * 6 * (int64_t)sizeof(float) : 0;
+}
+static int rays_check(const char *name, const int32_t *ridx, const float *depths, const int64_t *pack_start, int64_t N, int64_t M) {
+    PAG_CHECK_ARG(N >= 1, "%s: N %lld < 1", name, (long long)N);
+    PAG_CHECK_ARG(M == 0 || (ridx && depths && pack_start), "%s: NULL ridx / depths / pack_start", name);
+    return PAG_OK;
+}
+extern "C" int pag_hash_encode_bwd_rays(const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out, int grad_dtype,
+                                        int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat, int log2_T,
+                                        const float *resolutions_host, const float *feat_scale_host, const int32_t *ridx, const float *depths,
+                                        const int64_t *pack_start, int64_t N, float *out, void *workspace, int64_t workspace_bytes, int flags, void *stream) {
+    int rc = check_common("pag_hash_encode_bwd_rays", xyz, M, n_levels, n_feat);
+    if (rc) return rc;
+    rc = rays_check("pag_hash_encode_bwd_rays", ridx, depths, pack_start, N, M);
+    if (rc) return rc;
+    PAG_CHECK_ARG(log2_T >= 1 && log2_T <= 30, "pag_hash_encode_bwd_rays: log2_T %d not in [1,30]", log2_T);
+    PAG_CHECK_ARG(resolutions_host, "pag_hash_encode_bwd_rays: resolutions_host is NULL");
+    HashParams p;
+    p.L = n_levels;
+    p.log2T = log2_T;
+    p.has_scale = feat_scale_host != nullptr;
+    p.half_coords = (flags & PAG_ENC_HALF_COORDS) ? 1 : 0;
+    for (int l = 0; l < n_levels; ++l) p.res[l] = resolutions_host[l];
+    for (int c = 0; c < n_levels * n_feat; ++c) p.scale[c] = feat_scale_host ? feat_scale_host[c] : 1.0f;
+    PermutoParams unused{};
+    RaysArgs ra{ridx, depths, pack_start, N};
+    if (M == 0) return hipMemsetAsync(out, 0, (size_t)N * 6 * sizeof(float), (hipStream_t)stream) == hipSuccess ? PAG_OK : PAG_ERR_LAUNCH;
+    return launch_xyz_grad<0>("pag_hash_encode_bwd_rays", xyz, M, tables, table_dtype, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat,
+                              p, unused, out, workspace, workspace_bytes, (hipStream_t)stream, ra);
+}
+extern "C" int pag_permuto_encode_bwd_rays(const float *xyz, int64_t M, const void *tables, int table_dtype, const void *grad_out, int grad_dtype,
+                                           int64_t g_stride_m, int64_t g_stride_c, int layout, int n_levels, int n_feat, uint32_t capacity,
+                                           const float *scale_factor_host, const float *shift_host, const float *feat_scale_host, const int32_t *ridx,
+                                           const float *depths, const int64_t *pack_start, int64_t N, float *out, void *workspace, int64_t workspace_bytes,
+                                           int flags, void *stream) {
+    int rc = check_common("pag_permuto_encode_bwd_rays", xyz, M, n_levels, n_feat);
+    if (rc) return rc;
+    rc = rays_check("pag_permuto_encode_bwd_rays", ridx, depths, pack_start, N, M);
+    if (rc) return rc;
+    PAG_CHECK_ARG(capacity >= 1 && scale_factor_host && shift_host, "pag_permuto_encode_bwd_rays: capacity 0 or NULL scale_factor / shift");
+    PermutoParams p;
+    fill_permuto(p, n_levels, n_feat, capacity, scale_factor_host, shift_host, feat_scale_host, flags);
+    HashParams unused{};
+    RaysArgs ra{ridx, depths, pack_start, N};
+    if (M == 0) return hipMemsetAsync(out, 0, (size_t)N * 6 * sizeof(float), (hipStream_t)stream) == hipSuccess ? PAG_OK : PAG_ERR_LAUNCH;
+    return launch_xyz_grad<1>("pag_permuto_encode_bwd_rays", xyz, M, tables, table_dtype, grad_out, grad_dtype, g_stride_m, g_stride_c, layout, n_levels, n_feat,
+                              unused, p, out, workspace, workspace_bytes, (hipStream_t)stream, ra);
 }
 
 extern "C" int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int n_vertices, int64_t rows_per_level) {

@@ -77,7 +77,7 @@ class _PostMarch(nn.Module):
         smp = samples.reshape(ne, k, 3)
         dep = depths.reshape(ne, k)
         if origins is not None:
-            smp = ops.ray_samples(origins, ray_dirs, smp, dep, buf.pack_start_c, ops._ray_iota(N, samples.device))
+            smp = ops.ray_samples(origins, ray_dirs, smp, dep, buf.pack_start_c, ops._ray_iota(N, samples.device), ridx=buf.ridx_sample[:cap])
         # pack_start_c = min(pack_start, capacity): these launches are queued before the host has seen the sample count, and a batch that
         # overflows the capacity (its result is discarded afterwards) must not send a per-ray kernel past the capacity-sized tensors
         out = tracer.shade(self.nef, set(self.channels), set(), ray_dirs, N, buf.ridx_entry[:ne], buf.ridx_sample[:cap], buf.pidx[:ne], smp, dep,

@@ -106,7 +106,7 @@ class OccupancyBLAS(nn.Module):
             if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
                 # pose gradient: the k samples of a ray's nuggets are its pack (pack_start counts samples) - the same per-ray segmented
                 # sums as in 'ray' mode (pag_ray_sample_grad: one launch, fixed order)
-                samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack)
+                samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack, ridx=ridx_sample)
             return ridx64, pidx, samples, depths[..., None], deltas[:, None], boundary
         if raymarch_type != "ray":
             raise NotImplementedError("raymarch_type '%s'" % raymarch_type)
@@ -114,8 +114,11 @@ class OccupancyBLAS(nn.Module):
             rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, jitter, bits, self.blas_level, want_ridx64=True)
         self._pack_cache = (ridx64, ridx, pack_start, ray_of_pack)
         if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
-            samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack)   # pose gradient
-        return ridx64, pidx, samples[:, None], depths[:, None], deltas[:, None], boundary
+            samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack, ridx=ridx)   # pose gradient
+        out = samples[:, None]
+        if hasattr(samples, "_pag_rays"):
+            out._pag_rays = samples._pag_rays          # the tag travels with the [M,1,3] view the tracer hands to the nef
+        return ridx64, pidx, out, depths[:, None], deltas[:, None], boundary
 
 
 class _GridBase(OccupancyBLAS):
@@ -175,7 +178,7 @@ class _GridBase(OccupancyBLAS):
         """interpolate() with the nef's lod_weights folded into the kernel; layout="xcd8" returns the bf16
         [8, M, 8] XCD-grouped features the fused decoders consume (ops.encode); addend: see ops.encode."""
         return ops.encode(self._coords(coords), self.tables, self._spec, feat_scale, out_dtype, False, layout=layout, addend=addend,
-                          half_coords=self.rounds_coords())
+                          half_coords=self.rounds_coords(), rays=getattr(coords, "_pag_rays", None))
 
 
 class HashGridHIP(_GridBase):

@@ -240,12 +240,80 @@ class _Encode(torch.autograd.Function):
         return d_xyz, gt, None, None, None, None, None, None
 
 
-def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None, addend=None, half_coords=None):
+RAYS_FUSED = os.environ.get("PAG_RAYS_FUSED", "1") != "0"      # A/B switch: position gradient reduced per ray inside the gather pass (_EncodeRays)
+
+
+class _EncodeRays(torch.autograd.Function):
+    """encode() on samples that come straight from the ray march with a pose gradient attached (ray_samples(): samples = origins[ray] +
+    dirs[ray] * depth, pc_nerf/ba_pipeline.py:85-92) as ONE autograd node from (origins, dirs, tables) to the features: what the backward wants of
+    d loss / d xyz is its per-ray sum and its per-ray sum weighted by depth, and pag_*_encode_bwd_rays forms both inside the gather pass (6 floats per
+    wave and ray leave the kernel instead of 8 x 3 floats per sample - 1.4 GB and two launches less on a dense 24 576-ray step).  The samples
+    themselves enter detached: their _RaySamples node receives nothing from here."""
+
+    @staticmethod
+    def forward(ctx, origins, dirs, xyz, tables, spec, feat_scale, out_dtype, xcd8, flags, depths, pack_start, ridx):
+        _check_gpu(xyz, tables, depths, pack_start, ridx)
+        xyz = xyz.detach().contiguous().float()
+        M, C = xyz.shape[0], spec.L * spec.F
+        if tables.shape != (spec.L, spec.rows(), spec.F):
+            raise RuntimeError("tables shape %s does not match the encoder spec %s" % (tuple(tables.shape), (spec.L, spec.rows(), spec.F)))
+        out = torch.empty(8, M, 8, device=xyz.device, dtype=torch.bfloat16) if xcd8 else torch.empty(M, C, device=xyz.device, dtype=out_dtype)
+        tc = tables.detach().contiguous()
+        if M:
+            _encode_fwd(spec, xyz, tc, feat_scale, out, None, flags=flags)
+        ctx.spec, ctx.feat_scale, ctx.flags, ctx.N = spec, feat_scale, flags, origins.shape[0]
+        ctx.save_for_backward(xyz, tc, depths.detach().reshape(-1).float().contiguous(), pack_start, ridx.detach().reshape(-1).contiguous())
+        ctx.tshape, ctx.tdtype = tables.shape, tables.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, tc, depths, pack_start, ridx = ctx.saved_tensors
+        spec, N, M, dev = ctx.spec, ctx.N, ctx.saved_tensors[0].shape[0], ctx.saved_tensors[0].device
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        g = g.contiguous()
+        gt = d_o = d_d = None
+        if ctx.needs_input_grad[3]:
+            if M and (BWD_ALGO == "binned" or g.dim() == 3):
+                gt = torch.empty(ctx.tshape, device=dev, dtype=torch.float32)
+                _encode_bwd(spec, xyz, g, ctx.feat_scale, gt, overwrite=True, flags=ctx.flags)
+            else:
+                gt = torch.zeros(ctx.tshape, device=dev, dtype=torch.float32)
+                if M:
+                    _encode_bwd(spec, xyz, g, ctx.feat_scale, gt, flags=ctx.flags)
+            gt = gt.to(ctx.tdtype)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            out = torch.empty(N, 6, device=dev)
+            lib = L.load()
+            ws_bytes = lib.pag_encode_bwd_rays_workspace_bytes(max(M, 1), N)
+            ws = torch.empty(ws_bytes // 4, device=dev)
+            flags = spec.flags if ctx.flags is None else ctx.flags
+            fs = L.host_floats(ctx.feat_scale)
+            sm, sc, lay = _layout_args(g)
+            tail = (L.ptr(ridx), L.ptr(depths), L.ptr(pack_start), N, L.ptr(out), L.ptr(ws), ws_bytes, flags, L.stream())
+            if spec.kind == "hash":
+                _call("pag_hash_encode_bwd_rays", L.ptr(xyz), M, L.ptr(tc), L.dtype_code(tc), g.data_ptr(), L.dtype_code(g), sm, sc, lay, spec.L, spec.F, spec.log2_T,
+                      spec.res, fs, *tail)
+            else:
+                _call("pag_permuto_encode_bwd_rays", L.ptr(xyz), M, L.ptr(tc), L.dtype_code(tc), g.data_ptr(), L.dtype_code(g), sm, sc, lay, spec.L, spec.F, spec.capacity,
+                      spec.sf, spec.shift, fs, *tail)
+            d_o, d_d = out[:, :3], out[:, 3:]
+        return d_o, d_d, None, gt, None, None, None, None, None, None, None, None
+
+
+def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_major=False, layout=None, addend=None, half_coords=None, rays=None):
     """Grid features [M, L*F] (column = level*F + f); layout="xcd8" returns the bf16 [8, M, 8] XCD-grouped tensor the
     fused decoders consume directly.  Differentiable w.r.t. tables and (when xyz.requires_grad) xyz.
     addend (xcd8 only, treated as a constant): the result is bf16(addend + bf16(features)) in the same launch.
-    half_coords: None = as the spec says; True / False override it for this call (forward and both gradients)."""
+    half_coords: None = as the spec says; True / False override it for this call (forward and both gradients).
+    rays = ray_samples()'s tag of xyz (origins, dirs, depths, pack_start, ridx): the position gradient then goes to origins / dirs directly (_EncodeRays)."""
     flags = None if half_coords is None else (L.ENC_HALF_COORDS if half_coords else 0)
+    if rays is not None and RAYS_FUSED and addend is None and not feature_major and xyz.requires_grad and torch.is_grad_enabled() and xyz.shape[0]:
+        origins, dirs, depths, pack_start, ridx = rays
+        if depths.numel() == xyz.shape[0] and ridx.numel() == xyz.shape[0]:
+            # (xyz enters detached: as a differentiable input its _RaySamples node would still be run - on materialised zeros - by the engine)
+            return _EncodeRays.apply(origins, dirs, xyz.detach(), tables, spec, feat_scale, out_dtype, layout == "xcd8", flags, depths, pack_start, ridx)
     return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major, addend, flags)
 
 
@@ -968,9 +1036,14 @@ class _RaySamples(torch.autograd.Function):
         return seg[:, :3], seg[:, 3:], None, None, None, None
 
 
-def ray_samples(origins, dirs, samples, depths, pack_start, ray_of_pack):
-    """Attach the pose gradient to march-kernel samples (samples [M,3] or [M',k,3], depths alike, one pack per ray)."""
-    return _RaySamples.apply(origins, dirs, samples, depths, pack_start, ray_of_pack)
+def ray_samples(origins, dirs, samples, depths, pack_start, ray_of_pack, ridx=None):
+    """Attach the pose gradient to march-kernel samples (samples [M,3] or [M',k,3], depths alike, one pack per ray).
+    ridx (i32, the ray of every SAMPLE, as the march kernels write it): the result is tagged (`_pag_rays`) so that an encoder that interpolates exactly these
+    samples can send its position gradient to origins / dirs directly, reduced per ray inside its gather pass (encode(..., rays=...))."""
+    out = _RaySamples.apply(origins, dirs, samples, depths, pack_start, ray_of_pack)
+    if ridx is not None and _one_pack_per_ray(ray_of_pack, origins.shape[0]) and ridx.dtype == torch.int32:
+        out._pag_rays = (origins, dirs, depths, pack_start, ridx)
+    return out
 
 
 _TVALS = {}

@@ -358,3 +358,49 @@ def test_zero_gradient_tiles_take_the_early_outs_with_the_same_gradients(gpu_dev
         assert T._rel_l2(got.float(), want.float()) < 2e-5, (name, T._rel_l2(got.float(), want.float()))
     # rows of the table that only unused rays touch stay exactly zero
     assert float((g_full["grid.tables"][g_sub["grid.tables"] == 0]).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+@pytest.mark.parametrize("layout", ["xcd8", None])
+def test_position_gradient_reduced_per_ray_in_the_gather_pass(gpu_device, mode, layout):
+    """pag_permuto_encode_bwd_rays (ops._EncodeRays: d origins / d dirs formed per ray inside the position-gradient pass - a segmented scan over each wave's
+    lanes, one 6-float slot per (group, wave, ray)) against the per-sample form (pag_permuto_encode_bwd_xyz + pag_ray_sample_grad) on packed samples from the
+    real march: ragged rays (occupancy mask), rays without samples, waves that straddle several rays (voxel march: ~10 samples per ray), M % 64 != 0.
+    Same table gradient bit for bit; pose gradients to fp32 summation order."""
+    import pagnerf_amd
+    import test_gpu_parity as T
+    from pagnerf_amd import ops
+    dev = gpu_device
+    N, S = 300, 40
+    nef, tracer, rays, occ, jitter = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=12)
+    o = rays.origins.clone()
+    o[7] = 5.0                                              # a ray that misses the volume: no samples
+    g = nef.grid
+    res = {}
+    for fused in (True, False):
+        ops.RAYS_FUSED = fused
+        try:
+            oo, dd = o.clone().requires_grad_(True), rays.dirs.clone().requires_grad_(True)
+            r = pagnerf_amd.Rays(oo, dd, rays.dist_min, rays.dist_max)
+            if mode == "ray":
+                out = g.raymarch(r, level=None, num_samples=S, raymarch_type="ray", jitter=jitter.to(dev))
+            else:
+                out = g.raymarch(r, level=None, num_samples=2, raymarch_type="voxel", max_travel=0.9)
+            samples = out[2]
+            assert hasattr(samples, "_pag_rays") and samples.requires_grad
+            M = samples.reshape(-1, 3).shape[0]
+            g.tables.grad = None
+            feats = g.interpolate_scaled(samples, None, out_dtype=torch.bfloat16 if layout else torch.float32, layout=layout)
+            assert (type(feats.grad_fn).__name__ == "_EncodeRaysBackward") == fused
+            gen = torch.Generator().manual_seed(3)
+            w = torch.randn(feats.shape, generator=gen).to(dev)
+            (feats.float() * w).sum().backward()
+            res[fused] = (oo.grad.clone(), dd.grad.clone(), g.tables.grad.clone(), M)
+        finally:
+            ops.RAYS_FUSED = True
+    (o1, d1, t1, M1), (o0, d0, t0, M0) = res[True], res[False]
+    assert M1 == M0 and M1 % 64 != 0 and float(o0[7].abs().sum()) == 0.0 and float(o1[7].abs().sum()) == 0.0
+    assert torch.equal(t1, t0)
+    assert float(o0.abs().sum()) > 0 and float(d0.abs().sum()) > 0
+    np.testing.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(o0.abs().max()))
+    np.testing.assert_allclose(d1.cpu().numpy(), d0.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(d0.abs().max()))
