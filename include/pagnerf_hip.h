@@ -248,8 +248,16 @@ typedef struct pag_mlp_bwd_args {
      * the layers below the wide output layer: one read of the input and one write of the summed input gradient for both decoders.
      * The caller does not call pag_mlp_bwd for it. */
     const struct pag_mlp_bwd_args *pair;
+    /* Optional (ABI 11), colour-like decoder with wgrad_workspace and a per-ray x2 whose x2_index is NON-DECREASING (samples packed ray by ray): instead
+     * of the [M,64] dz[0] tensor the launch writes one f32 [64] row per (32-sample tile, ray) - the column sums of dz_0 over that ray's samples of the
+     * tile, formed on the matrix cores - at row tile + ray of dz0_slots (pag_mlp_dz0_slots_bytes(M, R) bytes, R = rows of x2); pag_mlp_dz0_slots_sum adds
+     * a ray's rows: the per-ray sum of dz_0 (x W_0[:, k1:] = the gradient of x2) for 8 B per sample instead of 128 written and 128 read again. */
+    float *dz0_slots;
 } pag_mlp_bwd_args;
 int pag_mlp_bwd(const pag_mlp_bwd_args *args, int64_t M, void *stream);
+int64_t pag_mlp_dz0_slots_bytes(int64_t M, int64_t R);
+/* out f32 [R,64] = per-ray sums of pag_mlp_bwd_args.dz0_slots; pack_start i64 [R+1] = the rays' sample ranges (one pack per ray).  (ABI 11) */
+int pag_mlp_dz0_slots_sum(const int64_t *pack_start, int64_t R, const float *slots, float *out, void *stream);
 /* 1 when pag_mlp_bwd has a fused weight-gradient kernel for these (fully filled in, wgrad_workspace aside) arguments.  Three
  * decoder shapes are covered - the narrow decoders of pc_nerf/panoptic_nef.py:114-164 on the bf16 path:
  *   density-like   XCD8 bf16 x1, dense bf16 grad_out, no output activation, out_dim % 4 == 0, XCD8 bf16 dx1

@@ -68,7 +68,7 @@ MlpBwdArgs._fields_ = [("grad_out", c_vp), ("out", c_vp), ("out_dtype", c_i32), 
                 ("x1", c_vp), ("x1_dtype", c_i32), ("x2", c_vp), ("k2p", c_i32), ("x2_index", c_vp),
                 ("wgrad_workspace", c_vp), ("wgrad_workspace_bytes", c_i64),
                 ("dW", c_vp * 3), ("db", c_vp * 3), ("b", c_vp * 3),
-                ("pair", ctypes.POINTER(MlpBwdArgs))]
+                ("pair", ctypes.POINTER(MlpBwdArgs)), ("dz0_slots", c_vp)]
 
 
 _SIGS = {
@@ -133,6 +133,8 @@ _SIGS = {
     "pag_pose_rays_bwd_workspace_bytes": (c_i64, [c_i64]),
     "pag_pose_rays_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pag_view_embed_bwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "pag_mlp_dz0_slots_bytes": (c_i64, [c_i64, c_i64]),
+    "pag_mlp_dz0_slots_sum": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "pag_encode_bwd_rays_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "pag_hash_encode_bwd_rays": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_fp, c_fp, c_vp, c_vp, c_vp, c_i64,
                                          c_vp, c_vp, c_i64, c_i32, c_vp]),

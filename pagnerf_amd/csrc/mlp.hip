@@ -100,6 +100,7 @@ struct BwdParams {
     int k2p;
     float *slabs[3];           // per layer: f32 [4 * gridDim.x][rows_pad][WG_SLAB_COLS]  (cols 0..63 dW, col 64 db)
     const float *b[3];         // biases of the hidden layers: mlp_bwd_fused recomputes the hidden activations instead of reading saved ones
+    float *dz0_slots;          // colour-like fused kernel, DZ0 == 2: f32 [(ceil(M / 32) + R)][64] column sums of dz_0 per (tile, ray), row = tile + ray
 };
 
 // Stage W [n_out x n_in] f32 row-major into LDS as bf16 [rows_pad][stride]; zero padding;
@@ -1543,8 +1544,12 @@ __global__ __launch_bounds__(256, (OBMAX == 2 ? 1 : PAG_BWD_WAVES)) void mlp_bwd
 //   KIND 2  semantic-like: XCD8 bf16 input, rank-1 gradient, softmax with saved bf16 probabilities (out_dim <= 8), XCD8 bf16 dx
 //                          (DXACC: added to the other head's gradient in place)
 // Full 32-sample tiles run in the main loop; a ragged last tile runs once after it with predicated stores.
-// DZ0: also write dz_0 (the gradient at the first hidden layer's pre-activation) as a bf16 [M,64] tensor (p.dz[0]) - what the caller sums per ray
+// DZ0 = 1: also write dz_0 (the gradient at the first hidden layer's pre-activation) as a bf16 [M,64] tensor (p.dz[0]) - what the caller sums per ray
 // and multiplies by W_0[:, k1:] for the gradient of the per-ray x2 (the view embedding: pose optimisation, pc_nerf/ba_pipeline.py:89-90).
+// DZ0 = 2 (x2_index non-decreasing: samples packed ray by ray): the per-ray sum starts HERE - the tile's dz_0 rows are summed per ray on the matrix
+// cores (dz_0^T . S with S[sample][j] = 1 where the sample belongs to the tile's j-th ray: the A fragments are the ones layer 0's weight gradient
+// reads anyway) and one 64-float row per (tile, ray) leaves the kernel (p.dz0_slots, row = tile + ray: strictly increasing along the samples, so
+// every pair owns a row): 8 B per sample on 512-sample rays instead of 128 written and 128 read again by the per-ray sum.
 #ifdef PAG_FUSED_PROF      // debug build: where a workgroup of mlp_bwd_fused spends its clocks outside the tile loop (printed per launch by pag_mlp_bwd)
 __device__ unsigned long long g_fused_prof[8];      // shader clocks summed over workgroups: [0] staging, [1] tile loop, [2] cross-wave sum, [4] workgroups
 #endif
@@ -1554,7 +1559,7 @@ __device__ unsigned long long g_fused_prof[8];      // shader clocks summed over
 #ifndef PAG_EXP_FUSED_WAVES
 #define PAG_EXP_FUSED_WAVES 1
 #endif
-template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */, bool DZ0 = false>
+template <int NL, int KIND, bool DXACC, int OBL = 1 /* 32-row blocks of the output layer; 2 only with KIND 0 */, int DZ0 = 0 /* 1: dz_0 rows, 2: per-(tile, ray) sums */>
 __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdParams p) {
     PAG_BLOCK_TIMER(2);
 #ifdef PAG_FUSED_PROF
@@ -1595,11 +1600,11 @@ __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdPar
     const int64_t tile_step = (int64_t)gridDim.x * 4;
     const bf16_t *x1b = reinterpret_cast<const bf16_t *>(p.x1);
     const int32_t *ridx = KIND == 1 ? p.x2_index : p.g_index;      // per-sample row of the per-ray tables
-    const auto rs_dz0 = __builtin_amdgcn_make_buffer_rsrc(DZ0 ? p.dz[0] : nullptr, 0, (int)(DZ0 ? M * HID * 2 : 0), 0x00020000);
+    const auto rs_dz0 = __builtin_amdgcn_make_buffer_rsrc(DZ0 == 1 ? p.dz[0] : nullptr, 0, (int)(DZ0 == 1 ? M * HID * 2 : 0), 0x00020000);
     // the masked dz_0 of the tile sits in the Tz image (row = sample, 4-unit chunks in natural order): whole rows leave as 16-byte pieces;
     // rows past M fall outside the buffer's bounds and are dropped
     auto store_dz0 = [&](int64_t tile) __attribute__((always_inline)) {
-        if constexpr (DZ0) {
+        if constexpr (DZ0 == 1) {
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             const unsigned voff = (unsigned)(tile * (32 * HID * 2)) + (unsigned)((lane >> 3) * (HID * 2) + (lane & 7) * 16);
@@ -1609,6 +1614,57 @@ __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdPar
                 const u32x2 lo = *reinterpret_cast<const u32x2 *>(Tz + tw_off(rowl, ch));
                 const u32x2 hi = *reinterpret_cast<const u32x2 *>(Tz + tw_off(rowl, ch + 1));
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, rs_dz0, voff + k * (8 * HID * 2), 0, 0);
+            }
+        }
+    };
+
+    // DZ0 == 2: wave-private scratch behind the tiles - the local ray number of each of the tile's 32 samples and the ray of each local number
+    int *lray_s = reinterpret_cast<int *>(reinterpret_cast<bf16_t *>(b1s + 64) + 4 * ((NL + 1) * TW_ELEMS)) + (threadIdx.x >> 6) * 64, *rid_s = lray_s + 32;
+    int ray_c = 0;             // x2 row (= ray) of this lane's sample in the CURRENT tile (DZ0 == 2)
+    unsigned heads_c = 0u;     // bit s: sample s of the current tile starts a new ray
+    auto note_rays = [&](int ray_here) __attribute__((always_inline)) {      // called at the top of a tile, before its first wave_lds_sync
+        if constexpr (DZ0 == 2) {
+            const int prev = __shfl_up(ray_here, 1, 32);
+            const bool head = r == 0 || prev != ray_here;
+            heads_c = (unsigned)__ballot(head);                      // lanes 0..31 and 32..63 hold the same rows: the low word
+            const int lr = __builtin_popcount(heads_c & (0xFFFFFFFFu >> (31 - r))) - 1;
+            if (h == 0) {
+                lray_s[r] = lr;
+                if (head) rid_s[lr] = ray_here;
+            }
+        }
+    };
+    auto store_dz0_slots = [&](int64_t tile) __attribute__((always_inline)) {
+        if constexpr (DZ0 == 2) {
+            f32x16 d[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4 l0 = *reinterpret_cast<const i32x4 *>(lray_s + 16 * ks + 8 * h), l1 = *reinterpret_cast<const i32x4 *>(lray_s + 16 * ks + 8 * h + 4);
+                bf16x8 sf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sf[e] = (bf16_t)(l0[e] == r ? 1.0f : 0.0f);
+                    sf[4 + e] = (bf16_t)(l1[e] == r ? 1.0f : 0.0f);
+                }
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) {
+                    const bf16x8 afr = tw_frag(Tz, ob, ks, lane);
+                    if (ks == 0) {
+                        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        d[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, sf, zero, 0, 0, 0);
+                    } else {
+                        d[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, sf, d[ob], 0, 0, 0);
+                    }
+                }
+            }
+            if (r < __builtin_popcount(heads_c)) {      // lane (j, h): the tile's j-th ray, channels 32 ob + 8 g + 4 h .. + 3
+                float *o = p.dz0_slots + ((int64_t)tile + rid_s[r]) * 64;
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4 *>(o + 32 * ob + 8 * g + 4 * h) = f32x4{d[ob][4 * g], d[ob][4 * g + 1], d[ob][4 * g + 2], d[ob][4 * g + 3]};
             }
         }
     };
@@ -1744,6 +1800,7 @@ __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdPar
         const bool live = FULL || m < M;
         // ---- this tile's layer-0 input and the hidden activations recomputed from it become LDS images (kept for the whole tile)
         wave_lds_sync();
+        note_rays(ray_c);
         {
             bf16x8 xb[4];
 #pragma unroll
@@ -1816,6 +1873,7 @@ __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdPar
         // ---- the previous tile's dx goes out, then everything of the next tile is requested (its row index was loaded one tile earlier)
         flush(true);
         prefetch(tile + tile_step, ray1);
+        ray_c = ray1;              // (the next tile's; this tile's local ray numbers are in LDS by now)
         ray1 = ray2;
         if constexpr (KIND != 0) ray2 = ridx[row_of(tile + 3 * tile_step)];
         bf16x8 zb[2 * OBL];
@@ -1850,6 +1908,7 @@ __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdPar
             for (int s = 0; s < 4; ++s) hb[s] = hb2[s];
         }
         store_dz0(tile);
+        store_dz0_slots(tile);
         // ---- dx1 = (W_0^T . dz_0)[0:k1], then layer 0's weight gradient
         wt_chain_pinned<(GRP ? 2 : 1), 4>(W0t, RS, hb, r, h, acc);
         wgrad_tile(Tx, aw0, -1);
@@ -1882,6 +1941,7 @@ __global__ __launch_bounds__(256, PAG_EXP_FUSED_WAVES) void mlp_bwd_fused(BwdPar
         ray2 = ridx[row_of(tile + 2 * tile_step)];
     }
     prefetch(tile, ray0);
+    ray_c = ray0;
     const bool any_tile = tile < ntiles;
     bool last_ragged = false;
     for (; tile < nfull; tile += tile_step) body(tile, std::true_type{});
@@ -4081,16 +4141,29 @@ extern "C" int pag_mlp_bwd(const pag_mlp_bwd_args *a, int64_t M, void *stream) {
     } while (0)
         const bool acc = a->dx1_accumulate != 0;
         p.dz[0] = kind == 1 ? a->dz[0] : nullptr;
-        if (kind == 1 && a->dz[0]) {      // colour-like with the per-ray input's gradient requested: dz_0 is written as well
+        p.dz0_slots = kind == 1 ? a->dz0_slots : nullptr;
+        if (kind == 1 && a->dz0_slots) {      // colour-like, per-ray input's gradient requested, samples packed ray by ray: per-(tile, ray) sums of dz_0
+            static bool attr2s = false, attr3s = false;
+            const size_t lds_s = lds + 4 * 64 * sizeof(int);
+            if (a->n_layers == 2) {
+                if (!attr2s) hipFuncSetAttribute((const void *)mlp_bwd_fused<2, 1, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2s = true;
+                hipLaunchKernelGGL((mlp_bwd_fused<2, 1, false, 1, 2>), dim3(grid), dim3(256), lds_s, st, p);
+            } else {
+                if (!attr3s) hipFuncSetAttribute((const void *)mlp_bwd_fused<3, 1, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr3s = true;
+                hipLaunchKernelGGL((mlp_bwd_fused<3, 1, false, 1, 2>), dim3(grid), dim3(256), lds_s, st, p);
+            }
+        } else if (kind == 1 && a->dz[0]) {      // colour-like with the per-ray input's gradient requested: dz_0 is written as well
             static bool attr2 = false, attr3 = false;
             if (a->n_layers == 2) {
-                if (!attr2) hipFuncSetAttribute((const void *)mlp_bwd_fused<2, 1, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (!attr2) hipFuncSetAttribute((const void *)mlp_bwd_fused<2, 1, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr2 = true;
-                hipLaunchKernelGGL((mlp_bwd_fused<2, 1, false, 1, true>), dim3(grid), dim3(256), lds, st, p);
+                hipLaunchKernelGGL((mlp_bwd_fused<2, 1, false, 1, 1>), dim3(grid), dim3(256), lds, st, p);
             } else {
-                if (!attr3) hipFuncSetAttribute((const void *)mlp_bwd_fused<3, 1, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (!attr3) hipFuncSetAttribute((const void *)mlp_bwd_fused<3, 1, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr3 = true;
-                hipLaunchKernelGGL((mlp_bwd_fused<3, 1, false, 1, true>), dim3(grid), dim3(256), lds, st, p);
+                hipLaunchKernelGGL((mlp_bwd_fused<3, 1, false, 1, 1>), dim3(grid), dim3(256), lds, st, p);
             }
         } else if (a->n_layers == 2) {
             if (kind == 0) MLP_BWD_FUSED(2, 0, false);
@@ -4310,6 +4383,30 @@ extern "C" int pag_affine_xcd8_bwd_dx(const float *grad_out, int64_t M, int x_le
     hipLaunchKernelGGL(affine_xcd8_bwd_dx_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_out, M, x_levels, x_feats, W, n_out, in_dim,
                        (bf16_t *)dx);
     PAG_CHECK_LAUNCH("pag_affine_xcd8_bwd_dx");
+    return PAG_OK;
+}
+
+// seg[ray][c] = sum of the ray's (tile, ray) rows of mlp_bwd_fused<.., DZ0 = 2>: one wave per ray, lane = channel, rows tile + ray for the tiles the ray's
+// samples span (fixed order: bitwise reproducible); rays without samples get zeros
+namespace {
+__global__ __launch_bounds__(256) void dz0_slots_sum_kernel(const int64_t *__restrict__ pack_start, int64_t R, const float *__restrict__ slots, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const int64_t beg = pack_start[ray], end = pack_start[ray + 1];
+    float a = 0.0f;
+    if (end > beg)
+        for (int64_t t = beg >> 5; t <= ((end - 1) >> 5); ++t) a += slots[(t + ray) * 64 + lane];
+    out[ray * 64 + lane] = a;
+}
+}  // namespace
+extern "C" int64_t pag_mlp_dz0_slots_bytes(int64_t M, int64_t R) { return (M > 0 && R > 0) ? ((M + 31) / 32 + R) * 64 * (int64_t)sizeof(float) : 0; }
+extern "C" int pag_mlp_dz0_slots_sum(const int64_t *pack_start, int64_t R, const float *slots, float *out, void *stream) {
+    PAG_CHECK_ARG(R >= 0, "pag_mlp_dz0_slots_sum: R < 0");
+    if (R == 0) return PAG_OK;
+    PAG_CHECK_ARG(pack_start && slots && out, "pag_mlp_dz0_slots_sum: NULL input/output");
+    hipLaunchKernelGGL(dz0_slots_sum_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pack_start, R, slots, out);
+    PAG_CHECK_LAUNCH("pag_mlp_dz0_slots_sum");
     return PAG_OK;
 }
 

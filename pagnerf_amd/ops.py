@@ -582,16 +582,23 @@ class _FusedMLP(torch.autograd.Function):
         # kernel for this decoder shape: no dz tensors, no second pass over the activations.  d x2 (pose optimisation) is formed
         # from dz_0, so that case keeps the dz tensors and the separate weight-gradient launches.
         fused = False
-        dz0_fused = None
+        dz0_fused = dz0_slots = None
         if WGRAD_FUSED and 0 < M <= L.MLP_FUSED_WIDE_MAX_M and mode == L.MLP_MFMA_BF16 and x1.dtype == torch.bfloat16 \
                 and (not need_dx2 or grouped is None):
             a.x1, a.x1_dtype = L.ptr(x1), L.BF16
             if x2 is not None:
                 a.x2, a.k2p, a.x2_index = L.ptr(x2), k2p, L.ptr(x2_index)
             fused = lib.pag_mlp_bwd_fused_supported(ctypes.byref(a)) == 1
-            if fused and need_dx2:        # colour-like kernel: dz_0 comes out as a tensor too (pag_mlp_bwd_args.dz[0]), d x2 is formed from it below
-                dz0_fused = torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
-                a.dz[0] = L.ptr(dz0_fused)
+            if fused and need_dx2:        # colour-like kernel: d x2 is formed from dz_0 below
+                packs = ctx.x2_packs
+                if DZ0_SLOTS and packs is not None and _one_pack_per_ray(packs[1], x2.shape[0]) and packs[0].shape[0] == x2.shape[0] + 1:
+                    # samples packed ray by ray (x2_index non-decreasing): the per-ray sum of dz_0 starts inside the kernel - one 64-float row per
+                    # (tile, ray) instead of the [M,64] tensor (pag_mlp_bwd_args.dz0_slots)
+                    dz0_slots = torch.empty(lib.pag_mlp_dz0_slots_bytes(M, x2.shape[0]) // 4, device=dev)
+                    a.dz0_slots = L.ptr(dz0_slots)
+                else:                     # dz_0 comes out as a tensor (pag_mlp_bwd_args.dz[0])
+                    dz0_fused = torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
+                    a.dz[0] = L.ptr(dz0_fused)
         if not fused and any(h is None for h in hidden):      # the forward counted on the fused kernels: rebuild what it skipped
             hidden = _recompute_hidden(x1, x2, x2_index, Wc, bc, in_dim, k1, grouped, mode, hidden)
         for i, h in enumerate(hidden):
@@ -667,8 +674,11 @@ class _FusedMLP(torch.autograd.Function):
             # d x2[r] = (sum of dz_0 over the samples that gathered row r) @ W_0[:, k1:]  - the per-ray view embedding's
             # gradient (pose optimisation: the view direction depends on the camera rotation, ba_pipeline.py:89-90)
             R = x2.shape[0]
-            if M == 0:
-                seg = torch.zeros(R, dz[0].shape[1], device=dev)
+            if dz0_slots is not None and M:                # the kernel left per-(tile, ray) sums: add each ray's rows
+                seg = torch.empty(R, 64, device=dev)
+                _call("pag_mlp_dz0_slots_sum", L.ptr(ctx.x2_packs[0]), R, L.ptr(dz0_slots), L.ptr(seg), L.stream())
+            elif M == 0:
+                seg = torch.zeros(R, 64, device=dev)
             elif ctx.x2_packs is not None:                 # rows gathered pack by pack: one segmented-sum launch
                 pack_start, ray_of_pack = ctx.x2_packs
                 seg = composite_feats(dz[0], torch.ones(M, device=dev), torch.ones(R, device=dev), pack_start, ray_of_pack, R)
@@ -680,6 +690,7 @@ class _FusedMLP(torch.autograd.Function):
         return (dx1, dx2, None, None, None, None, None, None, *gW, *gb)
 
 
+DZ0_SLOTS = os.environ.get("PAG_DZ0_SLOTS", "1") != "0"      # A/B switch: per-(tile, ray) sums of dz_0 inside the colour backward (pag_mlp_bwd_args.dz0_slots)
 WGRAD_MAX_BATCH = 6      # WG_MAX_BATCH of csrc/mlp.hip
 WGRAD_FUSED = os.environ.get("PAG_NO_FUSED_WGRAD") is None      # narrow decoders: weight gradients inside pag_mlp_bwd (no dz tensors)
 

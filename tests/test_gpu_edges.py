@@ -404,3 +404,45 @@ def test_position_gradient_reduced_per_ray_in_the_gather_pass(gpu_device, mode, 
     assert float(o0.abs().sum()) > 0 and float(d0.abs().sum()) > 0
     np.testing.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(o0.abs().max()))
     np.testing.assert_allclose(d1.cpu().numpy(), d0.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(d0.abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_view_embedding_gradient_from_per_tile_ray_sums(gpu_device, mode):
+    """pag_mlp_bwd_args.dz0_slots: the colour decoder's backward sums dz_0 per (32-sample tile, ray) on the matrix cores and pag_mlp_dz0_slots_sum adds a
+    ray's rows - against the [M,64] dz_0 tensor + per-ray segmented sum it replaces: the gradient of the camera extrinsics through the VIEW EMBEDDING alone
+    (the position path switched off by detaching the samples is not possible from outside, so the whole pose gradient is compared, to fp32 summation order)
+    and every decoder weight gradient bit for bit; ragged rays, tiles that span many rays (voxel march), a ray without samples, M % 32 != 0."""
+    import pagnerf_amd
+    import test_gpu_parity as T
+    from pagnerf_amd import ops
+    from pagnerf_amd.ba_pipeline import BAPipeline
+    dev = gpu_device
+    N, S = 200, 48
+    nef, tracer, rays, occ, jitter = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=12)
+    if mode == "voxel":
+        tracer.raymarch_type, tracer.num_steps, tracer.ray_max_travel = "voxel", 2, 0.9
+    o = rays.origins.clone()
+    o[11] = 5.0
+    views = torch.eye(4).repeat(2, 1, 1)
+    views[:, :3, 3] = torch.tensor([[0.01, -0.02, 0.0], [0.0, 0.015, -0.01]])
+    pipe = BAPipeline(nef, views, tracer=tracer, near=rays.dist_min, far=rays.dist_max).to(dev)
+    cam = (torch.arange(N, device=dev) * 2 // N).int()
+    gen = torch.Generator().manual_seed(8)
+    G = torch.randn(N, 3, generator=gen).to(dev)
+    res = {}
+    for slots in (True, False):
+        ops.DZ0_SLOTS = slots
+        try:
+            for p in list(nef.parameters()) + [pipe.camera_extrinsics]:
+                p.grad = None
+            r = pipe.transform_rays_indexed(o, rays.dirs, cam)
+            rb = tracer(nef, channels={"rgb"}, rays=r, jitter=jitter.to(dev), stage="train")
+            (rb.rgb * G).sum().backward()
+            res[slots] = (pipe.camera_extrinsics.grad.clone(), {n: p.grad.clone() for n, p in nef.named_parameters() if p.grad is not None})
+        finally:
+            ops.DZ0_SLOTS = True
+    (c1, w1), (c0, w0) = res[True], res[False]
+    assert float(c0.abs().sum()) > 0
+    np.testing.assert_allclose(c1.cpu().numpy(), c0.cpu().numpy(), rtol=5e-4, atol=5e-5 * float(c0.abs().max()))
+    for name in w0:
+        assert torch.equal(w1[name], w0[name]), name
