@@ -651,7 +651,9 @@ def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=
     pipe = pagnerf_amd.Pipeline(nef, tracer)
     bps = 12 + 24 * 4 * 2 * (2 if args.table_dtype == "fp16" else 4) + 24 * 2 * out_bytes
     with torch.no_grad():
-        for tag, chans in (("all_channels", sorted(all_ch)), ("rgb_depth", ["depth", "rgb"])):
+        big = 32768       # the same image with a render batch sized for this GPU's memory instead of the reference's 8000 (`render_batch` is a config key)
+        for tag, chans, render_batch in (("all_channels", sorted(all_ch), render_batch), ("rgb_depth", ["depth", "rgb"], render_batch),
+                                         ("all_channels_render_batch_%d" % big, sorted(all_ch), big)):
             warm = pagnerf_amd.Rays(rays.origins[:4 * render_batch], rays.dirs[:4 * render_batch], rays.dist_min, rays.dist_max)
             pagnerf_amd.batch_render(pipe, warm, channels=chans, render_batch=render_batch)
             torch.cuda.synchronize()
@@ -666,7 +668,7 @@ def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=
             prof = ops.profile_stop()
             per = {k.replace("pag_", ""): round(float(np.sum(v)), 3) for k, v in sorted(prof.items()) if float(np.sum(v)) > 0.05}
             enc = prof.get("pag_%s_encode_fwd" % args.grid, [])
-            ent = dict(channels=chans, ms_per_image=round(dt * 1e3, 2), rays_s=round(n / dt, 1),
+            ent = dict(channels=chans, render_batch=render_batch, ms_per_image=round(dt * 1e3, 2), rays_s=round(n / dt, 1),
                        entry_points_ms_per_image=per, device_ms_per_image=round(float(sum(np.sum(v) for v in prof.values())), 2))
             if not pruned:
                 ent["samples_s"] = round(n * 512 / dt, 1)

@@ -2467,9 +2467,9 @@ __global__ __launch_bounds__((OB + 1) * 64) void mlp_bwd_wide_blocks(BwdParams p
     // shares a SIMD with a block wave, so every VALU instruction it saves is issue time for both: all its global traffic goes through
     // buffer descriptors (scalar base + loop-invariant lane offset, out-of-range lanes read 0 / are not written) instead of per-lane
     // 64-bit address arithmetic with clamps.
-    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(hsrc), 0, (int)min(M * HID * 2, (int64_t)0x7fffffff), 0x00020000);
-    const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.g_index), 0, (int)min(M * 4, (int64_t)0x7fffffff), 0x00020000);
-    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(dzh, 0, (int)min((ntiles + 1) * 32 * HID * 2, (int64_t)0x7fffffff), 0x00020000);
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(hsrc), 0, (int)min(M * HID * 2, (int64_t)0xffffffffll), 0x00020000);
+    const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.g_index), 0, (int)min(M * 4, (int64_t)0xffffffffll), 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(dzh, 0, (int)min((ntiles + 1) * 32 * HID * 2, (int64_t)0xffffffffll), 0x00020000);
     const int voff_tile = (lane >> 3) * (HID * 2) + (lane & 7) * 16;          // + 8 rows per load
     auto load_rows = [&](float (&v)[4 * WB_RMAX], int ray_first, int ray_last) __attribute__((always_inline)) {      // WB_RMAX gradient rows
 #pragma unroll

@@ -446,3 +446,42 @@ def test_view_embedding_gradient_from_per_tile_ray_sums(gpu_device, mode):
     np.testing.assert_allclose(c1.cpu().numpy(), c0.cpu().numpy(), rtol=5e-4, atol=5e-5 * float(c0.abs().max()))
     for name in w0:
         assert torch.equal(w1[name], w0[name]), name
+
+
+def test_largest_batch_of_the_dedicated_decoder_kernels(gpu_device):
+    """PAG_MLP_FUSED_WIDE_MAX_M (include/pagnerf_hip.h: 2^24 samples - the dedicated decoder kernels address [M,64] bf16 tensors through 32-bit buffer
+    descriptors, 2^31 bytes at this size; beyond it the generic kernels run: tests/test_gpu_sizes.py::test_more_than_2pow24_samples_step).
+    A trace of exactly 2^24 samples (32768 rays x 512 steps, every sample inside an all-occupied volume), all channels, forward and backward: the rays at
+    both ends of the batch and in the middle render as in a trace of those rays alone - bit for bit; the 200-way head to 1e-7 - (what a truncated descriptor would break is exactly the
+    tail), gradients are finite and non-zero."""
+    import pagnerf_amd
+    import test_gpu_parity as T
+    dev = gpu_device
+    N, S = 32768, 512
+    nef, tracer, rays, occ, _ = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=14)
+    for grid in (nef.grid, nef.delta_grid):
+        grid.blas_init(torch.ones(occ.numel(), dtype=torch.bool))
+    gen = torch.Generator().manual_seed(12)
+    jit = torch.rand(N, S, generator=gen).to(dev)
+    chans = {"rgb", "depth", "semantics", "inst_embedding"}
+
+    def trace(sel, grad):
+        r = pagnerf_amd.Rays(rays.origins[sel], rays.dirs[sel], 0.0, 0.5)        # origins within +-0.3, travel <= 0.5: no sample leaves the volume
+        with torch.enable_grad() if grad else torch.no_grad():
+            return tracer(nef, channels=chans, rays=r, jitter=jit[sel], stage="train")
+    full = torch.arange(N, device=dev)
+    rb = trace(full, True)
+    (rb.rgb.sum() + rb.depth.sum() + rb.semantics.float().square().sum() + rb.inst_embedding.float().square().sum()).backward()
+    for name, p in nef.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), name
+    assert float(nef.grid.tables.grad.abs().sum()) > 0 and float(nef.delta_grid.tables.grad.abs().sum()) > 0
+    sub = torch.cat([full[:48], full[N // 2 - 24:N // 2 + 24], full[-48:]])
+    rs = trace(sub, False)
+    for ch in ("rgb", "depth", "semantics", "inst_embedding"):
+        a, b = getattr(rb, ch)[sub], getattr(rs, ch)
+        assert float(b.float().abs().sum()) > 0, ch
+        if ch == "inst_embedding":      # the wide head's per-ray sums are split over workgroups by batch position: fp32 summation order
+            assert float((a.detach().float() - b.float()).abs().max()) < 1e-7
+        else:
+            assert torch.equal(a, b), (ch, float((a.detach().float() - b.float()).abs().max()))
