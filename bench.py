@@ -332,7 +332,7 @@ def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assig
             pending = lin_assign.begin(inst, ids, stuff, pts)
             loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0)
             loss.backward()
-            reg = segment_consistency_regularizer(inst + 1e-27, ids) if seg_reg else None
+            reg = segment_consistency_regularizer(inst, ids, eps=1e-27) if seg_reg else None
             rest, _ = render_loss(term_a=NllTerm(rb.semantics, gt["sem"], weight=0.1))
             il = lin_assign.finish(pending)
             il = il.mean() if reg is None else il.mean() + 1.0 * reg
@@ -344,7 +344,7 @@ def train_step(nef, tracer, opt, rays, gt, channels, world, sync=None, lin_assig
             opt.step()
             return loss
         loss, _ = render_loss(rb.rgb, gt["rgb"], 10.0, NllTerm(rb.semantics, gt["sem"], weight=0.1))
-        reg = segment_consistency_regularizer(inst + 1e-27, ids) if seg_reg else None     # queued BEFORE the assignment's one synchronisation
+        reg = segment_consistency_regularizer(inst, ids, eps=1e-27) if seg_reg else None     # queued BEFORE the assignment's one synchronisation
         il = lin_assign(inst, ids, stuff, pts) if pts is not None else lin_assign(inst, ids, stuff)
         il = il.mean() if reg is None else il.mean() + 1.0 * reg                           # `inst_loss += w * reg` broadcasts the scalar over [B, P]; then .mean()
         loss = loss + 1000.0 * il

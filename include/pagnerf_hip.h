@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 11
+#define PAG_ABI_VERSION 12
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -561,6 +561,20 @@ int pag_assign_nll_bwd(const float *prob, int B, int64_t P, int64_t image_stride
                        const int64_t *virt, const uint8_t *valid, const int32_t *wrong, const float *grad, float *d_prob,
                        void *stream);
 
+/* segment_consistency_regularizer (ABI 12; loss/regularizers.py:5-35, called at pc_nerf/trainer.py:525-527 on `inst_embedding + 1e-27`) over a batch of B images
+ * without a host synchronisation.  prob f32: [B][P] rows of n_cols probabilities (element strides image_stride / row_stride), eps is added to every
+ * probability read (the caller's `+ 1e-27`), labels i64 [B,P] contiguous.  Per image every distinct value of labels is a segment (at most 2048 per image and
+ * never INT64_MIN - otherwise out is NaN and the gradient 0); per segment: histogram of its rays' first arg-max column (:22), skipped when every ray predicts
+ * column 0 (:24-25), label = first most frequent column among 1.. (:27) or 0 when bins[0] * 0.5 > bins[label] (:29-30), term = mean over its rays of
+ * -log(prob[ray, label] + eps) (:32); the running total is divided by each image's segment count in turn (:33) and finally by B (:35) -> out f32 [1].
+ * workspace (pag_segment_reg_workspace_bytes(B, P) bytes) keeps what the backward needs; pag_segment_reg_bwd writes EVERY element of d_prob f32 [B,P,n_cols]
+ * (contiguous) from grad f32 [1].  Sums are lane-strided with a fixed butterfly: bitwise reproducible. */
+int64_t pag_segment_reg_workspace_bytes(int B, int64_t P);
+int pag_segment_reg_fwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, float eps,
+                        const int64_t *labels, void *workspace, int64_t workspace_bytes, float *out, void *stream);
+int pag_segment_reg_bwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, float eps,
+                        const void *workspace, int64_t workspace_bytes, const float *grad, float *d_prob, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-ray training loss of the rendered buffers (pc_nerf/trainer.py:443-446 rgb, :459-465 semantics,
  * loss/lin_assignment_things.py:80 instance term after the assignment) - one launch forward, one backward
@@ -642,6 +656,12 @@ int pag_permuto_encode_bwd_rays(const float *xyz, int64_t M, const void *tables,
                                 const float *scale_factor_host, const float *shift_host, const float *feat_scale_host, const int32_t *ridx,
                                 const float *depths, const int64_t *pack_start, int64_t N, float *out, void *workspace, int64_t workspace_bytes,
                                 int flags, void *stream);
+
+/* utils/outlier_rejection.py:74-97 `rays_to_3d_points` as pc_nerf/trainer.py:508-518 calls it (ABI 12): points f32 [N,3] = the camera-frame base rays
+ * unprojected by depth f32 [N] and mapped to the world by the cameras' current extrinsics - sum_k (o_c - t + d_c depth)[k] R[k] with params / cam /
+ * rays_per_entry as in pag_pose_rays_fwd.  No gradient (the trainer wraps the call in torch.no_grad()). */
+int pag_pose_points(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
+                    const float *depth, int64_t N, float *points, void *stream);
 
 /* Gradient of pag_view_embed with respect to the directions (the view direction depends on the camera rotation: pc_nerf/ba_pipeline.py:89-90
  * -> pc_nerf/panoptic_delta_nef.py:196-200): d_dirs f32 [R,3] from g_out f32 [R, width].  (ABI 11) */

@@ -16,7 +16,7 @@ MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
 LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
 ENC_HALF_COORDS = 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 MLP_FUSED_WIDE_MAX_M = 1 << 24      # PAG_MLP_FUSED_WIDE_MAX_M
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -133,6 +133,10 @@ _SIGS = {
     "pag_pose_rays_bwd_workspace_bytes": (c_i64, [c_i64]),
     "pag_pose_rays_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pag_view_embed_bwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "pag_pose_points": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "pag_segment_reg_workspace_bytes": (c_i64, [c_i32, c_i64]),
+    "pag_segment_reg_fwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, ctypes.c_float, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "pag_segment_reg_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, ctypes.c_float, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "pag_mlp_dz0_slots_bytes": (c_i64, [c_i64, c_i64]),
     "pag_mlp_dz0_slots_sum": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "pag_encode_bwd_rays_workspace_bytes": (c_i64, [c_i64, c_i64]),

@@ -123,6 +123,10 @@ class BAPipeline(Pipeline):
         world by the cameras' inv_transform_rays (:91, the arithmetic of transform_rays above) and added to the transformed origins (:93).
         -> [C*n, 3] world points, no gradient (the trainer wraps the call in torch.no_grad())."""
         idx = self.camera_indices(cam_ids)
+        if self.camera_extrinsics.is_cuda and base_rays.origins.numel() and base_rays.origins.shape[0] % len(idx) == 0:
+            dev = self.camera_extrinsics.device
+            return ops.pose_points(self.camera_extrinsics, idx.int(), base_rays.origins.shape[0] // len(idx), base_rays.origins.reshape(-1, 3).to(dev),
+                                   base_rays.dirs.reshape(-1, 3).to(dev), depth.to(dev))
         prm = self.camera_extrinsics[idx]
         R, t = rotation_6d_to_matrix(prm[:, :6]), prm[:, 6:]
         o = base_rays.origins.reshape(len(idx), -1, 3).to(prm.device)
@@ -133,6 +137,10 @@ class BAPipeline(Pipeline):
     @torch.no_grad()
     def rays_to_3d_points_indexed(self, origins_c, dirs_c, depth, cam_idx):
         """Per-ray form of rays_to_3d_points() (ray i belongs to camera cam_idx[i]; see transform_rays_indexed)."""
+        if self.camera_extrinsics.is_cuda and origins_c.numel():
+            cam = cam_idx if (cam_idx.dtype == torch.int32 and cam_idx.device == self.camera_extrinsics.device) else \
+                cam_idx.to(device=self.camera_extrinsics.device, dtype=torch.int32)
+            return ops.pose_points(self.camera_extrinsics, cam, 1, origins_c.reshape(-1, 3), dirs_c.reshape(-1, 3), depth)
         idx = cam_idx.to(self.camera_extrinsics.device).long()
         R = rotation_6d_to_matrix(self.camera_extrinsics[:, :6]).index_select(0, idx)
         t = self.camera_extrinsics[:, 6:].index_select(0, idx)

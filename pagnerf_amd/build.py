@@ -31,6 +31,7 @@ SOURCES = {
     "loss.hip": ["-ffp-contract=off"],
     "optim.hip": ["-ffp-contract=off"],      # Adam: torch's op order, no contraction beyond the explicit fmaf
     "pose.hip": ["-ffp-contract=off"],       # the camera transform in the tensor-op form's op order
+    "regularizer.hip": ["-ffp-contract=off"],
 }
 
 

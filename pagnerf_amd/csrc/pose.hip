@@ -69,6 +69,26 @@ __global__ __launch_bounds__(256) void pose_rays_fwd_kernel(const float *__restr
     for (int j = 0; j < 3; ++j) dw[i * 3 + j] = u[j] / n;
 }
 
+// utils/outlier_rejection.py:74-97 (`rays_to_3d_points`, pc_nerf/trainer.py:508-518): the step's base rays unprojected by the rendered depth and mapped to the
+// world by the same inverse camera transform - points = R^T (o_c - t) + R^T (d_c depth) = sum_k (o_c - t + d_c depth)[k] R[k], in the op order of
+// ba_pipeline.rays_to_3d_points_indexed (as tensor ops: ~20 launches on [N,3] tensors in front of the assignment's cost matrix).
+__global__ __launch_bounds__(256) void pose_points_kernel(const float *__restrict__ params, int64_t C, const int32_t *__restrict__ cam, int64_t rays_per_entry,
+                                                          const float *__restrict__ oc, const float *__restrict__ dc, const float *__restrict__ depth, int64_t N,
+                                                          float *__restrict__ points) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    int64_t c = cam[i / rays_per_entry];
+    c = c < 0 ? 0 : (c >= C ? C - 1 : c);
+    const float *p = params + c * 9;
+    const Rot r = rotation(p);
+    const float t = depth[i];
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = (oc[i * 3 + k] - p[6 + k]) + dc[i * 3 + k] * t;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) points[i * 3 + j] = (v[0] * r.b[0][j] + v[1] * r.b[1][j]) + v[2] * r.b[2][j];
+}
+
 // Two launches, fixed summation order (bitwise reproducible).  Stage 1: workgroup (camera c, slice s) walks slice s of the rays (N / POSE_SLICES
 // consecutive rays) and sums the contributions of camera c's rays to d R (9) and d t (3): thread-strided partial sums, then a tree over the
 // workgroup -> part[c][s][12].  Stage 2: one thread per camera adds its slices in order and applies the chain through the Gram-Schmidt
@@ -201,6 +221,18 @@ extern "C" int pag_pose_rays_fwd(const float *params, int64_t C, const int32_t *
     hipLaunchKernelGGL(pose_rays_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, C, cam, rays_per_entry, origins_c,
                        dirs_c, N, origins_w, dirs_w);
     PAG_CHECK_LAUNCH("pag_pose_rays_fwd");
+    return PAG_OK;
+}
+
+extern "C" int pag_pose_points(const float *params, int64_t C, const int32_t *cam, int64_t rays_per_entry, const float *origins_c, const float *dirs_c,
+                               const float *depth, int64_t N, float *points, void *stream) {
+    int rc = pose_check("pag_pose_points", params, C, cam, rays_per_entry, origins_c, dirs_c, N);
+    if (rc) return rc;
+    if (N == 0) return PAG_OK;
+    PAG_CHECK_ARG(depth && points, "pag_pose_points: NULL depth / output");
+    hipLaunchKernelGGL(pose_points_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, C, cam, rays_per_entry, origins_c, dirs_c,
+                       depth, N, points);
+    PAG_CHECK_LAUNCH("pag_pose_points");
     return PAG_OK;
 }
 

@@ -12,6 +12,8 @@ reference (:45), and the relabelling (:47-53) is a table lookup on the device.  
 cost (utils/outlier_rejection.py:8-51) needs per-id 3-D centres (:56-71): the same kernel on the
 [P,3] points.
 """
+import os
+
 import numpy as np
 import scipy.optimize
 import torch
@@ -285,9 +287,43 @@ class LinAssignmentThingsLoss(nn.Module):
 SEGMENT_SLOTS = 2048        # distinct ground-truth ids per image segment_consistency_regularizer() has room for (more: the result is NaN)
 
 
-def segment_consistency_regularizer(embeddings, labels):
-    """loss/regularizers.py:5-35 on device tensors WITHOUT a host synchronisation: `embeddings` [B,P,I] probabilities (the caller adds the 1e-27,
-    pc_nerf/trainer.py:525-527), `labels` int64 [B,P] -> 0-dim tensor, differentiable with respect to `embeddings`.
+SEGMENT_KERNELS = os.environ.get("PAG_SEGMENT_KERNELS", "1") != "0"      # False / PAG_SEGMENT_KERNELS=0: the tensor-op form below on GPU tensors too (tests, A/B)
+
+
+class _SegmentReg(torch.autograd.Function):
+    """pag_segment_reg_fwd / _bwd (csrc/regularizer.hip): the regulariser in four launches forward and one backward."""
+
+    @staticmethod
+    def forward(ctx, prob, labels, eps):
+        B, P, I = prob.shape
+        dev = prob.device
+        nbytes = int(L.load().pag_segment_reg_workspace_bytes(B, P))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        out = torch.empty(1, device=dev)
+        ops._call("pag_segment_reg_fwd", prob.data_ptr(), B, P, prob.stride(0), prob.stride(1), I, float(eps), labels.data_ptr(), ws.data_ptr(), nbytes,
+                  out.data_ptr(), L.stream())
+        ctx.save_for_backward(prob, ws)
+        ctx.eps = float(eps)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, ws = ctx.saved_tensors
+        B, P, I = prob.shape
+        g = g.reshape(1).contiguous().float()
+        d = torch.empty(B, P, I, device=prob.device)
+        ops._call("pag_segment_reg_bwd", prob.data_ptr(), B, P, prob.stride(0), prob.stride(1), I, ctx.eps, ws.data_ptr(), ws.numel(), g.data_ptr(), d.data_ptr(),
+                  L.stream())
+        return d, None, None
+
+
+def segment_consistency_regularizer(embeddings, labels, eps=0.0):
+    """loss/regularizers.py:5-35 on device tensors WITHOUT a host synchronisation: `embeddings` [B,P,I] probabilities, `labels` int64 [B,P] -> 0-dim tensor,
+    differentiable with respect to `embeddings`.  The reference's caller adds 1e-27 to the probabilities first (pc_nerf/trainer.py:525-527:
+    `segment_consistency_regularizer((inst_embed + 1e-27).reshape(B, -1, I), ...)`); pass the bare probabilities and `eps=1e-27` instead and the kernels add
+    it as they read (one [B,P,I] temporary and its backward less; same fp32 sums).
+
+    fp32 CUDA tensors take pag_segment_reg_fwd / _bwd (four launches + one; every sum in a fixed order); anything else the tensor-op form below.
 
     The reference loops over images and segments on the host (unique -> .cpu() -> tensor_split, one bincount / arg-max / nll_loss per segment: a dozen
     device round trips per segment).  Same quantities here from ~25 launches over the whole batch: the rays' segment slot = rank of their id among the
@@ -297,6 +333,11 @@ def segment_consistency_regularizer(embeddings, labels):
     segments (:33); finally by the number of images (:35).  Values agree with the reference up to the fp32 summation order of the per-segment means
     (tests/test_gpu_loss.py against tests/golden/g6_reg.npz: value and gradient of the reference function)."""
     B, P, I = embeddings.shape
+    if SEGMENT_KERNELS and embeddings.is_cuda and embeddings.dtype == torch.float32 and labels.device == embeddings.device and B >= 1 and P >= 1 and I <= 4096:
+        prob = embeddings if embeddings.stride(-1) == 1 else embeddings.contiguous()
+        return _SegmentReg.apply(prob, labels.detach().reshape(B, P).contiguous().long(), eps)
+    if eps:
+        embeddings = embeddings + eps
     S = min(P, SEGMENT_SLOTS)
     arg = embeddings.detach().argmax(-1)                                                   # [B,P]  :22
     srt, order = torch.sort(labels, dim=1)                                                 # :11-12

@@ -1019,6 +1019,23 @@ def pose_rays(params, cam, rays_per_entry, origins_c, dirs_c):
     return _PoseRays.apply(params, cam.contiguous(), int(rays_per_entry), origins_c, dirs_c)
 
 
+def pose_points(params, cam, rays_per_entry, origins_c, dirs_c, depth):
+    """-> points f32 [N,3] (no gradient): sum_k (o_c - t + d_c * depth)[k] R[k] of ray i's camera cam[i // rays_per_entry] - utils/outlier_rejection.py:74-97."""
+    _check_gpu(params, cam, origins_c, dirs_c, depth)
+    N = origins_c.shape[0]
+    if origins_c.shape != dirs_c.shape or origins_c.dim() != 2 or origins_c.shape[1] != 3 or depth.numel() != N:
+        raise RuntimeError("pose_points: origins / dirs [N,3] and depth [N], got %s, %s, %s" % (tuple(origins_c.shape), tuple(dirs_c.shape), tuple(depth.shape)))
+    n_entries = (N + rays_per_entry - 1) // rays_per_entry
+    if cam.dtype != torch.int32 or cam.numel() < n_entries or params.dim() != 2 or params.shape[1] != 9:
+        raise RuntimeError("pose_points: cam must be int32 with one entry per %d rays, params [C,9]" % rays_per_entry)
+    prm, oc, dc = params.detach().contiguous().float(), origins_c.detach().contiguous().float(), dirs_c.detach().contiguous().float()
+    dep = depth.detach().reshape(-1).contiguous().float()
+    out = torch.empty(N, 3, device=oc.device)
+    _call("pag_pose_points", prm.data_ptr(), prm.shape[0], cam.contiguous().data_ptr(), int(rays_per_entry), oc.data_ptr(), dc.data_ptr(), dep.data_ptr(), N,
+          out.data_ptr(), L.stream())
+    return out
+
+
 class _RaySamples(torch.autograd.Function):
     """samples = origins[ray] + dirs[ray] * depth with the march kernel's values as the forward result (bit-identical to
     the non-differentiable path) and d/d origins, d/d dirs as per-ray segmented sums - what autograd gives through

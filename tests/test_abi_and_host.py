@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_assignment_entry_points_validate_without_gpu(lib):
@@ -59,6 +59,16 @@ def test_pose_entry_points_validate_without_gpu(lib):
     assert lib.pag_pose_rays_bwd(buf, 1, buf, 1, buf, buf, 4, buf, buf, None, buf, 1 << 20, None) == -1        # NULL d_params
     assert lib.pag_pose_rays_bwd(buf, 1, buf, 1, buf, buf, 4, buf, buf, buf, buf, 8, None) == -1               # workspace too small
     assert b"workspace" in lib.pag_last_error_string() and lib.pag_pose_rays_bwd_workspace_bytes(6) == 6 * 32 * 12 * 4
+    assert lib.pag_pose_points(None, 1, None, 1, None, None, None, 0, None, None) == 0                         # no ray
+    assert lib.pag_pose_points(buf, 1, buf, 1, buf, buf, None, 4, buf, None) == -1 and b"depth" in lib.pag_last_error_string()
+    # segment regulariser (ABI 12): sizes, NULL buffers and a short workspace are refused before any launch
+    need = lib.pag_segment_reg_workspace_bytes(6, 4096)
+    assert need >= 2 * 6 * 4096 * 4 + 3 * 6 * 2048 * 4
+    assert lib.pag_segment_reg_fwd(buf, 0, 8, 16, 2, 2, 0.0, buf, buf, need, buf, None) == -1                  # B < 1
+    assert lib.pag_segment_reg_fwd(buf, 1, 8, 16, 1, 2, 0.0, buf, buf, need, buf, None) == -1                  # row_stride < n_cols
+    assert lib.pag_segment_reg_fwd(buf, 1, 8, 16, 2, 2, 0.0, None, buf, need, buf, None) == -1 and b"NULL" in lib.pag_last_error_string()
+    assert lib.pag_segment_reg_fwd(buf, 1, 8, 16, 2, 2, 0.0, buf, buf, 64, buf, None) == -1 and b"workspace" in lib.pag_last_error_string()
+    assert lib.pag_segment_reg_bwd(buf, 1, 8, 16, 2, 2, 0.0, buf, 64, buf, buf, None) == -1 and b"workspace" in lib.pag_last_error_string()
     assert lib.pag_view_embed_bwd(None, 0, 4, 32, None, None, None) == 0
     assert lib.pag_view_embed_bwd(buf, 2, 4, 16, buf, buf, None) == -1                                        # width < 3 + 6 n_freq
     assert lib.pag_view_embed_bwd(buf, 2, 4, 32, None, buf, None) == -1
