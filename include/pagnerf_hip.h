@@ -168,6 +168,7 @@ int64_t pag_encode_bwd_workspace_bytes(int64_t M, int n_levels, int n_feat, int 
  *             activations of hidden layer i, or NULL when no backward will follow
  *   mode      PAG_MLP_MFMA_BF16: bf16 operands, fp32 accumulate on the matrix cores;
  *             PAG_MLP_FP32: fp32 FMA chain in k order (parity path) */
+struct pag_head_composite_args;
 typedef struct pag_mlp_fwd_args {
     const void *x1; int x1_dtype; int k1;
     int x1_layout; int x1_levels; int x1_feats;   /* PAG_LAYOUT_XCD8: x1 is the encoders' bf16 [8][M][8]
@@ -189,9 +190,23 @@ typedef struct pag_mlp_fwd_args {
      * out_dim <= 8, bf16 out, no hidden_save (the semantic head next to the instance head) - evaluated in this call's launch while the
      * tile is in registers.  The caller does not call pag_mlp_fwd for it.  pag_mlp_fwd_pair_supported() tells whether the pair qualifies. */
     const struct pag_mlp_fwd_args *pair;
+    /* Optional (ABI 12), statistics-only wide softmax head only: the per-ray weighted sum of pag_head_composite_fwd formed in the SAME launch, in one pass
+     * over the logits (each logit and each exponential once instead of twice) - out[ray] = alpha[ray] * sum_i weights[i] * softmax(...)[i] over the ray's
+     * pack.  softmax_stats and hidden_save[1] are written as without it (for the backward); samples past pack_start[P] (fillers of a padded batch) get
+     * statistics that rebuild to probability 0 and a zero hidden row.  The caller does not call pag_head_composite_fwd.
+     * pag_mlp_fwd_composite_supported() tells whether the arguments qualify (pair included). */
+    const struct pag_head_composite_args *composite;
 } pag_mlp_fwd_args;
+typedef struct pag_head_composite_args {
+    const int64_t *pack_start; const int32_t *ray_of_pack; int64_t P;      /* as pag_head_composite_fwd */
+    const float *weights;       /* f32 [M] compositing weights w_i */
+    const float *alpha;         /* f32 [N] */
+    float *out;                 /* f32 [N, out_dim]: rows of rays that have a pack are overwritten */
+    int64_t n_samples;          /* pack_start[P] as the host knows it (0 = unknown): a speed hint only */
+} pag_head_composite_args;
 int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
 int pag_mlp_fwd_pair_supported(const pag_mlp_fwd_args *args, const pag_mlp_fwd_args *pair);
+int pag_mlp_fwd_composite_supported(const pag_mlp_fwd_args *args, int64_t M);
 
 /* Data gradients of pag_mlp_fwd.  grad_out is d loss / d (activated output); `out` is the
  * activated output saved from the forward (needed for sigmoid / softmax).  Writes

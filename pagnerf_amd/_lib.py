@@ -25,6 +25,11 @@ c_i64, c_i32, c_u32, c_f32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_uint32
 c_fp = ctypes.POINTER(ctypes.c_float)
 
 
+class HeadCompositeArgs(ctypes.Structure):
+    """pag_head_composite_args (include/pagnerf_hip.h)."""
+    _fields_ = [("pack_start", c_vp), ("ray_of_pack", c_vp), ("P", c_i64), ("weights", c_vp), ("alpha", c_vp), ("out", c_vp), ("n_samples", c_i64)]
+
+
 class MlpFwdArgs(ctypes.Structure):
     pass
 
@@ -38,7 +43,8 @@ MlpFwdArgs._fields_ = [("x1", c_vp), ("x1_dtype", c_i32), ("k1", c_i32),
                 ("out", c_vp), ("out_dtype", c_i32),
                 ("hidden_save", c_vp * 2),
                 ("mode", c_i32),
-                ("softmax_stats", c_vp), ("x1_col0_relu", c_vp), ("pair", ctypes.POINTER(MlpFwdArgs))]
+                ("softmax_stats", c_vp), ("x1_col0_relu", c_vp), ("pair", ctypes.POINTER(MlpFwdArgs)),
+                ("composite", ctypes.POINTER(HeadCompositeArgs))]
 
 
 class WgradLayer(ctypes.Structure):
@@ -87,6 +93,7 @@ _SIGS = {
     "pag_encode_bwd_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32, c_i64]),
     "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
     "pag_mlp_fwd_pair_supported": (c_i32, [ctypes.POINTER(MlpFwdArgs), ctypes.POINTER(MlpFwdArgs)]),
+    "pag_mlp_fwd_composite_supported": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64]),
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd_fused_supported": (c_i32, [ctypes.POINTER(MlpBwdArgs)]),
     "pag_mlp_bwd_fused_workspace_bytes": (c_i64, [ctypes.POINTER(MlpBwdArgs), c_i64]),

@@ -891,6 +891,26 @@ __device__ __forceinline__ void tile64_store_buf(bf16_t *stg, RS_T rs, unsigned 
     wave_lds_sync();
 }
 
+// the same with only the first rows_valid rows written (tiles that end with their ray)
+template <typename RS_T>
+__device__ __forceinline__ void tile64_store_buf_rows(bf16_t *stg, RS_T rs, unsigned tile_off, int rows_valid, int lane, int r, int h, const f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v = {(bf16_t)acc[mb][4 * g], (bf16_t)acc[mb][4 * g + 1], (bf16_t)acc[mb][4 * g + 2], (bf16_t)acc[mb][4 * g + 3]};
+            *reinterpret_cast<bf16x4 *>(stg + r * ST_RS + 32 * mb + 8 * g + 4 * h) = v;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + row * ST_RS + c);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, row < rows_valid ? tile_off + row * (HID * 2) + c * 2 : BUF_OOB, 0, 0);
+    }
+    wave_lds_sync();
+}
+
 // KIND 0: XCD8 bf16 input, no output activation, bf16 out, out_dim % 4 == 0 (<= 32)                 (density decoder)
 // KIND 1: bf16 x1 [M,16] + f32 x2 [R,32] through x2_index, sigmoid, f32 out, out_dim <= 4, col0_relu   (colour decoder)
 // KIND 2: XCD8 bf16 input, softmax, bf16 out, out_dim <= 8                                             (semantic head)
@@ -3050,6 +3070,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_bwd_wide_mfma(BwdParams p) {
 // them by the sample weight and keeps the 7 x 16 per-lane partial sums in registers until the ray is finished.  The
 // sum over a tile's 32 samples is a sum over lanes: DPP row_shr 1/2/4/8 + row_bcast:15 put it on lanes 31 / 63, LDS
 // combines the four waves.  Reads 128 B per sample instead of 400 B, and the 839 MB tensor is never written.
+#ifndef PAG_HC_PER_WAVE_P
+#define PAG_HC_PER_WAVE_P 2048
+#endif
 struct HeadCompParams {
     const int64_t *pack_start;
     const int32_t *ray_of_pack;
@@ -3208,6 +3231,237 @@ __global__ __launch_bounds__(256, 2) void head_composite_fwd_kernel(HeadCompPara
             for (int c = threadIdx.x; c < p.out_dim; c += blockDim.x)
                 p.out[(int64_t)ray * p.out_dim + c] = al * (red[c] + red[OB * 32 + c] + red[2 * OB * 32 + c] + red[3 * OB * 32 + c]);
             __syncthreads();
+        }
+    }
+}
+
+// --------------------------------------------------- wide softmax head: decoder + per-ray weighted sum in ONE pass over the logits
+// mlp_fwd_wide_stats + head_composite_fwd_kernel form every logit twice (once for the softmax statistics, once - from the saved hidden layer - for the
+// weighted sum) and take 224 exponentials per sample where 112 are needed.  Here a wave owns whole 32-sample tiles OF ONE RAY: hidden layers (and
+// the companion narrow head, PAIR) as in mlp_fwd_wide_stats, then all seven 32-channel logit blocks stay in registers (112) while their maximum, the
+// exponentials and their sum are formed once; (max * log2e, 1 / sum) and the last hidden layer are written for the backward exactly where the two-launch
+// form writes them, and the exponentials - scaled by w_i / sum - go straight into the ray's 112 per-lane partial sums (the epilogue of
+// head_composite_fwd_kernel).  224 accumulator registers: one wave per SIMD; what hides latency is the next tile's features in flight and the
+// independent MFMA chains of the seven blocks.  Same logits bit for bit as the two-launch form (same fragments, same MFMA order); the sum of the
+// exponentials is formed directly instead of online over the blocks, so 1 / sum - and with it the outputs - may differ in the last bit.
+template <bool PAIR>
+__global__ __launch_bounds__(256, 1) void head_fwd_once_kernel(FwdParams p, HeadCompParams c) {
+    PAG_BLOCK_TIMER(7);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int OB = 7;
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16_t *W0s = reinterpret_cast<bf16_t *>(smem);
+    bf16_t *W1s = W0s + 64 * RS;
+    bf16_t *WLs = W1s + 64 * RS;                                     // [OB*32][RS] permuted k
+    bf16_t *W0s2 = WLs + OB * 32 * RS;                               // PAIR: [64][RS] natural k, [32][RS] permuted k
+    bf16_t *WLs2 = W0s2 + (PAIR ? 64 * RS : 0);
+    float *b0s = reinterpret_cast<float *>(WLs2 + (PAIR ? 32 * RS : 0));
+    float *b1s = b0s + 64;
+    float *bLs = b1s + 64;
+    float *b0s2 = bLs + OB * 32;
+    float *bLs2 = b0s2 + (PAIR ? 64 : 0);
+    float *red = bLs2 + (PAIR ? 32 : 0);                             // [4][OB*32]
+    bf16_t *stg = reinterpret_cast<bf16_t *>(red + 4 * OB * 32) + (threadIdx.x >> 6) * (ST_BYTES / 2);
+    stage_weight(W0s, RS, 64, 64, p.W[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
+    stage_weight(W1s, RS, 64, 64, p.W[1], HID, HID, true);
+    stage_weight(WLs, RS, OB * 32, 64, p.W[2], p.out_dim, HID, true);
+    if constexpr (PAIR) {
+        stage_weight(W0s2, RS, 64, 64, p.W2[0], HID, p.in_dim, false, p.grp_L, p.grp_F);
+        stage_weight(WLs2, RS, 32, 64, p.W2[1], p.out2_dim, HID, true);
+        for (int e = threadIdx.x; e < 64; e += blockDim.x) b0s2[e] = p.b2[0][e];
+        for (int e = threadIdx.x; e < 32; e += blockDim.x) bLs2[e] = e < p.out2_dim ? p.b2[1][e] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        b0s[e] = p.b[0][e];
+        b1s[e] = p.b[1][e];
+    }
+    // padding channels: a bias of -1e30 makes their exponential exactly 0 and never the maximum
+    for (int e = threadIdx.x; e < OB * 32; e += blockDim.x) bLs[e] = e < p.out_dim ? p.b[2][e] : -1e30f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int r = lane & 31, h = lane >> 5;
+    const int64_t M = p.M;
+    const auto rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x1), 0, (int)(M * 128), 0x00020000);
+    const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, (int)(M * 8), 0x00020000);
+    const auto rs_o2 = __builtin_amdgcn_make_buffer_rsrc(PAIR ? p.out2 : nullptr, 0, (int)(M * (PAIR ? p.out2_dim : 0) * 2), 0x00020000);
+    const auto rs_h1 = __builtin_amdgcn_make_buffer_rsrc(p.hsave[1], 0, (int)(M * HID * 2), 0x00020000);
+    const int pw = c.per_wave;
+    const int64_t pk0 = pw ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x, pk_step = pw ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
+    const int t_first = pw ? 0 : wave, t_step = pw ? 1 : 4;
+    // One wave per SIMD: a round trip to memory that is not already in flight is paid in full.  The next tile's features and weights are requested at the
+    // top of every tile - across the end of a ray too: the first tile of the wave's NEXT ray is requested during the last tile of the current one
+    // (its sample range was read a whole ray earlier).
+    // (straight-line: every request is issued unconditionally with an out-of-range offset for lanes - or whole tiles - that do not exist; a branch
+    // around the loads would make the compiler drain vmcnt at the join, i.e. wait for the prefetch right where it was issued)
+    bf16x8 xn[4];
+    float wn = 0.0f;
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c.weights), 0, (int)(M * 4), 0x00020000);
+    unsigned xoff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xoff[s] = (unsigned)(((int64_t)(2 * s + h) * M + r) * 16);
+    auto fetch = [&](int64_t fbeg, int64_t fend, int64_t t) __attribute__((always_inline)) {
+        const int64_t base = fbeg + 32 * t;
+        const bool lv = base + r < fend;                      // false for every lane when the tile does not exist: zeros, weight 0
+        const unsigned off = lv ? (unsigned)base * 16u : BUF_OOB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xn[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x1, xoff[s] + off, 0, 0));
+        wn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, lv ? (unsigned)(base + r) * 4u : BUF_OOB, 0, 0));
+    };
+    int64_t beg = 0, end = 0;
+    if (pk0 < c.P) {
+        beg = c.pack_start[pk0];
+        end = c.pack_start[pk0 + 1];
+        fetch(beg, end, t_first);
+    }
+    for (int64_t pk = pk0; pk < c.P; pk += pk_step) {
+        asm volatile("" : "+v"(r), "+v"(h));
+        const int64_t ntile = (end - beg + 31) / 32;
+        int64_t nbeg = 0, nend = 0;
+        if (pk + pk_step < c.P) {
+            nbeg = c.pack_start[pk + pk_step];
+            nend = c.pack_start[pk + pk_step + 1];
+        }
+        unsigned ooff2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ooff2[j] = (PAIR && 4 * h + j < p.out2_dim) ? (unsigned)((r * p.out2_dim + 4 * h + j) * 2) : BUF_OOB;
+        f32x16 acc[7];
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[ob][q] = 0.0f;
+        if (t_first >= ntile) fetch(nbeg, nend, t_first);      // no tile of this ray for this wave (wave-uniform): keep the chain of requests going
+        for (int64_t t = t_first; t < ntile; t += t_step) {
+            const int64_t base = beg + 32 * t;
+            const bool live = base + r < end;
+            const int rv = (int)min((int64_t)32, end - base);
+            const unsigned row0 = (unsigned)base;
+            bf16x8 xb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xb[s] = xn[s];
+            const float wcur = wn;
+            {
+                const bool same = t + t_step < ntile;
+                fetch(same ? beg : nbeg, same ? end : nend, same ? t + t_step : (int64_t)t_first);
+            }
+            f32x16 a2[2];
+            bf16x8 hb[4];
+            if constexpr (PAIR) {      // the companion head: hidden layer, <= 8 logits, softmax (as mlp_fwd_wide_stats<.., true>)
+                f32x16 o2;
+                hidden_layer_pinned<4>(W0s2, b0s2, xb, r, h, a2);
+                relu_pack(a2, hb);
+                out_block_pinned(WLs2, bLs2, 0, hb, r, h, o2);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * h + j < p.out2_dim) mx = fmaxf(mx, o2[j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mxs = mx * LOG2E;
+                float e[4], sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e[j] = (4 * h + j < p.out2_dim) ? __builtin_amdgcn_exp2f(fmaf(o2[j], LOG2E, -mxs)) : 0.0f;
+                    sum += e[j];
+                }
+                sum += __shfl_xor(sum, 32);
+                const float inv2 = 1.0f / sum;
+                const unsigned obase = live ? row0 * (unsigned)(p.out2_dim * 2) : BUF_OOB_ROW;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16_t y = (bf16_t)(e[j] * inv2);
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, y), rs_o2, ooff2[j] + obase, 0, 0);
+                }
+            }
+            hidden_layer_pinned<4>(W0s, b0s, xb, r, h, a2);
+            relu_pack(a2, hb);
+            hidden_layer_pinned<4>(W1s, b1s, hb, r, h, a2);
+            relu_pack(a2, hb);
+            tile64_store_buf_rows(stg, rs_h1, row0 * (HID * 2), rv, lane, r, h, a2);
+            // all seven logit blocks, then ONE pass: maximum, exponentials, sum
+            f32x16 o[7];
+#pragma unroll
+            for (int ob = 0; ob < 7; ++ob) out_block_pinned(WLs, bLs, ob, hb, r, h, o[ob]);
+            float mx = o[0][0];
+#pragma unroll
+            for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mx = fmaxf(mx, o[ob][q]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float Ms = mx * LOG2E;
+            const f32x2 l2 = {LOG2E, LOG2E}, nm2 = {-Ms, -Ms};
+            f32x2 s2 = {0.0f, 0.0f};
+#pragma unroll
+            for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x2 tt = f32x2{o[ob][2 * q], o[ob][2 * q + 1]} * l2 + nm2;
+                    const f32x2 ee = {__builtin_amdgcn_exp2f(tt[0]), __builtin_amdgcn_exp2f(tt[1])};
+                    o[ob][2 * q] = ee[0];
+                    o[ob][2 * q + 1] = ee[1];
+                    s2 += ee;
+                }
+            float sm = s2[0] + s2[1];
+            sm += __shfl_xor(sm, 32);
+            const float inv = 1.0f / sm;
+            const u32x2 st2 = {__builtin_bit_cast(unsigned, Ms), __builtin_bit_cast(unsigned, inv)};
+            __builtin_amdgcn_raw_buffer_store_b64(st2, rs_st, (live && h == 0) ? row0 * 8u + (unsigned)(r * 8) : BUF_OOB, 0, 0);
+            const float sw = inv * wcur;      // 0 for lanes past the ray's end
+#pragma unroll
+            for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ob][q] = fmaf(sw, o[ob][q], acc[ob][q]);
+        }
+        // ---- sum over the 32 sample lanes of each half, then over the four waves (as head_composite_fwd_kernel)
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = acc[ob][q];
+#define PAG_DPP_ADD16(ctl)                                                                                                         \
+            asm("s_nop 1\n\t"                                                                                                   \
+                "v_add_f32_dpp %0, %0, %0 " ctl "\n\tv_add_f32_dpp %1, %1, %1 " ctl "\n\tv_add_f32_dpp %2, %2, %2 " ctl "\n\t"   \
+                "v_add_f32_dpp %3, %3, %3 " ctl "\n\tv_add_f32_dpp %4, %4, %4 " ctl "\n\tv_add_f32_dpp %5, %5, %5 " ctl "\n\t"   \
+                "v_add_f32_dpp %6, %6, %6 " ctl "\n\tv_add_f32_dpp %7, %7, %7 " ctl "\n\tv_add_f32_dpp %8, %8, %8 " ctl "\n\t"   \
+                "v_add_f32_dpp %9, %9, %9 " ctl "\n\tv_add_f32_dpp %10, %10, %10 " ctl "\n\tv_add_f32_dpp %11, %11, %11 " ctl "\n\t" \
+                "v_add_f32_dpp %12, %12, %12 " ctl "\n\tv_add_f32_dpp %13, %13, %13 " ctl "\n\tv_add_f32_dpp %14, %14, %14 " ctl "\n\t" \
+                "v_add_f32_dpp %15, %15, %15 " ctl                                                                             \
+                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),     \
+                  "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+            PAG_DPP_ADD16("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+            PAG_DPP_ADD16("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+            PAG_DPP_ADD16("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+            PAG_DPP_ADD16("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+            PAG_DPP_ADD16("row_bcast:15 row_mask:0xa bank_mask:0xf");
+#undef PAG_DPP_ADD16
+            if (r == 31) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[wave * OB * 32 + 32 * ob + rho(q, h)] = v[q];
+            }
+        }
+        const int32_t ray = c.ray_of_pack[pk];
+        const float al = c.alpha[ray];
+        if (pw) {           // this wave's own section of `red`: LDS accesses of one wave complete in program order, no barrier
+            for (int cc = lane; cc < p.out_dim; cc += 64) c.out[(int64_t)ray * p.out_dim + cc] = al * red[wave * OB * 32 + cc];
+        } else {
+            __syncthreads();
+            for (int cc = threadIdx.x; cc < p.out_dim; cc += blockDim.x)
+                c.out[(int64_t)ray * p.out_dim + cc] = al * (red[cc] + red[OB * 32 + cc] + red[2 * OB * 32 + cc] + red[3 * OB * 32 + cc]);
+            __syncthreads();
+        }
+        beg = nbeg;
+        end = nend;
+    }
+    // Samples past the last pack (the filler samples of a padded batch, pagnerf_amd/graphs.py) belong to no ray: what the backward reads of them - always
+    // scaled by a zero weight - must be finite.  statistics (huge maximum, 1 / sum = 0): rebuilt probabilities are exactly 0; hidden layer and the
+    // companion head's output: zeros.
+    for (int64_t row = c.pack_start[c.P] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < M; row += (int64_t)gridDim.x * blockDim.x) {
+        *reinterpret_cast<float2 *>(p.stats + 2 * row) = float2{1e30f, 0.0f};
+        u32x4 *hrow = reinterpret_cast<u32x4 *>(reinterpret_cast<bf16_t *>(p.hsave[1]) + row * HID);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hrow[k] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (PAIR) {
+            bf16_t *orow = reinterpret_cast<bf16_t *>(p.out2) + row * p.out2_dim;
+            for (int k = 0; k < p.out2_dim; ++k) orow[k] = (bf16_t)0.0f;
         }
     }
 }
@@ -3652,6 +3906,14 @@ extern "C" int pag_mlp_fwd_pair_supported(const pag_mlp_fwd_args *a, const pag_m
     return wide && narrow ? 1 : 0;
 }
 
+extern "C" int pag_mlp_fwd_composite_supported(const pag_mlp_fwd_args *a, int64_t M) {
+    static const bool no_fast = getenv("PAG_NO_FAST_FWD") != nullptr;
+    if (!a || no_fast || M < 1 || M > PAG_MLP_FUSED_WIDE_MAX_M) return 0;
+    const bool wide = a->mode == PAG_MLP_MFMA_BF16 && a->x1_dtype == PAG_BF16 && a->x1_layout == PAG_LAYOUT_XCD8 && !a->out && a->n_layers == 3 &&
+                      a->softmax_stats && a->out_act == PAG_ACT_SOFTMAX && a->out_dim > 192 && a->out_dim <= 224 && a->hidden_save[1] && !a->hidden_save[0];
+    return wide && (!a->pair || pag_mlp_fwd_pair_supported(a, a->pair) == 1) ? 1 : 0;
+}
+
 extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
     PAG_CHECK_ARG(a, "pag_mlp_fwd: args is NULL");
     PAG_CHECK_ARG(M >= 0, "pag_mlp_fwd: M < 0");
@@ -3720,6 +3982,7 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
         else if (grp && a->out && a->out_dtype == PAG_BF16 && a->out_act == PAG_ACT_SOFTMAX && a->out_dim <= 8) kind = 2;
         else if (grp && !a->out && a->n_layers == 3 && p.stats && a->out_act == PAG_ACT_SOFTMAX && a->out_dim > 192 && a->hidden_save[1]) kind = 3;
         PAG_CHECK_ARG(!a->pair || (kind == 3 && pag_mlp_fwd_pair_supported(a, a->pair) == 1), "pag_mlp_fwd: pair is not supported for these arguments (pag_mlp_fwd_pair_supported)");
+        PAG_CHECK_ARG(!a->composite || kind == 3, "pag_mlp_fwd: composite rides only in the statistics-only wide softmax head (pag_mlp_fwd_composite_supported)");
         if (kind == 3) {
             static bool attr = false;
             if (!attr) {
@@ -3727,6 +3990,41 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
                 hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipFuncSetAttribute((const void *)mlp_fwd_wide_stats<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr = true;
+            }
+            if (a->composite) {      // decoder + per-ray weighted sum in one pass over the logits (head_fwd_once_kernel)
+                const pag_head_composite_args *hc = a->composite;
+                PAG_CHECK_ARG(hc->P >= 0 && (hc->P == 0 || (hc->pack_start && hc->ray_of_pack && hc->weights && hc->alpha && hc->out)),
+                              "pag_mlp_fwd: composite: NULL input/output");
+                PAG_CHECK_ARG(!a->hidden_save[0] && a->hidden_save[1] && a->softmax_stats, "pag_mlp_fwd: composite needs softmax_stats and hidden_save[1] only");
+                if (hc->P == 0) return PAG_OK;
+                HeadCompParams c{hc->pack_start, hc->ray_of_pack, hc->P, nullptr, nullptr, nullptr, a->out_dim, nullptr, 0, hc->weights, hc->alpha, hc->out};
+                c.per_wave = ((hc->n_samples > 0 && hc->n_samples < 160 * hc->P) || hc->P >= PAG_HC_PER_WAVE_P) ? 1 : 0;
+                static bool attr_once = false;
+                if (!attr_once) {
+                    hipFuncSetAttribute((const void *)head_fwd_once_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    hipFuncSetAttribute((const void *)head_fwd_once_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr_once = true;
+                }
+#ifndef PAG_HEAD_ONCE_GRID
+#define PAG_HEAD_ONCE_GRID 256
+#endif
+                const unsigned grid = (unsigned)std::min<int64_t>(c.per_wave ? (hc->P + 3) / 4 : hc->P, PAG_HEAD_ONCE_GRID);
+                if (a->pair) {
+                    const pag_mlp_fwd_args *b = a->pair;
+                    p.W2[0] = b->W[0];
+                    p.W2[1] = b->W[1];
+                    p.b2[0] = b->b[0];
+                    p.b2[1] = b->b[1];
+                    p.out2 = b->out;
+                    p.out2_dim = b->out_dim;
+                    const size_t lds = (size_t)(128 + 224 + 96) * RS * sizeof(bf16_t) + (size_t)(128 + 224 + 96 + 4 * 224) * sizeof(float) + 4 * ST_BYTES;
+                    hipLaunchKernelGGL((head_fwd_once_kernel<true>), dim3(grid), dim3(256), lds, st, p, c);
+                } else {
+                    const size_t lds = (size_t)(128 + 224) * RS * sizeof(bf16_t) + (size_t)(128 + 224 + 4 * 224) * sizeof(float) + 4 * ST_BYTES;
+                    hipLaunchKernelGGL((head_fwd_once_kernel<false>), dim3(grid), dim3(256), lds, st, p, c);
+                }
+                PAG_CHECK_LAUNCH("pag_mlp_fwd (wide head, decoder + per-ray sum)");
+                return PAG_OK;
             }
             if (a->pair) {
                 const pag_mlp_fwd_args *b = a->pair;
@@ -3773,6 +4071,7 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
             return PAG_OK;
         }
     }
+    PAG_CHECK_ARG(!a->composite, "pag_mlp_fwd: composite rides only in the straight-line wide-head launch (pag_mlp_fwd_composite_supported)");
     PAG_CHECK_ARG(!a->pair, "pag_mlp_fwd: pair rides only in the straight-line wide-head launch (M <= %lld, PAG_NO_FAST_FWD unset)", (long long)PAG_MLP_FUSED_WIDE_MAX_M);
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;

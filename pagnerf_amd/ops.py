@@ -506,6 +506,16 @@ class _FusedMLP(torch.autograd.Function):
                     and L.load().pag_mlp_fwd_pair_supported(ctypes.byref(a), ctypes.byref(pair_hold["args"])) == 1:
                 a.pair = ctypes.pointer(pair_hold["args"])
                 pair_hold["taken"] = True
+            # _HeadComposite: the per-ray weighted sum in the decoder's own launch, one pass over the logits (pag_mlp_fwd_args.composite)
+            comp = getattr(ctx, "fwd_composite", None)
+            ctx.composited = False
+            if comp is not None and HEAD_FWD_ONCE and stats_only and L.load().pag_mlp_fwd_composite_supported(ctypes.byref(a), M) == 1:
+                hc = L.HeadCompositeArgs()
+                hc.pack_start, hc.ray_of_pack, hc.P = L.ptr(comp["pack_start"]), L.ptr(comp["ray_of_pack"]), comp["ray_of_pack"].shape[0]
+                hc.weights, hc.alpha, hc.out = L.ptr(comp["weights"]), L.ptr(comp["alpha"]), L.ptr(comp["out"])
+                hc.n_samples = int(M if SAMPLES_HINT is None else SAMPLES_HINT)
+                a.composite = ctypes.pointer(hc)
+                ctx.composited = True
             _call("pag_mlp_fwd", ctypes.byref(a), M, L.stream())
         ctx.cfg = (in_dim, out_act, mode, n_layers, k1, grouped)
         ctx.x2_packs = None
@@ -1450,6 +1460,8 @@ def composite_features(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N):
 
 
 HEAD_REBUILD = True      # wide softmax heads under head_composite(): statistics-only forward + rebuilt probabilities
+HEAD_FWD_ONCE = os.environ.get("PAG_HEAD_FWD_ONCE", "1") != "0"      # wide softmax head: decoder + per-ray sum in one launch (0: statistics launch + pag_head_composite_fwd)
+HEAD_FWD_ONCE_MIN_PER_RAY = int(os.environ.get("PAG_HEAD_FWD_ONCE_MIN_PER_RAY", "160"))      # average samples per ray from which the one-launch form is taken
 TAIL_ZERO = False        # graphs.py: batches carry filler samples past pack_start[N] - per-sample tensors written pack by pack start as zeros
 SAMPLES_HINT = None      # graphs.py: the REAL sample count expected in a padded batch (pag_head_composite_fwd picks its per-pack work split from it)
 
@@ -1461,7 +1473,26 @@ class _HeadComposite(_FusedMLP):
 
     @staticmethod
     def forward(ctx, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, in_dim, out_act, out_dtype, grouped, *wb):
+        # wide softmax head: where the library can, the decoder's launch forms the per-ray sums itself (pag_mlp_fwd_args.composite) - the output
+        # tensor and the compositing arguments are prepared first and handed to _FusedMLP.forward through the ctx
+        C = wb[len(wb) // 2 - 1].shape[0]
+        M = x1.shape[1] if grouped is not None else x1.shape[0]
+        P = ray_of_pack.shape[0]
+        pre = None
+        # (one wave per SIMD holds a ray's 112 partial sums next to the 112 logits: worth it where rays are long - the dense march, 16 tiles per ray:
+        # 288 -> 260 us per 2.1 M samples; with the ~3 tiles per ray of the voxel march the two-launch form is faster, 375 against 434 us per 2.2 M)
+        long_rays = (M if SAMPLES_HINT is None else SAMPLES_HINT) >= HEAD_FWD_ONCE_MIN_PER_RAY * P
+        if HEAD_FWD_ONCE and long_rays and HEAD_REBUILD and C > 192 and P and M and out_act == L.ACT_SOFTMAX and out_dtype == torch.bfloat16:
+            full = _one_pack_per_ray(ray_of_pack, N)
+            pre = dict(pack_start=pack_start, ray_of_pack=ray_of_pack, weights=weights_w.detach().contiguous(), alpha=alpha.detach().contiguous(),
+                       out=(torch.empty if full else torch.zeros)(N, C, device=x1.device))
+            ctx.fwd_composite = pre
         probs = _HeadComposite._decode(ctx, x1, in_dim, out_act, out_dtype, grouped, *wb)
+        ctx.fwd_composite = None
+        if pre is not None and getattr(ctx, "composited", False):
+            ctx.fwd_state = None
+            ctx.hc = (pre["weights"], pre["alpha"], ridx)
+            return pre["out"]
         return _HeadComposite._composite(ctx, probs, x1, weights_w, alpha, ridx, pack_start, ray_of_pack, N, grouped, *wb)
 
     @staticmethod

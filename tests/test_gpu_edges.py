@@ -485,3 +485,58 @@ def test_largest_batch_of_the_dedicated_decoder_kernels(gpu_device):
             assert float((a.detach().float() - b.float()).abs().max()) < 1e-7
         else:
             assert torch.equal(a, b), (ch, float((a.detach().float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_wide_head_forward_in_one_pass_matches_the_two_launch_form(gpu_device, mode):
+    """pag_mlp_fwd_args.composite (ABI 12: the 200-way head's decoder and its per-ray weighted sum in one launch, every logit and exponential formed once)
+    against the statistics launch + pag_head_composite_fwd it replaces: ragged rays (occupancy mask), a ray without samples, rays shorter than a tile
+    (voxel march), M % 32 != 0.  Same logits bit for bit; the softmax denominator is summed directly instead of online over the blocks, so the instance
+    channel and what the backward rebuilds from (max, 1 / sum) may differ in the last bit: 2e-6 relative on the rendered probabilities, every other
+    channel identical, every parameter gradient within 3e-4 (relative L2: bf16 hidden gradients round differently here and there)."""
+    import pagnerf_amd
+    import test_gpu_parity as T
+    from pagnerf_amd import ops
+    dev = gpu_device
+    N, S = 300, 72
+    nef, tracer, rays, occ, jitter = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=12)
+    if mode == "voxel":
+        tracer.raymarch_type, tracer.num_steps, tracer.ray_max_travel = "voxel", 2, 0.9
+    o = rays.origins.clone()
+    o[5] = 5.0                                               # misses the volume
+    r = pagnerf_amd.Rays(o, rays.dirs, rays.dist_min, rays.dist_max)
+    gen = torch.Generator().manual_seed(21)
+    G = torch.randn(N, 200, generator=gen).to(dev)
+    Gs = torch.randn(N, 6, generator=gen).to(dev)
+    seen = {}
+    real = ops._call
+    res = {}
+    min_per_ray = ops.HEAD_FWD_ONCE_MIN_PER_RAY
+    for once in (True, False):
+        ops.HEAD_FWD_ONCE, ops.HEAD_FWD_ONCE_MIN_PER_RAY = once, 0       # 0: short rays take the one-launch form too (the default keeps it for long rays)
+        names = []
+
+        def spy(name, *args):
+            names.append(name)
+            return real(name, *args)
+        ops._call = spy
+        try:
+            for p in nef.parameters():
+                p.grad = None
+            rb = tracer(nef, channels={"rgb", "depth", "semantics", "inst_embedding"}, rays=r, jitter=jitter.to(dev), stage="train")
+            ((rb.inst_embedding.float() * G).sum() + (rb.semantics.float() * Gs).sum() + rb.rgb.sum()).backward()
+            res[once] = (rb, {n: p.grad.clone() for n, p in nef.named_parameters() if p.grad is not None})
+            seen[once] = names
+        finally:
+            ops._call = real
+            ops.HEAD_FWD_ONCE, ops.HEAD_FWD_ONCE_MIN_PER_RAY = True, min_per_ray
+    assert "pag_head_composite_fwd" not in seen[True] and "pag_head_composite_fwd" in seen[False]
+    (rb1, g1), (rb0, g0) = res[True], res[False]
+    for ch in ("rgb", "depth", "semantics", "alpha"):
+        assert torch.equal(getattr(rb1, ch), getattr(rb0, ch)), ch
+    a, b = rb1.inst_embedding.float(), rb0.inst_embedding.float()
+    assert float(b.abs().sum()) > 0 and float(a[5].abs().sum()) == 0.0
+    assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-9, float((a - b).abs().max())
+    assert set(g1) == set(g0)
+    for name in g0:
+        assert T._rel_l2(g1[name].float(), g0[name].float()) < 3e-4, (name, T._rel_l2(g1[name].float(), g0[name].float()))

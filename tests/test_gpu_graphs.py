@@ -75,6 +75,20 @@ def test_graph_replay_equals_eager(gpu_device, mode, use):
     assert (gt._graphs.captures, gt._graphs.replays) == before and torch.equal(rb_v.rgb, rb_e.rgb.detach())
 
 
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_graph_replay_equals_eager_with_the_one_launch_wide_head(gpu_device, mode):
+    """The same comparison with the 200-way head's forward in its one-launch form (pag_mlp_fwd_args.composite; by default only taken for long rays) on
+    these short rays: the padded batch's filler samples past the last pack belong to no ray - the launch gives them statistics that rebuild to
+    probability 0 and a zero hidden row, so the replayed backward (which reads them scaled by a zero weight) matches the eager one."""
+    from pagnerf_amd import ops
+    keep = ops.HEAD_FWD_ONCE_MIN_PER_RAY
+    ops.HEAD_FWD_ONCE_MIN_PER_RAY = 0
+    try:
+        test_graph_replay_equals_eager(gpu_device, mode, True)
+    finally:
+        ops.HEAD_FWD_ONCE_MIN_PER_RAY = keep
+
+
 def test_graph_training_tracks_eager_training(gpu_device):
     """Twenty Adam steps on fresh random rays with and without graphs from the same initial state: the losses follow each other
     (differences come only from the summation order of the weight gradients)."""
