@@ -450,7 +450,7 @@ def cpu_baseline(n_rays, n_samples, budget_s=9.0, points=((256, 64), (4096, 64))
 DECODER_MACS = dict(density=48 * 64 + 64 * 16, colour=43 * 64 + 64 * 64 + 64 * 3, sem=48 * 64 + 64 * 6, inst=48 * 64 + 64 * 64 + 64 * 200)
 
 
-def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16):
+def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16, head_once=None):
     """Per C-ABI entry point and STEP: dict(bytes=algorithmic HBM bytes, flops=useful matrix-core FLOPs, parts={launch: bytes per sample}).
     Bytes = every tensor a launch of the PRODUCTION path (bf16 features in the XCD8 layout, fused backward kernels: DESIGN 4.3b / 4.4b)
     must read or write once; table rows count as gathered bytes (rows x F x 4).  The per-sample figures are the table of DESIGN section 5
@@ -472,12 +472,19 @@ def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16):
                      colour=16 * s + 4 + 12 + 4)                               # x1, per-sample ray index, rgb f32, sigma f32 (view embedding: per ray)
     bwd_parts = dict(density=feat + 16 * s + feat,                             # features (recompute), upstream gradient, d features
                      colour=16 * s + 4 + 12 + 4 + 4 + 16 * s)                  # x1, ray index, d rgb, d sigma, sigma gate, d x1 (per-wave weight-gradient slabs: 11 - 45 MB per launch, not per sample)
-    if pan:
+    if head_once is None:
+        head_once = M >= 160 * N        # pagnerf_amd.ops.HEAD_FWD_ONCE_MIN_PER_RAY: long rays take the 200-way head's one-launch forward
+    if pan and head_once:
+        # features, last hidden layer out, softmax statistics, semantic probabilities, compositing weight (+ the [N,200] per-ray sums, below):
+        # decoder and per-ray weighted sum in ONE launch (pag_mlp_fwd_args.composite) - no pag_head_composite_fwd call
+        fwd_parts["inst_once+sem"] = feat + 64 * s + 8 + 6 * s + 4
+    elif pan:
         fwd_parts["inst_stats+sem"] = feat + 64 * s + 8 + 6 * s                # features, last hidden layer out, softmax statistics, semantic probabilities
+    if pan:
         bwd_parts["inst_stage_A"] = 64 * s + 8 + 64 * s                        # hidden layer, statistics, hidden gradient out (rank-1 upstream gradient: per ray)
         bwd_parts["inst_stage_B+sem"] = feat + 64 * s + 6 * s + feat           # features, hidden gradient in, semantic probabilities, summed d features
     out = {
-        "pag_mlp_fwd": dict(bytes=M * sum(fwd_parts.values()), flops=2 * M * macs_fwd, parts=fwd_parts),
+        "pag_mlp_fwd": dict(bytes=M * sum(fwd_parts.values()) + (N * 200 * 4 if pan and head_once else 0), flops=2 * M * macs_fwd, parts=fwd_parts),
         "pag_mlp_bwd": dict(bytes=M * sum(bwd_parts.values()), flops=2 * M * macs_bwd, parts=bwd_parts),
         "pag_composite_fwd": dict(bytes=M * (4 + 4 + 4 + 12 + 4) + N * 24, flops=0),
         "pag_composite_bwd": dict(bytes=M * (4 + 4 + 4 + 12 + 4 + 4 + 12) + N * 24, flops=0),
@@ -495,7 +502,8 @@ def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16):
     n_par = 2 * L_ * rows * F_ + 35169
     out["pag_adam_step"] = dict(bytes=28 * n_par, flops=0)
     if pan:
-        out["pag_head_composite_fwd"] = dict(bytes=M * (64 * s + 8 + 4) + N * 200 * 4, flops=0, rebuild_flops=2 * M * 64 * 200)
+        if not head_once:
+            out["pag_head_composite_fwd"] = dict(bytes=M * (64 * s + 8 + 4) + N * 200 * 4, flops=0, rebuild_flops=2 * M * 64 * 200)
         out["pag_composite_feats_fwd"] = dict(bytes=M * (6 * s + 4) + N * 6 * 4, flops=0)
     # pose optimisation (pc_nerf/ba_pipeline.py:85-92): the main grid's position gradient = a second gather pass (xyz, gradient row, the
     # gathered rows again, d xyz out; its per-XCD partial sums - 96 B per sample written and read once - are scratch, not counted), then the
@@ -542,7 +550,7 @@ def kernel_table(prof_all, n_steps, model, pmc_blob=None):
 PMC_KERNELS = {
     "pag_permuto_encode_fwd": ["permuto_fwd_kernel"], "pag_permuto_encode_fwd_add": ["permuto_fwd_add_kernel"],
     "pag_permuto_encode_bwd_set": ["bin_kernel", "reduce_kernel"],
-    "pag_mlp_fwd": ["mlp_fwd_fast<2, 0", "mlp_fwd_fast<3, 1", "mlp_fwd_wide_stats"],
+    "pag_mlp_fwd": ["mlp_fwd_fast<2, 0", "mlp_fwd_fast<3, 1", "mlp_fwd_wide_stats", "head_fwd_once_kernel"],
     "pag_mlp_bwd": ["mlp_bwd_fused<2, 0", "mlp_bwd_fused<3, 1", "mlp_bwd_wide_blocks", "mlp_bwd_pair", "wgrad_finish_kernel"],
     "pag_head_composite_fwd": ["head_composite_fwd_kernel"], "pag_composite_fwd": ["composite_fwd_kernel"],
     "pag_composite_bwd": ["composite_bwd_kernel"], "pag_composite_feats_fwd": ["composite_feats_small_fwd_kernel"],

@@ -393,7 +393,12 @@ def test_bench_byte_model_matches_design_table():
     M, N = 4096 * 512, 4096
     m = bench.algorithmic_model("permuto", M, N, {"rgb", "depth", "semantics", "inst_embedding"}, 24, 2, 4, True)
     per = {k: v["bytes"] / M for k, v in m.items()}
-    assert m["pag_mlp_fwd"]["parts"] == {"density": 160, "colour": 52, "inst_stats+sem": 276} and per["pag_mlp_fwd"] == 488
+    # 512 samples per ray: the 200-way head's forward is the one-launch form (decoder + per-ray sum, pag_mlp_fwd_args.composite) - no pag_head_composite_fwd
+    assert m["pag_mlp_fwd"]["parts"] == {"density": 160, "colour": 52, "inst_once+sem": 280} and m["pag_mlp_fwd"]["bytes"] == 492 * M + N * 800
+    assert "pag_head_composite_fwd" not in m
+    two = bench.algorithmic_model("permuto", M, N, {"rgb", "depth", "semantics", "inst_embedding"}, 24, 2, 4, True, head_once=False)
+    assert two["pag_mlp_fwd"]["parts"] == {"density": 160, "colour": 52, "inst_stats+sem": 276} and two["pag_mlp_fwd"]["bytes"] == 488 * M
+    assert two["pag_head_composite_fwd"]["bytes"] == M * 140 + N * 800
     assert m["pag_mlp_bwd"]["parts"] == {"density": 288, "colour": 88, "inst_stage_A": 264, "inst_stage_B+sem": 396} and per["pag_mlp_bwd"] == 1036
     assert per["pag_permuto_encode_fwd"] == 876 and per["pag_permuto_encode_fwd_add"] == 972 and per["pag_permuto_encode_bwd_set"] == 2 * 1644
     assert m["pag_mlp_fwd"]["flops"] == 2 * M * 34560 and m["pag_mlp_bwd"]["flops"] == 2 * M * (34560 + 32832)
@@ -404,7 +409,7 @@ def test_bench_byte_model_matches_design_table():
     pdir = os.path.join(root, "profiles")
     newest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic_per_launch.json"))[-1]
     blob = json.load(open(os.path.join(pdir, newest)))
-    for entry in ("pag_mlp_fwd", "pag_mlp_bwd", "pag_head_composite_fwd", "pag_composite_fwd"):
+    for entry in ("pag_mlp_fwd", "pag_mlp_bwd", "pag_composite_fwd"):
         pmc = bench.pmc_bytes_per_step(blob, entry, 1)
         assert pmc is not None and 1 / 1.3 < pmc / m[entry]["bytes"] < 1.3, (entry, pmc, m[entry]["bytes"])
 
