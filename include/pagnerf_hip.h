@@ -196,6 +196,12 @@ typedef struct pag_mlp_fwd_args {
      * statistics that rebuild to probability 0 and a zero hidden row.  The caller does not call pag_head_composite_fwd.
      * pag_mlp_fwd_composite_supported() tells whether the arguments qualify (pair included). */
     const struct pag_head_composite_args *composite;
+    /* Optional (ABI 12), colour-like decoder only (strided bf16 x1 [M,16] + per-ray x2, three layers, sigmoid, x1_col0_relu, no hidden_save): the
+     * density-like decoder whose `out` IS this decoder's x1 (XCD8 bf16 input, two layers, no activation, out_dim 16, bf16 out, no hidden_save) is
+     * evaluated in the same launch - its output is written as without this field and handed on in registers (pc_nerf/panoptic_delta_nef.py:184 ->
+     * :198-203 as one launch instead of two; bit-identical outputs).  The caller does not call pag_mlp_fwd for the producer.
+     * pag_mlp_fwd_producer_supported() tells whether the two argument blocks qualify. */
+    const struct pag_mlp_fwd_args *x1_producer;
 } pag_mlp_fwd_args;
 typedef struct pag_head_composite_args {
     const int64_t *pack_start; const int32_t *ray_of_pack; int64_t P;      /* as pag_head_composite_fwd */
@@ -207,6 +213,7 @@ typedef struct pag_head_composite_args {
 int pag_mlp_fwd(const pag_mlp_fwd_args *args, int64_t M, void *stream);
 int pag_mlp_fwd_pair_supported(const pag_mlp_fwd_args *args, const pag_mlp_fwd_args *pair);
 int pag_mlp_fwd_composite_supported(const pag_mlp_fwd_args *args, int64_t M);
+int pag_mlp_fwd_producer_supported(const pag_mlp_fwd_args *args, const pag_mlp_fwd_args *producer, int64_t M);
 
 /* Data gradients of pag_mlp_fwd.  grad_out is d loss / d (activated output); `out` is the
  * activated output saved from the forward (needed for sigmoid / softmax).  Writes

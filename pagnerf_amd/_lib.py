@@ -44,7 +44,7 @@ MlpFwdArgs._fields_ = [("x1", c_vp), ("x1_dtype", c_i32), ("k1", c_i32),
                 ("hidden_save", c_vp * 2),
                 ("mode", c_i32),
                 ("softmax_stats", c_vp), ("x1_col0_relu", c_vp), ("pair", ctypes.POINTER(MlpFwdArgs)),
-                ("composite", ctypes.POINTER(HeadCompositeArgs))]
+                ("composite", ctypes.POINTER(HeadCompositeArgs)), ("x1_producer", ctypes.POINTER(MlpFwdArgs))]
 
 
 class WgradLayer(ctypes.Structure):
@@ -94,6 +94,7 @@ _SIGS = {
     "pag_mlp_fwd": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64, c_vp]),
     "pag_mlp_fwd_pair_supported": (c_i32, [ctypes.POINTER(MlpFwdArgs), ctypes.POINTER(MlpFwdArgs)]),
     "pag_mlp_fwd_composite_supported": (c_i32, [ctypes.POINTER(MlpFwdArgs), c_i64]),
+    "pag_mlp_fwd_producer_supported": (c_i32, [ctypes.POINTER(MlpFwdArgs), ctypes.POINTER(MlpFwdArgs), c_i64]),
     "pag_mlp_bwd": (c_i32, [ctypes.POINTER(MlpBwdArgs), c_i64, c_vp]),
     "pag_mlp_bwd_fused_supported": (c_i32, [ctypes.POINTER(MlpBwdArgs)]),
     "pag_mlp_bwd_fused_workspace_bytes": (c_i64, [ctypes.POINTER(MlpBwdArgs), c_i64]),

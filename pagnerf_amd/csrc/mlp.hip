@@ -1048,6 +1048,121 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fast(FwdParams p) {
     }
 }
 
+// Density decoder and colour decoder in ONE launch (pag_mlp_fwd_args.x1_producer): the colour decoder's x1 is the density decoder's [M,16] output
+// (pc_nerf/panoptic_delta_nef.py:184 -> :198-203).  As two launches the second re-reads what the first just wrote and each pays its own ramp and tail
+// (81 + 58 us per 2.1 M samples).  Here a wave runs mlp_fwd_fast<2, 0> and then mlp_fwd_fast<3, 1> on its tile: the density features are written as
+// before (the backward reads them) and handed to the colour decoder in registers - as the bf16 values the store rounds to, brought from the accumulator
+// layout (a lane holds channels 0-3, 8-11 or 4-7, 12-15 of its sample) to the natural k order of the standalone launch (8 consecutive channels per
+// half) by two v_permlane32_swap: same fragments, same MFMA sequence, bit-identical outputs - the backward's recomputation stays consistent.
+__global__ __launch_bounds__(256, 2) void mlp_fwd_density_colour(FwdParams pd, FwdParams pc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr float LOG2E = 1.4426950408889634f;
+    bf16_t *W0d = reinterpret_cast<bf16_t *>(smem);                  // density: [64][RS] natural k, [32][RS] permuted k
+    bf16_t *WLd = W0d + 64 * RS;
+    bf16_t *W0c = WLd + 32 * RS;                                     // colour: [64][RS] natural k, [64][RS] permuted k, [32][RS] permuted k
+    bf16_t *W1c = W0c + 64 * RS;
+    bf16_t *WLc = W1c + 64 * RS;
+    float *b0d = reinterpret_cast<float *>(WLc + 32 * RS);
+    float *bLd = b0d + 64;
+    float *b0c = bLd + 32;
+    float *b1c = b0c + 64;
+    float *bLc = b1c + 64;
+    stage_weight(W0d, RS, 64, 64, pd.W[0], HID, pd.in_dim, false, pd.grp_L, pd.grp_F);
+    stage_weight(WLd, RS, 32, 64, pd.W[1], pd.out_dim, HID, true);
+    stage_weight(W0c, RS, 64, 64, pc.W[0], HID, pc.in_dim, false);
+    stage_weight(W1c, RS, 64, 64, pc.W[1], HID, HID, true);
+    stage_weight(WLc, RS, 32, 64, pc.W[2], pc.out_dim, HID, true);
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        b0d[e] = pd.b[0][e];
+        b0c[e] = pc.b[0][e];
+        b1c[e] = pc.b[1][e];
+    }
+    for (int e = threadIdx.x; e < 32; e += blockDim.x) {
+        bLd[e] = e < pd.out_dim ? pd.b[1][e] : 0.0f;
+        bLc[e] = e < pc.out_dim ? pc.b[2][e] : 0.0f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t M = pd.M, ntiles = (M + 31) / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pd.x1), 0, (int)(M * 128), 0x00020000);
+    const auto rs_xi = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(pc.x2_index), 0, (int)(M * 4), 0x00020000);
+    const auto rs_od = __builtin_amdgcn_make_buffer_rsrc(pd.out, 0, (int)(M * pd.out_dim * 2), 0x00020000);
+    const auto rs_oc = __builtin_amdgcn_make_buffer_rsrc(pc.out, 0, (int)(M * pc.out_dim * 4), 0x00020000);
+    const auto rs_c0 = __builtin_amdgcn_make_buffer_rsrc(pc.col0_relu, 0, (int)(M * 4), 0x00020000);
+    unsigned xoff[4], ooff_d[4], ooff_c[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xoff[s] = (unsigned)(((int64_t)(2 * s + h) * M + r) * 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        ooff_d[g] = (8 * g + 4 * h < pd.out_dim) ? (unsigned)((r * pd.out_dim + 8 * g + 4 * h) * 2) : BUF_OOB;
+        ooff_c[g] = (4 * h + g < pc.out_dim) ? (unsigned)((r * pc.out_dim + 4 * h + g) * 4) : BUF_OOB;
+    }
+    const unsigned c0off = h == 0 ? (unsigned)(r * 4) : BUF_OOB;
+    auto row_live = [&](int64_t tile) __attribute__((always_inline)) { return tile * 32 + r < M; };
+    auto load_x = [&](int64_t tile, int ray, bf16x8 (&xf)[4], bf16x8 (&pe)[2]) __attribute__((always_inline)) {
+        const unsigned base = row_live(tile) ? (unsigned)(tile * 32) * 16u : BUF_OOB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[s] + base, 0, 0));
+        const float *row = pc.x2 + (int64_t)ray * pc.k2p + 8 * h;          // ray is a valid index for every lane (0 for rows past M)
+        pe[0] = load8(row);
+        pe[1] = load8(row + 16);
+    };
+    auto load_ray = [&](int64_t tile) __attribute__((always_inline)) {
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_xi, row_live(tile) ? (unsigned)(tile * 32 + r) * 4u : BUF_OOB, 0, 0);
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    int ray1 = load_ray(tile + tile_step);
+    bf16x8 xn[4], pen[2];
+    load_x(tile, load_ray(tile), xn, pen);
+    for (; tile < ntiles; tile += tile_step) {
+        const bool live = row_live(tile);
+        const unsigned row0 = (unsigned)(tile * 32);
+        bf16x8 xb[4], xc[3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xb[s] = xn[s];
+        xc[1] = pen[0];
+        xc[2] = pen[1];
+        load_x(tile + tile_step, ray1, xn, pen);
+        ray1 = load_ray(tile + 2 * tile_step);
+        // ---- density decoder (mlp_fwd_fast<2, 0, false>)
+        f32x16 acc[2], o;
+        bf16x8 hb[4];
+        hidden_layer_pinned<4>(W0d, b0d, xb, r, h, acc);
+        relu_pack(acc, hb);
+        out_block_pinned(WLd, bLd, 0, hb, r, h, o);
+        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+        unsigned dw[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dw[k] = __builtin_bit_cast(unsigned, bf16x2{(bf16_t)o[2 * k], (bf16_t)o[2 * k + 1]});
+        const unsigned obase_d = live ? row0 * (unsigned)(pd.out_dim * 2) : BUF_OOB_ROW;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) __builtin_amdgcn_raw_buffer_store_b64(u32x2{dw[2 * g], dw[2 * g + 1]}, rs_od, ooff_d[g] + obase_d, 0, 0);
+        // ---- its 16 output channels as the colour decoder's first k-step, natural order: half 0 = channels 0-7, half 1 = channels 8-15
+        {
+            const auto s02 = __builtin_amdgcn_permlane32_swap(dw[0], dw[2], false, false);      // dw[0] upper half <-> dw[2] lower half
+            const auto s13 = __builtin_amdgcn_permlane32_swap(dw[1], dw[3], false, false);
+            const u32x4 v = {s02[0], s13[0], s02[1], s13[1]};
+            xc[0] = __builtin_bit_cast(bf16x8, v);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf((float)xc[0][0], 0.0f)), rs_c0, live ? c0off + row0 * 4 : BUF_OOB, 0, 0);
+        // ---- colour decoder (mlp_fwd_fast<3, 1, false>)
+        hidden_layer_pinned<3>(W0c, b0c, xc, r, h, acc);
+        relu_pack(acc, hb);
+        hidden_layer_pinned<4>(W1c, b1c, hb, r, h, acc);
+        relu_pack(acc, hb);
+        out_block_pinned(WLc, bLc, 0, hb, r, h, o);
+        const unsigned obase_c = live ? row0 * (unsigned)(pc.out_dim * 4) : BUF_OOB_ROW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * o[j]));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs_oc, ooff_c[j] + obase_c, 0, 0);
+        }
+    }
+}
+
 // Wide softmax head (three layers, XCD8 input, 192 < out_dim <= 224), statistics only: the forward of the instance head writes the
 // per-sample (max logit * log2e, 1 / sum exp) and the last hidden layer; pag_head_composite_fwd and the backward rebuild the
 // probabilities from them.  One 32-channel block is live at a time (online softmax over the blocks); block k+1's MFMAs are issued
@@ -3906,6 +4021,22 @@ extern "C" int pag_mlp_fwd_pair_supported(const pag_mlp_fwd_args *a, const pag_m
     return wide && narrow ? 1 : 0;
 }
 
+#ifndef PAG_FAST_FWD_GRID_CAP
+#define PAG_FAST_FWD_GRID_CAP 768      // three workgroups per CU are resident: one round, tiles grid-strided (1536 ran two rounds with a ragged second: colour forward 63 -> 57 us)
+#endif
+extern "C" int pag_mlp_fwd_producer_supported(const pag_mlp_fwd_args *a, const pag_mlp_fwd_args *d, int64_t M) {
+    static const bool no_fast = getenv("PAG_NO_FAST_FWD") != nullptr;
+    if (!a || !d || no_fast || M < 1 || M > PAG_MLP_FUSED_WIDE_MAX_M) return 0;
+    const bool density = d->mode == PAG_MLP_MFMA_BF16 && d->x1_dtype == PAG_BF16 && d->x1_layout == PAG_LAYOUT_XCD8 && d->k1 == 64 && !d->x2 && d->n_layers == 2 &&
+                         d->out && d->out_dtype == PAG_BF16 && d->out_act == PAG_ACT_NONE && d->out_dim == 16 && !d->hidden_save[0] && !d->hidden_save[1] &&
+                         !d->softmax_stats && !d->x1_col0_relu && !d->pair && !d->composite && !d->x1_producer && d->W[0] && d->W[1] && d->b[0] && d->b[1] &&
+                         d->in_dim == d->x1_levels * d->x1_feats && d->x1_feats >= 1 && ((d->x1_levels + 7) / 8) * d->x1_feats <= 8;
+    const bool colour = a->mode == PAG_MLP_MFMA_BF16 && a->x1_dtype == PAG_BF16 && a->x1_layout != PAG_LAYOUT_XCD8 && a->k1 == 16 && a->x1 == d->out && a->x2 &&
+                        a->k2p == 32 && a->x2_index && a->in_dim <= 48 && a->n_layers == 3 && a->out && a->out_dtype == PAG_F32 && a->out_act == PAG_ACT_SIGMOID &&
+                        a->out_dim <= 4 && a->x1_col0_relu && !a->hidden_save[0] && !a->hidden_save[1] && !a->pair && !a->composite;
+    return density && colour ? 1 : 0;
+}
+
 extern "C" int pag_mlp_fwd_composite_supported(const pag_mlp_fwd_args *a, int64_t M) {
     static const bool no_fast = getenv("PAG_NO_FAST_FWD") != nullptr;
     if (!a || no_fast || M < 1 || M > PAG_MLP_FUSED_WIDE_MAX_M) return 0;
@@ -4051,11 +4182,37 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
             PAG_CHECK_LAUNCH("pag_mlp_fwd (wide head statistics)");
             return PAG_OK;
         }
+        PAG_CHECK_ARG(!a->x1_producer || (kind == 1 && pag_mlp_fwd_producer_supported(a, a->x1_producer, M) == 1),
+                      "pag_mlp_fwd: x1_producer is not supported for these arguments (pag_mlp_fwd_producer_supported)");
+        if (a->x1_producer) {      // density decoder + colour decoder in one launch (mlp_fwd_density_colour)
+            const pag_mlp_fwd_args *d = a->x1_producer;
+            FwdParams pd = p;
+            pd.x1 = d->x1;
+            pd.x2 = nullptr;
+            pd.x2_index = nullptr;
+            pd.k1 = 64;
+            pd.k2p = 0;
+            pd.in_dim = d->in_dim;
+            pd.in_pad = 64;
+            pd.out_dim = d->out_dim;
+            pd.act = d->out_act;
+            pd.stats = nullptr;
+            pd.col0_relu = nullptr;
+            for (int l = 0; l < 3; ++l) {
+                pd.W[l] = l < 2 ? d->W[l] : nullptr;
+                pd.b[l] = l < 2 ? d->b[l] : nullptr;
+            }
+            pd.out = d->out;
+            pd.hsave[0] = pd.hsave[1] = nullptr;
+            pd.grp_L = d->x1_levels;
+            pd.grp_F = d->x1_feats;
+            const size_t lds = (size_t)(64 + 32 + 64 + 64 + 32) * RS * sizeof(bf16_t) + (64 + 32 + 64 + 64 + 32) * sizeof(float);
+            hipLaunchKernelGGL(mlp_fwd_density_colour, dim3(std::min<unsigned>(mlp_grid(M), PAG_FAST_FWD_GRID_CAP)), dim3(256), lds, st, pd, p);
+            PAG_CHECK_LAUNCH("pag_mlp_fwd (density + colour)");
+            return PAG_OK;
+        }
         if (kind >= 0 && (save_all || save_none)) {
             const size_t lds = (size_t)(64 + (a->n_layers == 3 ? 64 : 0) + 32) * RS * sizeof(bf16_t) + (128 + 32) * sizeof(float) + 4 * ST_BYTES;
-#ifndef PAG_FAST_FWD_GRID_CAP
-#define PAG_FAST_FWD_GRID_CAP 768      // three workgroups per CU are resident: one round, tiles grid-strided (1536 ran two rounds with a ragged second: colour forward 63 -> 57 us)
-#endif
 #define FWD_FAST(NL_, K_, S_) hipLaunchKernelGGL((mlp_fwd_fast<NL_, K_, S_>), dim3(std::min<unsigned>(mlp_grid(M), PAG_FAST_FWD_GRID_CAP)), dim3(256), lds, st, p)
 #define FWD_FAST_K(K_)                                                        \
     do {                                                                      \
@@ -4072,6 +4229,7 @@ extern "C" int pag_mlp_fwd(const pag_mlp_fwd_args *a, int64_t M, void *stream) {
         }
     }
     PAG_CHECK_ARG(!a->composite, "pag_mlp_fwd: composite rides only in the straight-line wide-head launch (pag_mlp_fwd_composite_supported)");
+    PAG_CHECK_ARG(!a->x1_producer, "pag_mlp_fwd: x1_producer rides only in the straight-line colour launch (pag_mlp_fwd_producer_supported)");
     PAG_CHECK_ARG(!a->pair, "pag_mlp_fwd: pair rides only in the straight-line wide-head launch (M <= %lld, PAG_NO_FAST_FWD unset)", (long long)PAG_MLP_FUSED_WIDE_MAX_M);
     if (a->mode == PAG_MLP_MFMA_BF16) {
         const int OB = (a->out_dim + 31) / 32;

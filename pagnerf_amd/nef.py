@@ -268,6 +268,8 @@ class PanopticDeltaNeF(nn.Module):
         # a captured step's memory pool
         self._feat_cache = (coords, feats if self._heads_read_live_features() else feats.detach())
         grp = self._grouped()
+        # with the colour decoder to follow, the density decoder's launch is parked and rides in the colour decoder's (ops.decoder_hold)
+        hold = ops.decoder_hold() if (ops.CD_FUSED and "rgb" in compute_channels and feats.is_cuda) else None
         density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
         self._density_feats = density_feats.detach()             # the delta-density variant adds to its (detached) column 0 (pre-ReLU)
         if "rgb" in compute_channels:                                                 # :188, :196-204
@@ -277,7 +279,8 @@ class PanopticDeltaNeF(nn.Module):
             W, b = self.decoder_color.weights()
             # colour decoder and the density column of its input as one node (ops._ColourDensity)
             rgb, sigma = ops.colour_and_density(density_feats, W, b, pe, index, self.decoder_color.input_dim, out_act=L.ACT_SIGMOID,
-                                                mode=mode, x2_packs=ray_packs if ridx is not None else None)
+                                                mode=mode, x2_packs=ray_packs if ridx is not None else None, producer=hold)
+            ops.flush_hold(hold)
             density = sigma.reshape(batch, num_samples, 1)
             out["rgb"] = rgb.reshape(batch, num_samples, 3)
         else:

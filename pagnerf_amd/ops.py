@@ -498,7 +498,22 @@ class _FusedMLP(torch.autograd.Function):
         # A pair of decoders on one input (_HeadCompositePair): the narrow one's launch is PREPARED and parked (ctx.fwd_hold) and rides
         # in the wide one's call (ctx.fwd_pair -> pag_mlp_fwd_args.pair) where the library can; else the caller issues it.
         hold, pair_hold = getattr(ctx, "fwd_hold", None), getattr(ctx, "fwd_pair", None)
+        global _NEXT_HOLD, _NEXT_PRODUCER
+        if hold is None and _NEXT_HOLD is not None:      # decoder_hold(): this launch is prepared and parked for the decoder that consumes its output
+            hold, _NEXT_HOLD = _NEXT_HOLD, None
+            if not (M and mode == L.MLP_MFMA_BF16 and all(t is None for t in hidden) and stats is None and ctx.col0_relu is None):
+                hold = None                              # nothing a consumer's launch could carry: issue it now
+        producer, _NEXT_PRODUCER = _NEXT_PRODUCER, None
+        if producer is not None and producer.get("args") is not None and not producer.get("taken"):
+            # the decoder whose output is this one's x1 waits in `producer`: in this launch where the library can (pag_mlp_fwd_args.x1_producer),
+            # else its own launch FIRST
+            if M and x1.data_ptr() == producer["out_ptr"] and L.load().pag_mlp_fwd_producer_supported(ctypes.byref(a), ctypes.byref(producer["args"]), M) == 1:
+                a.x1_producer = ctypes.pointer(producer["args"])
+            else:
+                _call("pag_mlp_fwd", ctypes.byref(producer["args"]), producer["M"], L.stream())
+            producer["taken"] = True
         if M and hold is not None:
+            hold["out_ptr"] = out.data_ptr() if out is not None else 0
             hold["args"], hold["M"] = a, M
             hold["keep"] = [v for v in locals().values() if isinstance(v, (torch.Tensor, list, tuple))]
         elif M:
@@ -798,8 +813,11 @@ class _ColourDensity(_FusedMLP):
 
 
 def colour_and_density(x1, weights, biases, x2, x2_index, in_dim, out_act=L.ACT_SIGMOID, mode=L.MLP_MFMA_BF16,
-                       out_dtype=torch.float32, x2_packs=None):
-    """-> (rgb [M,3], sigma f32 [M] = relu(x1[:,0])); x1 = the density decoder's [M,16] output (see _ColourDensity)."""
+                       out_dtype=torch.float32, x2_packs=None, producer=None):
+    """-> (rgb [M,3], sigma f32 [M] = relu(x1[:,0])); x1 = the density decoder's [M,16] output (see _ColourDensity).
+    producer: the decoder_hold() in which the density decoder's launch waits - evaluated in this decoder's launch where the library can."""
+    global _NEXT_PRODUCER
+    _NEXT_PRODUCER = producer
     rgb, sigma = _apply_decoder(_ColourDensity, x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
     if x2_packs is not None and x2 is not None and x2.requires_grad and rgb.grad_fn is not None:
         rgb.grad_fn.x2_packs = x2_packs
@@ -1460,6 +1478,29 @@ def composite_features(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N):
 
 
 HEAD_REBUILD = True      # wide softmax heads under head_composite(): statistics-only forward + rebuilt probabilities
+CD_FUSED = os.environ.get("PAG_CD_FUSED", "1") != "0"      # density decoder + colour decoder in one launch (pag_mlp_fwd_args.x1_producer)
+_NEXT_HOLD = None
+_NEXT_PRODUCER = None
+
+
+def decoder_hold():
+    """-> hold (dict): the NEXT fused_mlp() call prepares its launch and parks it in `hold` instead of issuing it; hand `hold` to the decoder that
+    consumes its output (colour_and_density(..., producer=hold)), which carries it in its own launch or issues it first, and call
+    flush_hold(hold) afterwards in any case (issues the parked launch if nobody took it)."""
+    global _NEXT_HOLD
+    _NEXT_HOLD = {}
+    return _NEXT_HOLD
+
+
+def flush_hold(hold):
+    global _NEXT_HOLD
+    if _NEXT_HOLD is hold:
+        _NEXT_HOLD = None                # the call it was meant for never came
+    if hold is not None and hold.get("args") is not None and not hold.get("taken"):
+        _call("pag_mlp_fwd", ctypes.byref(hold["args"]), hold["M"], L.stream())
+        hold["taken"] = True
+
+
 HEAD_FWD_ONCE = os.environ.get("PAG_HEAD_FWD_ONCE", "1") != "0"      # wide softmax head: decoder + per-ray sum in one launch (0: statistics launch + pag_head_composite_fwd)
 HEAD_FWD_ONCE_MIN_PER_RAY = int(os.environ.get("PAG_HEAD_FWD_ONCE_MIN_PER_RAY", "160"))      # average samples per ray from which the one-launch form is taken
 TAIL_ZERO = False        # graphs.py: batches carry filler samples past pack_start[N] - per-sample tensors written pack by pack start as zeros

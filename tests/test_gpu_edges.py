@@ -540,3 +540,53 @@ def test_wide_head_forward_in_one_pass_matches_the_two_launch_form(gpu_device, m
     assert set(g1) == set(g0)
     for name in g0:
         assert T._rel_l2(g1[name].float(), g0[name].float()) < 3e-4, (name, T._rel_l2(g1[name].float(), g0[name].float()))
+
+
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_density_and_colour_decoders_in_one_launch_are_bit_identical(gpu_device, mode):
+    """pag_mlp_fwd_args.x1_producer (ABI 12: the density decoder evaluated in the colour decoder's launch, its 16 output channels handed on in registers
+    in the k order of the standalone launch) against the two launches: rgb, depth, alpha - and with them every gradient - bit for bit, under autograd and
+    under no_grad; ragged rays, a ray without samples, M % 32 != 0.  The fused call really is taken (one pag_mlp_fwd less per trace)."""
+    import pagnerf_amd
+    import test_gpu_parity as T
+    from pagnerf_amd import ops
+    dev = gpu_device
+    N, S = 200, 40
+    nef, tracer, rays, occ, jitter = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=12)
+    if mode == "voxel":
+        tracer.raymarch_type, tracer.num_steps, tracer.ray_max_travel = "voxel", 2, 0.9
+    o = rays.origins.clone()
+    o[3] = 5.0
+    r = pagnerf_amd.Rays(o, rays.dirs, rays.dist_min, rays.dist_max)
+    gen = torch.Generator().manual_seed(5)
+    G = torch.randn(N, 3, generator=gen).to(dev)
+    real = ops._call
+    res, calls = {}, {}
+    for fused in (True, False):
+        ops.CD_FUSED = fused
+        names = []
+
+        def spy(name, *args):
+            names.append(name)
+            return real(name, *args)
+        ops._call = spy
+        try:
+            for p in nef.parameters():
+                p.grad = None
+            rb = tracer(nef, channels={"rgb", "depth"}, rays=r, jitter=jitter.to(dev), stage="train")
+            ((rb.rgb * G).sum() + rb.depth.sum()).backward()
+            with torch.no_grad():
+                rv = tracer(nef, channels={"rgb", "depth"}, rays=r, jitter=jitter.to(dev), stage="val")
+            res[fused] = (rb, rv, {n: p.grad.clone() for n, p in nef.named_parameters() if p.grad is not None})
+            calls[fused] = names.count("pag_mlp_fwd")
+        finally:
+            ops._call = real
+            ops.CD_FUSED = True
+    assert calls[True] == calls[False] - 2, calls                 # one launch less in the training trace, one less in the no_grad trace
+    (rb1, rv1, g1), (rb0, rv0, g0) = res[True], res[False]
+    for a, b in ((rb1, rb0), (rv1, rv0), (rb1, rv1)):
+        for ch in ("rgb", "depth", "alpha"):
+            assert torch.equal(getattr(a, ch).detach(), getattr(b, ch).detach()), ch
+    assert float(rb1.rgb.detach().sum()) != 0 and set(g1) == set(g0) and "decoder_density.layers.0.weight" in g1
+    for name in g0:
+        assert torch.equal(g1[name], g0[name]), name

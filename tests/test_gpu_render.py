@@ -22,7 +22,7 @@ def _spy_fwd_args(fn):
         snap = None
         if name == "pag_mlp_fwd":
             a = args[0]._obj
-            chain = [a] + ([a.pair.contents] if a.pair else [])
+            chain = [a] + ([a.pair.contents] if a.pair else []) + ([a.x1_producer.contents] if a.x1_producer else [])      # decoders riding in this launch
             snap = [dict(out_dim=s.out_dim, out=s.out, hidden=[s.hidden_save[i] for i in range(2)], stats=s.softmax_stats,
                          col0=s.x1_col0_relu, n_layers=s.n_layers, composite=bool(s.composite)) for s in chain]
         seen.append((name, snap))
