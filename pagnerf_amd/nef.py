@@ -269,8 +269,12 @@ class PanopticDeltaNeF(nn.Module):
         self._feat_cache = (coords, feats if self._heads_read_live_features() else feats.detach())
         grp = self._grouped()
         # with the colour decoder to follow, the density decoder's launch is parked and rides in the colour decoder's (ops.decoder_hold)
-        hold = ops.decoder_hold() if (ops.CD_FUSED and "rgb" in compute_channels and feats.is_cuda) else None
-        density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
+        hold = ops.decoder_hold(feats) if (ops.CD_FUSED and "rgb" in compute_channels and feats.is_cuda) else None
+        try:
+            density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
+        except BaseException:
+            ops.flush_hold(hold)
+            raise
         self._density_feats = density_feats.detach()             # the delta-density variant adds to its (detached) column 0 (pre-ReLU)
         if "rgb" in compute_channels:                                                 # :188, :196-204
             if num_samples != 1 and ridx is None:                                  # one direction per pack entry -> per sample

@@ -499,7 +499,8 @@ class _FusedMLP(torch.autograd.Function):
         # in the wide one's call (ctx.fwd_pair -> pag_mlp_fwd_args.pair) where the library can; else the caller issues it.
         hold, pair_hold = getattr(ctx, "fwd_hold", None), getattr(ctx, "fwd_pair", None)
         global _NEXT_HOLD, _NEXT_PRODUCER
-        if hold is None and _NEXT_HOLD is not None:      # decoder_hold(): this launch is prepared and parked for the decoder that consumes its output
+        if hold is None and _NEXT_HOLD is not None and _NEXT_HOLD.get("x1_ptr") == x1.data_ptr():
+            # decoder_hold(x1): this launch is prepared and parked for the decoder that consumes its output
             hold, _NEXT_HOLD = _NEXT_HOLD, None
             if not (M and mode == L.MLP_MFMA_BF16 and all(t is None for t in hidden) and stats is None and ctx.col0_relu is None):
                 hold = None                              # nothing a consumer's launch could carry: issue it now
@@ -1483,12 +1484,13 @@ _NEXT_HOLD = None
 _NEXT_PRODUCER = None
 
 
-def decoder_hold():
-    """-> hold (dict): the NEXT fused_mlp() call prepares its launch and parks it in `hold` instead of issuing it; hand `hold` to the decoder that
-    consumes its output (colour_and_density(..., producer=hold)), which carries it in its own launch or issues it first, and call
-    flush_hold(hold) afterwards in any case (issues the parked launch if nobody took it)."""
+def decoder_hold(x1):
+    """-> hold (dict): the next fused_mlp() call ON THE INPUT `x1` prepares its launch and parks it in `hold` instead of issuing it; hand `hold` to the
+    decoder that consumes its output (colour_and_density(..., producer=hold)), which carries it in its own launch or issues it first, and call
+    flush_hold(hold) afterwards in any case (issues the parked launch if nobody took it; forgets a hold no call picked up).  Single-threaded callers
+    only, as everything behind the plugin API."""
     global _NEXT_HOLD
-    _NEXT_HOLD = {}
+    _NEXT_HOLD = {"x1_ptr": x1.data_ptr()}
     return _NEXT_HOLD
 
 
