@@ -859,6 +859,12 @@ def run_rank(args):
             was = self.tracer.use_graphs
             if profile is not None:
                 self.tracer.use_graphs = False
+            # the interpreter's cyclic collector is not part of a step: collected before, kept from firing inside the timed region (one full
+            # collection is a ~10 ms host stall = +0.5 ms on each of 20 steps - seen once in a dozen runs), back on afterwards
+            import gc
+            gc.collect()
+            gc_was = gc.isenabled()
+            gc.disable()
             barrier()
             if profile is not None:
                 ops.profile_start(only=profile)
@@ -867,6 +873,8 @@ def run_rank(args):
                 self.step(channels)
             barrier()
             dt = time.perf_counter() - t0
+            if gc_was:
+                gc.enable()
             prof = ops.profile_stop() if profile is not None else None
             self.tracer.use_graphs = was
             return max_over_ranks(dt), prof
