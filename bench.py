@@ -550,7 +550,7 @@ def kernel_table(prof_all, n_steps, model, pmc_blob=None):
 PMC_KERNELS = {
     "pag_permuto_encode_fwd": ["permuto_fwd_kernel"], "pag_permuto_encode_fwd_add": ["permuto_fwd_add_kernel"],
     "pag_permuto_encode_bwd_set": ["bin_kernel", "reduce_kernel"],
-    "pag_mlp_fwd": ["mlp_fwd_fast<2, 0", "mlp_fwd_fast<3, 1", "mlp_fwd_wide_stats", "head_fwd_once_kernel"],
+    "pag_mlp_fwd": ["mlp_fwd_fast<2, 0", "mlp_fwd_fast<3, 1", "mlp_fwd_density_colour", "mlp_fwd_wide_stats", "head_fwd_once_kernel"],
     "pag_mlp_bwd": ["mlp_bwd_fused<2, 0", "mlp_bwd_fused<3, 1", "mlp_bwd_wide_blocks", "mlp_bwd_pair", "wgrad_finish_kernel"],
     "pag_head_composite_fwd": ["head_composite_fwd_kernel"], "pag_composite_fwd": ["composite_fwd_kernel"],
     "pag_composite_bwd": ["composite_bwd_kernel"], "pag_composite_feats_fwd": ["composite_feats_small_fwd_kernel"],
