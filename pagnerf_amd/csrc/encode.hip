@@ -162,6 +162,9 @@ __global__ __launch_bounds__(PAG_ENC_FWD_THREADS) void hash_bwd_kernel(const flo
     }
 }
 
+#ifdef PAG_EXP_JAC
+__device__ bf16_t *g_exp_jac = nullptr;
+#endif
 template <typename TableT, typename OutT, int F, int LPX>
 __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, int64_t M, const TableT *__restrict__ tables, const PermutoParams &p,
                                                  OutT *__restrict__ out, int64_t sm, int64_t sc, int grouped, const bf16_t *__restrict__ addend) {
@@ -225,6 +228,31 @@ __device__ __forceinline__ void permuto_fwd_body(const float *__restrict__ xyz, 
     }
     if constexpr (LPX * F <= 8 && sizeof(OutT) == 2)
         if (grouped) store_grouped<LPX * F>(out, M, g, i, gvals, addend != nullptr, addv);
+#ifdef PAG_EXP_JAC      // experiment (scripts/exp_jac_store.py): what would it cost the forward to write d feat / d xyz (6 values per level) next to the features?
+    if (g_exp_jac != nullptr && addend == nullptr) {
+        bf16_t jv[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) jv[q] = (bf16_t)0.0f;
+#pragma unroll
+        for (int j = 0; j < LPX; ++j) {
+            const int l = xcd8_level(g, j), le = l < p.L ? l : p.L - 1;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float d01 = e[j][0][f] - e[j][1][f], d12 = e[j][1][f] - e[j][2][f], d23 = e[j][2][f] - e[j][3][f], d30 = e[j][3][f] - e[j][0][f];
+                if (j * 6 + f * 3 + 2 < 24) {
+                    jv[j * 6 + f * 3 + 0] = (bf16_t)(0.25f * (d01 - d12) * p.sf[le][0]);
+                    jv[j * 6 + f * 3 + 1] = (bf16_t)(0.25f * (d01 + d12 - 2.0f * d23) * p.sf[le][1]);
+                    jv[j * 6 + f * 3 + 2] = (bf16_t)(0.25f * (d01 + d12 + d23 - 3.0f * d30) * p.sf[le][2]);
+                }
+            }
+        }
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t *dst = reinterpret_cast<u32x4_t *>(g_exp_jac + ((int64_t)g * M + i) * PAG_EXP_JAC);
+        const u32x4_t *srcv = reinterpret_cast<const u32x4_t *>(jv);
+#pragma unroll
+        for (int q = 0; q < PAG_EXP_JAC / 8; ++q) dst[q] = srcv[q];
+    }
+#endif
 }
 
 // Two kernel symbols for the same body: the plain launch (the roofline kernel of bench.py) and the `_add` launch of the delta grid, so that
@@ -1661,3 +1689,7 @@ extern "C" int pag_permuto_encode_bwd_set(const float *xyz, int64_t M, const voi
 }
 
 PAG_BLOCK_TIMING_EXPORT(encode)
+
+#ifdef PAG_EXP_JAC
+extern "C" int pag_debug_set_jac(void *ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_jac), &ptr, sizeof(ptr)); }
+#endif

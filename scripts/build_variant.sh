@@ -10,13 +10,13 @@ declare -A rebuilt
 for src in ${srcs//,/ }; do
   base=$(basename $src .hip)
   extra=""
-  case $base in encode|render|assign|loss|optim) extra="-ffp-contract=off";; mlp) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+  case $base in encode|render|assign|loss|optim|pose|regularizer) extra="-ffp-contract=off";; mlp) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-value $extra $flags -c $root/pagnerf_amd/csrc/$base.hip -o $lib/obj/${base}_$tag.o &
   rebuilt[$base]=1
 done
 wait
 objs=""
-for o in api encode render mlp assign loss optim; do
+for o in api encode render mlp assign loss optim pose regularizer; do
   if [ -n "${rebuilt[$o]}" ]; then objs="$objs $lib/obj/${o}_$tag.o"; else objs="$objs $lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/libpagnerf_hip_$tag.so $objs
