@@ -70,12 +70,17 @@ __global__ __launch_bounds__(256) void render_loss_fwd_kernel(LossArgs a, float 
     __threadfence();
     if (threadIdx.x == 0) last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
     __syncthreads();
-    if (!last || threadIdx.x != 0) return;
+    if (!last) return;                          // workgroup-uniform
     __threadfence();
-    float tot[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (unsigned b = 0; b < gridDim.x; ++b)
+    // the last workgroup adds the partial sums: thread b holds workgroup b's (gridDim.x <= RL_MAX_BLOCKS <= 256), then the fixed tree of block_sum - one
+    // thread walking them (5 x gridDim.x dependent L2 round trips) was 20 of the launch's 25 us
+    float tot[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) tot[q] += __hip_atomic_load(partials + b * 5 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < 5; ++q) {
+        const float v = threadIdx.x < gridDim.x ? __hip_atomic_load(partials + threadIdx.x * 5 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        tot[q] = block_sum(v, scratch);
+    }
+    if (threadIdx.x != 0) return;
     const float n_f = (float)a.N;
     const float rgb_term = a.rgb ? a.rgb_weight * (tot[0] / (3.0f * n_f)) : 0.0f;
     float term[2], den[2];
