@@ -333,3 +333,29 @@ def test_rays_to_3d_points_vs_oracle(gpu_device):
         want = oreg.rays_to_3d_points(o[sl].numpy(), d[sl].numpy(), depth[sl, 0].numpy(), R[c].numpy(), t[c].numpy())
         np.testing.assert_allclose(got[sl].numpy(), want, rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(got_i[sl].numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_segment_regulariser_kernel_edge_shapes(gpu_device):
+    """pag_segment_reg_fwd / _bwd at the edges of their argument ranges, against the numpy oracle: one ray, one image, one column (every segment is
+    skipped: no column 1.. exists - value 0, zero gradient), P not a multiple of the launch granules, the reserved id INT64_MIN (NaN, zero gradient)."""
+    from pagnerf_amd import loss as pl
+    from oracle import regularizers as oreg
+    dev = gpu_device
+    rs = np.random.RandomState(2)
+    for B, P, I in ((1, 1, 5), (1, 7, 1), (3, 1001, 9), (2, 64, 2)):
+        prob = torch.softmax(torch.from_numpy(rs.standard_normal(size=(B, P, I)).astype(np.float32)) * 2, -1)
+        labels = torch.from_numpy(rs.randint(-3, 4, size=(B, P)).astype(np.int64))
+        want, want_grad = oreg.segment_consistency_regularizer(prob.numpy() + np.float32(1e-27), labels.numpy(), want_grad=True)
+        x = prob.to(dev).requires_grad_(True)
+        v = pl.segment_consistency_regularizer(x, labels.to(dev), eps=1e-27)
+        assert type(v.grad_fn).__name__ == "_SegmentRegBackward"
+        v.backward()
+        np.testing.assert_allclose(float(v.detach()), float(want), rtol=2e-6, atol=0, err_msg=str((B, P, I)))
+        np.testing.assert_allclose(x.grad.cpu().numpy(), want_grad, rtol=2e-5, atol=0, err_msg=str((B, P, I)))
+    lab = torch.zeros(1, 16, dtype=torch.int64, device=dev)
+    lab[0, 3] = torch.iinfo(torch.int64).min
+    x = torch.softmax(torch.randn(1, 16, 4, device=dev), -1).requires_grad_(True)
+    v = pl.segment_consistency_regularizer(x, lab)
+    assert torch.isnan(v)
+    v.backward()
+    assert float(x.grad.abs().sum()) == 0.0
