@@ -1054,7 +1054,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fast(FwdParams p) {
 // before (the backward reads them) and handed to the colour decoder in registers - as the bf16 values the store rounds to, brought from the accumulator
 // layout (a lane holds channels 0-3, 8-11 or 4-7, 12-15 of its sample) to the natural k order of the standalone launch (8 consecutive channels per
 // half) by two v_permlane32_swap: same fragments, same MFMA sequence, bit-identical outputs - the backward's recomputation stays consistent.
-__global__ __launch_bounds__(256, 2) void mlp_fwd_density_colour(FwdParams pd, FwdParams pc) {
+#ifndef PAG_CD_WAVES
+#define PAG_CD_WAVES 2      // waves per SIMD asked of the compiler (146 VGPRs: three resident, grid cap 768 = one round; asking for 4 = 128 VGPRs: 123 us against 98; caps 512 / 1024: 101 / 105)
+#endif
+__global__ __launch_bounds__(256, PAG_CD_WAVES) void mlp_fwd_density_colour(FwdParams pd, FwdParams pc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr float LOG2E = 1.4426950408889634f;
     bf16_t *W0d = reinterpret_cast<bf16_t *>(smem);                  // density: [64][RS] natural k, [32][RS] permuted k
