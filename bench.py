@@ -47,6 +47,118 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA ~2.5 PFLOP/s
+LINE_BUDGET = 4096           # the driver parses the LAST stdout line: round 5's grew to 32 KB and was recorded as `parsed: null`
+
+
+# --------------------------------------------------------------------------------------------- the result line and its detail file
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def _config_key(name):
+    """'configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp16 tables + ...' -> a short unique key for the one-number-per-config map."""
+    head, _, rest = str(name).partition(":")
+    head = head.strip()
+    words = [w for w in rest.replace(",", " ").split() if w in ("hash", "permuto", "fp16", "fp32", "rgb", "all")]
+    return _short(head + ("/" + "+".join(dict.fromkeys(words)) if words else ""), 56)
+
+
+def compact_line(detail, detail_path=None):
+    """The ONE line the driver parses: the contract's scalars, `config`, `roofline` and `cpu_baseline` as flat objects, and one number per
+    extra measurement.  Everything else (per-entry-point tables, notes, per-regime breakdowns) lives in the detail file written beside
+    it.  Always <= LINE_BUDGET bytes: optional blocks are dropped, last first, if a run ever grows past it."""
+    out = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data")}
+    cfg = dict(detail.get("config") or {})
+    out["config"] = {k: (_short(v, 360) if isinstance(v, str) else v) for k, v in cfg.items() if isinstance(v, (str, int, float, bool, list)) or v is None}
+    out["rccl_ranks_seen"], out["backend"] = detail.get("rccl_ranks_seen"), detail.get("backend")
+    gs = detail.get("grad_sync")
+    out["grad_sync"] = (gs.get("comm_dtype") if isinstance(gs, dict) else gs)
+    if detail.get("dry_run"):
+        out["dry_run"] = True
+    rf = detail.get("roofline")
+    if isinstance(rf, dict):
+        keep = {k: v for k, v in rf.items() if isinstance(v, (int, float, bool)) or v is None or k in ("bound", "unit", "kernel")}
+        ts = rf.get("traffic_source")
+        keep["traffic_source"] = (ts.get("file") if isinstance(ts, dict) else ts)
+        out["roofline"] = keep
+    else:
+        out["roofline"] = None
+    cb = detail.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {k: (_short(cb.get(k), 300) if k == "sample" else cb.get(k)) for k in ("value", "unit", "cores", "cores_available", "kind", "sample")}
+    else:
+        out["cpu_baseline"] = None
+    optional = []          # (key, value), most important first
+
+    def num(block, *keys):
+        b = detail.get(block)
+        if isinstance(b, dict):
+            got = {k: b[k] for k in keys if isinstance(b.get(k), (int, float))}
+            if got:
+                optional.append((block, got))
+    num("mfma_util", "frac")
+    num("schedule_weighted", "ms_per_step", "rays_s")
+    num("sustained", "ms_per_step")
+    if isinstance(detail.get("configs"), list):
+        optional.append(("configs", {(c.get("key") or _config_key(c.get("name"))): c.get("ms_per_step") for c in detail["configs"] if isinstance(c, dict)}))
+    by = (detail.get("best_yaml_step") or {}).get("regimes") if isinstance(detail.get("best_yaml_step"), dict) else None
+    if isinstance(by, dict):
+        optional.append(("best_yaml_step", {k: v.get("ms_per_step") for k, v in by.items() if isinstance(v, dict)}))
+    num("rgb_only", "ms_per_step")
+    num("eager", "ms_per_step")
+    la = detail.get("with_lin_assignment")
+    if isinstance(la, dict):
+        optional.append(("with_lin_assignment", {k: v.get("ms_per_step") for k, v in la.items() if isinstance(v, dict)}))
+    for blk in ("render", "render_pruned"):
+        b = detail.get(blk)
+        if isinstance(b, dict):
+            optional.append((blk, {k: v.get("ms_per_image") for k, v in b.items() if isinstance(v, dict) and "ms_per_image" in v}))
+    if isinstance(detail.get("weak_regimes"), list):
+        optional.append(("weak_regimes", {_short(w.get("name"), 64): dict(ms_per_step=w.get("ms_per_step"),
+                                                                          grad_sync=((w.get("grad_sync") or {}).get("comm_dtype") if isinstance(w.get("grad_sync"), dict) else w.get("grad_sync")))
+                                          for w in detail["weak_regimes"] if isinstance(w, dict)}))
+    num("strong", "ms_per_step", "rays_s")
+    num("render_sharded", "ms", "rays_s")
+    kt = detail.get("kernels")
+    if isinstance(kt, dict):
+        optional.append(("kernels_ms", {k: v.get("ms_per_step") for k, v in kt.items() if isinstance(v, dict) and (v.get("ms_per_step") or 0) >= 0.02}))
+    if detail_path:
+        out["detail"] = detail_path
+    for k, v in optional:
+        out[k] = v
+    for k, _ in reversed(optional):
+        if len(json.dumps(out)) <= LINE_BUDGET:
+            break
+        del out[k]
+    assert len(json.dumps(out)) <= LINE_BUDGET, "bench.py: the result line cannot be brought under %d bytes" % LINE_BUDGET
+    return out
+
+
+def emit(detail):
+    """Write the full record to bench_detail.json (repo root; also gpurun_out/ when that directory exists; PAG_BENCH_DETAIL overrides the
+    path), a per-key digest of it to stderr, and the compact line - LAST, alone - to stdout."""
+    path = os.environ.get("PAG_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+    paths = [path]
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if "PAG_BENCH_DETAIL" not in os.environ and os.path.isdir(scratch):
+        paths.append(os.path.join(scratch, "bench_detail.json"))
+    written = None
+    for p_ in paths:
+        try:
+            with open(p_, "w") as f:
+                json.dump(detail, f, indent=1)
+            written = written or p_
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (p_, e), file=sys.stderr)
+    for k, v in detail.items():
+        if isinstance(v, (dict, list)):
+            print("[bench detail] %s: %s" % (k, _short(json.dumps(v), 700)), file=sys.stderr)
+    sys.stderr.flush()
+    line = compact_line(detail, os.path.relpath(written, ROOT) if written and written.startswith(ROOT) else written)
+    print(json.dumps(line), flush=True)
+    return line
 
 
 def parse(argv=None):
@@ -447,6 +559,7 @@ def cpu_baseline(n_rays, n_samples, budget_s=9.0, points=((256, 64), (4096, 64))
 
 
 # -------------------------------------------------------------------------- algorithmic bytes / flops per entry point
+DECODER_PARAMS_PANOPTIC = (48 * 64 + 64) + (64 * 6 + 6) + (48 * 64 + 64) + (64 * 64 + 64) + (64 * 200 + 200)      # sem 48-64-6 + inst 48-64-64-200, with biases
 DECODER_MACS = dict(density=48 * 64 + 64 * 16, colour=43 * 64 + 64 * 64 + 64 * 3, sem=48 * 64 + 64 * 6, inst=48 * 64 + 64 * 64 + 64 * 200)
 
 
@@ -499,7 +612,10 @@ def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16, head_once=None)
                                                bytes_min=((12 + C * s) * M + L_ * rows * F_ * 4) * (2 if pan else 1))
     # the optimiser: p, g, m, v read and p, m, v written per fp32 parameter - the two tables (rows x F per level) and the 35 k decoder weights;
     # independent of the batch
-    n_par = 2 * L_ * rows * F_ + 35169
+    # the delta grid only receives a gradient through the panoptic heads (panoptic_delta_nef.py:219-226: its features feed sem / inst only), and a
+    # parameter without a gradient is not stepped (torch.optim.Adam skips it; pagnerf_amd.optim.Adam issues no launch for it): one table in the rgb /
+    # rgb + depth regimes, two with the panoptic channels on
+    n_par = (2 if pan else 1) * L_ * rows * F_ + (35169 if pan else 35169 - DECODER_PARAMS_PANOPTIC)
     out["pag_adam_step"] = dict(bytes=28 * n_par, flops=0)
     if pan:
         if not head_once:
@@ -510,6 +626,9 @@ def algorithmic_model(grid, M, N, channels, L_, F_, verts, bf16, head_once=None)
     # per-ray sums of d xyz and d xyz * depth (d xyz + depth in, 24 B per ray out)
     out["pag_%s_encode_bwd_xyz" % grid] = dict(bytes=(12 + C * s + gather + 12) * M, flops=0, scratch_bytes=2 * 8 * 12 * M)
     out["pag_ray_sample_grad"] = dict(bytes=M * (12 + 4) + N * 24, flops=0)
+    # the same gather pass with the per-ray reduction inside it (ABI 11, what the tracer takes on marched samples): xyz, gradient row, the gathered rows
+    # again, the sample's depth and ray id in, 24 B per RAY out; the per-(XCD group, wave, ray) slots - 6 floats, written and read once - are scratch
+    out["pag_%s_encode_bwd_rays" % grid] = dict(bytes=(12 + C * s + gather + 4 + 4) * M + N * 24, flops=0, scratch_bytes=2 * 8 * 24 * (M // 64 + N))
     return out
 
 
@@ -757,12 +876,12 @@ def dry_run_rank(args, world, rank):
         rb = shard.all_gather_render(RenderBuffer(rgb=torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)), n_local * world)
         assert torch.equal(rb.rgb[:, 0], torch.arange(n_local * world, dtype=torch.float32))
     if rank == 0:
-        print(json.dumps(dict(metric="rays/sec (train step) on BUP20-shape scene", value=0.0, unit="rays/s", n_gpus=world,
-                              steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / max(args.steps, 1) * 1e3, 3),
-                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.precision, data="synthetic",
-                              config=dict(workload="DRY RUN: no kernels, gloo on CPU tensors - plumbing check only"),
-                              dry_run=True, rccl_ranks_seen=int(seen.item()), backend="gloo", grad_sync=args.grad_sync,
-                              weak_regimes=(weak if world > 1 else None))), flush=True)
+        emit(dict(metric="rays/sec (train step) on BUP20-shape scene", value=0.0, unit="rays/s", n_gpus=world,
+                  steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / max(args.steps, 1) * 1e3, 3),
+                  higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.precision, data="synthetic",
+                  config=dict(workload="DRY RUN: no kernels, gloo on CPU tensors - plumbing check only"),
+                  dry_run=True, rccl_ranks_seen=int(seen.item()), backend="gloo", grad_sync=args.grad_sync,
+                  weak_regimes=(weak if world > 1 else None)))
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -1053,7 +1172,7 @@ def run_rank(args):
         del job
         torch.cuda.empty_cache()
 
-        def short_run(name, n_steps, warm, **kw):
+        def short_run(name, n_steps, warm, key=None, **kw):
             j = Job(**kw)
             for _ in range(max(warm, 3)):                       # graphs: step 0 learns the sample count, step 1 captures
                 j.step()
@@ -1066,7 +1185,7 @@ def run_rank(args):
             lv, vt = (24, 4) if kw["grid"] == "permuto" else (kw.get("num_lods") or 16, 8)
             tb = 2 if (kw.get("table_dtype") or args.table_dtype) == "fp16" else 4
             bps = 12 + lv * vt * 2 * tb + lv * 2 * out_bytes
-            ent = dict(name=name, ms_per_step=round(ms, 3), rays_s=round(rays_total / ms * 1e3, 1), samples_per_step=int(m), steps=n_steps,
+            ent = dict(name=name, key=key, ms_per_step=round(ms, 3), rays_s=round(rays_total / ms * 1e3, 1), samples_per_step=int(m), steps=n_steps,
                        encode_bytes_per_sample=bps,
                        encode_frac=round(bps * m / (float(np.mean(e)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if e else None)
             if kw.get("raymarch") == "voxel":
@@ -1158,25 +1277,25 @@ def run_rank(args):
         if world == 1 and default_cfg:
             # ---- every other single-GPU BASELINE configuration, each a short run (configs[1] is the headline above)
             cfgs = []
-            cfgs.append(short_run("configs[0] on the GPU: hash L=16 T=2^19, 256 rays x 64 samples, rgb", 20, 5,
+            cfgs.append(short_run("configs[0] on the GPU: hash L=16 T=2^19, 256 rays x 64 samples, rgb", 20, 5, key="cfg0_hash_256x64_rgb",
                                   rays_n=256, samples=64, grid="hash", channels={"rgb"}))
-            cfgs.append(short_run("configs[2]: hash L=16 T=2^19 (16..2048) + fused MFMA decoders, 4096 rays x 512, all channels", 20, 5,
+            cfgs.append(short_run("configs[2]: hash L=16 T=2^19 (16..2048) + fused MFMA decoders, 4096 rays x 512, all channels", 20, 5, key="cfg2_hash_4096x512_all",
                                   rays_n=4096, samples=512, grid="hash", channels=all_ch))
             cfgs.append(short_run("other shipped head shapes (sem_num_layers 2 / inst_num_layers 1: lin_assign_delta_app.yaml:117,120 and three more YAMLs): 4096 rays x 512, "
-                                  "permuto, all channels - the two-layer 200-way head takes the generic decoder kernels", 10, 3,
+                                  "permuto, all channels - the two-layer 200-way head takes the generic decoder kernels", 10, 3, key="heads_2_1_permuto_4096x512_all",
                                   rays_n=4096, samples=512, grid="permuto", channels=all_ch, heads=(2, 1)))
-            cfgs.append(short_run("configs[3] on ONE GPU: 6 images x 4096 rays, ba_pipeline pose-opt, permuto, all channels", 5, 2,
+            cfgs.append(short_run("configs[3] on ONE GPU: 6 images x 4096 rays, ba_pipeline pose-opt, permuto, all channels", 5, 2, key="cfg3_one_gpu_24576x512_pose_all",
                                   rays_n=24576, samples=512, grid="permuto", channels=all_ch, pose=True))
-            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp16 tables + bf16 features, rgb", 10, 3,
+            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp16 tables + bf16 features, rgb", 10, 3, key="cfg4_shard_permuto_fp16",
                                   rays_n=131072, samples=64, grid="permuto", channels={"rgb"}, table_dtype="fp16"))
-            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp32 tables, rgb", 10, 3,
+            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, permuto, fp32 tables, rgb", 10, 3, key="cfg4_shard_permuto_fp32",
                                   rays_n=131072, samples=64, grid="permuto", channels={"rgb"}))
-            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, hash L=16 T=2^19 res 16..1024, fp16 tables, rgb", 10, 3,
+            cfgs.append(short_run("configs[4] per-GPU shard: 131072 rays x 64 samples, hash L=16 T=2^19 res 16..1024, fp16 tables, rgb", 10, 3, key="cfg4_shard_hash_fp16",
                                   rays_n=131072, samples=64, grid="hash", channels={"rgb"}, finest=1024, table_dtype="fp16"))
             cfgs.append(short_run("post-prune regime (f3): voxel march, %.0f %% occupancy, 2 samples per voxel, permuto, all channels"
-                                  % (100 * args.occupancy), 20, 5, rays_n=4096, samples=2, grid="permuto", channels=all_ch, raymarch="voxel"))
+                                  % (100 * args.occupancy), 20, 5, key="post_prune_4096_all", rays_n=4096, samples=2, grid="permuto", channels=all_ch, raymarch="voxel"))
             cfgs.append(short_run("post-prune regime, rgb only (epochs 201 - 600 of best.yaml: voxel march from 201, panoptic heads from 601): %.0f %% occupancy, permuto"
-                                  % (100 * args.occupancy), 20, 5, rays_n=4096, samples=2, grid="permuto", channels={"rgb"}, raymarch="voxel"))
+                                  % (100 * args.occupancy), 20, 5, key="post_prune_4096_rgb", rays_n=4096, samples=2, grid="permuto", channels={"rgb"}, raymarch="voxel"))
             line["configs"] = cfgs
             # ---- the 4096-ray, pose-free epoch-weighted number of rounds 3 - 4 (kept for continuity; NOT a step best.yaml executes - its
             #      batch is 6 images and its extrinsics are trainable in every epoch - see best_yaml_step / schedule_weighted below)
@@ -1260,7 +1379,7 @@ def run_rank(args):
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

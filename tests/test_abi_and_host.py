@@ -331,13 +331,21 @@ def test_bench_launches_its_own_ranks_dry_run():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    detail_path = os.path.join(tempfile.mkdtemp(), "bench_detail.json")
+    env["PAG_BENCH_DETAIL"] = detail_path          # the full record goes to a side file; stdout carries the compact line only
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]          # the result line is the LAST stdout line
+    assert len(lines[0]) < 4096
+    small = json.loads(lines[0])
+    assert small["n_gpus"] == 2 and small["rccl_ranks_seen"] == 2 and small["dry_run"] is True and small["steps"] == 3 and small["warmup"] == 1
+    assert "roofline" in small and "cpu_baseline" in small and small["detail"] == detail_path
+    assert {v["grad_sync"] for v in small["weak_regimes"].values()} == {"fp32", "bf16"}
+    d = json.load(open(detail_path))
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["warmup"] == 1
     # the weak-scaling regime lines: GradSync(comm_dtype="auto") keeps the fp32 all-reduce for the long (dense) step and switches to the bf16 direct
     # reduce for the short post-prune steps (step < 4 x the predicted exposed exchange), every rank at the same step
@@ -360,6 +368,34 @@ def test_bench_launches_its_own_ranks_dry_run():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                         env=env2, timeout=600)
     assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_result_line_stays_small_and_parseable():
+    """round 5's result line grew to 32 KB and the driver recorded `parsed: null`.  bench.compact_line() on the largest record this
+    repository has produced (the committed round-5 run: 32 KB, every optional block present) must stay under 4 KB, survive a JSON round trip and keep the
+    contract's keys with `roofline` and `cpu_baseline` as flat objects; an absurdly large record must still come out under the budget."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r05h_bench_default_run.json")))
+    assert len(json.dumps(full)) > 30000
+    line = bench.compact_line(full, "bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < 4096 and json.loads(text) == line and "\n" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["config"]["workload"].startswith("BUP20-shaped")
+    rf, cb = line["roofline"], line["cpu_baseline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and all(not isinstance(v, (dict, list)) for v in rf.values())
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert set(cb) == {"value", "unit", "cores", "cores_available", "kind", "sample"} and cb["kind"] == "port" and len(cb["sample"]) <= 300
+    assert line["mfma_util"] == {"frac": full["mfma_util"]["frac"]} and line["schedule_weighted"]["ms_per_step"] == full["schedule_weighted"]["ms_per_step"]
+    assert len(line["configs"]) == len(full["configs"]) and all(isinstance(v, (int, float)) for v in line["configs"].values())
+    fat = dict(full, configs=[dict(name="configs[9]: %d %s" % (i, "x" * 200), ms_per_step=1.0) for i in range(400)], kernels={("k%d" % i): dict(ms_per_step=1.0) for i in range(400)})
+    slim = bench.compact_line(fat, "bench_detail.json")
+    assert len(json.dumps(slim)) <= bench.LINE_BUDGET and "roofline" in slim and "cpu_baseline" in slim and slim["value"] == full["value"]
 
 
 def test_nef_option_decoder_widths_and_guards():
@@ -404,6 +440,9 @@ def test_bench_byte_model_matches_design_table():
     assert m["pag_mlp_fwd"]["flops"] == 2 * M * 34560 and m["pag_mlp_bwd"]["flops"] == 2 * M * (34560 + 32832)
     assert m["pag_adam_step"]["bytes"] == 28 * (2 * 24 * 262144 * 2 + 35169)          # 16 B read + 12 B written per fp32 parameter: 705.6 MB per step
     rgb = bench.algorithmic_model("permuto", M, N, {"rgb"}, 24, 2, 4, True)
+    # rgb / rgb + depth steps: the delta table and the panoptic heads carry no gradient and are not stepped (hbm_frac 1.39 came from counting both)
+    assert rgb["pag_adam_step"]["bytes"] == 28 * (24 * 262144 * 2 + 35169 - bench.DECODER_PARAMS_PANOPTIC) and bench.DECODER_PARAMS_PANOPTIC == 23822
+    assert rgb["pag_permuto_encode_bwd_rays"]["bytes"] == M * (12 + 96 + 768 + 8) + N * 24
     assert rgb["pag_mlp_fwd"]["bytes"] / M == 212 and rgb["pag_permuto_encode_bwd_set"]["bytes"] / M == 1644 and "pag_head_composite_fwd" not in rgb
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pdir = os.path.join(root, "profiles")
