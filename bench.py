@@ -116,9 +116,14 @@ def compact_line(detail, detail_path=None):
         if isinstance(b, dict):
             optional.append((blk, {k: v.get("ms_per_image") for k, v in b.items() if isinstance(v, dict) and "ms_per_image" in v}))
     if isinstance(detail.get("weak_regimes"), list):
-        optional.append(("weak_regimes", {_short(w.get("name"), 64): dict(ms_per_step=w.get("ms_per_step"),
-                                                                          grad_sync=((w.get("grad_sync") or {}).get("comm_dtype") if isinstance(w.get("grad_sync"), dict) else w.get("grad_sync")))
-                                          for w in detail["weak_regimes"] if isinstance(w, dict)}))
+        def _weak(w):
+            e = dict(ms_per_step=w.get("ms_per_step"), grad_sync=((w.get("grad_sync") or {}).get("comm_dtype") if isinstance(w.get("grad_sync"), dict) else w.get("grad_sync")))
+            if "exchanged_bytes" in w:
+                e.update(exchanged_bytes=w["exchanged_bytes"], dense_bytes=w.get("dense_bytes"))
+            elif isinstance(w.get("sparse_sync"), list):
+                e.update(exchanged_bytes=sum(t["exchanged_bytes"] for t in w["sparse_sync"]), dense_bytes=sum(t["dense_bytes"] for t in w["sparse_sync"]))
+            return e
+        optional.append(("weak_regimes", {_short(w.get("name"), 90): _weak(w) for w in detail["weak_regimes"] if isinstance(w, dict)}))
     num("strong", "ms_per_step", "rays_s")
     num("render_sharded", "ms", "rays_s")
     kt = detail.get("kernels")
@@ -191,6 +196,9 @@ def parse(argv=None):
     ap.add_argument("--grad-sync", default="auto", choices=["auto", "fp32", "bf16"],
                     help="N > 1: table gradients as RCCL fp32 all-reduce, as bf16 messages with fp32 accumulation (shard._DirectReduce), or (default) chosen "
                          "by regime: bf16 when the measured step is shorter than 4 x the predicted exposed fp32 exchange (shard.GradSync(comm_dtype='auto'))")
+    ap.add_argument("--sparse-sync", default="off", choices=["off", "bounded", "exact"],
+                    help="N > 1: table gradients travel as the union of the ranks' touched rows (shard.SparseRows): bounded = slots sized from earlier steps, the "
+                         "host never waits; exact = the host reads the per-level counts each step.  The --dry-run regime lines always run it (bounded unless said otherwise)")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: process group, shard collectives, timing and JSON plumbing only")
     return ap.parse_args(argv)
 
@@ -815,6 +823,8 @@ def render_image_line(args, dev, all_ch, out_bytes, H=720, W=1280, render_batch=
 def dry_run_rank(args, world, rank):
     """No kernels: the process group, shard.GradSync / all_gather_render on CPU tensors, the timing protocol and the JSON line."""
     import torch
+    if args.sparse_sync == "off":
+        args.sparse_sync = "bounded"
     import torch.distributed as dist
     from pagnerf_amd import shard, RenderBuffer
     if world > 1:
@@ -854,23 +864,35 @@ def dry_run_rank(args, world, rank):
             "GradSync over the bench's process group gave a wrong mean"
         # the weak-scaling regime lines of the real run, as plumbing: three "regimes" whose step time is a sleep, each with its own GradSync(comm_dtype=
         # "auto") over a table-sized gradient that is NOT early (the exposed exchange); the assumed bus bandwidth is set so that the predicted fp32
-        # exchange is 1 ms - the 6 ms "dense" step keeps fp32, the sub-millisecond "post-prune" steps switch to the bf16 direct reduce
+        # exchange is 15 ms - the 120 ms "dense" step keeps fp32, the short "post-prune" steps (under 60 ms) switch to the bf16 direct reduce
+        # Each regime also runs the touched-rows exchange (GradSync(sparse="bounded"), shard.SparseRows) on a table-shaped gradient [levels, rows, features]
+        # whose rows are zero outside a regime-dependent set: every row in the dense regime, the coarse half of the levels at 5 % after the "prune" -
+        # `exchanged_bytes` is what the last step moved per rank and table, `dense_bytes` what the whole table would have
         weak = []
-        tab_bytes = 64 * 8 * 4
-        bus = 2.0 * (world - 1) / world * tab_bytes / 1e-3 / 1e9
-        for name, sleep_ms in (("weak_dense_all_channels", 6.0), ("weak_post_prune_rgb", 0.3), ("weak_post_prune_all_channels", 0.6)):
-            ps = [torch.nn.Parameter(torch.zeros(64, 8)), torch.nn.Parameter(torch.zeros(16))]
-            sy = shard.GradSync(ps, comm_dtype="auto", big=256, bus_gbs=bus)
+        Lt, Tt, Ft = 4, 4096, 2
+        tab_bytes = Lt * Tt * Ft * 4
+        bus = 2.0 * (world - 1) / world * tab_bytes / 15e-3 / 1e9       # predicted fp32 exchange: 15 ms (gloo on CPU tensors: a step here is ~25 ms of host work)
+        gen = torch.Generator().manual_seed(5)                         # the same masks on every rank + a rank-dependent part
+        for name, sleep_ms, fill in (("weak_dense_all_channels", 120.0, (1.0, 1.0, 1.0, 1.0)), ("weak_post_prune_rgb", 0.3, (0.05, 0.05, 1.0, 1.0)),
+                                     ("weak_post_prune_all_channels", 0.6, (0.05, 0.05, 1.0, 1.0))):
+            ps = [torch.nn.Parameter(torch.zeros(Lt, Tt, Ft)), torch.nn.Parameter(torch.zeros(16))]
+            keep = (torch.rand(Lt, Tt, 1, generator=gen) < torch.tensor(fill)[:, None, None]).float()
+            sy = shard.GradSync(ps, comm_dtype="auto", big=256, bus_gbs=bus, sparse=(False if args.sparse_sync == "off" else args.sparse_sync))
             t1 = time.perf_counter()
             n_it = shard.AUTO_WARM + 4
             for _ in range(n_it):
                 for q_ in ps:
                     q_.grad = None
-                ((ps[0] * (rank + 1)).sum() + (ps[1] * 2).sum()).backward()
+                ((ps[0] * keep * (rank + 1)).sum() + (ps[1] * 2).sum()).backward()
                 time.sleep(sleep_ms * 1e-3)
                 sy.finish()
-            weak.append(dict(name=name, ms_per_step=round((time.perf_counter() - t1) / n_it * 1e3, 3), grad_sync=sy.auto_decision))
-            assert torch.allclose(ps[0].grad, torch.full((64, 8), mean), rtol=2.0 ** -7)
+            ent = dict(name=name, ms_per_step=round((time.perf_counter() - t1) / n_it * 1e3, 3), grad_sync=sy.auto_decision)
+            st = sy.sparse_stats()
+            if st:
+                ent.update(sparse_sync=args.sparse_sync, exchanged_bytes=st[0]["exchanged_bytes"], dense_bytes=st[0]["dense_bytes"], bitmap_bytes=st[0]["bitmap_bytes"],
+                           whole_levels=st[0]["whole_levels"], dropped_rows=st[0]["dropped_rows"])
+            weak.append(ent)
+            assert torch.allclose(ps[0].grad, keep.expand(Lt, Tt, Ft) * mean, rtol=2.0 ** -7)
             sy.remove()
         lo, hi = shard.shard_bounds(n_local * world, rank, world)
         rb = shard.all_gather_render(RenderBuffer(rgb=torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)), n_local * world)
@@ -944,7 +966,7 @@ def run_rank(args):
     class Job:
         """One configuration: model, tracer, rays, optimiser, gradient sync."""
 
-        def __init__(self, rays_n, samples, grid, channels, raymarch="ray", pose=False, total_rays=None, seed=0, **mk):
+        def __init__(self, rays_n, samples, grid, channels, raymarch="ray", pose=False, total_rays=None, seed=0, sparse=None, **mk):
             self.nef = make_model(args, dev, seed=seed, grid=grid, **mk)          # same seed everywhere: replicated parameters
             self.tracer = make_tracer(args, raymarch, samples)
             self.occupied = synthetic_prune(self.nef, args.occupancy) if raymarch == "voxel" else 1.0
@@ -966,7 +988,8 @@ def run_rank(args):
             if world > 1:
                 early = [self.nef.delta_grid.tables] if hasattr(self.nef, "delta_grid") else []
                 self.sync = shard.GradSync(list(self.nef.parameters()) + list(extra), early=early,
-                                           comm_dtype={"bf16": torch.bfloat16, "fp32": None, "auto": "auto"}[args.grad_sync])
+                                           comm_dtype={"bf16": torch.bfloat16, "fp32": None, "auto": "auto"}[args.grad_sync],
+                                           sparse=(sparse if sparse is not None else (False if args.sparse_sync == "off" else args.sparse_sync)))
 
         def step(self, channels=None):
             return train_step(self.nef, self.tracer, self.opt, self.rays, self.gt, channels or self.channels, world, self.sync,
@@ -1195,6 +1218,10 @@ def run_rank(args):
             ent["hip_graphs"] = j.graph_stats()
             if j.sync is not None:
                 ent["grad_sync"] = j.sync.auto_decision or dict(comm_dtype="bf16" if j.sync.comm_dtype is not None else "fp32", decided="flag")
+                st = j.sync.sparse_stats()
+                if st:
+                    ent["sparse_sync"] = [dict(exchanged_bytes=t["exchanged_bytes"], dense_bytes=t["dense_bytes"], whole_levels=t["whole_levels"],
+                                               dropped_rows=t["dropped_rows"]) for t in st]
             j.close()
             del j
             torch.cuda.empty_cache()
@@ -1343,7 +1370,12 @@ def run_rank(args):
                 short_run("weak: post-prune voxel march, rgb only, 4096 rays per GPU", 30, shard.AUTO_WARM + 6, rays_n=4096, samples=2, grid="permuto",
                           channels={"rgb"}, raymarch="voxel"),
                 short_run("weak: post-prune voxel march, all channels, 4096 rays per GPU", 30, shard.AUTO_WARM + 6, rays_n=4096, samples=2, grid="permuto",
-                          channels=all_ch, raymarch="voxel")]
+                          channels=all_ch, raymarch="voxel"),
+                # the same two regimes with the touched-rows exchange (unmeasured on hardware so far: the pair of lines is the A/B)
+                short_run("weak: post-prune voxel march, rgb only, 4096 rays per GPU, sparse table exchange", 30, shard.AUTO_WARM + 10, rays_n=4096, samples=2,
+                          grid="permuto", channels={"rgb"}, raymarch="voxel", sparse="bounded"),
+                short_run("weak: post-prune voxel march, all channels, 4096 rays per GPU, sparse table exchange", 30, shard.AUTO_WARM + 10, rays_n=4096, samples=2,
+                          grid="permuto", channels=all_ch, raymarch="voxel", sparse="bounded")]
             # ---- strong scaling, BASELINE configs[3]: one 24 576-ray step (6 images, pose-opt) split over the ranks
             total = 6 * 4096
             ent = short_run("configs[3]: 6 images x 4096 rays, ba_pipeline pose-opt, %d rays per GPU" % (total // world), 10, 3,

@@ -649,7 +649,8 @@ int pag_adam_step(int n_tensors, float *const *params, const float *const *grads
  * extrinsics_epoch_end 900 > epochs 800, pc_nerf/trainer.py:308) - and its gradient.
  *   params f32 [C,9] = (a1, a2, t) per camera:  b1 = a1/|a1|, b2 = normalise(a2 - (b1.a2) b1), b3 = b1 x b2,  R rows = (b1, b2, b3)
  *   cam i32 [ceil(N / rays_per_entry)]: ray i belongs to camera cam[i / rays_per_entry] (rays_per_entry = 1: one index per ray; = rays per
- *   image: one per image, the layout of `transform_rays`)
+ *   image: one per image, the layout of `transform_rays`).  Indices must lie in [0, C); one outside is clamped to 0 / C - 1 in the forward AND the backward
+ *   (the ray renders through that camera and sends its gradient there) - the tensor-op form would raise or wrap instead.
  *   origins_w[i] = sum_k (origins_c[i] - t)[k] R[k]        dirs_w[i] = normalise(sum_k dirs_c[i][k] R[k])          all f32 [N,3]
  * _bwd: d_params f32 [C,9] = d loss / d params from g_origins / g_dirs f32 [N,3] (either may be NULL = zero); EVERY row is written (zeros
  * for cameras without a ray in the batch); two launches (per-(camera, ray slice) partial sums into `workspace`, >= pag_pose_rays_bwd_workspace_bytes(C)

@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void pose_rays_bwd_kernel(const float *__restr
     const int64_t per = (N + POSE_SLICES - 1) / POSE_SLICES;
     const int64_t lo = sl * per, hi = lo + per < N ? lo + per : N;
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        if (cam[i / rays_per_entry] != c) continue;
+        // the forward's clamp: an index outside [0, C) renders through camera 0 / C - 1, so its gradient belongs to that camera too
+        int cc = cam[i / rays_per_entry];
+        cc = cc < 0 ? 0 : (cc >= (int)gridDim.x ? (int)gridDim.x - 1 : cc);
+        if (cc != c) continue;
         float v[3], d[3], u[3], go[3], gd[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {

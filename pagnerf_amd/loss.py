@@ -171,6 +171,12 @@ class LinAssignmentThingsLoss(nn.Module):
         instance term) runs while the host waits for that event and solves the assignments in _finish()."""
         B, P, I = prob.shape
         w = self._workspace(B, P, I, prob.device)
+        # ONE pending call per loss object: the workspace (cost rows, targets, pinned mirrors, the event) belongs to it until finish() has run; a second
+        # begin() - two micro-batches in flight, one object shared by two heads - would overwrite the first call's rows without any error
+        if w.get("busy"):
+            raise RuntimeError("LinAssignmentThingsLoss.begin() called again before finish() of the previous call: one pending call per loss object "
+                               "(use one LinAssignmentThingsLoss per concurrently pending batch)")
+        w["busy"] = True
         st = L.stream()
         pd = prob.detach()
         pts, slope, x_limit, margin = None, 0.0, 0.0, 0
@@ -198,6 +204,7 @@ class LinAssignmentThingsLoss(nn.Module):
         prob, labels_gt, stuff_mask, rej, w, _pts = pending
         B, P, I = prob.shape
         w["event"].synchronize()                                       # the step's one wait for the device: only for what _begin() queued
+        w["busy"] = False                                              # (the targets below are written and consumed inside this call)
         info = w["h_info"].numpy()
         if info[:, 1].any():
             return None                                                # more distinct ids than the device-side set holds: general path
@@ -228,7 +235,8 @@ class LinAssignmentThingsLoss(nn.Module):
                half of the backward - see INTEGRATION.md)...
             inst_loss = loss_fn.finish(pending)                      # waits for the event, SciPy per image (:45), pag_assign_nll_fwd
 
-        finish(begin(...)) == forward(...) (same launches, same values)."""
+        finish(begin(...)) == forward(...) (same launches, same values).  ONE pending call per loss object: begin() raises when the previous
+        call has not been finished (its workspace would be overwritten); a new workspace shape (another B / P / I) drops a pending call's state."""
         fast = self._gate(inst_probabilities, labels_gt, stuff_mask, points_3d)
         if fast is None:
             return ("general", inst_probabilities, labels_gt, stuff_mask, points_3d)

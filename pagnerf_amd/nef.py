@@ -270,25 +270,25 @@ class PanopticDeltaNeF(nn.Module):
         grp = self._grouped()
         # with the colour decoder to follow, the density decoder's launch is parked and rides in the colour decoder's (ops.decoder_hold)
         hold = ops.decoder_hold(feats) if (ops.CD_FUSED and "rgb" in compute_channels and feats.is_cuda) else None
+        # everything between decoder_hold() and flush_hold() sits in ONE try / finally: whatever raises in between (the density decoder, the view
+        # embedding, the colour decoder before it took the parked launch), the launch is issued or forgotten and no later trace can inherit it
         try:
             density_feats = self.decoder_density(feats, mode=mode, out_dtype=self.feat_dtype, x1_grouped=grp)     # :184
-        except BaseException:
+            self._density_feats = density_feats.detach()             # the delta-density variant adds to its (detached) column 0 (pre-ReLU)
+            if "rgb" in compute_channels:                                                 # :188, :196-204
+                if num_samples != 1 and ridx is None:                                  # one direction per pack entry -> per sample
+                    ray_d = ray_d[:, None].repeat(1, num_samples, 1).reshape(-1, 3)
+                pe, index = self._view_embedding(ray_d, ridx, ray_dirs)
+                W, b = self.decoder_color.weights()
+                # colour decoder and the density column of its input as one node (ops._ColourDensity)
+                rgb, sigma = ops.colour_and_density(density_feats, W, b, pe, index, self.decoder_color.input_dim, out_act=L.ACT_SIGMOID,
+                                                    mode=mode, x2_packs=ray_packs if ridx is not None else None, producer=hold)
+                density = sigma.reshape(batch, num_samples, 1)
+                out["rgb"] = rgb.reshape(batch, num_samples, 3)
+            else:
+                density = torch.relu(density_feats[:, 0:1].float()).reshape(batch, num_samples, 1)   # :188
+        finally:
             ops.flush_hold(hold)
-            raise
-        self._density_feats = density_feats.detach()             # the delta-density variant adds to its (detached) column 0 (pre-ReLU)
-        if "rgb" in compute_channels:                                                 # :188, :196-204
-            if num_samples != 1 and ridx is None:                                  # one direction per pack entry -> per sample
-                ray_d = ray_d[:, None].repeat(1, num_samples, 1).reshape(-1, 3)
-            pe, index = self._view_embedding(ray_d, ridx, ray_dirs)
-            W, b = self.decoder_color.weights()
-            # colour decoder and the density column of its input as one node (ops._ColourDensity)
-            rgb, sigma = ops.colour_and_density(density_feats, W, b, pe, index, self.decoder_color.input_dim, out_act=L.ACT_SIGMOID,
-                                                mode=mode, x2_packs=ray_packs if ridx is not None else None, producer=hold)
-            ops.flush_hold(hold)
-            density = sigma.reshape(batch, num_samples, 1)
-            out["rgb"] = rgb.reshape(batch, num_samples, 3)
-        else:
-            density = torch.relu(density_feats[:, 0:1].float()).reshape(batch, num_samples, 1)   # :188
         if "density" in compute_channels:
             out["density"] = density
         if "semantics" in compute_channels or "inst_embedding" in compute_channels:    # :210-236

@@ -819,7 +819,10 @@ def colour_and_density(x1, weights, biases, x2, x2_index, in_dim, out_act=L.ACT_
     producer: the decoder_hold() in which the density decoder's launch waits - evaluated in this decoder's launch where the library can."""
     global _NEXT_PRODUCER
     _NEXT_PRODUCER = producer
-    rgb, sigma = _apply_decoder(_ColourDensity, x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
+    try:
+        rgb, sigma = _apply_decoder(_ColourDensity, x1, x2, x2_index, int(in_dim), out_act, mode, out_dtype, None, *weights, *biases)
+    finally:
+        _NEXT_PRODUCER = None            # a call that raised before _FusedMLP.forward took the producer must not leave it for an unrelated decoder
     if x2_packs is not None and x2 is not None and x2.requires_grad and rgb.grad_fn is not None:
         rgb.grad_fn.x2_packs = x2_packs
     return rgb, sigma
@@ -1495,9 +1498,11 @@ def decoder_hold(x1):
 
 
 def flush_hold(hold):
-    global _NEXT_HOLD
+    global _NEXT_HOLD, _NEXT_PRODUCER
     if _NEXT_HOLD is hold:
         _NEXT_HOLD = None                # the call it was meant for never came
+    if hold is not None and _NEXT_PRODUCER is hold:
+        _NEXT_PRODUCER = None            # ... nor may a later, unrelated decoder pick this launch up as its producer
     if hold is not None and hold.get("args") is not None and not hold.get("taken"):
         _call("pag_mlp_fwd", ctypes.byref(hold["args"]), hold["M"], L.stream())
         hold["taken"] = True

@@ -160,6 +160,180 @@ def all_gather_render(rb, n_total, channels=None, label_channels=()):
     return RenderBuffer(**res)
 
 
+SPARSE_DENSE_FILL = 0.5      # a level whose union of touched rows exceeds this share of its table travels whole
+SPARSE_HEADROOM = 1.25       # bounded mode: slots per level = the recent maximum of the union count x this, in whole granules
+SPARSE_GRANULE = 1024        # rows
+SPARSE_HISTORY = 8           # steps whose counts size the slots
+
+
+class SparseRows:
+    """Touched-rows exchange of ONE table gradient [L, T, F] (levels x rows x features).
+
+    After the first prune (configs/bup20/best.yaml:187 `prune_every: 201`, pc_nerf/trainer.py:362-366: three quarters of a run) a step's
+    samples lie in the occupied cells only, and the coarse and middle lattice levels touch a small part of their 2^18 rows
+    (scripts/touched_rows.py, profiles/r06_touched_rows_post_prune_8_ranks.json: levels 0 - 12 under 20 % even as the union over 8
+    ranks; the fine levels are filled by hash collisions whatever the batch).  The reduce pass of the table gradient writes every row
+    (pag_*_encode_bwd_set), so an untouched row is an exact zero on every rank and stays zero in the sum: only the union of the ranks'
+    non-zero rows has to cross the links.  Per step and table:
+      1. mask = any(grad != 0) per row, packed to bits (L x T / 8 bytes: 786 KB for 24 x 2^18), ONE all_gather, OR over the ranks:
+         every rank holds the same union;
+      2. per level: fill = |union| / T; levels above SPARSE_DENSE_FILL travel whole, the others as their union rows compacted in row
+         order into a fixed number of slots;
+      3. ONE collective over the concatenated slots of all levels (fp32 all-reduce, or the bf16 direct reduce of _DirectReduce);
+      4. every row of the table gradient is rewritten from its slot (rows outside the union: zero).
+    The values on the union rows are those of the dense all-reduce (same collective, same operands); rows outside it are exact zeros
+    in both.
+
+    How many slots a level gets must be known to the host before the collective is queued.  mode="exact": the host reads the per-level
+    union counts (one device-to-host copy of L integers: the step's queue drains once) - nothing is ever dropped.  mode="bounded"
+    (default): the slots follow the counts of the PREVIOUS steps (recent maximum x SPARSE_HEADROOM, read from a pinned mailbox without
+    waiting), the host never waits; union rows beyond a level's slots are set to zero on EVERY rank alike (the replicas stay identical),
+    counted in `stats["dropped_rows"]` and reported by a warning, and the level's slots grow for the following steps.  reset() (call it when
+    the regime changes: after nef.prune(), a new batch size or march type) sends the next steps whole until new counts are in."""
+
+    def __init__(self, mode="bounded", dense_fill=SPARSE_DENSE_FILL, headroom=SPARSE_HEADROOM):
+        assert mode in ("bounded", "exact")
+        self.mode, self.dense_fill, self.headroom = mode, float(dense_fill), float(headroom)
+        self.history = []            # per finished step: list of L union counts
+        self._pending = []           # (event or None, pinned / cpu tensor [L + 1]) not yet read
+        self._caps = None            # per level: slots (T = whole level), host list
+        self._caps_dev = None
+        self.stats = dict(steps=0, exchanged_bytes=0, dense_bytes=0, bitmap_bytes=0, dropped_rows=0, last_fill=None, last_slots=None)
+        self._warned = False
+
+    def reset(self):
+        self.history, self._pending, self._caps, self._caps_dev = [], [], None, None      # counts still in flight belong to the old regime
+
+    # ---- host side: slots per level from the counts seen so far
+    def _poll(self):
+        keep = []
+        for ev, box in self._pending:
+            if ev is None or ev.query():
+                vals = box.tolist()
+                self.history.append(vals[:-1])
+                self.history = self.history[-SPARSE_HISTORY:]
+                if vals[-1] > 0:
+                    self.stats["dropped_rows"] += int(vals[-1])
+                    if not self._warned:
+                        import warnings
+                        warnings.warn("pagnerf_amd.shard.SparseRows: %d union rows did not fit the slots sized from earlier steps and were zeroed on every rank "
+                                      "(the slots grow from the next step; call reset() when the regime changes, or use mode='exact')" % int(vals[-1]))
+                        self._warned = True
+            else:
+                keep.append((ev, box))
+        self._pending = keep
+
+    def _plan(self, T, L):
+        if not self.history:
+            return [T] * L
+        caps = []
+        for l in range(L):
+            want = max(h[l] for h in self.history) * self.headroom
+            c = int(-(-want // SPARSE_GRANULE) * SPARSE_GRANULE)
+            caps.append(T if (want > self.dense_fill * T or c >= T) else max(c, SPARSE_GRANULE))
+        return caps
+
+    # ---- device side
+    @staticmethod
+    def union_mask(grad):
+        """bool [L, T]: rows that are non-zero on ANY rank (bit-packed all_gather + OR)."""
+        L, T, _ = grad.shape
+        mask = (grad != 0).any(-1)
+        pad = (-T) % 8
+        if pad:
+            mask = torch.cat([mask, mask.new_zeros(L, pad)], 1)
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], device=grad.device, dtype=torch.uint8)
+        bits = (mask.reshape(L, -1, 8).to(torch.uint8) * w).sum(-1, dtype=torch.uint8).reshape(-1)
+        _, world = world_info()
+        allb = torch.empty(world * bits.numel(), device=grad.device, dtype=torch.uint8)
+        dist.all_gather_into_tensor(allb, bits)
+        allb = allb.reshape(world, -1)
+        u = allb[0].clone()
+        for r in range(1, world):
+            u |= allb[r]
+        un = ((u[:, None] >> torch.arange(8, device=grad.device, dtype=torch.uint8)) & 1).bool().reshape(L, -1)[:, :T]
+        return un, bits.numel()
+
+    def start(self, grad, comm_dtype, average):
+        """Queue the exchange of `grad` ([L, T, F], contiguous fp32); returns a token for finish()."""
+        L, T, F = grad.shape
+        _, world = world_info()
+        self._poll()
+        union, bitmap_bytes = self.union_mask(grad)
+        counts = union.sum(1)
+        if self.mode == "exact":
+            c_host = counts.tolist()                                   # the one host wait of this mode
+            caps = [T if c > self.dense_fill * T else max(int(c), 1) for c in c_host]
+        else:
+            caps = self._plan(T, L)
+        if caps != self._caps:
+            self._caps, self._caps_dev = caps, torch.tensor(caps, device=grad.device, dtype=torch.int32)
+        cap_dev = self._caps_dev
+        total = int(sum(caps))
+        st = self.stats
+        st["steps"] += 1
+        st["dense_bytes"], st["bitmap_bytes"] = L * T * F * 4, bitmap_bytes
+        half = comm_dtype is not None and comm_dtype != torch.float32
+        if total == L * T:
+            # every level whole (the first steps of the bounded mode, a dense regime): the plain exchange of the gradient itself; the counts still
+            # go to the mailbox so that the following steps can size their slots
+            self._mail(torch.cat([counts, counts.new_zeros(1)]), grad)
+            if half:
+                handle, divide = _DirectReduce(grad, comm_dtype, average), False
+            else:
+                op, divide = _reduce_op(average)
+                handle = dist.all_reduce(grad, op=op, async_op=True)
+            st["exchanged_bytes"], st["last_slots"], st["whole_levels"] = L * T * F * (2 if half else 4), total, L
+            return (grad, None, None, handle, divide, world)
+        offs = torch.tensor([sum(caps[:l]) for l in range(L)], device=grad.device, dtype=torch.int64)
+        whole = (cap_dev >= T)[:, None]
+        member = union | whole                                         # a whole level: every row has a slot, its own
+        pos = torch.cumsum(member, 1, dtype=torch.int32)
+        valid = member & (pos <= cap_dev[:, None])
+        slot = torch.where(valid, offs[:, None] + (pos - 1).long(), torch.full((), total, device=grad.device, dtype=torch.int64)).reshape(-1)
+        row_of_slot = torch.zeros(total + 1, device=grad.device, dtype=torch.int64)
+        row_of_slot.scatter_(0, slot, torch.arange(L * T, device=grad.device, dtype=torch.int64))
+        filled = torch.zeros(total + 1, device=grad.device, dtype=torch.bool)
+        filled[slot] = True
+        flat = grad.reshape(L * T, F)
+        buf = flat.index_select(0, row_of_slot[:total]) * filled[:total, None].to(flat.dtype)
+        dropped = (union & ~valid).sum()
+        self._mail(torch.cat([counts, dropped[None]]), grad)
+        if half:
+            handle, divide = _DirectReduce(buf, comm_dtype, average), False
+        else:
+            op, divide = _reduce_op(average)
+            handle = dist.all_reduce(buf, op=op, async_op=True)
+        st["exchanged_bytes"], st["last_slots"], st["whole_levels"] = total * F * (2 if half else 4), total, int(sum(1 for c in caps if c >= T))
+        return (grad, buf, slot, handle, divide, world)
+
+    def _mail(self, box_dev, grad):
+        """Per-level union counts (+ rows dropped) of this step towards the host, without waiting: pinned copy + event on a device, a plain copy on CPU."""
+        box_dev = box_dev.to(torch.int64)
+        if grad.is_cuda:
+            box = torch.empty(box_dev.numel(), dtype=torch.int64).pin_memory()
+            box.copy_(box_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            box, ev = box_dev.clone(), None
+        self._pending.append((ev, box))
+
+    @staticmethod
+    def finish(token):
+        grad, buf, slot, handle, divide, world = token
+        if isinstance(handle, _DirectReduce):
+            handle.finish()
+        else:
+            handle.wait()
+            if divide:
+                (grad if buf is None else buf).div_(world)
+        if buf is None:
+            return
+        ext = torch.cat([buf, buf.new_zeros(1, buf.shape[1])], 0)
+        grad.copy_(ext.index_select(0, slot).reshape(grad.shape))
+
+
 def allreduce_grads(params, average=True, big=1 << 20, comm_dtype=None):
     """Gradients of >= `big` elements (the tables, ~50 MB each) are all-reduced in place, one message each; everything
     smaller (decoders, poses: ~0.14 MB) travels as ONE flat all_reduce.  No staging copy of the large tensors.
@@ -214,7 +388,7 @@ class GradSync:
     finish() waits for them, exchanges everything else as one flat all-reduce and averages.  On the xGMI mesh the 50 MB
     early message therefore travels while the GPU still computes; only the main table (produced last) is exposed."""
 
-    def __init__(self, params, early=(), average=True, comm_dtype=None, big=1 << 20, bus_gbs=AUTO_BUS_GBS):
+    def __init__(self, params, early=(), average=True, comm_dtype=None, big=1 << 20, bus_gbs=AUTO_BUS_GBS, sparse=False):
         """comm_dtype=torch.bfloat16: table-sized gradients travel as bf16 messages with fp32 accumulation (_DirectReduce): half the
         bytes of the fp32 all-reduce and direct per-link transfers; the default (None) keeps RCCL's fp32 all-reduce.
         comm_dtype="auto": chosen by REGIME after AUTO_WARM steps - the exposed part of the fp32 exchange is the largest table-sized gradient
@@ -227,11 +401,15 @@ class GradSync:
         self._auto = comm_dtype == "auto"
         self.bus_gbs = float(bus_gbs)
         self.auto_decision = None
-        self._t_prev, self._intervals = None, []
+        self._marks, self._intervals = [], []
         if self._auto:
             comm_dtype = None
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.big = big
+        # sparse: False | True / "bounded" | "exact" - table-shaped gradients ([L, T, F] with >= `big` elements) travel as the union of the ranks'
+        # touched rows (SparseRows); one state per parameter, `sparse_stats()` reports what the last step moved
+        self.sparse_mode = {False: None, None: None, True: "bounded", "bounded": "bounded", "exact": "exact"}[sparse]
+        self._sparse = {}
         self.early = [p for p in early]
         self._early_ids = {id(p) for p in self.early}
         self._handles = []
@@ -240,8 +418,29 @@ class GradSync:
             for p in self.early:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._launch))
 
+    def _sparse_state(self, p):
+        st = self._sparse.get(id(p))
+        if st is None:
+            st = self._sparse[id(p)] = SparseRows(self.sparse_mode)
+        return st
+
+    def _is_table(self, g):
+        return self.sparse_mode is not None and g.dim() == 3 and g.numel() >= self.big and g.is_contiguous() and g.dtype == torch.float32
+
+    def reset_sparse(self):
+        """Call when the set of touched rows changes regime (after nef.prune(), another batch size or march type): the next steps travel whole."""
+        for st in self._sparse.values():
+            st.reset()
+
+    def sparse_stats(self):
+        """Per table-shaped parameter (in `params` order): what its last exchange moved."""
+        return [dict(self._sparse[id(p)].stats) for p in self.params if id(p) in self._sparse]
+
     def _launch(self, p):
         if p.grad is None:
+            return
+        if self._is_table(p.grad):
+            self._handles.append((p, ("sparse", self._sparse_state(p).start(p.grad, self.comm_dtype, self.average)), None))
             return
         if self.comm_dtype is not None and p.grad.numel() >= self.big and p.grad.is_contiguous():
             self._handles.append((p, _DirectReduce(p.grad, self.comm_dtype, self.average), None))      # phase 1 in flight under the backward
@@ -251,24 +450,36 @@ class GradSync:
 
     def _decide(self, world):
         """comm_dtype="auto": one collective decision from the step cadence seen so far (called from finish(), after this step's exchange)."""
-        now = time.perf_counter()
-        if self._t_prev is not None:
-            self._intervals.append((now - self._t_prev) * 1e3)
-        self._t_prev = now
-        if len(self._intervals) < AUTO_WARM + 1:
+        dev = next((p.grad.device for p in self.params if p.grad is not None), torch.device("cpu"))
+        # the cadence is DEVICE time where there is a device (an event per finish(), read once at the decision): a host that runs ahead of its
+        # queue would otherwise report its own issue rate and take a dense run for a short one
+        if dev.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append(ev)
+        else:
+            self._marks.append(time.perf_counter())
+        if len(self._marks) < AUTO_WARM + 2:
             return
-        step_ms = sum(self._intervals[1:]) / (len(self._intervals) - 1)            # the first interval holds one-time set-up
+        if dev.type == "cuda":
+            self._marks[-1].synchronize()
+            iv = [a.elapsed_time(b) for a, b in zip(self._marks[1:-1], self._marks[2:])]      # the first interval holds one-time set-up
+        else:
+            iv = [(b - a) * 1e3 for a, b in zip(self._marks[1:-1], self._marks[2:])]
+        self._intervals = iv
+        step_ms = sum(iv) / len(iv)
         grads = [p.grad for p in self.params if p.grad is not None and id(p) not in self._early_ids and p.grad.numel() >= self.big]
         exposed = max([g.numel() * g.element_size() for g in grads], default=0)
-        dev = next((p.grad.device for p in self.params if p.grad is not None), torch.device("cpu"))
-        t = torch.tensor([step_ms], device=dev, dtype=torch.float64 if dev.type == "cpu" else torch.float32)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                                   # every rank decides from the same number
-        step_ms = float(t.item())
+        # BOTH numbers are agreed over the ranks (maximum): a rank whose set of gradient-carrying parameters differed would otherwise pick
+        # another collective than its peers and hang
+        t = torch.tensor([step_ms, float(exposed)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        step_ms, exposed = float(t[0].item()), int(t[1].item())
         pred = predicted_exchange_ms(exposed, world, self.bus_gbs)
         use_bf16 = exposed > 0 and step_ms < AUTO_FACTOR * pred
         self.comm_dtype = torch.bfloat16 if use_bf16 else None
         self.auto_decision = dict(step_ms=round(step_ms, 4), exposed_bytes=int(exposed), predicted_fp32_exchange_ms=round(pred, 4), factor=AUTO_FACTOR,
-                                  bus_gbs=self.bus_gbs, comm_dtype="bf16" if use_bf16 else "fp32", decided_after_steps=len(self._intervals) + 1)
+                                  bus_gbs=self.bus_gbs, comm_dtype="bf16" if use_bf16 else "fp32", decided_after_steps=len(self._marks))
         self._auto = False
 
     def finish(self):
@@ -276,8 +487,16 @@ class GradSync:
         if _single():
             return
         rest = [p for p in self.params if id(p) not in self._early_ids or not any(q is p for q, _, _ in self._handles)]
+        if self.sparse_mode is not None:
+            tables = [p for p in rest if p.grad is not None and self._is_table(p.grad)]
+            for p in tables:
+                self._handles.append((p, ("sparse", self._sparse_state(p).start(p.grad, self.comm_dtype, self.average)), None))
+            rest = [p for p in rest if not any(q is p for q in tables)]
         allreduce_grads(rest, average=self.average, big=self.big, comm_dtype=self.comm_dtype)
         for p, h, divide in self._handles:
+            if isinstance(h, tuple) and h[0] == "sparse":
+                SparseRows.finish(h[1])
+                continue
             if isinstance(h, _DirectReduce):
                 h.finish()
                 continue

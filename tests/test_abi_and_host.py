@@ -351,7 +351,15 @@ def test_bench_launches_its_own_ranks_dry_run():
     # reduce for the short post-prune steps (step < 4 x the predicted exposed exchange), every rank at the same step
     weak = {w["name"]: w["grad_sync"] for w in d["weak_regimes"]}
     assert weak["weak_dense_all_channels"]["comm_dtype"] == "fp32" and weak["weak_post_prune_rgb"]["comm_dtype"] == "bf16"
-    assert weak["weak_post_prune_all_channels"]["comm_dtype"] == "bf16" and all(abs(w["predicted_fp32_exchange_ms"] - 1.0) < 1e-6 for w in weak.values())
+    assert weak["weak_post_prune_all_channels"]["comm_dtype"] == "bf16" and all(abs(w["predicted_fp32_exchange_ms"] - 15.0) < 1e-6 for w in weak.values())
+    # ... and the touched-rows exchange per regime: the dense regime moves its whole table, the post-prune ones about half (two of
+    # four levels at 5 %), nothing dropped
+    by = {w["name"]: w for w in d["weak_regimes"]}
+    assert by["weak_dense_all_channels"]["exchanged_bytes"] == by["weak_dense_all_channels"]["dense_bytes"] == 4 * 4096 * 2 * 4
+    for name in ("weak_post_prune_rgb", "weak_post_prune_all_channels"):
+        assert by[name]["sparse_sync"] == "bounded" and by[name]["whole_levels"] == 2 and by[name]["dropped_rows"] == 0
+        assert by[name]["exchanged_bytes"] < 0.4 * by[name]["dense_bytes"], by[name]         # bf16 messages: 2 whole levels + the slots of two 5 % levels
+    assert small["weak_regimes"]["weak_post_prune_rgb"]["exchanged_bytes"] == by["weak_post_prune_rgb"]["exchanged_bytes"]
     # the driver's largest launch: 8 ranks (gloo here), with the fp32 all-reduce and with bf16 messages + fp32 accumulation
     for extra in (["--grad-sync", "fp32"], ["--grad-sync", "bf16"]):
         r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"] + extra,

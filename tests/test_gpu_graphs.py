@@ -382,9 +382,9 @@ def test_graph_key_follows_requires_grad(gpu_device):
     assert g["delta_grid.tables"] is not None and T._rel_l2(g["delta_grid.tables"].float(), ge["delta_grid.tables"].float()) < 1e-5
 
 
-@pytest.mark.parametrize("use", [True, "static"])
+@pytest.mark.parametrize("use", [True, "static", "default"])
 @pytest.mark.parametrize("mode", ["ray", "voxel"])
-def test_pose_optimisation_through_the_graph_path(gpu_device, mode, use):
+def test_pose_optimisation_through_the_graph_path(gpu_device, mode, use, monkeypatch):
     """configs/bup20/best.yaml runs EVERY step with learnable extrinsics (optimize_extrinsics, extrinsics_epoch_end 900 > epochs 800:
     pc_nerf/trainer.py:308, pc_nerf/ba_pipeline.py:85-92): rays that require a gradient take the graph path too.  Against the eager
     path on the same rays and jitter: forward bit for bit, d loss / d camera_extrinsics (through d origins / d dirs: the main grid's
@@ -421,8 +421,14 @@ def test_pose_optimisation_through_the_graph_path(gpu_device, mode, use):
         return out
     (rb_e, loss_e, g_e), = run(tracer, 1)
     assert float(g_e["camera_extrinsics"].abs().sum()) > 0
-    gt = pagnerf_amd.PanopticPackedRFTracer(raymarch_type=tracer.raymarch_type, num_steps=tracer.num_steps, bg_color="white",
-                                            ray_max_travel=tracer.ray_max_travel, use_graphs=use)
+    if use == "default":      # the product default: no use_graphs argument, no PAG_GRAPHS in the environment -> HIP graphs
+        monkeypatch.delenv("PAG_GRAPHS", raising=False)
+        gt = pagnerf_amd.PanopticPackedRFTracer(raymarch_type=tracer.raymarch_type, num_steps=tracer.num_steps, bg_color="white", ray_max_travel=tracer.ray_max_travel)
+        assert gt.use_graphs is True
+        use = True
+    else:
+        gt = pagnerf_amd.PanopticPackedRFTracer(raymarch_type=tracer.raymarch_type, num_steps=tracer.num_steps, bg_color="white",
+                                                ray_max_travel=tracer.ray_max_travel, use_graphs=use)
     for it, (rb_g, loss_g, g_g) in enumerate(run(gt, 4)):                  # 0: eager (learns the count), 1: capture, 2-3: replays
         for ch in ("rgb", "alpha", "depth", "semantics", "inst_embedding"):
             assert torch.equal(getattr(rb_g, ch), getattr(rb_e, ch)), (it, ch)

@@ -131,6 +131,15 @@ def test_one_sync_assignment_path_equals_general_path(gpu_device):
     slow.fast_path = False
     assert fast._fast(pm, many, sm.view(torch.uint8)) is None
     assert torch.equal(fast(pm, many, sm), slow(pm, many, sm))
+    # one pending begin() per loss object: a second begin() before finish() would overwrite the first call's cost rows / targets / event -
+    # it raises instead; after finish() the object is free again, and finish(begin()) equals forward()
+    p, t, m = cases[1]
+    two = pl.LinAssignmentThingsLoss()
+    pend = two.begin(p, t, m)
+    with pytest.raises(RuntimeError, match="before finish"):
+        two.begin(p, t, m)
+    first = two.finish(pend)
+    assert torch.equal(first, two.finish(two.begin(p, t, m))) and torch.equal(first, pl.LinAssignmentThingsLoss()(p, t, m))
     # with outlier rejection (best.yaml:106 `inst_outlier_rejection: true`): the id-range mask travels in the same copy as the cost
     p, t, m = cases[0]
     pts = torch.from_numpy(g["points_3d"]).to(dev)

@@ -1,7 +1,8 @@
 """RCCL under pagnerf_amd.shard on ONE GPU: a one-rank "nccl" process group (backend "nccl" is RCCL on ROCm) with
 shard.FORCE_COLLECTIVES, so that every collective the N > 1 path issues - ReduceOp.AVG all-reduce and its first-use probe,
 all_to_all_single + all_gather_into_tensor of the bf16 direct reduce, the flat all-reduce of the small gradients, the render
-all_gather, the early all-reduce from the post-accumulate hook, also behind the SPLIT backward graphs - runs through the real
+all_gather, the early all-reduce from the post-accumulate hook, also behind the SPLIT backward graphs, the touched-rows exchange
+(uint8 mask all_gather + one collective over the compacted slots) - runs through the real
 library on device buffers.  What a one-rank group cannot show is inter-GPU transport (xGMI) and scaling; what it does show: the
 library initialises on this image, every call is well-formed (dtypes, contiguity, sizes, stream use) and leaves the values a
 one-rank mean must leave.  Runs in a child process (its own process group; the parent's GPU state is untouched)."""
@@ -82,6 +83,27 @@ for it in range(shard.AUTO_WARM + 3):
     assert torch.equal(tab.grad, ref), it
 assert sy.auto_decision["comm_dtype"] == "fp32" and sy.auto_decision["predicted_fp32_exchange_ms"] == 0.0 and sy.auto_decision["exposed_bytes"] == (1 << 17) * 4, sy.auto_decision
 sy.remove()
+# the touched-rows exchange (shard.SparseRows) through RCCL: the bit-packed all_gather of the row masks (uint8), the slot compaction, the ONE collective over the
+# slots (fp32 all-reduce, then the bf16 direct reduce), the rewrite of every row - in both modes; on one rank the result must be the input (fp32) / the input
+# rounded once to bf16 on the touched rows and exact zeros elsewhere, and a sparse step must move fewer bytes than the table
+Lv, Tv, Fv = 24, 1 << 14, 2
+fills = [min(1.0, 0.0004 * 1.9 ** l) for l in range(Lv)]
+for mode in ("exact", "bounded"):
+    for comm in (None, torch.bfloat16):
+        tab = torch.nn.Parameter(torch.zeros(Lv, Tv, Fv, device=dev))
+        sy = shard.GradSync([tab], comm_dtype=comm, big=1 << 16, sparse=mode)
+        for it in range(4):
+            keep = torch.rand(Lv, Tv, device=dev, generator=gen) < torch.tensor(fills, device=dev)[:, None]
+            g0 = torch.randn(Lv, Tv, Fv, device=dev, generator=gen) * keep[..., None]
+            tab.grad = g0.clone()
+            sy.finish(); torch.cuda.synchronize()
+            want = g0 if comm is None else g0.bfloat16().float()
+            assert torch.equal(tab.grad, want), (mode, comm, it, float((tab.grad - want).abs().max()))
+            stt = sy.sparse_stats()[0]
+            if mode == "exact" or it >= 1:
+                assert stt["exchanged_bytes"] < 0.75 * Lv * Tv * Fv * (4 if comm is None else 2) and 0 < stt["whole_levels"] < Lv, stt
+        assert sy.sparse_stats()[0]["dropped_rows"] == 0
+        sy.remove()
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_SINGLE_RANK_OK")

@@ -138,3 +138,119 @@ def test_world_size_2_gloo_gather_and_allreduce():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def _touched_grad(rank, step, L, T, F, fills, seed=7):
+    """A table gradient as the encode backward leaves it: exact zeros outside the rows this rank's samples touched; level l touches about
+    fills[l] of its rows (rank- and step-dependent sets that overlap partly)."""
+    g = torch.Generator().manual_seed(seed + 1000 * rank + 17 * step)
+    grad = torch.zeros(L, T, F)
+    for l in range(L):
+        rows = torch.nonzero(torch.rand(T, generator=g) < fills[l]).reshape(-1)
+        grad[l, rows] = torch.randn(rows.numel(), F, generator=g) * 10.0 ** float(torch.randint(-3, 3, (1,), generator=g))
+    return grad
+
+
+def _sparse_worker(rank, world, port, q):
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, T, F = 6, 4096, 2
+        fills = [0.0005, 0.01, 0.08, 0.2, 0.45, 0.9]               # coarse -> fine: the last two exceed SPARSE_DENSE_FILL as a union and travel whole
+
+        def dense_reference(g):
+            allg = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(allg, g)
+            st = torch.stack(allg)
+            return st, st.mean(0)
+
+        for mode in ("exact", "bounded"):
+            for comm in (None, torch.bfloat16):
+                for early in (False, True):
+                    tab, small = torch.nn.Parameter(torch.zeros(L, T, F)), torch.nn.Parameter(torch.zeros(5))
+                    sync = shard.GradSync([tab, small], early=[tab] if early else [], comm_dtype=comm, big=1000, sparse=mode)
+                    for step in range(4):
+                        g = _touched_grad(rank, step, L, T, F, fills)
+                        st, mean = dense_reference(g)
+                        tab.grad = small.grad = None
+                        ((tab * g).sum() + (small * (rank + 1.0)).sum()).backward()
+                        sync.finish()
+                        got = tab.grad
+                        union = (st != 0).any(-1).any(0)                                   # [L, T]
+                        assert bool((got[~union] == 0).all()), "rows no rank touched must stay exact zeros"
+                        if comm is None:
+                            assert torch.allclose(got, mean, rtol=1e-6, atol=1e-12), (mode, early, step)   # the dense all-reduce's values on the touched rows
+                        else:
+                            bound = st.abs().double().mean(0) * 2.0 ** -7 + 1e-12
+                            assert bool(((got.double() - mean.double()).abs() <= bound).all()), (mode, early, step)
+                        assert torch.allclose(small.grad, torch.full((5,), sum(range(1, world + 1)) / world))
+                        stats = sync.sparse_stats()[0]
+                        elem = 2 if comm is not None else 4
+                        assert stats["dense_bytes"] == L * T * F * 4 and stats["bitmap_bytes"] == L * T // 8
+                        if mode == "bounded" and step == 0:
+                            assert stats["exchanged_bytes"] == L * T * F * elem and stats["whole_levels"] == L      # no counts yet: whole
+                        else:
+                            # levels 0 - 3 as slots (level 3: a 36 % union x 1.25 head-room), 4 - 5 whole: 2 / 6 + 0.2 of the dense message
+                            assert stats["whole_levels"] == 2 and stats["exchanged_bytes"] < 0.6 * L * T * F * elem, stats
+                        # every rank holds the SAME reduced tensor
+                        chk = [torch.empty_like(got) for _ in range(world)]
+                        dist.all_gather(chk, got.detach())
+                        assert all(torch.equal(chk[0], c) for c in chk[1:])
+                    assert sync.sparse_stats()[0]["dropped_rows"] == 0
+                    sync.remove()
+        # bounded mode when the regime changes under it: a level's union jumps past its slots.  The rows that do not fit are zero on EVERY rank alike
+        # (replicas stay identical), counted, warned about once; the slots grow; reset_sparse() sends the next step whole
+        tab = torch.nn.Parameter(torch.zeros(L, T, F))
+        sync = shard.GradSync([tab], comm_dtype=None, big=1000, sparse=True)
+        low, high = [0.001] * L, [0.001, 0.001, 0.3, 0.001, 0.001, 0.001]
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for step, f in enumerate((low, low, high, high, high)):
+                g = _touched_grad(rank, step, L, T, F, f)
+                st, mean = dense_reference(g)
+                tab.grad = None
+                (tab * g).sum().backward()
+                sync.finish()
+                chk = [torch.empty_like(tab.grad) for _ in range(world)]
+                dist.all_gather(chk, tab.grad.detach())
+                assert all(torch.equal(chk[0], c) for c in chk[1:]), step
+                wrong = (tab.grad - mean).abs() > 1e-6 * mean.abs() + 1e-12
+                if step == 2:          # slots sized from the 0.1 % steps: most of level 2's union is dropped - as zeros, nothing else is disturbed
+                    assert bool(wrong.any()) and bool((tab.grad[wrong] == 0).all()) and not bool(wrong[[0, 1, 3, 4, 5]].any())
+                elif step >= 3:        # the counts of step 2 have arrived: level 2 now fits (or travels whole)
+                    assert not bool(wrong.any()), step
+        assert sync.sparse_stats()[0]["dropped_rows"] > 0 and any("did not fit" in str(w.message) for w in caught)
+        sync.reset_sparse()
+        g = _touched_grad(rank, 9, L, T, F, low)
+        tab.grad = None
+        (tab * g).sum().backward()
+        sync.finish()
+        assert sync.sparse_stats()[0]["whole_levels"] == L
+        sync.remove()
+        q.put((rank, "ok"))
+    except Exception as e:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_sparse_table_exchange():
+    """the touched-rows exchange (shard.SparseRows behind GradSync(sparse=...)): values equal the dense all-reduce on the union of
+    touched rows and exact zeros elsewhere, for the fp32 all-reduce and the bf16 direct reduce, from the post-accumulate hook and from finish(),
+    in the exact (host reads the counts) and the bounded (slots from earlier steps) mode; the message shrinks; an overflow of the bounded
+    slots zeroes the same rows on every rank and is reported."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
