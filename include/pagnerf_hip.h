@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 12
+#define PAG_ABI_VERSION 13
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -575,6 +575,18 @@ int pag_assign_cost(const float *prob, int B, int64_t P, int64_t image_stride, i
                     const int64_t *labels_gt, int max_rows, float *sums_ws, int32_t *counts_ws, int32_t *info, int64_t *labels,
                     float *cost, const float *points, float id_slope, float id_x_limit, int id_margin, float *psums_ws,
                     int32_t *pcounts_ws, int32_t *id_lo_hi, void *stream);
+/* The Hungarian step itself on the device (ABI 13): replaces `rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))` of
+ * loss/lin_assignment_things.py:45 (loss/lin_assignment.py:22) for the batch pag_assign_cost prepared - no device-to-host copy, no host wait, the train step
+ * stays one uninterrupted stream of launches.  One wave per image runs SciPy's algorithm (rectangular_lsap.cpp: shortest augmenting paths, Crouse 2016) in
+ * float64 in SciPy's operation order and tie rule, so the assigned columns are the same integers (oracle/lin_assign.py::lsap_jv is the sequential
+ * restatement, pinned against the installed SciPy; tests/test_gpu_loss.py compares the kernel with SciPy itself on random, tie-heavy and masked matrices).
+ *   cost f32 [B,max_rows,n_ids] (pag_assign_cost's output; rows >= info[b][0] are not read), widened to float64; id_lo_hi i32 [B,max_rows,2] or NULL: columns
+ *   outside [lo, hi] of a row cost 10000 (utils/outlier_rejection.py:8-51); NaN -> 0, +-inf -> +-DBL_MAX (np.nan_to_num).
+ *   targets i64 [B,max_rows]: assigned column + 1 for the rows < info[b][0], 1 elsewhere (:47-53) - what pag_assign_nll_fwd reads.
+ *   status i32 [B]: 0 solved; 1 not attempted (info[b][1] set: more distinct ids than pag_assign_cost holds; targets all 1); 2 infeasible matrix (SciPy raises).
+ * max_rows, n_ids <= 256. */
+int pag_assign_solve(const float *cost, int B, int max_rows, int n_ids, const int32_t *info, const int32_t *id_lo_hi, int64_t *targets, int32_t *status,
+                     void *stream);
 int pag_assign_nll_fwd(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols,
                        const int64_t *labels_gt, const uint8_t *stuff_mask, const int64_t *labels, const int64_t *targets,
                        const int32_t *info, int max_rows, int64_t default_label, int64_t *virt, float *loss, uint8_t *valid,

@@ -79,3 +79,66 @@ def virtual_labels_things(prob, gt, points_3d=None, outlier_rejection=False):
     new = np.zeros_like(gt)
     new[things] = tl + 1
     return new
+
+
+def lsap_jv(cost):
+    """Restatement of SciPy's `linear_sum_assignment` for a float64 cost matrix with rows <= columns (the only shape the loss produces:
+    at most I - 1 labels against I - 1 columns, loss/lin_assignment_things.py:29), sequential, in SciPy's own operation order - the
+    specification the device kernel `pag_assign_solve` is checked against, itself PINNED against the SciPy installed here (1.15.3) in
+    tests/test_oracle_golden.py on thousands of matrices including tie-heavy integer ones.
+
+    Algorithm of record: scipy/optimize/rectangular_lsap/rectangular_lsap.cpp (SciPy >= 1.6; third-party, not in /root/reference, pinned by
+    no requirements file there - requirements.txt names `scipy` without a version): the shortest-augmenting-path form of Jonker-Volgenant
+    after D. F. Crouse, "On implementing 2D rectangular assignment algorithms", IEEE T-AES 52(4), 2016.  Per row curRow: a Dijkstra-like
+    search over the columns not yet scanned (`remaining`, filled in REVERSE order, removed by swap-with-last) with reduced costs
+    minVal + c[i,j] - u[i] - v[j]; among equal shortest-path costs a column WITHOUT a row wins (the last such in scan order); dual update;
+    augmentation along `path`.  Returns col4row int64 [rows] (row i -> column)."""
+    cost = np.asarray(cost, dtype=np.float64)
+    nr, nc = cost.shape
+    assert nr <= nc
+    u, v = np.zeros(nr), np.zeros(nc)
+    path = np.full(nc, -1, dtype=np.int64)
+    col4row = np.full(nr, -1, dtype=np.int64)
+    row4col = np.full(nc, -1, dtype=np.int64)
+    for cur in range(nr):
+        spc = np.full(nc, np.inf)
+        SR, SC = np.zeros(nr, dtype=bool), np.zeros(nc, dtype=bool)
+        remaining = [nc - it - 1 for it in range(nc)]
+        n_rem, min_val, i, sink = nc, 0.0, cur, -1
+        while sink == -1:
+            index, lowest = -1, np.inf
+            SR[i] = True
+            for it in range(n_rem):
+                j = remaining[it]
+                r = min_val + cost[i, j] - u[i] - v[j]
+                if r < spc[j]:
+                    path[j] = i
+                    spc[j] = r
+                if spc[j] < lowest or (spc[j] == lowest and row4col[j] == -1):
+                    lowest = spc[j]
+                    index = it
+            min_val = lowest
+            assert min_val != np.inf, "infeasible cost matrix"
+            j = remaining[index]
+            if row4col[j] == -1:
+                sink = j
+            else:
+                i = row4col[j]
+            SC[j] = True
+            n_rem -= 1
+            remaining[index] = remaining[n_rem]
+        u[cur] += min_val
+        for r_ in range(nr):
+            if SR[r_] and r_ != cur:
+                u[r_] += min_val - spc[col4row[r_]]
+        for c_ in range(nc):
+            if SC[c_]:
+                v[c_] -= min_val - spc[c_]
+        j = sink
+        while True:
+            i = path[j]
+            row4col[j] = i
+            col4row[i], j = j, col4row[i]
+            if i == cur:
+                break
+    return col4row

@@ -262,6 +262,144 @@ __global__ __launch_bounds__(256) void assign_nll_bwd_kernel(const float *__rest
     for (int c = lane; c < n_cols; c += 64) d_prob[ray * n_cols + c] = (on && c == v) ? g : 0.0f;
 }
 
+
+// ------------------------------------------------------------------------------------------------- the assignment itself, on the device
+// scipy.optimize.linear_sum_assignment(np.nan_to_num(cost)) of loss/lin_assignment_things.py:45 (loss/lin_assignment.py:22) without the host: one WAVE per image runs
+// SciPy's own algorithm (rectangular_lsap.cpp: shortest augmenting paths after Crouse 2016, restated sequentially in oracle/lin_assign.py::lsap_jv, which the CPU
+// suite pins against the installed SciPy) in float64 with SciPy's operation order, so that the assigned columns are the same integers:
+//   per row `cur`: columns not yet scanned live in `remaining` (filled in reverse order, removed by swap-with-last); every pass over them relaxes
+//   spc[j] = min(spc[j], (minVal + c[i][j] - u[i]) - v[j]) and selects the column of the lowest spc - among equal ones a column WITHOUT a row wins, the last such in
+//   scan order, else the first of the minimum (SciPy's sequential `<` / `==` rule, evaluated here as (min, first position of the min, last unassigned position of
+//   the min) over the lanes); dual update; augmentation along path[].
+// The 64 lanes share a pass (position `it` = lane + 64 k); everything else is as sequential as SciPy's loop.  cost is the fp32 matrix pag_assign_cost wrote, widened to
+// float64 as `.astype(np.float64)` does, with the outlier-rejection mask (10000 outside [lo, hi]) and nan_to_num applied on the fly.
+constexpr int SOLVE_MAX = 256;          // rows and columns one wave handles (I <= 257: BUP20 has 200)
+constexpr int SOLVE_STAGE = 6144;       // float64 entries of the cost matrix kept in LDS (48 KiB: 30 labels x 199 columns); larger ones are read from memory
+
+struct SolvePick {
+    double m;
+    int first, last_free;
+};
+__device__ __forceinline__ SolvePick solve_combine(const SolvePick &a, const SolvePick &b) {
+    if (a.m < b.m) return a;
+    if (b.m < a.m) return b;
+    SolvePick r;
+    r.m = a.m;
+    r.first = a.first < b.first ? a.first : b.first;
+    r.last_free = a.last_free > b.last_free ? a.last_free : b.last_free;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restrict__ cost, int R, int C, const int32_t *__restrict__ info,
+                                                          const int32_t *__restrict__ lo_hi, int64_t *__restrict__ targets, int32_t *__restrict__ status) {
+    __shared__ double stage[SOLVE_STAGE];
+    __shared__ double spc[SOLVE_MAX], v[SOLVE_MAX], u[SOLVE_MAX];
+    __shared__ int32_t remaining[SOLVE_MAX], path[SOLVE_MAX], row4col[SOLVE_MAX], col4row[SOLVE_MAX];
+    __shared__ uint8_t SR[SOLVE_MAX], SC[SOLVE_MAX];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = info[b * 2], over = info[b * 2 + 1];
+    cost += (int64_t)b * R * C;
+    targets += (int64_t)b * R;
+    if (lo_hi) lo_hi += (int64_t)b * R * 2;
+    for (int r = lane; r < R; r += 64) targets[r] = 1;          // ids that get no column keep 0 + 1 (:47-53)
+    if (over || n > R || n > C) {                                // more distinct ids than pag_assign_cost's set holds (or a shape SciPy would transpose): not solved here
+        if (lane == 0) status[b] = 1;
+        return;
+    }
+    if (lane == 0) status[b] = 0;
+    if (n <= 0) return;
+    auto widen = [&](int i, int j) -> double {
+        double d = (double)cost[(int64_t)i * C + j];
+        if (lo_hi && !(lo_hi[i * 2] <= j && j <= lo_hi[i * 2 + 1])) d = 10000.0;       // utils/outlier_rejection.py:8-51
+        if (d != d) d = 0.0;                                                          // np.nan_to_num
+        else if (d == INFINITY) d = 1.7976931348623157e308;
+        else if (d == -INFINITY) d = -1.7976931348623157e308;
+        return d;
+    };
+    const bool staged = n * C <= SOLVE_STAGE;
+    if (staged)
+        for (int e = lane; e < n * C; e += 64) stage[e] = widen(e / C, e % C);
+    for (int j = lane; j < C; j += 64) v[j] = 0.0, path[j] = -1, row4col[j] = -1;
+    for (int i = lane; i < n; i += 64) u[i] = 0.0, col4row[i] = -1;
+    __syncthreads();
+    for (int cur = 0; cur < n; ++cur) {
+        for (int j = lane; j < C; j += 64) spc[j] = INFINITY, SC[j] = 0, remaining[j] = C - j - 1;
+        for (int i = lane; i < n; i += 64) SR[i] = 0;
+        __syncthreads();
+        int n_rem = C, i = cur, sink = -1;
+        double min_val = 0.0;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            const double ui = u[i];
+            SolvePick pk;
+            pk.m = INFINITY, pk.first = 0x7FFFFFFF, pk.last_free = -1;
+            for (int it = lane; it < n_rem; it += 64) {
+                const int j = remaining[it];
+                const double c = staged ? stage[i * C + j] : widen(i, j);
+                const double r = ((min_val + c) - ui) - v[j];
+                double s = spc[j];
+                if (r < s) {
+                    path[j] = i;
+                    spc[j] = s = r;
+                }
+                const bool free_col = row4col[j] == -1;
+                if (s < pk.m) {
+                    pk.m = s, pk.first = it, pk.last_free = free_col ? it : -1;
+                } else if (s == pk.m) {
+                    if (pk.first == 0x7FFFFFFF) pk.first = it;                  // s == m == +inf before anything finite was seen: SciPy's `==` branch
+                    if (free_col) pk.last_free = it;
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                SolvePick o;
+                o.m = __shfl_xor(pk.m, d);
+                o.first = __shfl_xor(pk.first, d);
+                o.last_free = __shfl_xor(pk.last_free, d);
+                pk = solve_combine(pk, o);
+            }
+            min_val = pk.m;
+            if (!(min_val < INFINITY)) {                                        // infeasible (SciPy raises): leave the defaults, report
+                if (lane == 0) status[b] = 2;
+                return;
+            }
+            const int index = pk.last_free >= 0 ? pk.last_free : pk.first;
+            const int j = remaining[index];
+            const int owner = row4col[j];
+            const int tail = remaining[n_rem - 1];
+            __syncthreads();
+            if (lane == 0) {
+                SC[j] = 1;
+                remaining[index] = tail;
+            }
+            --n_rem;
+            if (owner == -1) sink = j; else i = owner;
+            __syncthreads();
+        }
+        // dual variables
+        for (int r = lane; r < n; r += 64) {
+            if (r == cur) u[r] += min_val;
+            else if (SR[r]) u[r] += min_val - spc[col4row[r]];
+        }
+        for (int j = lane; j < C; j += 64)
+            if (SC[j]) v[j] -= min_val - spc[j];
+        __syncthreads();
+        if (lane == 0) {                                                       // augment the previous solution
+            int j = sink;
+            while (true) {
+                const int r = path[j];
+                row4col[j] = r;
+                const int t = col4row[r];
+                col4row[r] = j;
+                j = t;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    for (int r = lane; r < n; r += 64) targets[r] = (int64_t)col4row[r] + 1;   // :47-53: assigned column + 1
+}
+
 }  // namespace
 
 extern "C" int pag_assign_cost(const float *prob, int B, int64_t P, int64_t image_stride, int64_t row_stride, int n_cols, int col0, const int64_t *labels_gt,
@@ -286,6 +424,18 @@ extern "C" int pag_assign_cost(const float *prob, int B, int64_t P, int64_t imag
                            C, id_lo_hi);
     }
     PAG_CHECK_LAUNCH("pag_assign_cost");
+    return PAG_OK;
+}
+
+extern "C" int pag_assign_solve(const float *cost, int B, int max_rows, int n_ids, const int32_t *info, const int32_t *id_lo_hi, int64_t *targets, int32_t *status,
+                                void *stream) {
+    PAG_CHECK_ARG(B >= 0 && B <= 65535, "pag_assign_solve: B not in [0,65535]");
+    PAG_CHECK_ARG(max_rows >= 1 && max_rows <= SOLVE_MAX && n_ids >= 1 && n_ids <= SOLVE_MAX, "pag_assign_solve: max_rows %d / n_ids %d not in [1,%d]", max_rows, n_ids,
+                  SOLVE_MAX);
+    if (B == 0) return PAG_OK;
+    PAG_CHECK_ARG(cost && info && targets && status, "pag_assign_solve: NULL input/output");
+    hipLaunchKernelGGL(assign_solve_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cost, max_rows, n_ids, info, id_lo_hi, targets, status);
+    PAG_CHECK_LAUNCH("pag_assign_solve");
     return PAG_OK;
 }
 

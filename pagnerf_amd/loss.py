@@ -120,6 +120,9 @@ class LinAssignmentThingsLoss(nn.Module):
         self.min_distance, self.max_distance = min_distance, max_distance
         self._ws = None          # device scratch + pinned host mirrors of the one-synchronisation path, keyed by (B, P, I, device)
         self.fast_path = True
+        # solver: "device" (default; pag_assign_solve - SciPy's algorithm on the GPU, the step never waits for the host) or "scipy" (one copy + wait, SciPy per
+        # image on the host).  Same assigned columns either way (tests/test_gpu_loss.py).  PAG_ASSIGN_SOLVER overrides the default.
+        self.solver = kwargs.pop("solver", None) or os.environ.get("PAG_ASSIGN_SOLVER", "device")
         self.last_virtual_labels = None
 
     @torch.no_grad()
@@ -157,10 +160,30 @@ class LinAssignmentThingsLoss(nn.Module):
                      cost=torch.zeros(B, R, C, device=dev), targets=torch.ones(B, R, device=dev, dtype=torch.int64),
                      psums=torch.zeros(B, R, 3, device=dev), pcounts=torch.zeros(B, R, device=dev, dtype=torch.int32),
                      lo_hi=torch.zeros(B, R, 2, device=dev, dtype=torch.int32))
-            for name in ("info", "cost", "targets", "lo_hi"):
+            f["status"] = torch.zeros(B, device=dev, dtype=torch.int32)
+            for name in ("info", "cost", "targets", "lo_hi", "status"):
                 f["h_" + name] = torch.empty(f[name].shape, dtype=f[name].dtype).pin_memory()
             self._ws = f
         return self._ws
+
+    DEVICE_SOLVE_MAX = 256       # rows / columns pag_assign_solve takes (BUP20: 199)
+
+    def _device_solver(self, I):
+        return self.solver == "device" and I - 1 <= self.DEVICE_SOLVE_MAX
+
+    def _check_last_status(self, w):
+        """The device solver reports per image 0 = solved, 1 = more distinct ids than the device-side set holds, 2 = infeasible matrix.  The report of the
+        PREVIOUS call is read here, without waiting, once its copy has landed: anything but 0 switches this object to the host solver (whose general path
+        covers those inputs) and says so - the call it belongs to trained that image's instance term against all-ones targets."""
+        ev = w.get("status_event")
+        if ev is not None and ev.query():
+            w["status_event"] = None
+            bad = w["h_status"].numpy()
+            if bad.any():
+                import warnings
+                warnings.warn("LinAssignmentThingsLoss: the device assignment was not solved for image(s) %s of an earlier step (status %s: 1 = more distinct ids "
+                              "than the device-side set holds, 2 = infeasible cost matrix); switching to solver='scipy'" % (np.nonzero(bad)[0].tolist(), bad[bad != 0].tolist()))
+                self.solver = "scipy"
 
     def _fast(self, prob, labels_gt, stuff_mask, points_3d=None):
         return self._finish(self._begin(prob, labels_gt, stuff_mask, points_3d))
@@ -192,17 +215,36 @@ class LinAssignmentThingsLoss(nn.Module):
         ops._call("pag_assign_cost", pd.data_ptr(), B, P, pd.stride(0), pd.stride(1), I, 1, labels_gt.data_ptr(), I - 1, w["sums"].data_ptr(), w["counts"].data_ptr(),
                   w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), pts.data_ptr() if pts is not None else None, slope, x_limit, margin,
                   w["psums"].data_ptr(), w["pcounts"].data_ptr(), w["lo_hi"].data_ptr(), st)          # every image of the step in one set of launches
+        if self._device_solver(I):
+            self._check_last_status(w)
+        if self._device_solver(I):
+            # the Hungarian step on the device: targets are written where pag_assign_nll_fwd reads them - nothing to copy, nothing to wait for
+            ops._call("pag_assign_solve", w["cost"].data_ptr(), B, I - 1, I - 1, w["info"].data_ptr(), w["lo_hi"].data_ptr() if pts is not None else None,
+                      w["targets"].data_ptr(), w["status"].data_ptr(), st)
+            if w.get("status_event") is None:             # one report in flight at a time (the pinned mirror is single-buffered)
+                w["h_status"].copy_(w["status"], non_blocking=True)
+                sev = w.get("status_event_obj")
+                if sev is None:
+                    sev = w["status_event_obj"] = torch.cuda.Event()
+                sev.record(torch.cuda.current_stream(prob.device))
+                w["status_event"] = sev
+            return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts, True)
         for name in names:
             w["h_" + name].copy_(w[name], non_blocking=True)
         ev = w.get("event")
         if ev is None:
             ev = w["event"] = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(prob.device))
-        return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts)
+        return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts, False)
 
     def _finish(self, pending):
-        prob, labels_gt, stuff_mask, rej, w, _pts = pending
+        prob, labels_gt, stuff_mask, rej, w, _pts, on_device = pending
         B, P, I = prob.shape
+        if on_device:
+            w["busy"] = False
+            loss, virt = _AssignNLL.apply(prob, labels_gt, stuff_mask, w["labels"], w["targets"], w["info"])
+            self.last_virtual_labels = virt
+            return loss
         w["event"].synchronize()                                       # the step's one wait for the device: only for what _begin() queued
         w["busy"] = False                                              # (the targets below are written and consumed inside this call)
         info = w["h_info"].numpy()

@@ -371,3 +371,33 @@ def test_g9_base_nef_channels_and_gradients(tag):
     if tag != "dd":
         rel = np.abs(want - g["dd_dtables"]).max() / np.abs(g["dd_dtables"]).max()
         assert (rel > 1e-2) == (tag in ("ll", "ld")), rel          # 'pos': the instance head never touches the grid
+
+
+def test_lsap_restatement_equals_scipy():
+    """oracle.lin_assign.lsap_jv - the sequential restatement of SciPy's rectangular LSAP solver that the device kernel pag_assign_solve follows - against
+    scipy.optimize.linear_sum_assignment itself (the solver loss/lin_assignment_things.py:45 calls; SciPy %s here): identical columns on random, tie-heavy
+    integer, constant, fp32-valued and outlier-masked (10000) matrices with rows <= columns, and on the golden batch's own cost matrices.""" % __import__("scipy").__version__
+    from scipy.optimize import linear_sum_assignment
+    from oracle.lin_assign import lsap_jv
+    rs = np.random.RandomState(0)
+    for trial in range(1200):
+        nr = rs.randint(1, 13)
+        nc = rs.randint(nr, 26)
+        kind = trial % 6
+        if kind == 0:
+            c = rs.randn(nr, nc)
+        elif kind == 1:
+            c = rs.randint(0, 3, (nr, nc)).astype(np.float64)              # many ties
+        elif kind == 2:
+            c = -rs.rand(nr, nc).astype(np.float32).astype(np.float64)     # what the loss produces: -mean probability, fp32 widened
+        elif kind == 3:
+            c = np.zeros((nr, nc))
+        elif kind == 4:
+            c = -rs.rand(nr, nc).astype(np.float32).astype(np.float64)
+            c[rs.rand(nr, nc) < 0.6] = 10000                               # outlier-rejection mask
+        else:
+            c = np.round(rs.randn(nr, nc) * 2) / 2
+        rows, cols = linear_sum_assignment(c)
+        assert np.array_equal(rows, np.arange(nr)) and np.array_equal(cols, lsap_jv(c)), (trial, kind)
+    big = -rs.rand(60, 199).astype(np.float32).astype(np.float64)
+    assert np.array_equal(linear_sum_assignment(big)[1], lsap_jv(big))
