@@ -1173,7 +1173,8 @@ def run_rank(args):
             # ---- the late-training step as the trainer runs it: instance term = LinAssignmentThingsLoss on the rendered probabilities
             from pagnerf_amd.loss import LinAssignmentThingsLoss
             la = {}
-            for tag, mod in (("device_cost_matrix", LinAssignmentThingsLoss()), ("device_cost_matrix_two_call", LinAssignmentThingsLoss()),
+            for tag, mod in (("device_solver", LinAssignmentThingsLoss()), ("device_solver_two_call", LinAssignmentThingsLoss()),
+                             ("device_cost_matrix", LinAssignmentThingsLoss(solver="scipy")), ("device_cost_matrix_two_call", LinAssignmentThingsLoss(solver="scipy")),
                              ("reference_formulation", ReferenceFormulationThingsLoss())):
                 job.lin_assign = mod
                 two = tag.endswith("two_call")
@@ -1185,7 +1186,8 @@ def run_rank(args):
                 la[tag] = dict(ms_per_step=round(d_la / n_la * 1e3, 3), rays_s=round(args.rays * n_la / d_la, 1))
             job.lin_assign, job.overlap, job.tracer.graph_split = None, False, None
             la["labels_per_image"] = int((torch.unique(job.gt["inst_ids"]) > 0).sum())
-            la["note"] = ("same step with the instance term of trainer.py:483-520 (per-image Hungarian relabelling + NLL); device_cost_matrix = "
+            la["note"] = ("same step with the instance term of trainer.py:483-520 (per-image Hungarian relabelling + NLL); device_solver = the default since round 6: "
+                          "pag_assign_cost + pag_assign_solve (SciPy's algorithm on the device, same columns) + pag_assign_nll - no host wait in the step; device_cost_matrix = "
                           "pagnerf_amd.loss.LinAssignmentThingsLoss: pag_assign_cost (ids, sums, cost rows on the device), ONE copy + wait, SciPy, pag_assign_nll; "
                           "device_cost_matrix_two_call = the same with loss_fn.begin() / rgb_loss.backward() / loss_fn.finish() / rest.backward(): the colour / "
                           "density / main-grid backward runs while the host waits and solves the assignment; reference_formulation = one masked sum and one "
@@ -1239,6 +1241,8 @@ def run_rank(args):
                       set(all_ch), 1, 20),
                      ("post_prune_all_assign", late + "; two-call form (INTEGRATION.md): loss_rgb.backward() - colour / density / main grid / pose - is queued "
                       "before the host waits for the cost matrices, the panoptic half follows the assignment", "voxel", 2, set(all_ch), 2, 20))
+            specs = specs + (("post_prune_all_assign_host_solver", late + "; ONE loss.backward(), LinAssignmentThingsLoss(solver='scipy'): cost matrices copied to the host, the step waits "
+                              "for them and for SciPy (the default of round 5; the other two lines solve the assignment on the device)", "voxel", 2, set(all_ch), 4, 20),)
             specs = specs + (("dense_rgb_trained_scene", "the dense regime on a LEARNABLE scene (analytic textured sphere, white background) after 300 training steps: most "
                               "samples in front of the surface are empty space with sigma = relu(pre) = 0 exactly, their gradients are exactly zero and the encoders' backward "
                               "skips their waves (bin pass) and row requests (position gradient), bit-identically; the untrained random scene of the other lines has no such samples", "ray", 512, {"rgb", "depth"}, 3, 6),)
@@ -1253,8 +1257,11 @@ def run_rank(args):
                     j.gt["rgb"] = rgb_gt.to(dev)
                     for _ in range(300):
                         j.step()
+                host_solver = assign == 4
+                if host_solver:
+                    assign = 1
                 if assign:
-                    j.lin_assign, j.images, j.points_fn, j.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True), images, j.pose.points_3d, True
+                    j.lin_assign, j.images, j.points_fn, j.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True, solver="scipy" if host_solver else None), images, j.pose.points_3d, True
                 if assign == 2:
                     j.overlap, j.tracer.graph_split = True, True
                 for _ in range(4):                                  # step 0 learns the sample count, step 1 captures, 2 - 3 replay

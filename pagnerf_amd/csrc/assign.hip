@@ -274,28 +274,42 @@ __global__ __launch_bounds__(256) void assign_nll_bwd_kernel(const float *__rest
 // The 64 lanes share a pass (position `it` = lane + 64 k); everything else is as sequential as SciPy's loop.  cost is the fp32 matrix pag_assign_cost wrote, widened to
 // float64 as `.astype(np.float64)` does, with the outlier-rejection mask (10000 outside [lo, hi]) and nan_to_num applied on the fly.
 constexpr int SOLVE_MAX = 256;          // rows and columns one wave handles (I <= 257: BUP20 has 200)
-constexpr int SOLVE_STAGE = 6144;       // float64 entries of the cost matrix kept in LDS (48 KiB: 30 labels x 199 columns); larger ones are read from memory
+constexpr int SOLVE_STAGE = 12288;      // fp32 entries of the cost matrix kept in LDS (48 KiB: 61 labels x 199 columns); larger ones are read from memory
 
-struct SolvePick {
-    double m;
-    int first, last_free;
-};
-__device__ __forceinline__ SolvePick solve_combine(const SolvePick &a, const SolvePick &b) {
-    if (a.m < b.m) return a;
-    if (b.m < a.m) return b;
-    SolvePick r;
-    r.m = a.m;
-    r.first = a.first < b.first ? a.first : b.first;
-    r.last_free = a.last_free > b.last_free ? a.last_free : b.last_free;
-    return r;
+// Register-resident form: lane l owns columns l, l + 64, l + 128, l + 192 (spc, v, row4col, path and the column's POSITION in SciPy's `remaining` array live in
+// registers; a removal moves the tail column into the freed position: two compares per lane) and rows l, l + 64, ... (u, col4row).  One pass = one LDS read
+// of the cost row, the relaxation, and TWO wave reductions on DPP moves: the minimum of the float64 path costs (compared as float64, as SciPy does), then - among the lanes
+// that hold it - the minimum of q, which encodes SciPy's tie rule in one number: a column without a row gets q = 255 - position (the LAST free one in scan order
+// wins), a column with a row q = 256 + position (only if no free column shares the minimum; the FIRST in scan order wins).  ~3x fewer cycles per pass than the
+// first form (every per-column array in LDS, six rounds of shuffles on a three-field record): 0.44 -> see profiles/README.md round 6.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t solve_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);      // lanes without a source keep their own value
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void solve_minf64_step(double &v) {      // float64 compare itself (as SciPy's `<`): two DPP moves, one compare, two selects
+    const long long b = __double_as_longlong(v);
+    const uint32_t ohi = solve_dpp<CTRL, ROW_MASK>((uint32_t)(b >> 32)), olo = solve_dpp<CTRL, ROW_MASK>((uint32_t)b);
+    const double o = __longlong_as_double((long long)(((uint64_t)ohi << 32) | olo));
+    v = o < v ? o : v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void solve_min32_step(uint32_t &v) {
+    const uint32_t o = solve_dpp<CTRL, ROW_MASK>(v);
+    v = o < v ? o : v;
+}
+template <typename T>
+__device__ __forceinline__ T solve_pick4(const T (&a)[4], int k) {   // k is wave-uniform
+    return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3]));
 }
 
 __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restrict__ cost, int R, int C, const int32_t *__restrict__ info,
                                                           const int32_t *__restrict__ lo_hi, int64_t *__restrict__ targets, int32_t *__restrict__ status) {
-    __shared__ double stage[SOLVE_STAGE];
-    __shared__ double spc[SOLVE_MAX], v[SOLVE_MAX], u[SOLVE_MAX];
-    __shared__ int32_t remaining[SOLVE_MAX], path[SOLVE_MAX], row4col[SOLVE_MAX], col4row[SOLVE_MAX];
-    __shared__ uint8_t SR[SOLVE_MAX], SC[SOLVE_MAX];
+    constexpr int K = SOLVE_MAX / 64;
+    // the cost matrix as fp32 in LDS (mask and NaN -> 0 applied; an infinity is kept as such and becomes +-DBL_MAX when it is widened): 61 labels x 199 columns
+    __shared__ float stage[SOLVE_STAGE];
+    __shared__ double spc_l[SOLVE_MAX];
+    __shared__ int32_t path_l[SOLVE_MAX], row4col_l[SOLVE_MAX], col4row_l[SOLVE_MAX];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = info[b * 2], over = info[b * 2 + 1];
     cost += (int64_t)b * R * C;
@@ -317,87 +331,186 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
         return d;
     };
     const bool staged = n * C <= SOLVE_STAGE;
-    if (staged)
-        for (int e = lane; e < n * C; e += 64) stage[e] = widen(e / C, e % C);
-    for (int j = lane; j < C; j += 64) v[j] = 0.0, path[j] = -1, row4col[j] = -1;
-    for (int i = lane; i < n; i += 64) u[i] = 0.0, col4row[i] = -1;
-    __syncthreads();
-    for (int cur = 0; cur < n; ++cur) {
-        for (int j = lane; j < C; j += 64) spc[j] = INFINITY, SC[j] = 0, remaining[j] = C - j - 1;
-        for (int i = lane; i < n; i += 64) SR[i] = 0;
-        __syncthreads();
-        int n_rem = C, i = cur, sink = -1;
-        double min_val = 0.0;
-        while (sink == -1) {
-            if (lane == 0) SR[i] = 1;
-            const double ui = u[i];
-            SolvePick pk;
-            pk.m = INFINITY, pk.first = 0x7FFFFFFF, pk.last_free = -1;
-            for (int it = lane; it < n_rem; it += 64) {
-                const int j = remaining[it];
-                const double c = staged ? stage[i * C + j] : widen(i, j);
-                const double r = ((min_val + c) - ui) - v[j];
-                double s = spc[j];
-                if (r < s) {
-                    path[j] = i;
-                    spc[j] = s = r;
-                }
-                const bool free_col = row4col[j] == -1;
-                if (s < pk.m) {
-                    pk.m = s, pk.first = it, pk.last_free = free_col ? it : -1;
-                } else if (s == pk.m) {
-                    if (pk.first == 0x7FFFFFFF) pk.first = it;                  // s == m == +inf before anything finite was seen: SciPy's `==` branch
-                    if (free_col) pk.last_free = it;
+    if (staged) {
+        // four rows per trip: 16 independent loads in flight per lane (a row per trip cost one memory round trip per label: ~45 us of a 55 us solve)
+        for (int r0 = 0; r0 < n; r0 += 4) {
+            float f[4][K];
+            int lo[4], hi[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int r = r0 + a < n ? r0 + a : n - 1;
+                lo[a] = lo_hi ? lo_hi[r * 2] : 0;
+                hi[a] = lo_hi ? lo_hi[r * 2 + 1] : C;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int j = lane + 64 * k;
+                    f[a][k] = cost[(int64_t)r * C + (j < C ? j : C - 1)];
                 }
             }
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                SolvePick o;
-                o.m = __shfl_xor(pk.m, d);
-                o.first = __shfl_xor(pk.first, d);
-                o.last_free = __shfl_xor(pk.last_free, d);
-                pk = solve_combine(pk, o);
+            for (int a = 0; a < 4; ++a) {
+                if (r0 + a >= n) break;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int j = lane + 64 * k;
+                    float g = f[a][k];
+                    if (!(lo[a] <= j && j <= hi[a])) g = 10000.0f;
+                    if (j < C) stage[(r0 + a) * C + j] = g != g ? 0.0f : g;
+                }
             }
-            min_val = pk.m;
+        }
+    }
+    double spc[K], v[K], u[K];
+    int r4c[K], pos[K], pth[K], c4r[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = 0.0, u[k] = 0.0, r4c[k] = -1, pth[k] = -1, c4r[k] = -1, spc[k] = INFINITY, pos[k] = -2;
+        const int j = lane + 64 * k;
+        if (j < C) row4col_l[j] = -1;
+        if (j < n) col4row_l[j] = -1;
+    }
+    __syncthreads();
+    for (int cur = 0; cur < n; ++cur) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = lane + 64 * k;
+            spc[k] = INFINITY;
+            pos[k] = j < C ? C - 1 - j : -2;                    // SciPy fills `remaining` in reverse order; -1 = scanned (SC), -2 = no such column
+        }
+        unsigned sr_bits = 0;
+        int n_rem = C, i = cur, sink = -1;
+        double min_val = 0.0;
+        while (sink < 0) {
+            const int irow_lane = i & 63, irow_k = i >> 6;
+            if (lane == irow_lane) sr_bits |= 1u << irow_k;                       // SR[i] = true
+            double ui;
+            {
+                const double mine = solve_pick4(u, irow_k);
+                const long long bits = __double_as_longlong(mine);
+                const int lo = __builtin_amdgcn_readlane((int)bits, irow_lane), hi = __builtin_amdgcn_readlane((int)(bits >> 32), irow_lane);
+                ui = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+            }
+            double bm = INFINITY;
+            uint32_t bq = 0xFFFFFFFFu;
+            if (staged) {          // wave-uniform; the pass itself is straight-line code: selects, no branches
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int j = lane + 64 * k;
+                    const bool act = pos[k] >= 0;
+                    const float cf = stage[i * C + (j < C ? j : 0)];
+                    double c = (double)cf;
+                    c = cf == INFINITY ? 1.7976931348623157e308 : (cf == -INFINITY ? -1.7976931348623157e308 : c);
+                    const double r = ((min_val + c) - ui) - v[k];
+                    const bool better = act && r < spc[k];
+                    spc[k] = better ? r : spc[k];
+                    pth[k] = better ? i : pth[k];
+                    const double sk = act ? spc[k] : (double)INFINITY;
+                    const uint32_t q = !act ? 0xFFFFFFFFu : (r4c[k] == -1 ? (uint32_t)(255 - pos[k]) : (uint32_t)(256 + pos[k]));
+                    const bool take = sk < bm || (sk == bm && q < bq);
+                    bm = take ? sk : bm;
+                    bq = take ? q : bq;
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < K; ++k) {
+                    if (pos[k] >= 0) {
+                        const int j = lane + 64 * k;
+                        const double r = ((min_val + widen(i, j)) - ui) - v[k];
+                        if (r < spc[k]) {
+                            spc[k] = r;
+                            pth[k] = i;
+                        }
+                        const uint32_t q = r4c[k] == -1 ? (uint32_t)(255 - pos[k]) : (uint32_t)(256 + pos[k]);
+                        if (spc[k] < bm || (spc[k] == bm && q < bq)) bm = spc[k], bq = q;
+                    }
+                }
+            }
+            double wm = bm;
+            solve_minf64_step<0x111, 0xF>(wm);
+            solve_minf64_step<0x112, 0xF>(wm);
+            solve_minf64_step<0x114, 0xF>(wm);
+            solve_minf64_step<0x118, 0xF>(wm);
+            solve_minf64_step<0x142, 0xA>(wm);
+            solve_minf64_step<0x143, 0xC>(wm);
+            {
+                const long long bits = __double_as_longlong(wm);
+                const int lo = __builtin_amdgcn_readlane((int)bits, 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+                min_val = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+            }
             if (!(min_val < INFINITY)) {                                        // infeasible (SciPy raises): leave the defaults, report
                 if (lane == 0) status[b] = 2;
                 return;
             }
-            const int index = pk.last_free >= 0 ? pk.last_free : pk.first;
-            const int j = remaining[index];
-            const int owner = row4col[j];
-            const int tail = remaining[n_rem - 1];
-            __syncthreads();
-            if (lane == 0) {
-                SC[j] = 1;
-                remaining[index] = tail;
+            uint32_t q = bm == min_val ? bq : 0xFFFFFFFFu;
+            solve_min32_step<0x111, 0xF>(q);
+            solve_min32_step<0x112, 0xF>(q);
+            solve_min32_step<0x114, 0xF>(q);
+            solve_min32_step<0x118, 0xF>(q);
+            solve_min32_step<0x142, 0xA>(q);
+            solve_min32_step<0x143, 0xC>(q);
+            const int qmin = __builtin_amdgcn_readlane((int)q, 63);
+            const bool free_col = qmin < 256;
+            const int index = free_col ? 255 - qmin : qmin - 256;
+            // the column at position `index`: exactly one (lane, k)
+            int myk = -1, myr = -1;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const bool hit = pos[k] == index;
+                myk = hit ? k : myk;
+                myr = hit ? r4c[k] : myr;
+            }
+            const int jl = __builtin_ctzll(__ballot(myk >= 0));
+            const int jsel = jl + 64 * __builtin_amdgcn_readlane(myk, jl), owner = __builtin_amdgcn_readlane(myr, jl);
+            const int tail = n_rem - 1;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (pos[k] == index) pos[k] = -1;                               // SC[j] = true; remaining[index] = remaining[--n_rem]
+                else if (pos[k] == tail) pos[k] = index;
             }
             --n_rem;
-            if (owner == -1) sink = j; else i = owner;
-            __syncthreads();
+            if (free_col) sink = jsel; else i = owner;
         }
-        // dual variables
-        for (int r = lane; r < n; r += 64) {
-            if (r == cur) u[r] += min_val;
-            else if (SR[r]) u[r] += min_val - spc[col4row[r]];
+        // dual variables, then the augmentation along path[] (sequential, as SciPy's)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = lane + 64 * k;
+            if (j < C) spc_l[j] = spc[k], path_l[j] = pth[k];
         }
-        for (int j = lane; j < C; j += 64)
-            if (SC[j]) v[j] -= min_val - spc[j];
         __syncthreads();
-        if (lane == 0) {                                                       // augment the previous solution
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int r = lane + 64 * k;
+            if (r < n) {
+                if (r == cur) u[k] += min_val;
+                else if ((sr_bits >> k) & 1u) u[k] += min_val - spc_l[c4r[k]];
+            }
+            if (pos[k] == -1) v[k] -= min_val - spc[k];
+        }
+        if (lane == 0) {
             int j = sink;
             while (true) {
-                const int r = path[j];
-                row4col[j] = r;
-                const int t = col4row[r];
-                col4row[r] = j;
+                const int r = path_l[j];
+                row4col_l[j] = r;
+                const int t = col4row_l[r];
+                col4row_l[r] = j;
                 j = t;
                 if (r == cur) break;
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = lane + 64 * k;
+            if (j < C) r4c[k] = row4col_l[j];
+            if (j < n) c4r[k] = col4row_l[j];
+        }
+        __syncthreads();
     }
-    for (int r = lane; r < n; r += 64) targets[r] = (int64_t)col4row[r] + 1;   // :47-53: assigned column + 1
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int r = lane + 64 * k;
+        if (r < n) targets[r] = (int64_t)c4r[k] + 1;                           // :47-53: assigned column + 1
+    }
 }
 
 }  // namespace

@@ -188,10 +188,12 @@ class LinAssignmentThingsLoss(nn.Module):
     def _fast(self, prob, labels_gt, stuff_mask, points_3d=None):
         return self._finish(self._begin(prob, labels_gt, stuff_mask, points_3d))
 
-    def _begin(self, prob, labels_gt, stuff_mask, points_3d=None):
-        """Queue the device side of the assignment (ids, sums, cost rows, id ranges: pag_assign_cost) and the copies to pinned memory, and record an EVENT
-        behind them: whatever the caller queues on the stream afterwards (other loss terms, the part of the backward that does not depend on the
-        instance term) runs while the host waits for that event and solves the assignments in _finish()."""
+    def _begin(self, prob, labels_gt, stuff_mask, points_3d=None, side=False):
+        """Queue the device side of the assignment.  solver="device": ids, sums, cost rows, id ranges (pag_assign_cost) and the Hungarian step itself
+        (pag_assign_solve) - nothing for the host to wait for; with side=True (the two-call form) on a SECOND STREAM that waits for what the caller has queued so
+        far, so that the latency-bound solve (one wave per image) runs beside whatever the caller queues next on its own stream (the colour / density / main-grid
+        half of the backward); _finish() makes the caller's stream wait for it.  solver="scipy": pag_assign_cost, the copies to pinned memory and an EVENT behind
+        them - the host waits for that event and solves the assignments in _finish()."""
         B, P, I = prob.shape
         w = self._workspace(B, P, I, prob.device)
         # ONE pending call per loss object: the workspace (cost rows, targets, pinned mirrors, the event) belongs to it until finish() has run; a second
@@ -200,7 +202,6 @@ class LinAssignmentThingsLoss(nn.Module):
             raise RuntimeError("LinAssignmentThingsLoss.begin() called again before finish() of the previous call: one pending call per loss object "
                                "(use one LinAssignmentThingsLoss per concurrently pending batch)")
         w["busy"] = True
-        st = L.stream()
         pd = prob.detach()
         pts, slope, x_limit, margin = None, 0.0, 0.0, 0
         names = ("info", "cost")
@@ -212,36 +213,54 @@ class LinAssignmentThingsLoss(nn.Module):
             slope = (30 + margin) / 0.3
             x_limit = ((I - 1) - margin) / slope
             names = ("info", "cost", "lo_hi")
-        ops._call("pag_assign_cost", pd.data_ptr(), B, P, pd.stride(0), pd.stride(1), I, 1, labels_gt.data_ptr(), I - 1, w["sums"].data_ptr(), w["counts"].data_ptr(),
-                  w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), pts.data_ptr() if pts is not None else None, slope, x_limit, margin,
-                  w["psums"].data_ptr(), w["pcounts"].data_ptr(), w["lo_hi"].data_ptr(), st)          # every image of the step in one set of launches
         if self._device_solver(I):
             self._check_last_status(w)
-        if self._device_solver(I):
-            # the Hungarian step on the device: targets are written where pag_assign_nll_fwd reads them - nothing to copy, nothing to wait for
-            ops._call("pag_assign_solve", w["cost"].data_ptr(), B, I - 1, I - 1, w["info"].data_ptr(), w["lo_hi"].data_ptr() if pts is not None else None,
-                      w["targets"].data_ptr(), w["status"].data_ptr(), st)
-            if w.get("status_event") is None:             # one report in flight at a time (the pinned mirror is single-buffered)
-                w["h_status"].copy_(w["status"], non_blocking=True)
-                sev = w.get("status_event_obj")
-                if sev is None:
-                    sev = w["status_event_obj"] = torch.cuda.Event()
-                sev.record(torch.cuda.current_stream(prob.device))
-                w["status_event"] = sev
-            return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts, True)
+        on_device = self._device_solver(I)
+        main = torch.cuda.current_stream(prob.device)
+        other = None
+        if on_device and side:
+            other = w.get("side_stream")
+            if other is None:
+                other = w["side_stream"] = torch.cuda.Stream(device=prob.device)
+            other.wait_stream(main)                       # the probabilities, the gt ids and the 3-D points are produced on the caller's stream
+        with torch.cuda.stream(other if other is not None else main):
+            st = L.stream()
+            ops._call("pag_assign_cost", pd.data_ptr(), B, P, pd.stride(0), pd.stride(1), I, 1, labels_gt.data_ptr(), I - 1, w["sums"].data_ptr(), w["counts"].data_ptr(),
+                      w["info"].data_ptr(), w["labels"].data_ptr(), w["cost"].data_ptr(), pts.data_ptr() if pts is not None else None, slope, x_limit, margin,
+                      w["psums"].data_ptr(), w["pcounts"].data_ptr(), w["lo_hi"].data_ptr(), st)          # every image of the step in one set of launches
+            if on_device:
+                # the Hungarian step on the device: targets are written where pag_assign_nll_fwd reads them - nothing to copy, nothing for the host to wait for
+                ops._call("pag_assign_solve", w["cost"].data_ptr(), B, I - 1, I - 1, w["info"].data_ptr(), w["lo_hi"].data_ptr() if pts is not None else None,
+                          w["targets"].data_ptr(), w["status"].data_ptr(), st)
+                if w.get("status_event") is None:             # one report in flight at a time (the pinned mirror is single-buffered)
+                    w["h_status"].copy_(w["status"], non_blocking=True)
+                    sev = w.get("status_event_obj")
+                    if sev is None:
+                        sev = w["status_event_obj"] = torch.cuda.Event()
+                    sev.record(torch.cuda.current_stream(prob.device))
+                    w["status_event"] = sev
+                done = None
+                if other is not None:
+                    done = w.get("side_done")
+                    if done is None:
+                        done = w["side_done"] = torch.cuda.Event()
+                    done.record(other)
+                return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts, True, done)
         for name in names:
             w["h_" + name].copy_(w[name], non_blocking=True)
         ev = w.get("event")
         if ev is None:
             ev = w["event"] = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(prob.device))
-        return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts, False)
+        return (prob, labels_gt, stuff_mask, points_3d is not None, w, pts, False, None)
 
     def _finish(self, pending):
-        prob, labels_gt, stuff_mask, rej, w, _pts, on_device = pending
+        prob, labels_gt, stuff_mask, rej, w, _pts, on_device, side_done = pending
         B, P, I = prob.shape
         if on_device:
             w["busy"] = False
+            if side_done is not None:
+                torch.cuda.current_stream(prob.device).wait_event(side_done)      # a wait of the STREAM: the host queues on
             loss, virt = _AssignNLL.apply(prob, labels_gt, stuff_mask, w["labels"], w["targets"], w["info"])
             self.last_virtual_labels = virt
             return loss
@@ -282,7 +301,7 @@ class LinAssignmentThingsLoss(nn.Module):
         fast = self._gate(inst_probabilities, labels_gt, stuff_mask, points_3d)
         if fast is None:
             return ("general", inst_probabilities, labels_gt, stuff_mask, points_3d)
-        return ("fast", self._begin(*fast), inst_probabilities, labels_gt, stuff_mask, points_3d)
+        return ("fast", self._begin(*fast, side=True), inst_probabilities, labels_gt, stuff_mask, points_3d)
 
     def finish(self, pending):
         if pending[0] == "fast":
