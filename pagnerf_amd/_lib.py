@@ -208,7 +208,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """The raw handle of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object per call (~10 us: a tenth of
+    the host time of a forward-only trace, which asks nine times); the C-level getter returns the same handle in well under a microsecond."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

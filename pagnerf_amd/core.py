@@ -112,7 +112,12 @@ def batch_render(pipeline, rays, channels=("rgb",), render_batch=4000, cam_ids=N
     everything rendered so far for every chunk (116 chunks of a 720 x 1280 image: ~45 GB of copies for 0.8 GB of output)."""
     if hasattr(pipeline, "transform_rays") and cam_ids is not None:
         rays = pipeline.transform_rays(rays, cam_ids)
-    parts = [pipeline(rays=pack, lod_idx=None, channels=channels) for pack in rays.split(render_batch)]
+    tracer = getattr(pipeline, "tracer", None)
+    if tracer is not None and hasattr(tracer, "render_packs") and not torch.is_grad_enabled():
+        # this package's tracer marches pack i + 1 on a second stream while pack i is shaded (same launches, same values: PanopticPackedRFTracer.render_packs)
+        parts = tracer.render_packs(pipeline.nef, rays.split(render_batch), channels=channels, lod_idx=None)
+    else:
+        parts = [pipeline(rays=pack, lod_idx=None, channels=channels) for pack in rays.split(render_batch)]
     if not parts:
         return None
     if len(parts) == 1:

@@ -87,6 +87,24 @@ class OccupancyBLAS(nn.Module):
         m = ((bits[:, None] >> torch.arange(32, device=bits.device)) & 1).bool().reshape(-1)
         return m[:self.num_cells]
 
+    def raymarch_voxel_begin(self, rays, num_samples, max_travel=None):
+        """The voxel march's walk, queued (ops.raymarch_voxel_begin); raymarch_voxel_finish() sizes and fills the packed tensors.  raymarch(..., 'voxel') = both."""
+        bits = None if self._all_occupied else self.blas_bits
+        if bits is not None and bits.device != rays.origins.device:
+            self.blas_bits = bits = bits.to(rays.origins.device)
+        coarse = self._coarse_bits(bits) if bits is not None else None
+        return ops.raymarch_voxel_begin(rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, bits, self.blas_level, max_travel=max_travel,
+                                        occupancy_coarse_bits=coarse, want_packs=True)
+
+    def raymarch_voxel_finish(self, state, rays, num_samples):
+        ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack, ridx_sample, ridx64 = ops.raymarch_voxel_finish(state)
+        self._pack_cache = (ridx64, ridx_sample, pack_start, ray_of_pack)
+        if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
+            # pose gradient: the k samples of a ray's nuggets are its pack (pack_start counts samples) - the same per-ray segmented
+            # sums as in 'ray' mode (pag_ray_sample_grad: one launch, fixed order)
+            samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack, ridx=ridx_sample)
+        return ridx64, pidx, samples, depths[..., None], deltas[:, None], boundary
+
     accepts_max_travel = True      # raymarch(..., max_travel=) applies the tracer's travel filter inside the voxel walk
 
     def raymarch(self, rays, level=None, num_samples=64, raymarch_type="ray", jitter=None, max_travel=None):
@@ -98,16 +116,7 @@ class OccupancyBLAS(nn.Module):
         if bits is not None and bits.device != rays.origins.device:
             self.blas_bits = bits = bits.to(rays.origins.device)
         if raymarch_type == "voxel":
-            coarse = self._coarse_bits(bits) if bits is not None else None
-            ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack, ridx_sample, ridx64 = ops.raymarch_voxel(
-                rays.origins, rays.dirs, rays.dist_min, rays.dist_max, num_samples, bits, self.blas_level, max_travel=max_travel,
-                occupancy_coarse_bits=coarse, want_packs=True)
-            self._pack_cache = (ridx64, ridx_sample, pack_start, ray_of_pack)
-            if torch.is_grad_enabled() and (rays.origins.requires_grad or rays.dirs.requires_grad) and ridx.numel():
-                # pose gradient: the k samples of a ray's nuggets are its pack (pack_start counts samples) - the same per-ray segmented
-                # sums as in 'ray' mode (pag_ray_sample_grad: one launch, fixed order)
-                samples = ops.ray_samples(rays.origins, rays.dirs, samples, depths, pack_start, ray_of_pack, ridx=ridx_sample)
-            return ridx64, pidx, samples, depths[..., None], deltas[:, None], boundary
+            return self.raymarch_voxel_finish(self.raymarch_voxel_begin(rays, num_samples, max_travel), rays, num_samples)
         if raymarch_type != "ray":
             raise NotImplementedError("raymarch_type '%s'" % raymarch_type)
         ridx, pidx, samples, depths, deltas, boundary, pack_start, ray_of_pack, ridx64 = ops.raymarch_ray(

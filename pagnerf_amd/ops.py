@@ -1138,6 +1138,16 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     want_packs: also (pack_start i64[N+1] in samples, ray_of_pack i32[N] = arange, ridx_sample i32[M'*k], ridx64 i64[M']) - one
     (possibly empty) pack per ray, straight from the kernels: no unique / nonzero / repeat_interleave passes, and the sample
     count reaches the host through the polled mailbox of raymarch_ray()."""
+    return raymarch_voxel_finish(raymarch_voxel_begin(origins, dirs, dist_min, dist_max, samples_per_voxel, occupancy_bits, blas_level, max_travel,
+                                                      occupancy_coarse_bits, want_packs))
+
+
+def raymarch_voxel_begin(origins, dirs, dist_min, dist_max, samples_per_voxel, occupancy_bits=None, blas_level=7, max_travel=None,
+                         occupancy_coarse_bits=None, want_packs=False):
+    """First half of raymarch_voxel(): the walk (nugget counts / candidates) and the pack offsets are QUEUED, nothing is waited for.  -> state for
+    raymarch_voxel_finish(), which reads the sample count, sizes the packed tensors and queues the expansion.  A caller with several marches to do
+    (PanopticPackedRFTracer.render_packs) begins the next one before it finishes this one: the walk - a latency-bound DDA per ray - then runs while the
+    host is busy elsewhere, and the count is there when it is asked for."""
     _check_gpu(origins, dirs)
     dev = origins.device
     N, k = origins.shape[0], int(samples_per_voxel)
@@ -1165,6 +1175,14 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
     if mailbox is not None:
         mailbox[1][0] = -1
     _call("pag_pack_offsets", L.ptr(counts), N, L.ptr(pack_start), mailbox[0].data_ptr() if mailbox is not None else None, st)
+    return (origins, dirs, N, k, float(dist_min), float(dist_max), occupancy_bits, occupancy_coarse_bits, occ, coarse, blas_level, travel, counts, nug_t, nug_cell,
+            pack_start, mailbox, want_packs)
+
+
+def raymarch_voxel_finish(state):
+    (origins, dirs, N, k, dist_min, dist_max, _occ_t, _coarse_t, occ, coarse, blas_level, travel, counts, nug_t, nug_cell, pack_start, mailbox, want_packs) = state
+    dev = origins.device
+    st = L.stream()
     total = _poll_count(mailbox) if mailbox is not None else -1
     if total < 0:
         total = int(pack_start[N].item())          # stream-synchronising read-back
@@ -1185,7 +1203,7 @@ def raymarch_voxel(origins, dirs, dist_min, dist_max, samples_per_voxel, occupan
         _call("pag_raymarch_voxel_pack_nuggets", L.ptr(origins), L.ptr(dirs), N, k, L.ptr(pack_start), L.ptr(nug_t), L.ptr(nug_cell), blas_level,
               L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary), L.ptr(ridx_sample), L.ptr(ridx64), st)
     elif Mn:
-        _call("pag_raymarch_voxel_pack", L.ptr(origins), L.ptr(dirs), N, k, float(dist_min), float(dist_max), occ, coarse, blas_level,
+        _call("pag_raymarch_voxel_pack", L.ptr(origins), L.ptr(dirs), N, k, dist_min, dist_max, occ, coarse, blas_level,
               travel, L.ptr(pack_start), L.ptr(ridx), L.ptr(pidx), L.ptr(samples), L.ptr(depths), L.ptr(deltas), L.ptr(boundary),
               L.ptr(ridx_sample), L.ptr(ridx64), st)
     if want_packs:

@@ -57,6 +57,11 @@ class PanopticPackedRFTracer(nn.Module):
     def forward(self, nef, channels=None, extra_channels=None, **kwargs):
         """wisp BaseTracer.forward: trace() arguments come from kwargs, else
         from a same-named attribute of the tracer, else from the Python default."""
+        requested, extra, args = self._resolve(nef, channels, extra_channels, kwargs)
+        return self.trace(nef, requested - extra, extra, **args)
+
+    def _resolve(self, nef, channels, extra_channels, kwargs, skip=()):
+        """wisp BaseTracer.forward's bookkeeping: -> (requested channels, extra channels, trace() arguments from kwargs / attributes / defaults)."""
         missing = self.get_required_nef_channels() - nef.get_supported_channels()
         if missing:
             raise Exception("nef does not supply the channels this tracer needs: %s" % missing)
@@ -77,7 +82,7 @@ class PanopticPackedRFTracer(nn.Module):
         if sig is None:
             sig = _TRACE_PARAMS[type(self)] = tuple(inspect.signature(self.trace).parameters.items())
         for name, prm in sig:
-            if name in ("nef", "channels", "extra_channels"):
+            if name in ("nef", "channels", "extra_channels") or name in skip:
                 continue
             if name in kwargs:
                 args[name] = kwargs[name]
@@ -85,7 +90,7 @@ class PanopticPackedRFTracer(nn.Module):
                 args[name] = getattr(self, name)
             elif prm.default is not inspect.Parameter.empty:
                 args[name] = prm.default
-        return self.trace(nef, requested - extra, extra, **args)
+        return requested, extra, args
 
     def trace(self, nef, channels, extra_channels, rays, lod_idx=None, raymarch_type="voxel", num_steps=64, step_size=1.0,
               bg_color="white", stage="val", jitter=None):
@@ -103,15 +108,28 @@ class PanopticPackedRFTracer(nn.Module):
                 rb, gkey, jitter = self._graphs.run(self, nef, channels, rays, lod_idx, raymarch_type, num_steps, bg_color, stage, jitter)
                 if rb is not None:
                     return rb           # else: no capacity known yet, or this batch overflowed it - the eager path below, same jitter
+        marched = self._march(nef, rays, lod_idx, raymarch_type, num_steps, jitter)
+        if gkey is not None:
+            self._graphs.observe(gkey, marched[2].shape[0] * marched[6])
+        return self._shade_marched(nef, channels, extra_channels, rays, marched, lod_idx, bg_color, stage)
+
+    def _march(self, nef, rays, lod_idx, raymarch_type, num_steps, jitter=None, begun=None):
+        """The ray march of trace() (:85-114) with everything that needs the host (the sample count sizes the packed tensors) -
+        -> (ridx, pidx, samples, depths, deltas, boundary, k, ridx32, pack_start, ray_of_pack), the arguments of shade().
+        begun: the state of grid.raymarch_voxel_begin() for these rays (render_packs queues the walk of a later pack early)."""
+        dev = rays.origins.device
         kw = {"jitter": jitter} if jitter is not None else {}
         # voxel mode: grids of this package apply the travel filter of :88-108 inside the walk (pag_raymarch_voxel_*: same
         # strict `<` on the same fp32 difference) and hand back one pack per ray - no unique / repeat_interleave / mask passes
         filtered = raymarch_type == "voxel" and getattr(nef.grid, "accepts_max_travel", False)
         if filtered:
             kw["max_travel"] = self.ray_max_travel
-        ridx, pidx, samples, depths, deltas, boundary = nef.grid.raymarch(                 # :85-86
-            rays, level=nef.grid.active_lods[lod_idx], num_samples=num_steps, raymarch_type=raymarch_type, **kw)
-        if samples.shape[0] and hasattr(nef, "prefetch_features") and (raymarch_type == "ray" or filtered):
+        if begun is not None:
+            ridx, pidx, samples, depths, deltas, boundary = nef.grid.raymarch_voxel_finish(begun, rays, num_steps)
+        else:
+            ridx, pidx, samples, depths, deltas, boundary = nef.grid.raymarch(                 # :85-86
+                rays, level=nef.grid.active_lods[lod_idx], num_samples=num_steps, raymarch_type=raymarch_type, **kw)
+        if samples.shape[0] and hasattr(nef, "prefetch_features") and (raymarch_type == "ray" or filtered) and self._prefetch:
             nef.prefetch_features(samples)        # first encode launch queued before the bookkeeping below (GPU idle otherwise)
         if raymarch_type == "voxel" and depths.numel() != 0 and not filtered:             # :88-108
             # drop nuggets further than ray_max_travel past the first hit of their ray (strict <)
@@ -125,17 +143,86 @@ class PanopticPackedRFTracer(nn.Module):
             boundary = boundary.reshape(depths.shape)[valid_mask].reshape(-1)
             ridx, pidx, samples, depths = ridx[valid_mask], pidx[valid_mask], samples[valid_mask], depths[valid_mask]
         k = samples.shape[1] if samples.dim() == 3 else 1                                   # samples per pack entry
-        if gkey is not None:
-            self._graphs.observe(gkey, samples.shape[0] * k)
         cache = getattr(nef.grid, "_pack_cache", None)
         if cache is not None and cache[0] is ridx:
             _, ridx32, pack_start, ray_of_pack = cache
         else:                                                                              # :114
             ridx32 = ridx.int() if k == 1 else ridx.int().repeat_interleave(k)            # one entry per SAMPLE
             pack_start, ray_of_pack = ops.packs_from_boundary(ridx32, boundary)
-        outputs = self.shade(nef, channels, extra_channels, rays.dirs, N, ridx, ridx32, pidx, samples, depths, deltas, pack_start,
+        return ridx, pidx, samples, depths, deltas, boundary, k, ridx32, pack_start, ray_of_pack
+
+    def _shade_marched(self, nef, channels, extra_channels, rays, marched, lod_idx, bg_color, stage):
+        ridx, pidx, samples, depths, deltas, _boundary, _k, ridx32, pack_start, ray_of_pack = marched
+        outputs = self.shade(nef, channels, extra_channels, rays.dirs, rays.origins.shape[0], ridx, ridx32, pidx, samples, depths, deltas, pack_start,
                              ray_of_pack, lod_idx, bg_color, stage)
         return RenderBuffer(**outputs)
+
+    _prefetch = True
+
+    def render_packs(self, nef, packs, channels=None, extra_channels=None, **kwargs):
+        """The reference's validation loop `for ray_pack in rays.split(render_batch): rb += pipeline(rays=ray_pack, ...)` (pc_nerf/trainer.py:637-649) with the
+        ray march of pack i + 1 running on a SECOND STREAM while pack i is shaded: the march is a latency-bound walk (a 128^3 DDA per ray: ~80 us whether 8 000 or
+        32 768 rays are in flight) whose sample count the host must read before it can size the packed tensors - in the plain loop the GPU idles through both, 116
+        times per 720 x 1280 image at the reference's render_batch 8000.  Same launches on the same data in the same order per stream: the buffers are bit-identical
+        to the plain loop's.  -> list of RenderBuffers, one per pack.  Inference only (torch.no_grad(); the caller's traces that need gradients go through
+        forward())."""
+        packs = list(packs)
+        if not packs:
+            return []
+        own = type(self).shade is PanopticPackedRFTracer.shade and type(self).trace is PanopticPackedRFTracer.trace      # subclasses with their own trace / shade: the plain loop
+        if torch.is_grad_enabled() or not packs[0].origins.is_cuda or not own:
+            return [self.forward(nef, channels=channels, extra_channels=extra_channels, rays=p, **kwargs) for p in packs]
+        requested, extra, args = self._resolve(nef, channels, extra_channels, kwargs, skip=("rays",))
+        lod_idx = args.get("lod_idx")
+        if lod_idx is None:
+            lod_idx = nef.grid.num_lods - 1
+        rm, steps, bg, stage, jitter = args["raymarch_type"], args["num_steps"], args["bg_color"], args.get("stage", "val"), args.get("jitter")
+        if jitter is not None:
+            return [self.forward(nef, channels=channels, extra_channels=extra_channels, rays=p, **kwargs) for p in packs]
+        dev = packs[0].origins.device
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_march_stream", None)
+        if side is None or side.device != dev:
+            side = self._march_stream = torch.cuda.Stream(device=dev)
+        out = []
+
+        side.wait_stream(main)                           # the rays come from the caller's stream - waited for ONCE: a wait per pack would put the march of
+                                                         # pack i + 1 behind the shading of pack i, which is queued on that stream by then
+
+        # two deep for the voxel march of this package's grids: the walk of pack i + 2 is QUEUED (grid.raymarch_voxel_begin) before the host asks for the sample
+        # count of pack i + 1, so the count is there when asked for; other marches (the 'ray' march: device-bound anyway) one deep
+        split = rm == "voxel" and getattr(nef.grid, "accepts_max_travel", False) and hasattr(nef.grid, "raymarch_voxel_begin")
+
+        def begin(pack):
+            if not split:
+                return None
+            with torch.cuda.stream(side):
+                return nef.grid.raymarch_voxel_begin(pack, steps, self.ray_max_travel)
+
+        def march(pack, begun):
+            with torch.cuda.stream(side):
+                m = self._march(nef, pack, lod_idx, rm, steps, None, begun=begun)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for t in m:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)                # allocated under the side stream, consumed (and released) on the caller's
+            return m, ev
+        self._prefetch = False                           # the first encode launch belongs to the shading stream
+        try:
+            b1 = begin(packs[1]) if len(packs) > 1 else None
+            nxt = march(packs[0], begin(packs[0]))
+            for i, pack in enumerate(packs):
+                marched, ev = nxt
+                main.wait_event(ev)
+                out.append(self._shade_marched(nef, requested - extra, extra, pack, marched, lod_idx, bg, stage))     # queued on the caller's stream ...
+                if i + 1 < len(packs):
+                    b2 = begin(packs[i + 2]) if i + 2 < len(packs) else None
+                    nxt = march(packs[i + 1], b1)        # ... and running while the host waits for the next pack's sample count
+                    b1 = b2
+        finally:
+            self._prefetch = True
+        return out
 
     def shade(self, nef, channels, extra_channels, ray_dirs, N, ridx, ridx32, pidx, samples, depths, deltas, pack_start, ray_of_pack,
               lod_idx, bg_color, stage):

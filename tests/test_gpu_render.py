@@ -71,13 +71,18 @@ def test_inference_trace_writes_no_training_only_tensors(gpu_device, mode):
     assert all(not t.requires_grad for t in (rb.rgb, rb.semantics, rb.inst_embedding))
 
 
-def test_batch_render_image_equals_per_chunk_traces(gpu_device):
+@pytest.mark.parametrize("mode", ["ray", "voxel"])
+def test_batch_render_image_equals_per_chunk_traces(gpu_device, mode):
     """pagnerf_amd.batch_render (trainer.py:637-649): a 60 x 40 'image' in chunks of 700 rays equals the concatenation of the
     per-chunk traces and - rays are independent - one trace of all rays, bit for bit (dense occupancy: no jitter-free march needed,
-    the jitter is fixed per chunk through the generator)."""
+    the jitter is fixed per chunk through the generator).  batch_render marches pack i + 1 on a second stream while pack i is shaded
+    (PanopticPackedRFTracer.render_packs): the plain loop beside it is the reference's; 'voxel' = the march every validation after the first prune runs."""
     import pagnerf_amd
     dev = gpu_device
     nef, tracer, rays, occ, _ = T._make_scene(dev, "bf16", N=2400, S=32)
+    if mode == "voxel":
+        tracer.raymarch_type, tracer.num_steps, tracer.ray_max_travel = "voxel", 2, 0.8
+        rays.dist_max = 3.0
     pipe = pagnerf_amd.Pipeline(nef, tracer)
     chunk = 700
     with torch.no_grad():
