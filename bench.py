@@ -47,6 +47,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA ~2.5 PFLOP/s
+SETTLE_STEPS = 6             # untimed steps between the interpreter's garbage collection and the barrier that opens a timed region (Job.timed)
 LINE_BUDGET = 4096           # the driver parses the LAST stdout line: round 5's grew to 32 KB and was recorded as `parsed: null`
 
 
@@ -1007,6 +1008,11 @@ def run_rank(args):
             gc.collect()
             gc_was = gc.isenabled()
             gc.disable()
+            # the collection above leaves the GPU idle for ~10 ms and the chip answers with a few slow steps (scripts/step_series.py: 3.73, 3.61, 3.56, 3.55 ms
+            # after such a pause against 3.43 in steady state): a handful of UNTIMED steps bring it back to the state every other step of a training run sees
+            # before the barrier + synchronize that open the timed region (reported as config.settle_steps)
+            for _ in range(SETTLE_STEPS if profile is None else 0):
+                self.step(channels)
             barrier()
             if profile is not None:
                 ops.profile_start(only=profile)
@@ -1112,6 +1118,7 @@ def run_rank(args):
                     rays_per_gpu=args.rays, samples_per_ray=args.samples, grid=args.grid, channels=sorted(channels),
                     raymarch=args.raymarch, half_coords=(args.grid == "permuto" and not args.fp32_coords), table_dtype=args.table_dtype,
                     hip_graphs=bool(graphs_on and job.tracer.use_graphs is True), static_buffers=bool(job.tracer.use_graphs == "static"),
+                    settle_steps=SETTLE_STEPS,
                     parallelism="ray-sharded data parallel x%d" % world),
         rccl_ranks_seen=ranks_seen, backend=backend, grad_sync=((job.sync.auto_decision or args.grad_sync) if world > 1 else None), roofline=roofline,
         graphs=(dict(job.graph_stats(), priming_steps=priming) if job.graph_stats() is not None else None))

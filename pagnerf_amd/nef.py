@@ -13,6 +13,7 @@ ray and gathered through ridx instead of being repeated per sample.
 """
 import copy
 import inspect
+import os
 
 import numpy as np
 import torch
@@ -329,6 +330,26 @@ class PanopticDeltaNeF(nn.Module):
         grp = self._pan_grouped()
         return (pan, grp), (pan, grp)
 
+    WIDE_HEAD_PAD = os.environ.get("PAG_WIDE_HEAD_PAD", "1") != "0"
+
+    def _wide_head_weights(self, dec, x):
+        """(weights, biases) of a wide softmax head for the fused kernels.  The dedicated wide-softmax kernels (one-launch forward with the per-ray sum,
+        statistics-only forward, block-wise backward: include/pagnerf_hip.h) are written for best.yaml's THREE-layer 200-way head (`inst_num_layers: 2`,
+        pc_nerf/panoptic_nef.py:157-164).  The two-layer head of `inst_num_layers: 1` (configs/bup20/config_hp_base.yaml:71, lin_assign_delta_app.yaml:120 and
+        two more YAMLs) reaches them as the same network with an IDENTITY middle layer: h1 = relu(I h0 + 0) = h0 bit for bit (h0 is a ReLU output already
+        rounded to bf16; every product is h0[k] x 1 or x 0 and the fp32 accumulator holds h0[j] exactly), and backwards dz0 = (I^T dz1) masked by h0 > 0 - the
+        mask dz1 already carries - so the values are those of the two-layer network at ~12 % more decoder arithmetic, instead of the generic kernels'
+        +23 % of the whole step.  The identity and the zero bias are constants (no gradient; what the kernels form for them is dropped).
+        PAG_WIDE_HEAD_PAD=0 keeps the generic path."""
+        W, b = dec.weights()
+        if not (self.WIDE_HEAD_PAD and len(W) == 2 and x.is_cuda and self.precision == "bf16" and W[0].shape[0] == 64 and 192 < W[1].shape[0] <= 224
+                and b[0] is not None and b[1] is not None):
+            return W, b
+        pad = getattr(self, "_wide_pad", None)
+        if pad is None or pad[0].device != W[0].device:
+            pad = self._wide_pad = (torch.eye(64, device=W[0].device), torch.zeros(64, device=W[0].device))
+        return [W[0], pad[0], W[1]], [b[0], pad[1], b[1]]
+
     def can_fuse_panoptic(self, channels):
         """True when the semantic / instance heads can run as decoder + compositing in one autograd node."""
         if self.precision != "bf16" or self._pan_grouped() is None:
@@ -357,13 +378,14 @@ class PanopticDeltaNeF(nn.Module):
         out = {}
         if "semantics" in channels and "inst_embedding" in channels and sem_in is inst_in and sem_grp is not None:
             # both heads read the same features: one autograd node, the input gradient is summed inside the kernels
-            heads = tuple((*dec.weights(), dec.input_dim) for dec in (self.decoder_inst, self.decoder_semantics))
+            heads = ((*self._wide_head_weights(self.decoder_inst, sem_in), self.decoder_inst.input_dim),
+                     (*self.decoder_semantics.weights(), self.decoder_semantics.input_dim))
             out["inst_embedding"], out["semantics"] = ops.head_composite_pair(sem_in, heads, w, alpha, ridx, pack_start, ray_of_pack, N,
                                                                               out_dtype=self.feat_dtype, x1_grouped=sem_grp)
             return out
         for ch, dec, x, grp in (("semantics", self.decoder_semantics, sem_in, sem_grp), ("inst_embedding", self.decoder_inst, inst_in, inst_grp)):
             if ch in channels:
-                W, b = dec.weights()
+                W, b = self._wide_head_weights(dec, x) if ch == "inst_embedding" else dec.weights()
                 out[ch] = ops.head_composite(x, W, b, w, alpha, ridx, pack_start, ray_of_pack, N, in_dim=dec.input_dim,
                                              out_act=L.ACT_SOFTMAX, out_dtype=self.feat_dtype, x1_grouped=grp)
         return out

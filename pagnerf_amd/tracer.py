@@ -183,7 +183,10 @@ class PanopticPackedRFTracer(nn.Module):
         main = torch.cuda.current_stream(dev)
         side = getattr(self, "_march_stream", None)
         if side is None or side.device != dev:
-            side = self._march_stream = torch.cuda.Stream(device=dev)
+            # high priority: its own hardware queue class (a process that has created many streams - graph captures, other side streams - otherwise
+            # finds this one sharing a queue with the caller's stream, and the march serialises behind the shading it should run beside); the march
+            # kernels are short walks that should never wait behind a 100 us decoder launch
+            side = self._march_stream = torch.cuda.Stream(device=dev, priority=-1)
         out = []
 
         side.wait_stream(main)                           # the rays come from the caller's stream - waited for ONCE: a wait per pack would put the march of
