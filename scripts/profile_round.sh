@@ -14,11 +14,12 @@ python3 scripts/pmc_traffic.py $(find $out/fetch -name "*counter_collection.csv"
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 rm -rf $out/trace $out/fetch $out/write
 # the step best.yaml runs (6 images x 4096 rays, pose optimisation): kernel stats of its three regimes
-for reg in "dense_rgbd:--channels rgbd" "post_prune_rgbd:--raymarch voxel --channels rgbd" "post_prune_all_assign:--raymarch voxel --channels all --lin-assign --two-call"; do
+for reg in "dense_rgbd:--channels rgbd" "post_prune_rgbd:--raymarch voxel --channels rgbd" "post_prune_all_assign:--raymarch voxel --channels all --lin-assign --two-call" "post_prune_all_assign_one_backward:--raymarch voxel --channels all --lin-assign"; do
   name=${reg%%:*}; flags=${reg#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$name -- python3 bench.py --pose-opt --rays 24576 $flags --steps 5 --warmup 3 --no-cpu-baseline --no-aux > $out/bench_${name}_under_rocprof.json 2> $out/t_$name.err
   cp $(find $out/t_$name -name "*kernel_stats.csv" | head -1) $out/kernel_stats_best_yaml_$name.csv
   rm -rf $out/t_$name
 done
 python3 bench.py > $out/bench_default_run.json 2> $out/bench_default.err
+cp bench_detail.json $out/bench_detail.json        # the full record behind the compact line (round 6: the line itself stays under 4 KB)
 tail -c 600 $out/bench_default_run.json
