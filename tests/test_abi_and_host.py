@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 13
 
 
 def test_assignment_entry_points_validate_without_gpu(lib):
@@ -69,6 +69,11 @@ def test_pose_entry_points_validate_without_gpu(lib):
     assert lib.pag_segment_reg_fwd(buf, 1, 8, 16, 2, 2, 0.0, None, buf, need, buf, None) == -1 and b"NULL" in lib.pag_last_error_string()
     assert lib.pag_segment_reg_fwd(buf, 1, 8, 16, 2, 2, 0.0, buf, buf, 64, buf, None) == -1 and b"workspace" in lib.pag_last_error_string()
     assert lib.pag_segment_reg_bwd(buf, 1, 8, 16, 2, 2, 0.0, buf, 64, buf, buf, None) == -1 and b"workspace" in lib.pag_last_error_string()
+    # the device Hungarian step (ABI 13): shapes beyond one wave's 256 x 256 and NULL buffers are refused before any launch; no image = no-op
+    assert lib.pag_assign_solve(None, 0, 199, 199, None, None, None, None, None) == 0
+    assert lib.pag_assign_solve(buf, 1, 257, 199, buf, None, buf, buf, None) == -1 and b"max_rows" in lib.pag_last_error_string()
+    assert lib.pag_assign_solve(buf, 1, 199, 300, buf, None, buf, buf, None) == -1
+    assert lib.pag_assign_solve(buf, 1, 199, 199, buf, None, None, buf, None) == -1 and b"NULL" in lib.pag_last_error_string()
     assert lib.pag_view_embed_bwd(None, 0, 4, 32, None, None, None) == 0
     assert lib.pag_view_embed_bwd(buf, 2, 4, 16, buf, buf, None) == -1                                        # width < 3 + 6 n_freq
     assert lib.pag_view_embed_bwd(buf, 2, 4, 32, None, buf, None) == -1
