@@ -314,7 +314,7 @@ def encode(xyz, tables, spec, feat_scale=None, out_dtype=torch.float32, feature_
         if depths.numel() == xyz.shape[0] and ridx.numel() == xyz.shape[0]:
             # (xyz enters detached: as a differentiable input its _RaySamples node would still be run - on materialised zeros - by the engine)
             return _EncodeRays.apply(origins, dirs, xyz.detach(), tables, spec, feat_scale, out_dtype, layout == "xcd8", flags, depths, pack_start, ridx)
-    return _Encode.apply(xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major, addend, flags)
+    return _apply(_Encode, xyz, tables, spec, feat_scale, out_dtype, "xcd8" if layout == "xcd8" else feature_major, addend, flags)
 
 
 def xcd8_supported(n_levels, n_feat):
@@ -416,6 +416,37 @@ _NO_FAST_FWD = os.environ.get("PAG_NO_FAST_FWD") is not None
 _OUTER_GRAD = True          # grad mode of the code that called the decoder op (see _apply_decoder)
 
 
+class _InferCtx:
+    """Stand-in for the autograd ctx of a Function whose result nobody will differentiate (torch.no_grad(): validation renders, prune): nothing is saved,
+    nothing needs a gradient; attributes a forward() parks on the ctx for its backward land on a plain object and die with it."""
+    saved_tensors = ()
+
+    def __init__(self, n):
+        self.needs_input_grad = (False,) * n
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def __getattr__(self, name):          # only reached for attributes nobody set: the optional hand-offs (fwd_pair, fwd_hold, ...) read as absent
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return None
+
+
+def _apply(fn, *args):
+    """fn.apply(*args); under torch.no_grad() the forward is called directly with an _InferCtx - torch.autograd.Function.apply costs 10 - 15 us of host time
+    per call whether or not a graph is recorded, six to eight of them per forward-only trace (a third of the host side of a validation pack)."""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_InferCtx(len(args)), *args)
+
+
 def _apply_decoder(fn, *args):
     """fn.apply(*args) with the caller's grad mode visible to the forward: under torch.no_grad() (validation renders, prune) the decoder
     launches keep nothing for a backward - no hidden activations, no softmax statistics beyond what the statistics-only wide head hands to
@@ -423,7 +454,7 @@ def _apply_decoder(fn, *args):
     global _OUTER_GRAD
     prev, _OUTER_GRAD = _OUTER_GRAD, torch.is_grad_enabled()
     try:
-        return fn.apply(*args)
+        return _apply(fn, *args)
     finally:
         _OUTER_GRAD = prev
 
@@ -1006,7 +1037,7 @@ class _ViewEmbed(torch.autograd.Function):
 def view_embed_grad(dirs, n_freq, width):
     """view_embed() differentiable with respect to `dirs` (f32 [R,3] on the GPU)."""
     _check_gpu(dirs)
-    return _ViewEmbed.apply(dirs, n_freq, width)
+    return _apply(_ViewEmbed, dirs, n_freq, width)
 
 
 class _PoseRays(torch.autograd.Function):
@@ -1393,7 +1424,7 @@ class _Composite(torch.autograd.Function):
 
 def composite(sigma, rgb, deltas, depths, pack_start, ray_of_pack, N, bg_white=True):
     """-> (alpha [N], hit u8 [N], rgb [N,3] | None, depth [N] | None, weights [M]); tracer :134-176."""
-    return _Composite.apply(sigma, rgb, deltas, depths, pack_start, ray_of_pack, N, bg_white)
+    return _apply(_Composite, sigma, rgb, deltas, depths, pack_start, ray_of_pack, N, bg_white)
 
 
 class _CompositeFeats(torch.autograd.Function):
@@ -1431,7 +1462,7 @@ class _CompositeFeats(torch.autograd.Function):
 
 def composite_feats(feats, weights, alpha, pack_start, ray_of_pack, N):
     """out[ray] = alpha[ray] * sum_i w_i feats[i]  (weights/alpha detached; tracer :148-155,:197-205)."""
-    return _CompositeFeats.apply(feats, weights, alpha, pack_start, ray_of_pack, N)
+    return _apply(_CompositeFeats, feats, weights, alpha, pack_start, ray_of_pack, N)
 
 
 class _CompositeFeatsWeights(torch.autograd.Function):
@@ -1496,7 +1527,7 @@ class _CompositeFeatsWeights(torch.autograd.Function):
 
 def composite_features(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N):
     """-> (out f32 [N,C], alpha f32 [N]) with gradients to sigma AND feats (delta-density tracer); ridx i32 [M]."""
-    return _CompositeFeatsWeights.apply(sigma, deltas, feats, ridx, pack_start, ray_of_pack, N)
+    return _apply(_CompositeFeatsWeights, sigma, deltas, feats, ridx, pack_start, ray_of_pack, N)
 
 
 HEAD_REBUILD = True      # wide softmax heads under head_composite(): statistics-only forward + rebuilt probabilities
