@@ -306,9 +306,11 @@ __device__ __forceinline__ T solve_pick4(const T (&a)[4], int k) {   // k is wav
 __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restrict__ cost, int R, int C, const int32_t *__restrict__ info,
                                                           const int32_t *__restrict__ lo_hi, int64_t *__restrict__ targets, int32_t *__restrict__ status) {
     constexpr int K = SOLVE_MAX / 64;
+    static_assert(K == 4, "the pass combines its four columns pairwise");
     // the cost matrix as fp32 in LDS (mask and NaN -> 0 applied; an infinity is kept as such and becomes +-DBL_MAX when it is widened): 61 labels x 199 columns
     __shared__ float stage[SOLVE_STAGE];
-    __shared__ double spc_l[SOLVE_MAX];
+    double *stage64 = reinterpret_cast<double *>(stage);       // the same 48 KiB as float64 when n * C <= SOLVE_STAGE / 2 (30 labels x 199): widened once, not per pass
+    __shared__ double spc_l[SOLVE_MAX], u_l[SOLVE_MAX];
     __shared__ int32_t path_l[SOLVE_MAX], row4col_l[SOLVE_MAX], col4row_l[SOLVE_MAX];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = info[b * 2], over = info[b * 2 + 1];
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
         return d;
     };
     const bool staged = n * C <= SOLVE_STAGE;
+    const bool staged64 = 2 * n * C <= SOLVE_STAGE;
     if (staged) {
         // four rows per trip: 16 independent loads in flight per lane (a row per trip cost one memory round trip per label: ~45 us of a 55 us solve)
         for (int r0 = 0; r0 < n; r0 += 4) {
@@ -355,19 +358,24 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
                     const int j = lane + 64 * k;
                     float g = f[a][k];
                     if (!(lo[a] <= j && j <= hi[a])) g = 10000.0f;
-                    if (j < C) stage[(r0 + a) * C + j] = g != g ? 0.0f : g;
+                    g = g != g ? 0.0f : g;
+                    if (j < C) {
+                        if (staged64) stage64[(r0 + a) * C + j] = g == INFINITY ? 1.7976931348623157e308 : (g == -INFINITY ? -1.7976931348623157e308 : (double)g);
+                        else stage[(r0 + a) * C + j] = g;
+                    }
                 }
             }
         }
     }
     double spc[K], v[K], u[K];
     int r4c[K], pos[K], pth[K], c4r[K];
+    uint32_t qk[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         v[k] = 0.0, u[k] = 0.0, r4c[k] = -1, pth[k] = -1, c4r[k] = -1, spc[k] = INFINITY, pos[k] = -2;
         const int j = lane + 64 * k;
         if (j < C) row4col_l[j] = -1;
-        if (j < n) col4row_l[j] = -1;
+        if (j < n) col4row_l[j] = -1, u_l[j] = 0.0;
     }
     __syncthreads();
     for (int cur = 0; cur < n; ++cur) {
@@ -376,6 +384,8 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
             const int j = lane + 64 * k;
             spc[k] = INFINITY;
             pos[k] = j < C ? C - 1 - j : -2;                    // SciPy fills `remaining` in reverse order; -1 = scanned (SC), -2 = no such column
+            // the tie code of an unscanned column (see above): kept in a register, touched only when the column's position changes
+            qk[k] = j < C ? (r4c[k] == -1 ? (uint32_t)(255 - pos[k]) : (uint32_t)(256 + pos[k])) : 0xFFFFFFFFu;
         }
         unsigned sr_bits = 0;
         int n_rem = C, i = cur, sink = -1;
@@ -383,33 +393,38 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
         while (sink < 0) {
             const int irow_lane = i & 63, irow_k = i >> 6;
             if (lane == irow_lane) sr_bits |= 1u << irow_k;                       // SR[i] = true
-            double ui;
-            {
-                const double mine = solve_pick4(u, irow_k);
-                const long long bits = __double_as_longlong(mine);
-                const int lo = __builtin_amdgcn_readlane((int)bits, irow_lane), hi = __builtin_amdgcn_readlane((int)(bits >> 32), irow_lane);
-                ui = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-            }
+            const double ui = u_l[i];                                            // an LDS broadcast (the register copy sat behind a four-way branch on i >> 6)
             double bm = INFINITY;
             uint32_t bq = 0xFFFFFFFFu;
             if (staged) {          // wave-uniform; the pass itself is straight-line code: selects, no branches
+                double sk[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int j = lane + 64 * k;
-                    const bool act = pos[k] >= 0;
-                    const float cf = stage[i * C + (j < C ? j : 0)];
-                    double c = (double)cf;
-                    c = cf == INFINITY ? 1.7976931348623157e308 : (cf == -INFINITY ? -1.7976931348623157e308 : c);
+                    const int e = i * C + (j < C ? j : 0);
+                    double c;
+                    if (staged64) {
+                        c = stage64[e];
+                    } else {
+                        const float cf = stage[e];
+                        c = (double)cf;
+                        c = cf == INFINITY ? 1.7976931348623157e308 : (cf == -INFINITY ? -1.7976931348623157e308 : c);
+                    }
                     const double r = ((min_val + c) - ui) - v[k];
-                    const bool better = act && r < spc[k];
+                    const bool act = qk[k] != 0xFFFFFFFFu;                       // unscanned and existing
+                    const bool better = act & (r < spc[k]);          // bitwise on purpose: `&&` / `||` become exec-mask branches in this loop
                     spc[k] = better ? r : spc[k];
                     pth[k] = better ? i : pth[k];
-                    const double sk = act ? spc[k] : (double)INFINITY;
-                    const uint32_t q = !act ? 0xFFFFFFFFu : (r4c[k] == -1 ? (uint32_t)(255 - pos[k]) : (uint32_t)(256 + pos[k]));
-                    const bool take = sk < bm || (sk == bm && q < bq);
-                    bm = take ? sk : bm;
-                    bq = take ? q : bq;
+                    sk[k] = act ? spc[k] : (double)INFINITY;
                 }
+                // pairwise: (0,1), (2,3), then the two winners - two dependent compares instead of four
+                const bool t01 = (sk[1] < sk[0]) | ((sk[1] == sk[0]) & (qk[1] < qk[0]));
+                const bool t23 = (sk[3] < sk[2]) | ((sk[3] == sk[2]) & (qk[3] < qk[2]));
+                const double m01 = t01 ? sk[1] : sk[0], m23 = t23 ? sk[3] : sk[2];
+                const uint32_t q01 = t01 ? qk[1] : qk[0], q23 = t23 ? qk[3] : qk[2];
+                const bool tt = (m23 < m01) | ((m23 == m01) & (q23 < q01));
+                bm = tt ? m23 : m01;
+                bq = tt ? q23 : q01;
             } else {
 #pragma unroll 1
                 for (int k = 0; k < K; ++k) {
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
                             spc[k] = r;
                             pth[k] = i;
                         }
-                        const uint32_t q = r4c[k] == -1 ? (uint32_t)(255 - pos[k]) : (uint32_t)(256 + pos[k]);
+                        const uint32_t q = qk[k];
                         if (spc[k] < bm || (spc[k] == bm && q < bq)) bm = spc[k], bq = q;
                     }
                 }
@@ -464,8 +479,10 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
             const int tail = n_rem - 1;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if (pos[k] == index) pos[k] = -1;                               // SC[j] = true; remaining[index] = remaining[--n_rem]
-                else if (pos[k] == tail) pos[k] = index;
+                const bool gone = pos[k] == index, moved = (pos[k] == tail) & !gone;      // SC[j] = true; remaining[index] = remaining[--n_rem]
+                pos[k] = gone ? -1 : (moved ? index : pos[k]);
+                // q = 255 - pos (free) or 256 + pos: the moved column's position drops from `tail` to `index`
+                qk[k] = gone ? 0xFFFFFFFFu : (moved ? (qk[k] < 256u ? qk[k] + (uint32_t)(tail - index) : qk[k] - (uint32_t)(tail - index)) : qk[k]);
             }
             --n_rem;
             if (free_col) sink = jsel; else i = owner;
@@ -483,6 +500,7 @@ __global__ __launch_bounds__(64) void assign_solve_kernel(const float *__restric
             if (r < n) {
                 if (r == cur) u[k] += min_val;
                 else if ((sr_bits >> k) & 1u) u[k] += min_val - spc_l[c4r[k]];
+                u_l[r] = u[k];
             }
             if (pos[k] == -1) v[k] -= min_val - spc[k];
         }
