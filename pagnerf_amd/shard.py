@@ -166,6 +166,9 @@ SPARSE_GRANULE = 1024        # rows
 SPARSE_HISTORY = 8           # steps whose counts size the slots
 
 
+_BIT_WEIGHTS = {}         # device -> uint8 [8] (a per-step torch.tensor(..., device=) would be a synchronising copy)
+
+
 class SparseRows:
     """Touched-rows exchange of ONE table gradient [L, T, F] (levels x rows x features).
 
@@ -196,8 +199,9 @@ class SparseRows:
         self.mode, self.dense_fill, self.headroom = mode, float(dense_fill), float(headroom)
         self.history = []            # per finished step: list of L union counts
         self._pending = []           # (event or None, pinned / cpu tensor [L + 1]) not yet read
+        self._free_boxes = []        # pinned tensors read and ready for reuse
         self._caps = None            # per level: slots (T = whole level), host list
-        self._caps_dev = None
+        self._caps_dev = self._offs_dev = None
         self.stats = dict(steps=0, exchanged_bytes=0, dense_bytes=0, bitmap_bytes=0, dropped_rows=0, last_fill=None, last_slots=None)
         self._warned = False
 
@@ -210,6 +214,8 @@ class SparseRows:
         for ev, box in self._pending:
             if ev is None or ev.query():
                 vals = box.tolist()
+                if ev is not None and len(self._free_boxes) < 8:
+                    self._free_boxes.append(box)
                 self.history.append(vals[:-1])
                 self.history = self.history[-SPARSE_HISTORY:]
                 if vals[-1] > 0:
@@ -242,7 +248,9 @@ class SparseRows:
         pad = (-T) % 8
         if pad:
             mask = torch.cat([mask, mask.new_zeros(L, pad)], 1)
-        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], device=grad.device, dtype=torch.uint8)
+        w = _BIT_WEIGHTS.get(grad.device)
+        if w is None:
+            w = _BIT_WEIGHTS[grad.device] = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], device=grad.device, dtype=torch.uint8)
         bits = (mask.reshape(L, -1, 8).to(torch.uint8) * w).sum(-1, dtype=torch.uint8).reshape(-1)
         _, world = world_info()
         allb = torch.empty(world * bits.numel(), device=grad.device, dtype=torch.uint8)
@@ -266,8 +274,10 @@ class SparseRows:
             caps = [T if c > self.dense_fill * T else max(int(c), 1) for c in c_host]
         else:
             caps = self._plan(T, L)
-        if caps != self._caps:
+        if caps != self._caps or self._caps_dev is None or self._caps_dev.device != grad.device:
+            # two small host-to-device copies, only when the slots change (a per-step torch.tensor(..., device=) is a synchronising pageable copy)
             self._caps, self._caps_dev = caps, torch.tensor(caps, device=grad.device, dtype=torch.int32)
+            self._offs_dev = torch.tensor([sum(caps[:l]) for l in range(L)], device=grad.device, dtype=torch.int64)
         cap_dev = self._caps_dev
         total = int(sum(caps))
         st = self.stats
@@ -285,7 +295,7 @@ class SparseRows:
                 handle = dist.all_reduce(grad, op=op, async_op=True)
             st["exchanged_bytes"], st["last_slots"], st["whole_levels"] = L * T * F * (2 if half else 4), total, L
             return (grad, None, None, handle, divide, world)
-        offs = torch.tensor([sum(caps[:l]) for l in range(L)], device=grad.device, dtype=torch.int64)
+        offs = self._offs_dev
         whole = (cap_dev >= T)[:, None]
         member = union | whole                                         # a whole level: every row has a slot, its own
         pos = torch.cumsum(member, 1, dtype=torch.int32)
@@ -311,7 +321,10 @@ class SparseRows:
         """Per-level union counts (+ rows dropped) of this step towards the host, without waiting: pinned copy + event on a device, a plain copy on CPU."""
         box_dev = box_dev.to(torch.int64)
         if grad.is_cuda:
-            box = torch.empty(box_dev.numel(), dtype=torch.int64).pin_memory()
+            # pinned words come from a small pool (pin_memory() is a host allocation of its own: ~1 ms per call)
+            box = self._free_boxes.pop() if self._free_boxes else torch.empty(box_dev.numel(), dtype=torch.int64).pin_memory()
+            if box.numel() != box_dev.numel():
+                box = torch.empty(box_dev.numel(), dtype=torch.int64).pin_memory()
             box.copy_(box_dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
