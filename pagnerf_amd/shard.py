@@ -9,6 +9,9 @@ of rays against replicated tables / decoders / occupancy.  Two collectives exist
     from a post-accumulate hook, the rest (50.3 MB main table + 0.14 MB decoders) as ONE flat all_reduce (GradSync).
 Both are single large messages - on MI355X's point-to-point xGMI mesh a ring is bound by one link, so
 fewer, larger collectives let RCCL spread traffic over all 7 links.
+Options of GradSync: comm_dtype=torch.bfloat16 (bf16 messages, fp32 accumulation, two direct exchanges: _DirectReduce),
+comm_dtype="auto" (fp32 or bf16 by regime), sparse=True / "exact" (only the union of the ranks' touched table rows travels:
+SparseRows - measured a loss on an xGMI node, useful on slow interconnects).
 """
 import time
 
