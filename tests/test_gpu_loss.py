@@ -477,3 +477,43 @@ def test_device_and_host_solver_paths_are_identical(gpu_device):
         second = dv(pm, many, sm)
     assert dv.solver == "scipy" and any("switching to solver='scipy'" in str(c.message) for c in caught)
     assert torch.equal(second, hs(pm, many, sm))
+
+
+def test_training_with_the_device_solver_follows_the_host_solver_bit_for_bit(gpu_device):
+    """Twelve Adam steps of the late-training objective (rgb L1 + the per-image Hungarian instance term on the rendered probabilities, trainer.py:443-446,483-533)
+    on a small scene, once with LinAssignmentThingsLoss(solver="device") and once with solver="scipy", from the same initial state: the assignment indices are
+    the same integers every step, so the losses - and with them the parameters - are IDENTICAL, not merely close; ten of the steps also change the labels the
+    assignment picks (the head is being trained), so this is the solver under moving cost matrices, not one matrix twelve times."""
+    import copy
+    import pagnerf_amd
+    import test_gpu_parity as T
+    from pagnerf_amd import loss as pl
+    dev = gpu_device
+    N, S, B = 512, 32, 2
+    nef0, tracer, rays, occ, jitter = T._make_scene(dev, "bf16", N=N, S=S, cap_log2=12)
+    gen = torch.Generator().manual_seed(21)
+    gt_rgb = torch.rand(N, 3, generator=gen).to(dev)
+    ids = (torch.arange(N) * 9 // N + 1).reshape(B, -1)                      # nine instances over the two images
+    ids = torch.where(torch.rand(B, N // B, generator=gen) < 0.2, torch.zeros_like(ids), ids).to(dev)
+    stuff = (ids == 0)
+    jit = jitter.to(dev)
+    curves, labels = {}, {}
+    for solver in ("device", "scipy"):
+        nef = copy.deepcopy(nef0)
+        opt = pagnerf_amd.optim.Adam(nef.parameters(), lr=1e-2, eps=1e-15)
+        fn = pl.LinAssignmentThingsLoss(solver=solver)
+        out, lab = [], []
+        for it in range(12):
+            opt.zero_grad(set_to_none=True)
+            rb = tracer(nef, channels={"rgb", "inst_embedding"}, rays=rays, jitter=jit, stage="train")
+            inst = rb.inst_embedding.float().reshape(B, -1, rb.inst_embedding.shape[-1])
+            loss = 10.0 * torch.abs(rb.rgb - gt_rgb).mean() + 100.0 * fn(inst, ids, stuff).mean()
+            loss.backward()
+            opt.step()
+            out.append(loss.detach().clone())
+            lab.append(fn.last_virtual_labels.clone())
+        curves[solver], labels[solver] = torch.stack(out), torch.stack(lab)
+    assert torch.equal(curves["device"], curves["scipy"]), (curves["device"] - curves["scipy"]).abs().max()
+    assert torch.equal(labels["device"], labels["scipy"])
+    assert float(curves["device"][-1]) < float(curves["device"][0])                                   # it trains
+    assert int((labels["device"][1:] != labels["device"][:-1]).any(-1).any(-1).sum()) >= 1            # and the assignment moved while it did
