@@ -199,6 +199,26 @@ def _sparse_worker(rank, world, port, q):
                         assert all(torch.equal(chk[0], c) for c in chk[1:])
                     assert sync.sparse_stats()[0]["dropped_rows"] == 0
                     sync.remove()
+        # a row count that is no multiple of 8 (the bit-packing pads the last byte) with slots smaller than a level (granule 64 instead of 1024)
+        gran, shard.SPARSE_GRANULE = shard.SPARSE_GRANULE, 64
+        try:
+            Lo, To = 3, 1001
+            for mode in ("exact", "bounded"):
+                tab = torch.nn.Parameter(torch.zeros(Lo, To, F))
+                sync = shard.GradSync([tab], comm_dtype=None, big=1000, sparse=mode)
+                for step in range(3):
+                    g = _touched_grad(rank, step, Lo, To, F, [0.02, 0.1, 0.9], seed=3)
+                    st, mean = dense_reference(g)
+                    tab.grad = None
+                    (tab * g).sum().backward()
+                    sync.finish()
+                    assert torch.allclose(tab.grad, mean, rtol=1e-6, atol=1e-12), (mode, step)
+                    assert bool((tab.grad[~(st != 0).any(-1).any(0)] == 0).all())
+                stats = sync.sparse_stats()[0]
+                assert stats["bitmap_bytes"] == Lo * 126 and stats["whole_levels"] == 1 and stats["exchanged_bytes"] < stats["dense_bytes"] and stats["dropped_rows"] == 0, stats
+                sync.remove()
+        finally:
+            shard.SPARSE_GRANULE = gran
         # bounded mode when the regime changes under it: a level's union jumps past its slots.  The rows that do not fit are zero on EVERY rank alike
         # (replicas stay identical), counted, warned about once; the slots grow; reset_sparse() sends the next step whole
         tab = torch.nn.Parameter(torch.zeros(L, T, F))
