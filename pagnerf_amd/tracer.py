@@ -161,7 +161,7 @@ class PanopticPackedRFTracer(nn.Module):
 
     def render_packs(self, nef, packs, channels=None, extra_channels=None, **kwargs):
         """The reference's validation loop `for ray_pack in rays.split(render_batch): rb += pipeline(rays=ray_pack, ...)` (pc_nerf/trainer.py:637-649) with the
-        ray march of pack i + 1 running on a SECOND STREAM while pack i is shaded: the march is a latency-bound walk (a 128^3 DDA per ray: ~80 us whether 8 000 or
+        VOXEL march of pack i + 1 running on a SECOND STREAM while pack i is shaded ('ray' marches take the plain loop, below): the march is a latency-bound walk (a 128^3 DDA per ray: ~80 us whether 8 000 or
         32 768 rays are in flight) whose sample count the host must read before it can size the packed tensors - in the plain loop the GPU idles through both, 116
         times per 720 x 1280 image at the reference's render_batch 8000.  Same launches on the same data in the same order per stream: the buffers are bit-identical
         to the plain loop's.  -> list of RenderBuffers, one per pack.  Inference only (torch.no_grad(); the caller's traces that need gradients go through
@@ -195,6 +195,11 @@ class PanopticPackedRFTracer(nn.Module):
         # two deep for the voxel march of this package's grids: the walk of pack i + 2 is QUEUED (grid.raymarch_voxel_begin) before the host asks for the sample
         # count of pack i + 1, so the count is there when asked for; other marches (the 'ray' march: device-bound anyway) one deep
         split = rm == "voxel" and getattr(nef.grid, "accepts_max_travel", False) and hasattr(nef.grid, "raymarch_voxel_begin")
+        if not split:
+            # the 'ray' march is no latency-bound walk but a streaming writer (512 samples per ray: 0.55 GB per 32 768 rays): beside the shading it has nothing to
+            # hide - the dense image is device-bound either way - and its stores push the level tables out of the L2 / MALL the gathers live on (measured:
+            # 720 x 1280 dense image 241 -> 299 ms when the march overlapped, encode launches 10 % slower).  Plain loop.
+            return [self.forward(nef, channels=channels, extra_channels=extra_channels, rays=p, **kwargs) for p in packs]
 
         def begin(pack):
             if not split:
