@@ -1250,6 +1250,9 @@ def run_rank(args):
                       "before the host waits for the cost matrices, the panoptic half follows the assignment", "voxel", 2, set(all_ch), 2, 20))
             specs = specs + (("post_prune_all_assign_host_solver", late + "; ONE loss.backward(), LinAssignmentThingsLoss(solver='scipy'): cost matrices copied to the host, the step waits "
                               "for them and for SciPy (the default of round 5; the other two lines solve the assignment on the device)", "voxel", 2, set(all_ch), 4, 20),)
+            specs = specs + (("post_prune_all_assign_one_backward_trained_head", late + "; ONE loss.backward(), after 300 training steps of this very objective: the instance head then tells the "
+                              "labels apart, each label prefers its own columns and the device assignment takes a few dozen search passes per image instead of the ~300 of an UNTRAINED head "
+                              "(every label's mean row about the same: each new label's search walks through all the earlier ones) - what the late epochs of a run look like", "voxel", 2, set(all_ch), 5, 20),)
             specs = specs + (("dense_rgb_trained_scene", "the dense regime on a LEARNABLE scene (analytic textured sphere, white background) after 300 training steps: most "
                               "samples in front of the surface are empty space with sigma = relu(pre) = 0 exactly, their gradients are exactly zero and the encoders' backward "
                               "skips their waves (bin pass) and row requests (position gradient), bit-identically; the untrained random scene of the other lines has no such samples", "ray", 512, {"rgb", "depth"}, 3, 6),)
@@ -1264,14 +1267,14 @@ def run_rank(args):
                     j.gt["rgb"] = rgb_gt.to(dev)
                     for _ in range(300):
                         j.step()
-                host_solver = assign == 4
-                if host_solver:
+                host_solver, trained_head = assign == 4, assign == 5
+                if host_solver or trained_head:
                     assign = 1
                 if assign:
                     j.lin_assign, j.images, j.points_fn, j.seg_reg = LinAssignmentThingsLoss(outlier_rejection=True, solver="scipy" if host_solver else None), images, j.pose.points_3d, True
                 if assign == 2:
                     j.overlap, j.tracer.graph_split = True, True
-                for _ in range(4):                                  # step 0 learns the sample count, step 1 captures, 2 - 3 replay
+                for _ in range(304 if trained_head else 4):         # step 0 learns the sample count, step 1 captures, 2 - 3 replay
                     j.step()
                 d, _ = j.timed(n_steps)
                 ms = d / n_steps * 1e3
