@@ -22,7 +22,11 @@ equal N, as must `n_gpus`, or the run fails.  Next to the weak line the N > 1 ru
 `strong` (BASELINE configs[3]: 6 images x 4096 rays with ba_pipeline pose optimisation, the 24 576
 rays split over the ranks) and `render_sharded` (validation render + the all_gather of the buffers).
 
-The JSON line also carries
+Output: ONE compact JSON line (<= 4 KB, compact_line(): the contract's keys, `roofline` and `cpu_baseline` as flat objects, one number
+per extra measurement) as the LAST stdout line; the full record - every block below with its notes and per-entry-point tables - goes
+to bench_detail.json beside this file (and to gpurun_out/ when that exists; PAG_BENCH_DETAIL overrides the path), a digest to stderr.
+
+The record carries
   roofline      the permutohedral encode forward launch (the grid-interpolate kernel north_star sets
                 the 40 % HBM target on): algorithmic bytes per launch / its mean duration measured
                 with HIP events on the launch stream inside the timed region
