@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PAG_ABI_VERSION 13
+#define PAG_ABI_VERSION 14
 
 enum { PAG_F32 = 0, PAG_F16 = 1, PAG_BF16 = 2 };
 enum { PAG_OK = 0, PAG_ERR_ARG = -1, PAG_ERR_LAUNCH = -2, PAG_ERR_UNSUPPORTED = -3 };
@@ -701,6 +701,23 @@ int pag_pose_points(const float *params, int64_t C, const int32_t *cam, int64_t 
 /* Gradient of pag_view_embed with respect to the directions (the view direction depends on the camera rotation: pc_nerf/ba_pipeline.py:89-90
  * -> pc_nerf/panoptic_delta_nef.py:196-200): d_dirs f32 [R,3] from g_out f32 [R, width].  (ABI 11) */
 int pag_view_embed_bwd(const float *dirs, int64_t R, int n_freq, int width, const float *g_out, float *d_dirs, void *stream);
+
+/* Touched-rows exchange of a table gradient (ABI 14; this build's multi-GPU addition, pagnerf_amd/shard.py::SparseRows - the reference is single-GPU): the four passes
+ * around the collective.  After the first prune (configs/bup20/best.yaml:187, pc_nerf/trainer.py:362-366) the coarse and middle lattice levels touch few of their rows and
+ * pag_*_encode_bwd_set leaves exact zeros elsewhere, so only the UNION over the ranks of the non-zero rows has to travel.
+ *   pag_sparse_rows_mask    grad f32 [L][T][F] -> bits u32 [L][W], W = ceil(T / 32): bit r of word w = any(grad[l][32 w + r][:] != 0)
+ *                           (the caller all_gathers the ranks' bits and ORs them)
+ *   pag_sparse_rows_plan    union bits, caps i32 [L] (slots per level; caps[l] >= T: the level travels whole) -> word_prefix i32 [L][W] (union rows of the level before
+ *                           word w; 32 w for a whole level), counts i64 [L + 1] (union rows per level; [L] = rows that do not fit their level's slots)
+ *   pag_sparse_rows_pack    member rows in row order -> buf f32 [sum of slots][F] at offs[l] + rank while rank < caps[l] (offs i64 [L]); the caller zero-fills buf
+ *   pag_sparse_rows_unpack  EVERY row of grad rewritten: a member with rank < caps[l] takes buf[offs[l] + rank], any other row 0
+ * 1 <= F <= 64, T <= 2^31. */
+int pag_sparse_rows_mask(const float *grad, int L, int64_t T, int F, uint32_t *bits, void *stream);
+int pag_sparse_rows_plan(const uint32_t *bits, int L, int64_t T, const int32_t *caps, int32_t *word_prefix, int64_t *counts, void *stream);
+int pag_sparse_rows_pack(const float *grad, int L, int64_t T, int F, const uint32_t *bits, const int32_t *word_prefix, const int32_t *caps, const int64_t *offs,
+                         float *buf, void *stream);
+int pag_sparse_rows_unpack(const float *buf, int L, int64_t T, int F, const uint32_t *bits, const int32_t *word_prefix, const int32_t *caps, const int64_t *offs,
+                           float *grad, void *stream);
 
 #ifdef __cplusplus
 }

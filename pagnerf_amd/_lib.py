@@ -16,7 +16,7 @@ MLP_MFMA_BF16, MLP_FP32 = 0, 1
 BG_BLACK, BG_WHITE = 0, 1
 LAYOUT_STRIDED, LAYOUT_XCD8 = 0, 1
 ENC_HALF_COORDS = 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 MLP_FUSED_WIDE_MAX_M = 1 << 24      # PAG_MLP_FUSED_WIDE_MAX_M
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -124,6 +124,10 @@ _SIGS = {
     "pag_label_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "pag_assign_cost": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_i32,
                                 c_vp, c_vp, c_vp, c_vp]),
+    "pag_sparse_rows_mask": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    "pag_sparse_rows_plan": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "pag_sparse_rows_pack": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pag_sparse_rows_unpack": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_assign_solve": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_assign_nll_fwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pag_assign_nll_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -32,6 +32,7 @@ SOURCES = {
     "optim.hip": ["-ffp-contract=off"],      # Adam: torch's op order, no contraction beyond the explicit fmaf
     "pose.hip": ["-ffp-contract=off"],       # the camera transform in the tensor-op form's op order
     "regularizer.hip": ["-ffp-contract=off"],
+    "sparse.hip": [],                         # the touched-rows exchange's mask / plan / pack / unpack passes: integer and copy work only
 }
 
 

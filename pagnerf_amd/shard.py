@@ -11,7 +11,7 @@ Both are single large messages - on MI355X's point-to-point xGMI mesh a ring is 
 fewer, larger collectives let RCCL spread traffic over all 7 links.
 Options of GradSync: comm_dtype=torch.bfloat16 (bf16 messages, fp32 accumulation, two direct exchanges: _DirectReduce),
 comm_dtype="auto" (fp32 or bf16 by regime), sparse=True / "exact" (only the union of the ranks' touched table rows travels:
-SparseRows - measured a loss on an xGMI node, useful on slow interconnects).
+SparseRows: the exact-sum exchange a quarter cheaper after the prune, no match for the bf16 one on xGMI).
 """
 import time
 
@@ -169,6 +169,7 @@ SPARSE_GRANULE = 1024        # rows
 SPARSE_HISTORY = 8           # steps whose counts size the slots
 
 
+SPARSE_KERNELS = True      # GPU gradients: the mask / plan / pack / unpack passes of csrc/sparse.hip (False: the tensor-op form, as on CPU tensors)
 _BIT_WEIGHTS = {}         # device -> uint8 [8] (a per-step torch.tensor(..., device=) would be a synchronising copy)
 
 
@@ -266,7 +267,11 @@ class SparseRows:
         return un, bits.numel()
 
     def start(self, grad, comm_dtype, average):
-        """Queue the exchange of `grad` ([L, T, F], contiguous fp32); returns a token for finish()."""
+        """Queue the exchange of `grad` ([L, T, F], contiguous fp32); returns a token for finish().  GPU gradients take the four passes of csrc/sparse.hip
+        (pag_sparse_rows_mask / _plan / _pack / _unpack: ~170 MB of traffic for a 50 MB table); CPU tensors (the gloo tests) and SPARSE_KERNELS = False the
+        tensor-op form below - same slots, same values."""
+        if grad.is_cuda and SPARSE_KERNELS:
+            return self._start_kernels(grad, comm_dtype, average)
         L, T, F = grad.shape
         _, world = world_info()
         self._poll()
@@ -320,6 +325,61 @@ class SparseRows:
         st["exchanged_bytes"], st["last_slots"], st["whole_levels"] = total * F * (2 if half else 4), total, int(sum(1 for c in caps if c >= T))
         return (grad, buf, slot, handle, divide, world)
 
+    def _start_kernels(self, grad, comm_dtype, average):
+        from . import ops
+        L, T, F = grad.shape
+        W = (T + 31) // 32
+        dev = grad.device
+        _, world = world_info()
+        self._poll()
+        st_ = ops.L.stream
+        bits = torch.empty(L * W, device=dev, dtype=torch.int32)
+        ops._call("pag_sparse_rows_mask", grad.data_ptr(), L, T, F, bits.data_ptr(), st_())
+        allb = torch.empty(world * L * W, device=dev, dtype=torch.int32)
+        dist.all_gather_into_tensor(allb, bits)
+        allb = allb.reshape(world, -1)
+        union = allb[0].clone()
+        for r in range(1, world):
+            union |= allb[r]
+        prefix = torch.empty(L * W, device=dev, dtype=torch.int32)
+        counts = torch.empty(L + 1, device=dev, dtype=torch.int64)
+
+        def plan(caps):
+            if caps != self._caps or self._caps_dev is None or self._caps_dev.device != dev:
+                self._caps, self._caps_dev = caps, torch.tensor(caps, device=dev, dtype=torch.int32)
+                self._offs_dev = torch.tensor([sum(caps[:l]) for l in range(L)], device=dev, dtype=torch.int64)
+            ops._call("pag_sparse_rows_plan", union.data_ptr(), L, T, self._caps_dev.data_ptr(), prefix.data_ptr(), counts.data_ptr(), st_())
+        if self.mode == "exact":
+            plan([0] * L)                                              # counts only
+            c_host = counts[:L].tolist()                               # the one host wait of this mode
+            caps = [T if c > self.dense_fill * T else max(int(c), 1) for c in c_host]
+        else:
+            caps = self._plan(T, L)
+        plan(caps)
+        total = int(sum(caps))
+        st = self.stats
+        st["steps"] += 1
+        st["dense_bytes"], st["bitmap_bytes"] = L * T * F * 4, L * W * 4
+        half = comm_dtype is not None and comm_dtype != torch.float32
+        self._mail(counts, grad)
+        if total == L * T:                                             # every level whole: the plain exchange of the gradient itself
+            if half:
+                handle, divide = _DirectReduce(grad, comm_dtype, average), False
+            else:
+                op, divide = _reduce_op(average)
+                handle = dist.all_reduce(grad, op=op, async_op=True)
+            st["exchanged_bytes"], st["last_slots"], st["whole_levels"] = L * T * F * (2 if half else 4), total, L
+            return (grad, None, None, handle, divide, world)
+        buf = torch.zeros(total, F, device=dev)
+        ops._call("pag_sparse_rows_pack", grad.data_ptr(), L, T, F, union.data_ptr(), prefix.data_ptr(), self._caps_dev.data_ptr(), self._offs_dev.data_ptr(), buf.data_ptr(), st_())
+        if half:
+            handle, divide = _DirectReduce(buf, comm_dtype, average), False
+        else:
+            op, divide = _reduce_op(average)
+            handle = dist.all_reduce(buf, op=op, async_op=True)
+        st["exchanged_bytes"], st["last_slots"], st["whole_levels"] = total * F * (2 if half else 4), total, int(sum(1 for c in caps if c >= T))
+        return (grad, buf, ("kernels", union, prefix, self._caps_dev, self._offs_dev), handle, divide, world)
+
     def _mail(self, box_dev, grad):
         """Per-level union counts (+ rows dropped) of this step towards the host, without waiting: pinned copy + event on a device, a plain copy on CPU."""
         box_dev = box_dev.to(torch.int64)
@@ -345,6 +405,12 @@ class SparseRows:
             if divide:
                 (grad if buf is None else buf).div_(world)
         if buf is None:
+            return
+        if isinstance(slot, tuple):                                    # the kernel form: every row rewritten from its slot in one pass
+            from . import ops
+            _, union, prefix, caps_dev, offs_dev = slot
+            L, T, F = grad.shape
+            ops._call("pag_sparse_rows_unpack", buf.data_ptr(), L, T, F, union.data_ptr(), prefix.data_ptr(), caps_dev.data_ptr(), offs_dev.data_ptr(), grad.data_ptr(), ops.L.stream())
             return
         ext = torch.cat([buf, buf.new_zeros(1, buf.shape[1])], 0)
         grad.copy_(ext.index_select(0, slot).reshape(grad.shape))

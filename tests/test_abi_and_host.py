@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pag_abi_version() == _lib.ABI_VERSION == 13
+    assert lib.pag_abi_version() == _lib.ABI_VERSION == 14
 
 
 def test_assignment_entry_points_validate_without_gpu(lib):
@@ -74,6 +74,12 @@ def test_pose_entry_points_validate_without_gpu(lib):
     assert lib.pag_assign_solve(buf, 1, 257, 199, buf, None, buf, buf, None) == -1 and b"max_rows" in lib.pag_last_error_string()
     assert lib.pag_assign_solve(buf, 1, 199, 300, buf, None, buf, buf, None) == -1
     assert lib.pag_assign_solve(buf, 1, 199, 199, buf, None, None, buf, None) == -1 and b"NULL" in lib.pag_last_error_string()
+    # the touched-rows exchange's passes (ABI 14): sizes and NULL buffers are refused before any launch
+    assert lib.pag_sparse_rows_mask(buf, 0, 64, 2, buf, None) == -1 and lib.pag_sparse_rows_mask(buf, 4, 0, 2, buf, None) == -1
+    assert lib.pag_sparse_rows_mask(buf, 4, 64, 65, buf, None) == -1 and b"F 65" in lib.pag_last_error_string()
+    assert lib.pag_sparse_rows_mask(None, 4, 64, 2, buf, None) == -1 and b"NULL" in lib.pag_last_error_string()
+    assert lib.pag_sparse_rows_plan(buf, 4, 64, None, buf, buf, None) == -1
+    assert lib.pag_sparse_rows_pack(buf, 4, 64, 2, buf, buf, buf, None, buf, None) == -1 and lib.pag_sparse_rows_unpack(None, 4, 64, 2, buf, buf, buf, buf, buf, None) == -1
     assert lib.pag_view_embed_bwd(None, 0, 4, 32, None, None, None) == 0
     assert lib.pag_view_embed_bwd(buf, 2, 4, 16, buf, buf, None) == -1                                        # width < 3 + 6 n_freq
     assert lib.pag_view_embed_bwd(buf, 2, 4, 32, None, buf, None) == -1

@@ -104,6 +104,29 @@ for mode in ("exact", "bounded"):
                 assert stt["exchanged_bytes"] < 0.75 * Lv * Tv * Fv * (4 if comm is None else 2) and 0 < stt["whole_levels"] < Lv, stt
         assert sy.sparse_stats()[0]["dropped_rows"] == 0
         sy.remove()
+# the kernel passes (csrc/sparse.hip, the default on GPU gradients) and the tensor-op form give the same table, also when rows do not fit their slots
+for kern in (True, False):
+    shard.SPARSE_KERNELS = kern
+    tab = torch.nn.Parameter(torch.zeros(Lv, Tv, Fv, device=dev))
+    sy = shard.GradSync([tab], big=1 << 16, sparse="bounded")
+    g2 = torch.Generator(device=dev).manual_seed(77)
+    outs = []
+    for it, f in enumerate(([0.002] * Lv, [0.002] * Lv, [0.002] * 10 + [0.2] + [0.002] * (Lv - 11), [0.002] * 10 + [0.2] + [0.002] * (Lv - 11))):
+        keep = torch.rand(Lv, Tv, device=dev, generator=g2) < torch.tensor(f, device=dev)[:, None]
+        tab.grad = torch.randn(Lv, Tv, Fv, device=dev, generator=g2) * keep[..., None]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sy.finish()
+        torch.cuda.synchronize()
+        outs.append(tab.grad.clone())
+    if kern:
+        res_k = outs
+    else:
+        res_t = outs
+    sy.remove()
+shard.SPARSE_KERNELS = True
+assert all(torch.equal(a, b) for a, b in zip(res_k, res_t)) and float((res_k[2] == 0).float().mean()) > 0.9
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_SINGLE_RANK_OK")
