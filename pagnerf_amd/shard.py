@@ -167,6 +167,7 @@ SPARSE_DENSE_FILL = 0.5      # a level whose union of touched rows exceeds this 
 SPARSE_HEADROOM = 1.25       # bounded mode: slots per level = the recent maximum of the union count x this, in whole granules
 SPARSE_GRANULE = 1024        # rows
 SPARSE_HISTORY = 8           # steps whose counts size the slots
+SPARSE_LAG = 2               # bounded mode: a step's slots come from the counts of the steps at least this many exchanges back (the same ones on every rank)
 
 
 SPARSE_KERNELS = True      # GPU gradients: the mask / plan / pack / unpack passes of csrc/sparse.hip (False: the tensor-op form, as on CPU tensors)
@@ -193,8 +194,9 @@ class SparseRows:
 
     How many slots a level gets must be known to the host before the collective is queued.  mode="exact": the host reads the per-level
     union counts (one device-to-host copy of L integers: the step's queue drains once) - nothing is ever dropped.  mode="bounded"
-    (default): the slots follow the counts of the PREVIOUS steps (recent maximum x SPARSE_HEADROOM, read from a pinned mailbox without
-    waiting), the host never waits; union rows beyond a level's slots are set to zero on EVERY rank alike (the replicas stay identical),
+    (default): the slots follow the counts of EARLIER steps (recent maximum x SPARSE_HEADROOM over the steps SPARSE_LAG or more exchanges back: a FIXED
+    lag, so that every rank sizes the same collective whatever the arrival time of its mailboxes - which have long landed in pinned memory by then), the
+    host does not wait for the step in flight; union rows beyond a level's slots are set to zero on EVERY rank alike (the replicas stay identical),
     counted in `stats["dropped_rows"]` and reported by a warning, and the level's slots grow for the following steps.  reset() (call it when
     the regime changes: after nef.prune(), a new batch size or march type) sends the next steps whole until new counts are in."""
 
@@ -214,24 +216,25 @@ class SparseRows:
 
     # ---- host side: slots per level from the counts seen so far
     def _poll(self):
-        keep = []
-        for ev, box in self._pending:
-            if ev is None or ev.query():
-                vals = box.tolist()
-                if ev is not None and len(self._free_boxes) < 8:
-                    self._free_boxes.append(box)
-                self.history.append(vals[:-1])
-                self.history = self.history[-SPARSE_HISTORY:]
-                if vals[-1] > 0:
-                    self.stats["dropped_rows"] += int(vals[-1])
-                    if not self._warned:
-                        import warnings
-                        warnings.warn("pagnerf_amd.shard.SparseRows: %d union rows did not fit the slots sized from earlier steps and were zeroed on every rank "
-                                      "(the slots grow from the next step; call reset() when the regime changes, or use mode='exact')" % int(vals[-1]))
-                        self._warned = True
-            else:
-                keep.append((ev, box))
-        self._pending = keep
+        """Take in the counts of the steps that lie SPARSE_LAG or more exchanges back - exactly those, on every rank: the slots of a step must be the same
+        everywhere (they size the collective), so they cannot depend on WHEN a mailbox happens to arrive on this rank.  A report that old has normally landed;
+        if the host has run that far ahead of its queue, it waits for it here (a run-ahead of SPARSE_LAG steps at most)."""
+        while len(self._pending) >= SPARSE_LAG:
+            ev, box = self._pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            vals = box.tolist()
+            if ev is not None and len(self._free_boxes) < 8:
+                self._free_boxes.append(box)
+            self.history.append(vals[:-1])
+            self.history = self.history[-SPARSE_HISTORY:]
+            if vals[-1] > 0:
+                self.stats["dropped_rows"] += int(vals[-1])
+                if not self._warned:
+                    import warnings
+                    warnings.warn("pagnerf_amd.shard.SparseRows: %d union rows did not fit the slots sized from earlier steps and were zeroed on every rank "
+                                  "(the slots grow within %d steps; call reset() when the regime changes, or use mode='exact')" % (int(vals[-1]), SPARSE_LAG + 1))
+                    self._warned = True
 
     def _plan(self, T, L):
         if not self.history:
