@@ -625,7 +625,43 @@ def g9(nef_mod):
     np.savez_compressed(os.path.join(HERE, "g9_base_nef.npz"), **save)
 
 
+def g10():
+    """SciPy's own answers (scipy.optimize.linear_sum_assignment - the call of loss/lin_assignment_things.py:45 / loss/lin_assignment.py:22 - of the SciPy installed
+    here) on 48 small cost matrices with rows <= columns: random fp32-valued, tie-heavy integer, constant, half-integer and outlier-masked (10000) ones.  The
+    oracle's sequential restatement (oracle/lin_assign.py::lsap_jv) and the device kernel (pag_assign_solve) must give these columns whatever SciPy a later
+    image ships."""
+    import scipy
+    from scipy.optimize import linear_sum_assignment
+    rs = np.random.RandomState(10)
+    save = {"scipy_version": np.array(scipy.__version__)}
+    for t in range(48):
+        nr = int(rs.randint(1, 25))
+        nc = int(rs.randint(nr, 64))
+        kind = t % 6
+        if kind == 0:
+            c = rs.randn(nr, nc)
+        elif kind == 1:
+            c = rs.randint(0, 3, (nr, nc)).astype(np.float64)
+        elif kind == 2:
+            c = -rs.rand(nr, nc).astype(np.float32).astype(np.float64)
+        elif kind == 3:
+            c = np.full((nr, nc), 0.25)
+        elif kind == 4:
+            c = -rs.rand(nr, nc).astype(np.float32).astype(np.float64)
+            c[rs.rand(nr, nc) < 0.6] = 10000
+        else:
+            c = np.round(rs.randn(nr, nc) * 2) / 2
+        c = c.astype(np.float32)                                   # what pag_assign_cost hands over: fp32, widened to float64 by the solver
+        rows, cols = linear_sum_assignment(c.astype(np.float64))
+        assert np.array_equal(rows, np.arange(nr))
+        save["cost_%d" % t], save["cols_%d" % t] = c, cols.astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "g10_lsap.npz"), **save)
+
+
 def main():
+    if "--only-g10" in sys.argv:
+        g10()
+        return
     install_stubs()
     torch.set_num_threads(1)
     import importlib
@@ -662,6 +698,7 @@ def main():
     g8(dd_nef, importlib.import_module("tracers.panoptic_dd_packed_rf_tracer"))
     with _CudaToCpu():
         g9(importlib.import_module("pc_nerf.panoptic_nef"))
+    g10()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

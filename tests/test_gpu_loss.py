@@ -517,3 +517,29 @@ def test_training_with_the_device_solver_follows_the_host_solver_bit_for_bit(gpu
     assert torch.equal(labels["device"], labels["scipy"])
     assert float(curves["device"][-1]) < float(curves["device"][0])                                   # it trains
     assert int((labels["device"][1:] != labels["device"][:-1]).any(-1).any(-1).sum()) >= 1            # and the assignment moved while it did
+
+
+def test_device_hungarian_equals_the_committed_scipy_answers(gpu_device):
+    """pag_assign_solve on the 48 matrices of g10_lsap.npz (batched six at a time, padded to one shape): the committed SciPy 1.15.3 columns, bit for bit."""
+    from pagnerf_amd import ops
+    from pagnerf_amd import _lib as L
+    dev = gpu_device
+    g = golden("g10_lsap.npz")
+    R = C = 64
+    for b0 in range(0, 48, 6):
+        cost = np.zeros((6, R, C), dtype=np.float32)
+        info = np.zeros((6, 2), dtype=np.int32)
+        want = np.ones((6, R), dtype=np.int64)
+        for b in range(6):
+            c = g["cost_%d" % (b0 + b)]
+            # the kernel takes ONE column count per batch: pad the matrix with columns no row can prefer (they stay free, as if absent: +1e30 is never the minimum)
+            cost[b, :c.shape[0], :c.shape[1]] = c
+            cost[b, :c.shape[0], c.shape[1]:] = 1e30
+            info[b, 0] = c.shape[0]
+            want[b, :c.shape[0]] = g["cols_%d" % (b0 + b)] + 1
+        d_cost, d_info = torch.from_numpy(cost).to(dev), torch.from_numpy(info).to(dev)
+        targets = torch.zeros(6, R, device=dev, dtype=torch.int64)
+        status = torch.zeros(6, device=dev, dtype=torch.int32)
+        ops._call("pag_assign_solve", d_cost.data_ptr(), 6, R, C, d_info.data_ptr(), None, targets.data_ptr(), status.data_ptr(), L.stream())
+        torch.cuda.synchronize()
+        assert not status.any() and np.array_equal(targets.cpu().numpy(), want), b0

@@ -401,3 +401,15 @@ def test_lsap_restatement_equals_scipy():
         assert np.array_equal(rows, np.arange(nr)) and np.array_equal(cols, lsap_jv(c)), (trial, kind)
     big = -rs.rand(60, 199).astype(np.float32).astype(np.float64)
     assert np.array_equal(linear_sum_assignment(big)[1], lsap_jv(big))
+
+
+def test_lsap_restatement_equals_the_committed_scipy_answers():
+    """g10_lsap.npz: 48 cost matrices with the columns scipy.optimize.linear_sum_assignment (SciPy 1.15.3, tests/golden/make_golden.py::g10) assigned - the
+    definition of record for the Hungarian step should a later image ship a SciPy with another tie rule.  oracle.lin_assign.lsap_jv reproduces every one."""
+    from oracle.lin_assign import lsap_jv
+    g = golden("g10_lsap.npz")
+    n = 0
+    while "cost_%d" % n in g:
+        assert np.array_equal(lsap_jv(g["cost_%d" % n].astype(np.float64)), g["cols_%d" % n]), n
+        n += 1
+    assert n == 48
